@@ -1,0 +1,157 @@
+// api_common.hpp -- glue shared by the C-ABI translation units: casts between the public ckzg.h
+// structs and the internal 32-bit-limb types (identical bytes), the hidden header that ties a
+// KZGSettings to its GPU context, small host helpers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cinttypes>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/ckzg_hip.h"
+#include "device.hpp"
+#include "host_pairing.hpp"
+
+namespace ckzg {
+namespace api {
+
+constexpr size_t NUM_G1_POINTS = 4096;  // src/setup/setup.c:34-43
+constexpr size_t NUM_G2_POINTS = 65;
+
+static_assert(sizeof(fr_t) == sizeof(Fr), "fr_t layout");
+static_assert(sizeof(g1_t) == sizeof(G1Jac), "g1_t layout");
+static_assert(sizeof(g2_t) == sizeof(host::G2Jac), "g2_t layout");
+static_assert(sizeof(KZGSettings) == 80, "KZGSettings is ABI (src/setup/settings.h:27-79)");
+
+inline Fr *as_fr(fr_t *p) { return reinterpret_cast<Fr *>(p); }
+inline const Fr *as_fr(const fr_t *p) { return reinterpret_cast<const Fr *>(p); }
+inline G1Jac *as_g1(g1_t *p) { return reinterpret_cast<G1Jac *>(p); }
+inline const G1Jac *as_g1(const g1_t *p) { return reinterpret_cast<const G1Jac *>(p); }
+inline const host::G2Jac *as_g2(const g2_t *p) { return reinterpret_cast<const host::G2Jac *>(p); }
+
+struct Options {
+    int device = -1;        // -1: env CKZG_HIP_DEVICE, else LOCAL_RANK, else 0
+    int commit_wbits = 10;  // env CKZG_HIP_COMMIT_WBITS overrides the default
+    int fk20_wbits = 0;     // 0: max(8, precompute); env CKZG_HIP_FK20_WBITS
+};
+extern Options g_opts;
+
+// Lives immediately in front of KZGSettings::roots_of_unity.
+constexpr uint64_t SETTINGS_MAGIC = 0x434b5a47484950ULL;  // "CKZGHIP"
+struct alignas(64) SettingsHeader {
+    uint64_t magic;
+    dev::DeviceCtx *ctx;
+};
+
+inline SettingsHeader *header_of(const KZGSettings *s) {
+    if (!s || !s->roots_of_unity) return nullptr;
+    SettingsHeader *h = reinterpret_cast<SettingsHeader *>(s->roots_of_unity) - 1;
+    return h->magic == SETTINGS_MAGIC ? h : nullptr;
+}
+
+inline dev::DeviceCtx *ctx_of(const KZGSettings *s) {
+    SettingsHeader *h = header_of(s);
+    if (!h || !h->ctx) {
+        fprintf(stderr, "[ckzg-hip] KZGSettings has no GPU context (not loaded by this library, or freed)\n");
+        return nullptr;
+    }
+    return h->ctx;
+}
+
+// implemented in device_ctx.hip
+C_KZG_RET create_device_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affine,
+                            const G1Affine *monomial_affine);
+void destroy_device_ctx(dev::DeviceCtx *ctx);
+
+struct DeviceBuffer {
+    void *p = nullptr;
+    bool alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1) == hipSuccess; }
+    ~DeviceBuffer() {
+        if (p) (void)hipFree(p);
+    }
+};
+
+// src/common/utils.c:103-140 (n must be a power of two)
+inline void bit_reversal_permutation(void *values, size_t size, size_t n) {
+    if (n < 2) return;
+    unsigned bits = 0;
+    while (((size_t)1 << bits) < n) bits++;
+    uint8_t *v = static_cast<uint8_t *>(values);
+    std::vector<uint8_t> tmp(size);
+    for (size_t i = 0; i < n; i++) {
+        size_t j = 0;
+        for (unsigned b = 0; b < bits; b++) j |= ((i >> b) & 1) << (bits - 1 - b);
+        if (j > i) {
+            memcpy(tmp.data(), v + i * size, size);
+            memcpy(v + i * size, v + j * size, size);
+            memcpy(v + j * size, tmp.data(), size);
+        }
+    }
+}
+
+inline size_t reverse_bits_limited(size_t n, size_t v) {
+    unsigned bits = 0;
+    while (((size_t)1 << bits) < n) bits++;
+    size_t j = 0;
+    for (unsigned b = 0; b < bits; b++) j |= ((v >> b) & 1) << (bits - 1 - b);
+    return j;
+}
+
+inline void be_to_raw8(uint32_t raw[8], const uint8_t *b) {
+    for (int i = 0; i < 8; i++) {
+        const uint8_t *p = b + 4 * (7 - i);
+        raw[i] = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+    }
+}
+
+// src/common/bytes.c:64-70
+inline bool fr_from_bytes_canonical(Fr &out, const uint8_t *b) {
+    uint32_t raw[8], m[8];
+    be_to_raw8(raw, b);
+    mod_limbs<FrParams>(m);
+    if (limbs_geq<8>(raw, m)) return false;
+    out = from_raw<FrParams>(raw);
+    return true;
+}
+
+// src/common/bytes.c:123-127 (hash_to_bls_field: reduce, never reject)
+inline Fr fr_from_bytes_reduce(const uint8_t *b) {
+    uint32_t raw[8];
+    be_to_raw8(raw, b);
+    return from_raw<FrParams>(raw);
+}
+
+// src/common/bytes.c:52-56
+inline void fr_to_bytes(uint8_t *out, const Fr &a) {
+    uint32_t raw[8];
+    to_raw<FrParams>(raw, a);
+    for (int i = 0; i < 8; i++) {
+        uint32_t v = raw[7 - i];
+        out[4 * i] = (uint8_t)(v >> 24);
+        out[4 * i + 1] = (uint8_t)(v >> 16);
+        out[4 * i + 2] = (uint8_t)(v >> 8);
+        out[4 * i + 3] = (uint8_t)v;
+    }
+}
+
+inline void be64(uint8_t out[8], uint64_t v) {
+    for (int i = 7; i >= 0; i--) {
+        out[i] = (uint8_t)v;
+        v >>= 8;
+    }
+}
+
+// src/common/bytes.c:81-95: decompress, accept infinity, otherwise require the prime-order subgroup
+inline C_KZG_RET validate_kzg_g1(G1Jac &out, const uint8_t *b) {
+    G1Affine a;
+    if (g1_uncompress(a, b) != 0) return C_KZG_BADARGS;
+    out = jac_from_affine(a);
+    if (out.is_inf()) return C_KZG_OK;
+    uint32_t r[8];
+    mod_limbs<FrParams>(r);
+    return jac_mul(out, r, 255).is_inf() ? C_KZG_OK : C_KZG_BADARGS;
+}
+
+}  // namespace api
+}  // namespace ckzg

@@ -1,0 +1,267 @@
+// ckzg_api.hip -- the extern "C" boundary: ckzg.h (reference ABI) + ckzg_hip.h (batch/device
+// extensions).  Host-side protocol logic lives here; every MSM / NTT goes to the HIP kernels via
+// device.hpp.  There is no CPU fallback for the hot path: if no GPU context is attached to the
+// KZGSettings (or the HIP runtime fails) the call returns C_KZG_ERROR and says why on stderr.
+#include "api_common.hpp"
+
+using namespace ckzg;
+using namespace ckzg::host;
+using namespace ckzg::api;
+
+// ------------------------------------------------------------------------------------------
+// options
+// ------------------------------------------------------------------------------------------
+
+namespace ckzg {
+namespace api {
+Options g_opts;
+}
+}  // namespace ckzg
+
+extern "C" C_KZG_RET ckzg_hip_set_option(const char *key, int64_t value) {
+    if (!key) return C_KZG_BADARGS;
+    if (!strcmp(key, "device")) {
+        if (value < -1 || value > 1023) return C_KZG_BADARGS;
+        g_opts.device = (int)value;
+    } else if (!strcmp(key, "commit_wbits")) {
+        if (value < 4 || value > 15) return C_KZG_BADARGS;
+        g_opts.commit_wbits = (int)value;
+    } else if (!strcmp(key, "fk20_wbits")) {
+        if (value != 0 && (value < 4 || value > 15)) return C_KZG_BADARGS;
+        g_opts.fk20_wbits = (int)value;
+    } else {
+        return C_KZG_BADARGS;
+    }
+    return C_KZG_OK;
+}
+
+extern "C" int ckzg_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------
+// trusted setup (src/setup/setup.c)
+// ------------------------------------------------------------------------------------------
+
+static const uint32_t ROOT_8192[8] = {FR_ROOT_8192_MONT[0], FR_ROOT_8192_MONT[1], FR_ROOT_8192_MONT[2],
+                                      FR_ROOT_8192_MONT[3], FR_ROOT_8192_MONT[4], FR_ROOT_8192_MONT[5],
+                                      FR_ROOT_8192_MONT[6], FR_ROOT_8192_MONT[7]};
+
+static C_KZG_RET compute_roots_of_unity(KZGSettings *s) {  // setup.c:99-153
+    Fr *roots = as_fr(s->roots_of_unity);
+    Fr root;
+    for (int i = 0; i < 8; i++) root.l[i] = ROOT_8192[i];
+    roots[0] = Fr::one();
+    roots[1] = root;
+    size_t i;
+    for (i = 2; i <= FIELD_ELEMENTS_PER_EXT_BLOB; i++) {
+        roots[i] = mul(roots[i - 1], root);
+        if (roots[i] == Fr::one()) break;
+    }
+    if (i != FIELD_ELEMENTS_PER_EXT_BLOB || roots[FIELD_ELEMENTS_PER_EXT_BLOB] != Fr::one()) return C_KZG_BADARGS;
+    memcpy(s->brp_roots_of_unity, s->roots_of_unity, sizeof(fr_t) * FIELD_ELEMENTS_PER_EXT_BLOB);
+    bit_reversal_permutation(s->brp_roots_of_unity, sizeof(fr_t), FIELD_ELEMENTS_PER_EXT_BLOB);
+    for (i = 0; i <= FIELD_ELEMENTS_PER_EXT_BLOB; i++) {
+        s->reverse_roots_of_unity[i] = s->roots_of_unity[FIELD_ELEMENTS_PER_EXT_BLOB - i];
+    }
+    return C_KZG_OK;
+}
+
+extern "C" void free_trusted_setup(KZGSettings *s) {  // setup.c:162-190
+    if (s == NULL) return;
+    if (s->roots_of_unity) {
+        SettingsHeader *h = header_of(s);
+        if (h && h->ctx) destroy_device_ctx(h->ctx);
+        free(h ? (void *)h : (void *)s->roots_of_unity);
+    }
+    free(s->brp_roots_of_unity);
+    free(s->reverse_roots_of_unity);
+    free(s->g1_values_monomial);
+    free(s->g1_values_lagrange_brp);
+    free(s->g2_values_monomial);
+    if (s->x_ext_fft_columns) {
+        for (size_t i = 0; i < CELLS_PER_EXT_BLOB; i++) free(s->x_ext_fft_columns[i]);
+    }
+    free(s->x_ext_fft_columns);
+    memset(s, 0, sizeof *s);
+}
+
+extern "C" C_KZG_RET load_trusted_setup(KZGSettings *out, const uint8_t *g1_monomial_bytes,
+                                        uint64_t num_g1_monomial_bytes,
+                                        const uint8_t *g1_lagrange_bytes,
+                                        uint64_t num_g1_lagrange_bytes,
+                                        const uint8_t *g2_monomial_bytes,
+                                        uint64_t num_g2_monomial_bytes, uint64_t precompute) {
+    // setup.c:392-505
+    C_KZG_RET ret = C_KZG_OK;
+    std::vector<G1Affine> lagr_affine(NUM_G1_POINTS), mono_affine(NUM_G1_POINTS);
+    memset(out, 0, sizeof *out);
+    if (precompute > 15) return C_KZG_BADARGS;
+    out->wbits = precompute;
+    if (num_g1_monomial_bytes != NUM_G1_POINTS * 48 || num_g1_lagrange_bytes != NUM_G1_POINTS * 48 ||
+        num_g2_monomial_bytes != NUM_G2_POINTS * 96) {
+        return C_KZG_BADARGS;
+    }
+    // roots_of_unity carries the hidden header that links this struct to its GPU context
+    {
+        size_t bytes = sizeof(SettingsHeader) + (FIELD_ELEMENTS_PER_EXT_BLOB + 1) * sizeof(fr_t);
+        SettingsHeader *h = (SettingsHeader *)calloc(1, bytes);
+        if (!h) return C_KZG_MALLOC;
+        h->magic = SETTINGS_MAGIC;
+        h->ctx = nullptr;
+        out->roots_of_unity = (fr_t *)(h + 1);
+    }
+    out->brp_roots_of_unity = (fr_t *)calloc(FIELD_ELEMENTS_PER_EXT_BLOB, sizeof(fr_t));
+    out->reverse_roots_of_unity = (fr_t *)calloc(FIELD_ELEMENTS_PER_EXT_BLOB + 1, sizeof(fr_t));
+    out->g1_values_monomial = (g1_t *)calloc(NUM_G1_POINTS, sizeof(g1_t));
+    out->g1_values_lagrange_brp = (g1_t *)calloc(NUM_G1_POINTS, sizeof(g1_t));
+    out->g2_values_monomial = (g2_t *)calloc(NUM_G2_POINTS, sizeof(g2_t));
+    if (!out->brp_roots_of_unity || !out->reverse_roots_of_unity || !out->g1_values_monomial ||
+        !out->g1_values_lagrange_brp || !out->g2_values_monomial) {
+        ret = C_KZG_MALLOC;
+        goto fail;
+    }
+    // The file is trusted: curve membership only, no subgroup check (setup.c:447-477)
+    for (size_t i = 0; i < NUM_G1_POINTS; i++) {
+        if (g1_uncompress(mono_affine[i], g1_monomial_bytes + 48 * i) != 0 ||
+            g1_uncompress(lagr_affine[i], g1_lagrange_bytes + 48 * i) != 0) {
+            ret = C_KZG_BADARGS;
+            goto fail;
+        }
+        *as_g1(&out->g1_values_monomial[i]) = jac_from_affine(mono_affine[i]);
+        *as_g1(&out->g1_values_lagrange_brp[i]) = jac_from_affine(lagr_affine[i]);
+    }
+    for (size_t i = 0; i < NUM_G2_POINTS; i++) {
+        G2Affine a;
+        if (g2_uncompress(a, g2_monomial_bytes + 96 * i) != 0) {
+            ret = C_KZG_BADARGS;
+            goto fail;
+        }
+        G2Jac j = a.is_inf() ? G2Jac::inf() : G2Jac{a.x, a.y, Fp2::one()};
+        memcpy(&out->g2_values_monomial[i], &j, sizeof j);
+    }
+    // setup.c:339-358: reject a setup whose "Lagrange" points are really the monomial ones
+    if (pairings_verify(*as_g1(&out->g1_values_lagrange_brp[1]), *as_g2(&out->g2_values_monomial[0]),
+                        *as_g1(&out->g1_values_lagrange_brp[0]), *as_g2(&out->g2_values_monomial[1]))) {
+        ret = C_KZG_BADARGS;
+        goto fail;
+    }
+    ret = compute_roots_of_unity(out);
+    if (ret != C_KZG_OK) goto fail;
+    bit_reversal_permutation(out->g1_values_lagrange_brp, sizeof(g1_t), NUM_G1_POINTS);
+    bit_reversal_permutation(lagr_affine.data(), sizeof(G1Affine), NUM_G1_POINTS);
+    // GPU context: commitment tables, NTT twiddles, FK20 columns and tables (setup.c:238-330)
+    ret = create_device_ctx(out, lagr_affine.data(), mono_affine.data());
+    if (ret != C_KZG_OK) goto fail;
+    return C_KZG_OK;
+fail:
+    free_trusted_setup(out);
+    return ret;
+}
+
+extern "C" C_KZG_RET load_trusted_setup_file(KZGSettings *out, FILE *in, uint64_t precompute) {
+    // setup.c:519-600: "<n_g1> <n_g2>" then hex of: G1 Lagrange, G2 monomial, G1 monomial
+    uint64_t n1 = 0, n2 = 0;
+    memset(out, 0, sizeof *out);
+    std::vector<uint8_t> mono(NUM_G1_POINTS * 48), lagr(NUM_G1_POINTS * 48), g2(NUM_G2_POINTS * 96);
+    if (fscanf(in, "%" SCNu64, &n1) != 1 || n1 != NUM_G1_POINTS) return C_KZG_BADARGS;
+    if (fscanf(in, "%" SCNu64, &n2) != 1 || n2 != NUM_G2_POINTS) return C_KZG_BADARGS;
+    for (auto &b : lagr) {
+        if (fscanf(in, "%2hhx", &b) != 1) return C_KZG_BADARGS;
+    }
+    for (auto &b : g2) {
+        if (fscanf(in, "%2hhx", &b) != 1) return C_KZG_BADARGS;
+    }
+    for (auto &b : mono) {
+        if (fscanf(in, "%2hhx", &b) != 1) return C_KZG_BADARGS;
+    }
+    return load_trusted_setup(out, mono.data(), mono.size(), lagr.data(), lagr.size(), g2.data(),
+                              g2.size(), precompute);
+}
+
+// ------------------------------------------------------------------------------------------
+// byte <-> element helpers (src/common/bytes.c)
+// ------------------------------------------------------------------------------------------
+
+extern "C" C_KZG_RET bytes_to_bls_field(fr_t *out, const Bytes32 *b) {
+    return fr_from_bytes_canonical(*as_fr(out), b->bytes) ? C_KZG_OK : C_KZG_BADARGS;
+}
+
+extern "C" void bytes_from_bls_field(Bytes32 *out, const fr_t *in) { fr_to_bytes(out->bytes, *as_fr(in)); }
+
+extern "C" void bytes_from_g1(Bytes48 *out, const g1_t *in) {
+    g1_compress_affine(out->bytes, jac_to_affine(*as_g1(in)));
+}
+
+extern "C" C_KZG_RET bytes_to_kzg_commitment(g1_t *out, const Bytes48 *b) {
+    return validate_kzg_g1(*as_g1(out), b->bytes);
+}
+
+extern "C" C_KZG_RET bytes_to_kzg_proof(g1_t *out, const Bytes48 *b) {
+    return validate_kzg_g1(*as_g1(out), b->bytes);
+}
+
+// ------------------------------------------------------------------------------------------
+// blob_to_kzg_commitment (src/eip4844/eip4844.c:264-280) and its batch forms
+// ------------------------------------------------------------------------------------------
+
+extern "C" C_KZG_RET ckzg_hip_blob_to_kzg_commitment_batch_device(void *d_out48, void *d_status,
+                                                                  const void *d_blobs, uint64_t n,
+                                                                  const KZGSettings *s) {
+    dev::DeviceCtx *ctx = ctx_of(s);
+    if (!ctx) return C_KZG_ERROR;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (hipSetDevice(ctx->device) != hipSuccess) return C_KZG_ERROR;
+    return (C_KZG_RET)dev::commit_blobs_device(ctx, (uint8_t *)d_out48, (uint8_t *)d_status,
+                                               (const uint8_t *)d_blobs, n);
+}
+
+extern "C" C_KZG_RET ckzg_hip_blob_to_kzg_commitment_batch(KZGCommitment *out, uint8_t *status,
+                                                           const Blob *blobs, uint64_t n,
+                                                           const KZGSettings *s) {
+    dev::DeviceCtx *ctx = ctx_of(s);
+    if (!ctx) return C_KZG_ERROR;
+    if (n == 0) return C_KZG_OK;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (hipSetDevice(ctx->device) != hipSuccess) return C_KZG_ERROR;
+    // chunk so that blobs + digits stay within a bounded staging footprint
+    const uint64_t CH = 1024;
+    DeviceBuffer d_blobs, d_out, d_status;
+    uint64_t m = n < CH ? n : CH;
+    if (!d_blobs.alloc(m * BYTES_PER_BLOB) || !d_out.alloc(m * 48) || !d_status.alloc(m)) return C_KZG_MALLOC;
+    std::vector<uint8_t> st(m);
+    C_KZG_RET ret = C_KZG_OK;
+    for (uint64_t off = 0; off < n; off += CH) {
+        uint64_t k = n - off < CH ? n - off : CH;
+        if (hipMemcpyAsync(d_blobs.p, blobs + off, k * BYTES_PER_BLOB, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+            return C_KZG_ERROR;
+        int rc = dev::commit_blobs_device(ctx, (uint8_t *)d_out.p, (uint8_t *)d_status.p, (const uint8_t *)d_blobs.p, k);
+        if (rc) return (C_KZG_RET)rc;
+        if (hipMemcpy(out + off, d_out.p, k * 48, hipMemcpyDeviceToHost) != hipSuccess) return C_KZG_ERROR;
+        if (hipMemcpy(st.data(), d_status.p, k, hipMemcpyDeviceToHost) != hipSuccess) return C_KZG_ERROR;
+        for (uint64_t i = 0; i < k; i++) {
+            if (status) status[off + i] = st[i];
+            if (st[i]) ret = C_KZG_BADARGS;
+        }
+    }
+    return ret;
+}
+
+extern "C" C_KZG_RET blob_to_kzg_commitment(KZGCommitment *out, const Blob *blob, const KZGSettings *s) {
+    uint8_t st = 0;
+    return ckzg_hip_blob_to_kzg_commitment_batch(out, &st, blob, 1, s);
+}
+
+extern "C" double ckzg_hip_last_kernel_ms(const KZGSettings *s, int which) {
+    dev::DeviceCtx *ctx = ctx_of(s);
+    if (!ctx || which < 0 || which > 3) return -1.0;
+    return ctx->last_ms[which];
+}
+
+extern "C" uint64_t ckzg_hip_table_bytes(const KZGSettings *s) {
+    dev::DeviceCtx *ctx = ctx_of(s);
+    if (!ctx) return 0;
+    return ctx->commit.bytes() + ctx->fk20.bytes();
+}

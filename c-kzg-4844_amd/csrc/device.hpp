@@ -1,0 +1,81 @@
+// device.hpp -- the GPU context that hangs off a loaded KZGSettings, and the launchers the C-ABI
+// layer (ckzg_api.hip) calls.  One context per load_trusted_setup; immutable tables in HBM, one
+// stream, one growable scratch arena guarded by a mutex (the reference allows concurrent readers
+// of one KZGSettings, bindings/rust/src/bindings/mod.rs:910-913; here they serialise on the GPU).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <mutex>
+#include "g1.hpp"
+
+namespace ckzg {
+namespace dev {
+
+constexpr int N_BLOB = 4096;       // FIELD_ELEMENTS_PER_BLOB
+constexpr int N_EXT = 8192;        // FIELD_ELEMENTS_PER_EXT_BLOB
+constexpr int N_CELL = 64;         // FIELD_ELEMENTS_PER_CELL
+constexpr int N_CELLS_EXT = 128;   // CELLS_PER_EXT_BLOB
+
+// Fixed-base table over `npoints` bases: entry (w, i, e) = (e+1) * 2^(wbits*w) * P_i, affine,
+// Montgomery form, laid out [w][i][e] with e < half = 2^(wbits-1).  A scalar is recoded into
+// nwin = floor(255/wbits)+1 signed digits in [-half, half]; the MSM is then a plain sum of
+// npoints*nwin table entries -- no buckets, no doublings, no data-dependent scatter.
+struct FixedBaseTable {
+    G1Affine *d_table = nullptr;
+    int npoints = 0;
+    int wbits = 0;
+    int nwin = 0;
+    size_t half = 0;
+    size_t bytes() const { return (size_t)nwin * npoints * half * sizeof(G1Affine); }
+};
+
+struct Scratch {
+    void *ptr = nullptr;
+    size_t cap = 0;
+};
+
+struct DeviceCtx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    FixedBaseTable commit;        // over g1_values_lagrange_brp (4096 points)
+    Scratch scratch;              // reused by every call under `mu`
+    hipEvent_t ev[8] = {};        // timing events
+    float last_ms[4] = {-1, -1, -1, -1};
+    // Fr tables for NTTs and evaluation (Montgomery form, 8 x u32)
+    Fr *d_roots = nullptr;        // w^i, 8193 entries
+    Fr *d_brp_roots = nullptr;    // 8192
+    // FK20
+    FixedBaseTable fk20;          // over x_ext_fft columns: point index = col*64 + row
+    G1Affine *d_xext = nullptr;   // [128][64] affine
+};
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            fprintf(stderr, "[ckzg-hip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(_e), \
+                    __FILE__, __LINE__);                                                       \
+            return _e == hipErrorOutOfMemory ? 3 : 2;                                          \
+        }                                                                                      \
+    } while (0)
+
+// returns 0 ok / 2 error / 3 out of memory (C_KZG_RET values)
+int scratch_reserve(DeviceCtx *ctx, size_t bytes);
+
+// Build a fixed-base table for `npoints` affine bases already in HBM.
+int build_fixed_base_table(DeviceCtx *ctx, FixedBaseTable *t, const G1Affine *d_bases, int npoints,
+                           int wbits);
+
+// Commit n blobs resident in HBM: d_out48[n][48], d_status[n] (0 ok, 1 non-canonical element).
+int commit_blobs_device(DeviceCtx *ctx, uint8_t *d_out48, uint8_t *d_status, const uint8_t *d_blobs,
+                        size_t n);
+
+// Generic: sum_i scalar_i * P_i over the ctx->commit table for n independent scalar vectors that
+// are already canonical little-endian 8xu32 integers in HBM ([n][4096][8]); writes n compressed
+// points.  Used by compute_kzg_proof (quotient polynomial) and friends.
+int msm_commit_table_raw_device(DeviceCtx *ctx, uint8_t *d_out48, const uint32_t *d_scalars, size_t n);
+
+}  // namespace dev
+}  // namespace ckzg

@@ -1,0 +1,93 @@
+// device_ctx.hip -- creation / destruction of the per-KZGSettings GPU context: device selection,
+// stream + timing events, upload of setup points and twiddles, fixed-base table construction.
+// This is the GPU half of load_trusted_setup (src/setup/setup.c:392-505): the reference builds
+// x_ext_fft_columns and (optionally) blst fixed-base tables on the CPU (setup.c:238-330); here the
+// 64 G1 FFTs and all tables are produced by kernels and stay resident in HBM.
+#include "api_common.hpp"
+
+namespace ckzg {
+namespace api {
+
+static int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    if (!v || !*v) return dflt;
+    return atoi(v);
+}
+
+void destroy_device_ctx(dev::DeviceCtx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->commit.d_table) (void)hipFree(ctx->commit.d_table);
+    if (ctx->fk20.d_table) (void)hipFree(ctx->fk20.d_table);
+    if (ctx->d_xext) (void)hipFree(ctx->d_xext);
+    if (ctx->d_roots) (void)hipFree(ctx->d_roots);
+    if (ctx->d_brp_roots) (void)hipFree(ctx->d_brp_roots);
+    if (ctx->scratch.ptr) (void)hipFree(ctx->scratch.ptr);
+    for (auto &e : ctx->ev) {
+        if (e) (void)hipEventDestroy(e);
+    }
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+#define CTX_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            fprintf(stderr, "[ckzg-hip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(_e),   \
+                    __FILE__, __LINE__);                                                         \
+            destroy_device_ctx(ctx);                                                             \
+            return _e == hipErrorOutOfMemory ? C_KZG_MALLOC : C_KZG_ERROR;                       \
+        }                                                                                        \
+    } while (0)
+
+C_KZG_RET create_device_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affine,
+                            const G1Affine *monomial_affine) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        fprintf(stderr, "[ckzg-hip] no HIP device available: this build has no CPU fallback for the MSM/FFT hot path\n");
+        return C_KZG_ERROR;
+    }
+    int device = g_opts.device;
+    if (device < 0) device = env_int("CKZG_HIP_DEVICE", -1);
+    if (device < 0) device = env_int("LOCAL_RANK", 0) % ndev;
+    if (device >= ndev) {
+        fprintf(stderr, "[ckzg-hip] device %d out of range (%d visible)\n", device, ndev);
+        return C_KZG_ERROR;
+    }
+    dev::DeviceCtx *ctx = new dev::DeviceCtx();
+    ctx->device = device;
+    CTX_TRY(hipSetDevice(device));
+    CTX_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    for (auto &e : ctx->ev) CTX_TRY(hipEventCreate(&e));
+
+    // Fr twiddles
+    CTX_TRY(hipMalloc(&ctx->d_roots, (dev::N_EXT + 1) * sizeof(Fr)));
+    CTX_TRY(hipMalloc(&ctx->d_brp_roots, dev::N_EXT * sizeof(Fr)));
+    CTX_TRY(hipMemcpy(ctx->d_roots, s->roots_of_unity, (dev::N_EXT + 1) * sizeof(Fr), hipMemcpyHostToDevice));
+    CTX_TRY(hipMemcpy(ctx->d_brp_roots, s->brp_roots_of_unity, dev::N_EXT * sizeof(Fr), hipMemcpyHostToDevice));
+
+    // commitment table over the bit-reversed Lagrange points
+    {
+        int wbits = env_int("CKZG_HIP_COMMIT_WBITS", g_opts.commit_wbits);
+        if (wbits < 4 || wbits > 15) wbits = 10;
+        DeviceBuffer d_bases;
+        if (!d_bases.alloc(NUM_G1_POINTS * sizeof(G1Affine))) {
+            destroy_device_ctx(ctx);
+            return C_KZG_MALLOC;
+        }
+        CTX_TRY(hipMemcpy(d_bases.p, lagrange_brp_affine, NUM_G1_POINTS * sizeof(G1Affine), hipMemcpyHostToDevice));
+        int rc = dev::build_fixed_base_table(ctx, &ctx->commit, (const G1Affine *)d_bases.p, (int)NUM_G1_POINTS, wbits);
+        if (rc) {
+            destroy_device_ctx(ctx);
+            return (C_KZG_RET)rc;
+        }
+    }
+    (void)monomial_affine;
+    header_of(s)->ctx = ctx;
+    return C_KZG_OK;
+}
+
+}  // namespace api
+}  // namespace ckzg

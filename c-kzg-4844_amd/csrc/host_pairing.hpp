@@ -1,0 +1,368 @@
+// host_pairing.hpp -- host-only part of the BLS12-381 stack the C-ABI needs outside the GPU hot
+// path: the Fp2/Fp6/Fp12 tower, G2, the two-pairing product check and SHA-256.  These back
+// pairings_verify (src/common/utils.c:172-196), g2_mul/g2_sub (src/eip4844/eip4844.c:114-130),
+// blst_p2_uncompress at setup (src/setup/setup.c:467-477) and blst_sha256
+// (src/eip4844/eip4844.c:176).  They run once or twice per API call and are not worth a kernel;
+// the MSM/FFT work that dominates every call is in the .hip files.
+//
+// Tower: Fp2 = Fp[u]/(u^2+1), Fp6 = Fp2[v]/(v^3-(1+u)), Fp12 = Fp6[w]/(w^2-v).
+#pragma once
+#include <cstring>
+#include "g1.hpp"
+
+namespace ckzg {
+namespace host {
+
+struct Fp2 {
+    Fp c0, c1;
+    static Fp2 zero() { return {Fp::zero(), Fp::zero()}; }
+    static Fp2 one() { return {Fp::one(), Fp::zero()}; }
+    bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+    bool operator==(const Fp2 &o) const { return c0 == o.c0 && c1 == o.c1; }
+};
+
+inline Fp2 add(const Fp2 &a, const Fp2 &b) { return {add(a.c0, b.c0), add(a.c1, b.c1)}; }
+inline Fp2 sub(const Fp2 &a, const Fp2 &b) { return {sub(a.c0, b.c0), sub(a.c1, b.c1)}; }
+inline Fp2 neg(const Fp2 &a) { return {neg(a.c0), neg(a.c1)}; }
+inline Fp2 dbl(const Fp2 &a) { return add(a, a); }
+inline Fp2 mul(const Fp2 &a, const Fp2 &b) {
+    // Karatsuba: 3 base-field products
+    Fp t0 = mul(a.c0, b.c0), t1 = mul(a.c1, b.c1);
+    Fp t2 = mul(add(a.c0, a.c1), add(b.c0, b.c1));
+    return {sub(t0, t1), sub(sub(t2, t0), t1)};
+}
+inline Fp2 sqr(const Fp2 &a) {
+    Fp m = mul(a.c0, a.c1);
+    return {mul(add(a.c0, a.c1), sub(a.c0, a.c1)), dbl(m)};
+}
+inline Fp2 mul_fp(const Fp2 &a, const Fp &k) { return {mul(a.c0, k), mul(a.c1, k)}; }
+inline Fp2 mul_xi(const Fp2 &a) { return {sub(a.c0, a.c1), add(a.c0, a.c1)}; }  // * (1+u)
+inline Fp2 inv(const Fp2 &a) {
+    Fp n = fp_inv(add(sqr(a.c0), sqr(a.c1)));
+    return {mul(a.c0, n), neg(mul(a.c1, n))};
+}
+
+inline bool fp_sqrt(Fp &out, const Fp &a) {
+    uint32_t e[12];
+    for (int i = 0; i < 12; i++) e[i] = FP_SQRT_EXP[i];
+    Fp s = pow_limbs(a, e, 381);
+    out = s;
+    return sqr(s) == a;
+}
+
+// norm method; false if a is a non-residue in Fp2
+inline bool fp2_sqrt(Fp2 &out, const Fp2 &a) {
+    Fp2 cand;
+    if (a.c1.is_zero()) {
+        Fp s;
+        if (fp_sqrt(s, a.c0)) {
+            cand = {s, Fp::zero()};
+        } else {
+            if (!fp_sqrt(s, neg(a.c0))) return false;
+            cand = {Fp::zero(), s};
+        }
+    } else {
+        Fp s, x0;
+        if (!fp_sqrt(s, add(sqr(a.c0), sqr(a.c1)))) return false;
+        Fp half = fp_inv(dbl(Fp::one()));
+        if (!fp_sqrt(x0, mul(add(a.c0, s), half))) {
+            if (!fp_sqrt(x0, mul(sub(a.c0, s), half))) return false;
+        }
+        cand = {x0, mul(a.c1, fp_inv(dbl(x0)))};
+    }
+    if (!(sqr(cand) == a)) return false;
+    out = cand;
+    return true;
+}
+
+struct Fp6 {
+    Fp2 c0, c1, c2;
+};
+inline Fp6 add(const Fp6 &a, const Fp6 &b) { return {add(a.c0, b.c0), add(a.c1, b.c1), add(a.c2, b.c2)}; }
+inline Fp6 sub(const Fp6 &a, const Fp6 &b) { return {sub(a.c0, b.c0), sub(a.c1, b.c1), sub(a.c2, b.c2)}; }
+inline Fp6 neg(const Fp6 &a) { return {neg(a.c0), neg(a.c1), neg(a.c2)}; }
+inline Fp6 mul(const Fp6 &a, const Fp6 &b) {
+    Fp2 v0 = mul(a.c0, b.c0), v1 = mul(a.c1, b.c1), v2 = mul(a.c2, b.c2);
+    // Toom/Karatsuba-style cross terms
+    Fp2 t12 = sub(sub(mul(add(a.c1, a.c2), add(b.c1, b.c2)), v1), v2);  // a1b2 + a2b1
+    Fp2 t01 = sub(sub(mul(add(a.c0, a.c1), add(b.c0, b.c1)), v0), v1);  // a0b1 + a1b0
+    Fp2 t02 = sub(sub(mul(add(a.c0, a.c2), add(b.c0, b.c2)), v0), v2);  // a0b2 + a2b0
+    return {add(v0, mul_xi(t12)), add(t01, mul_xi(v2)), add(t02, v1)};
+}
+inline Fp6 mul_v(const Fp6 &a) { return {mul_xi(a.c2), a.c0, a.c1}; }
+inline Fp6 inv(const Fp6 &a) {
+    Fp2 t0 = sub(sqr(a.c0), mul_xi(mul(a.c1, a.c2)));
+    Fp2 t1 = sub(mul_xi(sqr(a.c2)), mul(a.c0, a.c1));
+    Fp2 t2 = sub(sqr(a.c1), mul(a.c0, a.c2));
+    Fp2 d = add(mul(a.c0, t0), mul_xi(add(mul(a.c2, t1), mul(a.c1, t2))));
+    Fp2 di = inv(d);
+    return {mul(t0, di), mul(t1, di), mul(t2, di)};
+}
+
+struct Fp12 {
+    Fp6 c0, c1;
+    static Fp12 one() {
+        Fp12 r;
+        std::memset(&r, 0, sizeof r);
+        r.c0.c0.c0 = Fp::one();
+        return r;
+    }
+    bool is_one() const {
+        Fp12 o = one();
+        return std::memcmp(this, &o, sizeof o) == 0;
+    }
+};
+inline Fp12 mul(const Fp12 &a, const Fp12 &b) {
+    Fp6 v0 = mul(a.c0, b.c0), v1 = mul(a.c1, b.c1);
+    Fp6 c1 = sub(sub(mul(add(a.c0, a.c1), add(b.c0, b.c1)), v0), v1);
+    return {add(v0, mul_v(v1)), c1};
+}
+inline Fp12 conj(const Fp12 &a) { return {a.c0, neg(a.c1)}; }
+inline Fp12 inv(const Fp12 &a) {
+    Fp6 d = inv(sub(mul(a.c0, a.c0), mul_v(mul(a.c1, a.c1))));
+    return {mul(a.c0, d), neg(mul(a.c1, d))};
+}
+
+// ---- G2: y^2 = x^3 + 4(1+u), Jacobian; same layout as blst_p2 (the reference's g2_t) ----
+
+struct G2Affine {
+    Fp2 x, y;
+    bool is_inf() const { return x.is_zero() && y.is_zero(); }
+};
+struct G2Jac {
+    Fp2 x, y, z;
+    bool is_inf() const { return z.is_zero(); }
+    static G2Jac inf() { return {Fp2::zero(), Fp2::zero(), Fp2::zero()}; }
+};
+
+inline G2Jac g2_generator() {
+    G2Jac g;
+    for (int i = 0; i < 12; i++) {
+        g.x.c0.l[i] = G2_GEN_X0[i];
+        g.x.c1.l[i] = G2_GEN_X1[i];
+        g.y.c0.l[i] = G2_GEN_Y0[i];
+        g.y.c1.l[i] = G2_GEN_Y1[i];
+    }
+    g.z = Fp2::one();
+    return g;
+}
+
+inline G1Jac g1_generator() {
+    G1Jac g;
+    for (int i = 0; i < 12; i++) {
+        g.x.l[i] = G1_GEN_X[i];
+        g.y.l[i] = G1_GEN_Y[i];
+    }
+    g.z = Fp::one();
+    return g;
+}
+
+inline G2Jac g2_dbl(const G2Jac &p) {
+    Fp2 a = sqr(p.x), b = sqr(p.y), c = sqr(b);
+    Fp2 d = dbl(sub(sub(sqr(add(p.x, b)), a), c));
+    Fp2 e = add(dbl(a), a);
+    Fp2 x3 = sub(sqr(e), dbl(d));
+    Fp2 y3 = sub(mul(e, sub(d, x3)), dbl(dbl(dbl(c))));
+    return {x3, y3, dbl(mul(p.y, p.z))};
+}
+
+inline G2Jac g2_add(const G2Jac &p, const G2Jac &q) {
+    if (p.is_inf()) return q;
+    if (q.is_inf()) return p;
+    Fp2 z1z1 = sqr(p.z), z2z2 = sqr(q.z);
+    Fp2 u1 = mul(p.x, z2z2), u2 = mul(q.x, z1z1);
+    Fp2 s1 = mul(mul(p.y, q.z), z2z2), s2 = mul(mul(q.y, p.z), z1z1);
+    Fp2 h = sub(u2, u1), rr = sub(s2, s1);
+    if (h.is_zero()) return rr.is_zero() ? g2_dbl(p) : G2Jac::inf();
+    rr = dbl(rr);
+    Fp2 i = sqr(dbl(h));
+    Fp2 j = mul(h, i), v = mul(u1, i);
+    Fp2 x3 = sub(sub(sqr(rr), j), dbl(v));
+    Fp2 y3 = sub(mul(rr, sub(v, x3)), dbl(mul(s1, j)));
+    Fp2 z3 = mul(sub(sub(sqr(add(p.z, q.z)), z1z1), z2z2), h);
+    return {x3, y3, z3};
+}
+
+inline G2Jac g2_neg(const G2Jac &p) { return {p.x, neg(p.y), p.z}; }
+
+inline G2Jac g2_mul(const G2Jac &p, const uint32_t *k, int nbits) {
+    G2Jac acc = G2Jac::inf();
+    for (int i = nbits - 1; i >= 0; i--) {
+        acc = g2_dbl(acc);
+        if ((k[i >> 5] >> (i & 31)) & 1u) acc = g2_add(acc, p);
+    }
+    return acc;
+}
+
+inline G2Affine g2_to_affine(const G2Jac &p) {
+    if (p.is_inf()) return {Fp2::zero(), Fp2::zero()};
+    Fp2 zi = inv(p.z);
+    Fp2 zi2 = sqr(zi);
+    return {mul(p.x, zi2), mul(p.y, mul(zi2, zi))};
+}
+
+inline bool fp2_is_lex_largest(const Fp2 &a) {
+    return a.c1.is_zero() ? fp_is_lex_largest(a.c0) : fp_is_lex_largest(a.c1);
+}
+
+inline bool fp_from_be48(Fp &out, const uint8_t *in, bool mask_flags) {
+    uint32_t raw[12], m[12];
+    for (int i = 0; i < 12; i++) {
+        const uint8_t *p = in + 4 * (11 - i);
+        raw[i] = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+    }
+    if (mask_flags) raw[11] &= 0x1fffffffu;
+    mod_limbs<FpParams>(m);
+    if (limbs_geq<12>(raw, m)) return false;
+    out = from_raw<FpParams>(raw);
+    return true;
+}
+
+// 96-byte ZCash encoding: x.c1 (with flag bits) || x.c0.  0 ok, 1 bad encoding, 2 not on curve
+inline int g2_uncompress(G2Affine &out, const uint8_t *in) {
+    uint8_t b0 = in[0];
+    if (!(b0 & 0x80)) return 1;
+    if (b0 & 0x40) {
+        if (b0 & 0x3f) return 1;
+        for (int i = 1; i < 96; i++) {
+            if (in[i]) return 1;
+        }
+        out = {Fp2::zero(), Fp2::zero()};
+        return 0;
+    }
+    Fp2 x, y;
+    if (!fp_from_be48(x.c1, in, true)) return 1;
+    if (!fp_from_be48(x.c0, in + 48, false)) return 1;
+    Fp four = dbl(dbl(Fp::one()));
+    Fp2 rhs = add(mul(sqr(x), x), Fp2{four, four});
+    if (!fp2_sqrt(y, rhs)) return 2;
+    if (fp2_is_lex_largest(y) != ((b0 & 0x20) != 0)) y = neg(y);
+    out = {x, y};
+    return 0;
+}
+
+// ---- pairing product check ----------------------------------------------------------------
+
+// line through the twist point (xt, yt) with slope lam, evaluated at the G1 point p, scaled into
+// Fp12 as (lam*xt - yt) + (-lam*xp) v + yp v*w  (the scale factor lies in Fp4 and dies in the
+// final exponentiation)
+inline Fp12 line_eval(const Fp2 &lam, const Fp2 &xt, const Fp2 &yt, const G1Affine &p) {
+    Fp12 l;
+    std::memset(&l, 0, sizeof l);
+    l.c0.c0 = sub(mul(lam, xt), yt);
+    l.c0.c1 = neg(mul_fp(lam, p.x));
+    l.c1.c1.c0 = p.y;
+    return l;
+}
+
+inline Fp12 miller_loop(const G2Affine &q, const G1Affine &p) {
+    Fp12 f = Fp12::one();
+    if (p.is_inf() || q.is_inf()) return f;
+    Fp2 tx = q.x, ty = q.y;
+    const uint64_t xabs = BLS_X_ABS;
+    for (int i = 62; i >= 0; i--) {
+        f = mul(f, f);
+        Fp2 x2 = sqr(tx);
+        Fp2 lam = mul(add(dbl(x2), x2), inv(dbl(ty)));
+        f = mul(f, line_eval(lam, tx, ty, p));
+        Fp2 x3 = sub(sub(sqr(lam), tx), tx);
+        Fp2 y3 = sub(mul(lam, sub(tx, x3)), ty);
+        tx = x3;
+        ty = y3;
+        if ((xabs >> i) & 1) {
+            lam = mul(sub(q.y, ty), inv(sub(q.x, tx)));
+            f = mul(f, line_eval(lam, tx, ty, p));
+            x3 = sub(sub(sqr(lam), tx), q.x);
+            y3 = sub(mul(lam, sub(tx, x3)), ty);
+            tx = x3;
+            ty = y3;
+        }
+    }
+    return f;  // conjugation for x < 0 omitted: applied to both factors of the product or neither
+}
+
+inline Fp12 final_exp(const Fp12 &f) {
+    Fp12 a = mul(conj(f), inv(f));  // f^(p^6-1)
+    Fp12 acc = Fp12::one();
+    for (int i = FINAL_EXP_BITS - 1; i >= 0; i--) {
+        acc = mul(acc, acc);
+        if ((FINAL_EXP_P6P1_DIV_R[i >> 5] >> (i & 31)) & 1u) acc = mul(acc, a);
+    }
+    return acc;
+}
+
+// e(a1, a2) == e(b1, b2)
+inline bool pairings_verify(const G1Jac &a1, const G2Jac &a2, const G1Jac &b1, const G2Jac &b2) {
+    G1Affine pa = jac_to_affine(jac_neg(a1)), pb = jac_to_affine(b1);
+    G2Affine qa = g2_to_affine(a2), qb = g2_to_affine(b2);
+    Fp12 f = mul(miller_loop(qa, pa), miller_loop(qb, pb));
+    return final_exp(f).is_one();
+}
+
+// ---- SHA-256 ------------------------------------------------------------------------------
+
+inline uint32_t rotr32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+
+inline void sha256_block(uint32_t h[8], const uint8_t *blk) {
+    static const uint32_t K[64] = {
+        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+        0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+        0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+        0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+        0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+        0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+        0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+        0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+    uint32_t w[64];
+    for (int i = 0; i < 16; i++) {
+        w[i] = ((uint32_t)blk[4 * i] << 24) | ((uint32_t)blk[4 * i + 1] << 16) |
+               ((uint32_t)blk[4 * i + 2] << 8) | blk[4 * i + 3];
+    }
+    for (int i = 16; i < 64; i++) {
+        uint32_t s0 = rotr32(w[i - 15], 7) ^ rotr32(w[i - 15], 18) ^ (w[i - 15] >> 3);
+        uint32_t s1 = rotr32(w[i - 2], 17) ^ rotr32(w[i - 2], 19) ^ (w[i - 2] >> 10);
+        w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    for (int i = 0; i < 64; i++) {
+        uint32_t t1 = hh + (rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
+        uint32_t t2 = (rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+        hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+
+// incremental interface so transcripts need not be copied into one buffer
+struct Sha256 {
+    uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    uint8_t buf[64];
+    size_t fill = 0;
+    uint64_t total = 0;
+    void update(const uint8_t *p, size_t n) {
+        total += n;
+        if (fill) {
+            size_t take = 64 - fill < n ? 64 - fill : n;
+            std::memcpy(buf + fill, p, take);
+            fill += take; p += take; n -= take;
+            if (fill == 64) { sha256_block(h, buf); fill = 0; }
+        }
+        while (n >= 64) { sha256_block(h, p); p += 64; n -= 64; }
+        if (n) { std::memcpy(buf, p, n); fill = n; }
+    }
+    void finish(uint8_t out[32]) {
+        uint64_t bits = total * 8;
+        uint8_t pad[72] = {0x80};
+        size_t padlen = (fill < 56) ? 56 - fill : 120 - fill;
+        uint8_t lenb[8];
+        for (int i = 0; i < 8; i++) lenb[7 - i] = (uint8_t)(bits >> (8 * i));
+        update(pad, padlen);
+        update(lenb, 8);
+        for (int i = 0; i < 8; i++) {
+            out[4 * i] = (uint8_t)(h[i] >> 24); out[4 * i + 1] = (uint8_t)(h[i] >> 16);
+            out[4 * i + 2] = (uint8_t)(h[i] >> 8); out[4 * i + 3] = (uint8_t)h[i];
+        }
+    }
+};
+
+}  // namespace host
+}  // namespace ckzg

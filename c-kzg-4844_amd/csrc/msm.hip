@@ -1,0 +1,367 @@
+// msm.hip -- fixed-base multi-scalar multiplication over BLS12-381 G1 for gfx950.
+//
+// Replaces g1_lincomb_fast -> blst_p1s_mult_pippenger (src/common/lincomb.c:65-123) for the MSMs
+// whose bases are fixed by the trusted setup: poly_to_kzg_commitment (src/eip4844/eip4844.c:253),
+// the quotient commitment in compute_kzg_proof_impl (:484) and the 128 FK20 column MSMs
+// (src/eip7594/fk20.c:222-247, where the reference itself switches to fixed-base tables when
+// precompute > 0).
+//
+// MI355X-first design.  A CPU Pippenger spends its time scattering points into data-dependent
+// buckets; on a 64-wide machine that scatter is divergence and atomics.  The bases here never
+// change and the card has 288 GB of HBM, so the table is widened instead: for every base P_i and
+// window w it holds e*2^(c*w)*P_i for e = 1..2^(c-1) in affine form.  After signed-digit
+// recoding a scalar vector selects exactly one entry per (window, base), and the MSM is a plain,
+// perfectly regular sum of nwin*npoints table entries per blob: coalesced digit reads, one
+// 96-byte gather per addition, 8M+2S mixed additions into an XYZZ accumulator held in VGPRs, an
+// LDS tree to fold a workgroup, no buckets, no doublings, no atomics.  Arithmetic intensity is
+// ~3000 integer multiply-adds per 96-byte gather: the kernel is VALU-bound, not HBM-bound.
+#include "device.hpp"
+
+namespace ckzg {
+namespace dev {
+
+int scratch_reserve(DeviceCtx *ctx, size_t bytes) {
+    if (ctx->scratch.cap >= bytes) return 0;
+    if (ctx->scratch.ptr) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipFree(ctx->scratch.ptr));
+        ctx->scratch.ptr = nullptr;
+        ctx->scratch.cap = 0;
+    }
+    size_t want = bytes + (bytes >> 2);
+    hipError_t e = hipMalloc(&ctx->scratch.ptr, want);
+    if (e != hipSuccess) {
+        want = bytes;
+        HIP_TRY(hipMalloc(&ctx->scratch.ptr, want));
+    }
+    ctx->scratch.cap = want;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// table construction (setup time)
+// ------------------------------------------------------------------------------------------
+
+// wb[w][i] = 2^(wbits*w) * P_i
+__global__ void k_window_bases(G1XYZZ *wb, const G1Affine *bases, int npoints, int wbits, int nwin) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npoints) return;
+    G1Jac acc = jac_from_affine(bases[i]);
+    for (int w = 0; w < nwin; w++) {
+        wb[(size_t)w * npoints + i] = xyzz_from_jac(acc);
+        for (int k = 0; k < wbits; k++) acc = jac_dbl(acc);
+    }
+}
+
+constexpr int CHAIN_SEG = 64;
+
+// tmp[i*half + e] = (e+1) * B_i for one window; each thread owns a run of CHAIN_SEG multiples
+__global__ void k_table_chain(G1XYZZ *tmp, const G1XYZZ *wb, int npoints, size_t half) {
+    size_t gid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    size_t segs = (half + CHAIN_SEG - 1) / CHAIN_SEG;
+    if (gid >= (size_t)npoints * segs) return;
+    size_t i = gid / segs, s = gid % segs;
+    G1XYZZ b = wb[i];
+    uint32_t m = (uint32_t)(s * CHAIN_SEG + 1);
+    G1XYZZ acc = G1XYZZ::inf();
+    for (int bit = 31 - __builtin_clz(m); bit >= 0; bit--) {
+        acc = xyzz_dbl(acc);
+        if ((m >> bit) & 1u) acc = xyzz_add(acc, b);
+    }
+    size_t e0 = s * CHAIN_SEG;
+    size_t e1 = e0 + CHAIN_SEG < half ? e0 + CHAIN_SEG : half;
+    for (size_t e = e0; e < e1; e++) {
+        tmp[i * half + e] = acc;
+        acc = xyzz_add(acc, b);
+    }
+}
+
+// Montgomery simultaneous inversion: each thread normalises a run of L points
+__global__ void k_batch_to_affine(G1Affine *out, const G1XYZZ *in, Fp *prefix, size_t n, int L) {
+    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    size_t b = t * (size_t)L;
+    if (b >= n) return;
+    size_t e = b + L < n ? b + L : n;
+    Fp acc = Fp::one();
+    for (size_t k = b; k < e; k++) {
+        prefix[k] = acc;
+        Fp z = in[k].zzz;
+        if (!z.is_zero()) acc = mul(acc, z);
+    }
+    Fp inv = fp_inv(acc);
+    for (size_t k = e; k-- > b;) {
+        G1XYZZ p = in[k];
+        if (p.zz.is_zero()) {
+            out[k] = G1Affine::inf();
+            continue;
+        }
+        Fp ti = mul(inv, prefix[k]);  // 1/zzz_k
+        inv = mul(inv, p.zzz);
+        Fp u = mul(p.zz, ti);  // 1/z
+        out[k] = {mul(p.x, sqr(u)), mul(p.y, ti)};
+    }
+}
+
+int build_fixed_base_table(DeviceCtx *ctx, FixedBaseTable *t, const G1Affine *d_bases, int npoints,
+                           int wbits) {
+    if (wbits < 2 || wbits > 15) return 1;
+    t->npoints = npoints;
+    t->wbits = wbits;
+    t->nwin = 255 / wbits + 1;
+    t->half = (size_t)1 << (wbits - 1);
+    size_t slab = (size_t)npoints * t->half;
+    G1XYZZ *d_wb = nullptr, *d_tmp = nullptr;
+    Fp *d_prefix = nullptr;
+    HIP_TRY(hipMalloc(&t->d_table, t->bytes()));
+    HIP_TRY(hipMalloc(&d_wb, (size_t)t->nwin * npoints * sizeof(G1XYZZ)));
+    HIP_TRY(hipMalloc(&d_tmp, slab * sizeof(G1XYZZ)));
+    HIP_TRY(hipMalloc(&d_prefix, slab * sizeof(Fp)));
+    hipLaunchKernelGGL(k_window_bases, dim3((npoints + 63) / 64), dim3(64), 0, ctx->stream, d_wb,
+                       d_bases, npoints, wbits, t->nwin);
+    const int L = 128;
+    size_t segs = (t->half + CHAIN_SEG - 1) / CHAIN_SEG;
+    size_t chain_threads = (size_t)npoints * segs;
+    size_t aff_threads = (slab + L - 1) / L;
+    for (int w = 0; w < t->nwin; w++) {
+        hipLaunchKernelGGL(k_table_chain, dim3((unsigned)((chain_threads + 63) / 64)), dim3(64), 0,
+                           ctx->stream, d_tmp, d_wb + (size_t)w * npoints, npoints, t->half);
+        hipLaunchKernelGGL(k_batch_to_affine, dim3((unsigned)((aff_threads + 63) / 64)), dim3(64), 0,
+                           ctx->stream, t->d_table + (size_t)w * slab, d_tmp, d_prefix, slab, L);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(d_wb));
+    HIP_TRY(hipFree(d_tmp));
+    HIP_TRY(hipFree(d_prefix));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// scalar recoding
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ void load_be256(uint32_t s[8], const uint8_t *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 a = q[0], b = q[1];
+    s[7] = __builtin_bswap32(a.x);
+    s[6] = __builtin_bswap32(a.y);
+    s[5] = __builtin_bswap32(a.z);
+    s[4] = __builtin_bswap32(a.w);
+    s[3] = __builtin_bswap32(b.x);
+    s[2] = __builtin_bswap32(b.y);
+    s[1] = __builtin_bswap32(b.z);
+    s[0] = __builtin_bswap32(b.w);
+}
+
+// signed base-2^wbits digits of a 256-bit integer, digit w written at dst[w * stride]
+__device__ __forceinline__ void recode_signed(int16_t *dst, size_t stride, uint32_t s[8], int wbits,
+                                              int nwin) {
+    const uint32_t mask = (1u << wbits) - 1u, half = 1u << (wbits - 1);
+    uint32_t carry = 0;
+    for (int w = 0; w < nwin; w++) {
+        int d = (int)((s[0] & mask) + carry);
+#pragma unroll
+        for (int k = 0; k < 7; k++) s[k] = (s[k] >> wbits) | (s[k + 1] << (32 - wbits));
+        s[7] >>= wbits;
+        carry = 0;
+        if ((uint32_t)d > half) {
+            d -= (int)(mask + 1u);
+            carry = 1;
+        }
+        dst[(size_t)w * stride] = (int16_t)d;
+    }
+}
+
+// One thread per field element of the batch: big-endian bytes -> canonical check (blob.c:31-38 /
+// bytes.c:64-70: a value >= r makes the whole blob BADARGS) -> digits[blob][w][i].
+__global__ void k_blob_digits(int16_t *digits, uint32_t *bad, const uint8_t *blobs, size_t total,
+                              int wbits, int nwin) {
+    size_t gid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    size_t blob = gid >> 12;
+    uint32_t i = (uint32_t)(gid & 4095);
+    uint32_t s[8], r[8];
+    load_be256(s, blobs + gid * 32);
+#pragma unroll
+    for (int k = 0; k < 8; k++) r[k] = FR_R[k];
+    if (limbs_geq<8>(s, r)) atomicOr(&bad[blob], 1u);
+    recode_signed(digits + blob * (size_t)nwin * N_BLOB + i, N_BLOB, s, wbits, nwin);
+}
+
+// Same for scalars that are already canonical little-endian integers ([n][4096][8] u32)
+__global__ void k_raw_digits(int16_t *digits, const uint32_t *scalars, size_t total, int wbits,
+                             int nwin) {
+    size_t gid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    size_t vec = gid >> 12;
+    uint32_t i = (uint32_t)(gid & 4095);
+    uint32_t s[8];
+    const uint4 *q = reinterpret_cast<const uint4 *>(scalars + gid * 8);
+    uint4 a = q[0], b = q[1];
+    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
+    s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+    recode_signed(digits + vec * (size_t)nwin * N_BLOB + i, N_BLOB, s, wbits, nwin);
+}
+
+// ------------------------------------------------------------------------------------------
+// accumulate: the dominant kernel
+// ------------------------------------------------------------------------------------------
+
+constexpr int ACC_THREADS = 256;
+
+// Fold the 256 per-thread XYZZ accumulators of a workgroup into thread 0.  LDS is limb-major
+// ([48][128] u32, 24 KB) so that a wave's 64 lanes hit 64 consecutive banks.
+__device__ __forceinline__ void block_reduce_xyzz(G1XYZZ &acc, uint32_t (*sh)[ACC_THREADS / 2]) {
+    const int tid = threadIdx.x;
+    for (int s = ACC_THREADS / 2; s >= 1; s >>= 1) {
+        if (tid >= s && tid < 2 * s) {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(&acc);
+#pragma unroll
+            for (int k = 0; k < 48; k++) sh[k][tid - s] = src[k];
+        }
+        __syncthreads();
+        if (tid < s) {
+            G1XYZZ o;
+            uint32_t *dst = reinterpret_cast<uint32_t *>(&o);
+#pragma unroll
+            for (int k = 0; k < 48; k++) dst[k] = sh[k][tid];
+            acc = xyzz_add(acc, o);
+        }
+        __syncthreads();
+    }
+}
+
+// grid: nvec * blocks_per_vec workgroups.  Workgroup (v, c) sums the table entries selected by
+// digits[v][c*pairs_per_block .. +pairs_per_block) into partials[v*blocks_per_vec + c].
+// A "pair" index p = w*npoints + i addresses both the digit array and the table ([p][e]).
+__global__ __launch_bounds__(ACC_THREADS) void k_msm_accumulate(
+    G1XYZZ *partials, const G1Affine *table, const int16_t *digits, uint32_t pairs_per_vec,
+    uint32_t pairs_per_block, int half_shift, uint32_t blocks_per_vec) {
+    __shared__ uint32_t sh[48][ACC_THREADS / 2];
+    const uint32_t vec = blockIdx.x / blocks_per_vec, chunk = blockIdx.x % blocks_per_vec;
+    const uint32_t p0 = chunk * pairs_per_block;
+    const uint32_t p1 = p0 + pairs_per_block < pairs_per_vec ? p0 + pairs_per_block : pairs_per_vec;
+    const int16_t *dg = digits + (size_t)vec * pairs_per_vec;
+    G1XYZZ acc = G1XYZZ::inf();
+    for (uint32_t p = p0 + threadIdx.x; p < p1; p += ACC_THREADS) {
+        int d = dg[p];
+        if (d != 0) {
+            uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+            G1Affine pt = table[((size_t)p << half_shift) + (mag - 1)];
+            if (d < 0) pt.y = neg(pt.y);
+            xyzz_madd(acc, pt);
+        }
+    }
+    block_reduce_xyzz(acc, sh);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+// One thread per vector: fold the per-workgroup partials, normalise, compress (bytes.c:42-44).
+__global__ void k_msm_finalize(uint8_t *out48, uint8_t *status, const G1XYZZ *partials,
+                               const uint32_t *bad, uint32_t blocks_per_vec, size_t n) {
+    size_t v = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    G1XYZZ acc = partials[v * blocks_per_vec];
+    for (uint32_t j = 1; j < blocks_per_vec; j++) acc = xyzz_add(acc, partials[v * blocks_per_vec + j]);
+    G1Affine a = xyzz_to_affine(acc);
+    uint8_t buf[48];
+    g1_compress_affine(buf, a);
+    for (int k = 0; k < 48; k++) out48[v * 48 + k] = buf[k];
+    if (status) status[v] = (bad && bad[v]) ? 1 : 0;
+}
+
+static uint32_t pick_pairs_per_block(size_t nvec, uint32_t pairs_per_vec) {
+    // big chunks amortise the workgroup reduction; small batches need more workgroups to fill
+    // 256 CUs x 4 resident workgroups
+    const uint32_t cands[] = {16384, 8192, 4096, 2048, 1024, 512};
+    for (uint32_t c : cands) {
+        size_t blocks = nvec * ((pairs_per_vec + c - 1) / c);
+        if (blocks >= 2048) return c;
+    }
+    return 256;
+}
+
+// digits already in scratch; runs accumulate + finalize.  Scratch layout is owned by callers.
+static int run_msm(DeviceCtx *ctx, const FixedBaseTable &t, uint8_t *d_out48, uint8_t *d_status,
+                   const int16_t *d_digits, const uint32_t *d_bad, G1XYZZ *d_partials, size_t nvec,
+                   uint32_t ppb) {
+    uint32_t pairs_per_vec = (uint32_t)t.nwin * t.npoints;
+    uint32_t bpv = (pairs_per_vec + ppb - 1) / ppb;
+    HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+    hipLaunchKernelGGL(k_msm_accumulate, dim3((unsigned)(nvec * bpv)), dim3(ACC_THREADS), 0,
+                       ctx->stream, d_partials, t.d_table, d_digits, pairs_per_vec, ppb, t.wbits - 1,
+                       bpv);
+    HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
+    hipLaunchKernelGGL(k_msm_finalize, dim3((unsigned)((nvec + 63) / 64)), dim3(64), 0, ctx->stream,
+                       d_out48, d_status, d_partials, d_bad, bpv, nvec);
+    HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static void collect_times(DeviceCtx *ctx) {
+    float ms;
+    if (hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]) == hipSuccess) ctx->last_ms[0] = ms;
+    if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_ms[1] = ms;
+    if (hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]) == hipSuccess) ctx->last_ms[2] = ms;
+    if (hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[4]) == hipSuccess) ctx->last_ms[3] = ms;
+}
+
+int commit_blobs_device(DeviceCtx *ctx, uint8_t *d_out48, uint8_t *d_status, const uint8_t *d_blobs,
+                        size_t n) {
+    if (n == 0) return 0;
+    const FixedBaseTable &t = ctx->commit;
+    if (!t.d_table) return 2;
+    uint32_t pairs_per_vec = (uint32_t)t.nwin * t.npoints;
+    uint32_t ppb = pick_pairs_per_block(n, pairs_per_vec);
+    uint32_t bpv = (pairs_per_vec + ppb - 1) / ppb;
+    size_t dig_bytes = align_up(n * (size_t)pairs_per_vec * sizeof(int16_t), 256);
+    size_t bad_bytes = align_up(n * sizeof(uint32_t), 256);
+    size_t part_bytes = align_up(n * (size_t)bpv * sizeof(G1XYZZ), 256);
+    int rc = scratch_reserve(ctx, dig_bytes + bad_bytes + part_bytes);
+    if (rc) return rc;
+    uint8_t *base = static_cast<uint8_t *>(ctx->scratch.ptr);
+    int16_t *d_digits = reinterpret_cast<int16_t *>(base);
+    uint32_t *d_bad = reinterpret_cast<uint32_t *>(base + dig_bytes);
+    G1XYZZ *d_partials = reinterpret_cast<G1XYZZ *>(base + dig_bytes + bad_bytes);
+    HIP_TRY(hipMemsetAsync(d_bad, 0, n * sizeof(uint32_t), ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+    size_t total = n * N_BLOB;
+    hipLaunchKernelGGL(k_blob_digits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       d_digits, d_bad, d_blobs, total, t.wbits, t.nwin);
+    rc = run_msm(ctx, t, d_out48, d_status, d_digits, d_bad, d_partials, n, ppb);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    collect_times(ctx);
+    return 0;
+}
+
+int msm_commit_table_raw_device(DeviceCtx *ctx, uint8_t *d_out48, const uint32_t *d_scalars, size_t n) {
+    if (n == 0) return 0;
+    const FixedBaseTable &t = ctx->commit;
+    if (!t.d_table) return 2;
+    uint32_t pairs_per_vec = (uint32_t)t.nwin * t.npoints;
+    uint32_t ppb = pick_pairs_per_block(n, pairs_per_vec);
+    uint32_t bpv = (pairs_per_vec + ppb - 1) / ppb;
+    size_t dig_bytes = align_up(n * (size_t)pairs_per_vec * sizeof(int16_t), 256);
+    size_t part_bytes = align_up(n * (size_t)bpv * sizeof(G1XYZZ), 256);
+    int rc = scratch_reserve(ctx, dig_bytes + part_bytes);
+    if (rc) return rc;
+    uint8_t *base = static_cast<uint8_t *>(ctx->scratch.ptr);
+    int16_t *d_digits = reinterpret_cast<int16_t *>(base);
+    G1XYZZ *d_partials = reinterpret_cast<G1XYZZ *>(base + dig_bytes);
+    HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+    size_t total = n * N_BLOB;
+    hipLaunchKernelGGL(k_raw_digits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       d_digits, d_scalars, total, t.wbits, t.nwin);
+    rc = run_msm(ctx, t, d_out48, nullptr, d_digits, nullptr, d_partials, n, ppb);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    collect_times(ctx);
+    return 0;
+}
+
+}  // namespace dev
+}  // namespace ckzg

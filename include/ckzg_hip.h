@@ -1,0 +1,68 @@
+/*
+ * ckzg_hip.h -- additive entry points of the MI355X build (not in the reference).
+ *
+ * The reference C API is one-blob-per-call except for the two verify_*_batch functions
+ * (src/eip4844/eip4844.h:43-81, src/eip7594/eip7594.h:35-57); its only batched use is the Go
+ * benchmark's goroutine fan-out (bindings/go/main_test.go:953-971).  A GPU wants the batch in one
+ * call, and a caller that already holds blobs in HBM wants to pass device pointers.  These
+ * symbols sit next to the unchanged ckzg.h ones; every one of them is plain C: pointers + sizes.
+ *
+ * "_device" variants take/return HIP device pointers on the GPU the settings were loaded on and
+ * enqueue on the context's stream, returning after the work has completed.
+ */
+#ifndef CKZG_HIP_H
+#define CKZG_HIP_H
+
+#include "ckzg.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Global options read by load_trusted_setup*.  Keys:
+ *   "device"        HIP device ordinal (default: env CKZG_HIP_DEVICE, else LOCAL_RANK, else 0)
+ *   "commit_wbits"  window width c (4..16) of the fixed-base table over the 4096 Lagrange points
+ *                   used by blob_to_kzg_commitment / compute_*_proof (table bytes =
+ *                   (floor(255/c)+1) * 4096 * 2^(c-1) * 96; default 10 -> 5.2 GB)
+ *   "fk20_wbits"    window width of the FK20 fixed-base tables (8192 points); default: max(8, precompute)
+ * Returns C_KZG_BADARGS for an unknown key or out-of-range value. */
+C_KZG_RET ckzg_hip_set_option(const char *key, int64_t value);
+
+/* Number of visible HIP devices (0 if none / runtime missing). */
+int ckzg_hip_device_count(void);
+
+/* blob_to_kzg_commitment (src/eip4844/eip4844.c:264-280) over n blobs.  Host pointers.
+ * out[i] is written for every blob whose field elements are all canonical; the call returns
+ * C_KZG_BADARGS if any blob is not (exactly the blobs for which the one-blob call would), and
+ * per-blob status is returned in status[i] (C_KZG_RET values) when status != NULL. */
+C_KZG_RET ckzg_hip_blob_to_kzg_commitment_batch(KZGCommitment *out, uint8_t *status,
+                                                const Blob *blobs, uint64_t n,
+                                                const KZGSettings *s);
+
+/* Same with blobs/out/status resident in HBM (device pointers). */
+C_KZG_RET ckzg_hip_blob_to_kzg_commitment_batch_device(void *d_out48, void *d_status,
+                                                       const void *d_blobs, uint64_t n,
+                                                       const KZGSettings *s);
+
+/* compute_cells_and_kzg_proofs (src/eip7594/eip7594.c:61-157) over n blobs; cells and/or proofs
+ * may be NULL (not both).  cells: n*128 Cell, proofs: n*128 KZGProof. */
+C_KZG_RET ckzg_hip_compute_cells_and_kzg_proofs_batch(Cell *cells, KZGProof *proofs,
+                                                      uint8_t *status, const Blob *blobs,
+                                                      uint64_t n, const KZGSettings *s);
+C_KZG_RET ckzg_hip_compute_cells_and_kzg_proofs_batch_device(void *d_cells, void *d_proofs,
+                                                             void *d_status, const void *d_blobs,
+                                                             uint64_t n, const KZGSettings *s);
+
+/* Timing hook for bench.py: elapsed milliseconds of the named kernel family inside the last
+ * batch call, measured with hipEvents on the stream the kernels were launched on.
+ * which: 0 = scalar recoding, 1 = MSM bucket-free accumulate (dominant), 2 = reduce+compress,
+ *        3 = whole device section.  Returns a negative value if unavailable. */
+double ckzg_hip_last_kernel_ms(const KZGSettings *s, int which);
+
+/* Bytes of HBM held by the context's tables. */
+uint64_t ckzg_hip_table_bytes(const KZGSettings *s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CKZG_HIP_H */

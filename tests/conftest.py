@@ -1,0 +1,43 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+
+ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+HIP_SO = os.path.join(ROOT, "c-kzg-4844_amd", "libckzg_hip.so")
+SHIM_SO = os.path.join(ROOT, "c-kzg-4844_amd", "csrc", "libhost_shim.so")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _ensure_oracle():
+    if not os.path.exists(ORACLE_SO):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    return ORACLE_SO
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """CPU oracle (test infrastructure) with the mainnet trusted setup, precompute=0."""
+    from kzg_ctypes import Kzg
+    api = Kzg(_ensure_oracle(), "okzg_", precompute=0)
+    yield api
+    api.close()
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The product: libckzg_hip.so through the reference's C-ABI.  Fails loudly if absent."""
+    from kzg_ctypes import Kzg
+    if not os.path.exists(HIP_SO):
+        pytest.fail("libckzg_hip.so is not built: run python -c 'import __graft_entry__ as g; g.build()'")
+    api = Kzg(HIP_SO, "", precompute=0)
+    yield api
+    api.close()
