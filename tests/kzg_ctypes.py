@@ -1,167 +1,30 @@
-"""ctypes binding used by the tests for BOTH libraries that speak the ckzg.h calling convention:
-
-* oracle/liboracle.so            (symbols prefixed ``okzg_``)  -- CPU oracle, test infrastructure
-* c-kzg-4844_amd/libckzg_hip.so  (unprefixed ckzg.h symbols)   -- the HIP product
-
-It plays the role bindings/python/ckzg_wrap.c plays for the reference: length checks happen here
-(a wrong-sized blob/commitment/cell is an error before the C call, ckzg_wrap.c:48-73), a non-zero
-C_KZG_RET raises, outputs are returned as ``bytes``.
-"""
-import ctypes as C
+"""Test-side access to the package's ctypes binding (c-kzg-4844_amd/ckzg.py).  The package
+directory name is not an importable identifier, so it is loaded by path."""
+import importlib.util
 import os
+import sys
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_PKG = os.path.join(ROOT, "c-kzg-4844_amd")
+
+
+def _load():
+    name = "ckzg_4844_amd"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(_PKG, "__init__.py"),
+                                                  submodule_search_locations=[_PKG])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+_m = _load()
+Kzg = _m.Kzg
+KzgError = _m.KzgError
+KZGSettings = _m.KZGSettings
+HIP_SO = _m.HIP_SO
+TRUSTED_SETUP = _m.TRUSTED_SETUP
 BYTES_PER_BLOB = 131072
 BYTES_PER_CELL = 2048
-CELLS_PER_EXT_BLOB = 128
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TRUSTED_SETUP = os.path.join(ROOT, "tests", "golden", "trusted_setup.txt")
-
-
-class KzgError(Exception):
-    pass
-
-
-class KZGSettings(C.Structure):
-    # src/setup/settings.h:27-79 -- 8 pointers + 2 size_t = 80 bytes
-    _fields_ = [(n, C.c_void_p) for n in (
-        "roots_of_unity", "brp_roots_of_unity", "reverse_roots_of_unity", "g1_values_monomial",
-        "g1_values_lagrange_brp", "g2_values_monomial", "x_ext_fft_columns", "tables")] + [
-        ("wbits", C.c_size_t), ("scratch_size", C.c_size_t)]
-
-
-def _check(cond, what):
-    if not cond:
-        raise KzgError("bad length: " + what)
-
-
-class Kzg:
-    def __init__(self, libpath, prefix="", precompute=0, setup_path=TRUSTED_SETUP):
-        self.lib = C.CDLL(libpath)
-        self.prefix = prefix
-        self.s = KZGSettings()
-        libc = C.CDLL(None)
-        libc.fopen.restype = C.c_void_p
-        libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
-        libc.fclose.argtypes = [C.c_void_p]
-        fp = libc.fopen(setup_path.encode(), b"r")
-        if not fp:
-            raise KzgError("cannot open " + setup_path)
-        f = self._fn("load_trusted_setup_file")
-        f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
-        ret = f(C.byref(self.s), fp, precompute)
-        libc.fclose(fp)
-        if ret != 0:
-            raise KzgError("load_trusted_setup_file -> %d" % ret)
-        self._loaded = True
-
-    def _fn(self, name):
-        f = getattr(self.lib, self.prefix + name)
-        f.restype = C.c_int
-        return f
-
-    def close(self):
-        if getattr(self, "_loaded", False):
-            f = self._fn("free_trusted_setup")
-            f.restype = None
-            f.argtypes = [C.c_void_p]
-            f(C.byref(self.s))
-            self._loaded = False
-
-    def _call(self, name, *args):
-        ret = self._fn(name)(*args)
-        if ret != 0:
-            raise KzgError("%s -> C_KZG_RET %d" % (name, ret))
-
-    @property
-    def sp(self):
-        return C.byref(self.s)
-
-    # ---- EIP-4844 (src/eip4844/eip4844.h:43-81) ----
-    def blob_to_kzg_commitment(self, blob):
-        _check(len(blob) == BYTES_PER_BLOB, "blob")
-        out = C.create_string_buffer(48)
-        self._call("blob_to_kzg_commitment", out, bytes(blob), self.sp)
-        return out.raw
-
-    def compute_kzg_proof(self, blob, z):
-        _check(len(blob) == BYTES_PER_BLOB, "blob")
-        _check(len(z) == 32, "z")
-        proof, y = C.create_string_buffer(48), C.create_string_buffer(32)
-        self._call("compute_kzg_proof", proof, y, bytes(blob), bytes(z), self.sp)
-        return proof.raw, y.raw
-
-    def compute_blob_kzg_proof(self, blob, commitment):
-        _check(len(blob) == BYTES_PER_BLOB, "blob")
-        _check(len(commitment) == 48, "commitment")
-        out = C.create_string_buffer(48)
-        self._call("compute_blob_kzg_proof", out, bytes(blob), bytes(commitment), self.sp)
-        return out.raw
-
-    def verify_kzg_proof(self, commitment, z, y, proof):
-        _check(len(commitment) == 48 and len(proof) == 48, "commitment/proof")
-        _check(len(z) == 32 and len(y) == 32, "z/y")
-        ok = C.c_bool(False)
-        self._call("verify_kzg_proof", C.byref(ok), bytes(commitment), bytes(z), bytes(y),
-                   bytes(proof), self.sp)
-        return ok.value
-
-    def verify_blob_kzg_proof(self, blob, commitment, proof):
-        _check(len(blob) == BYTES_PER_BLOB, "blob")
-        _check(len(commitment) == 48 and len(proof) == 48, "commitment/proof")
-        ok = C.c_bool(False)
-        self._call("verify_blob_kzg_proof", C.byref(ok), bytes(blob), bytes(commitment),
-                   bytes(proof), self.sp)
-        return ok.value
-
-    def verify_blob_kzg_proof_batch(self, blobs, commitments, proofs):
-        n = len(blobs)
-        _check(len(commitments) == n and len(proofs) == n, "list lengths")
-        for b in blobs:
-            _check(len(b) == BYTES_PER_BLOB, "blob")
-        for c in list(commitments) + list(proofs):
-            _check(len(c) == 48, "commitment/proof")
-        ok = C.c_bool(False)
-        self._call("verify_blob_kzg_proof_batch", C.byref(ok), b"".join(blobs),
-                   b"".join(commitments), b"".join(proofs), C.c_uint64(n), self.sp)
-        return ok.value
-
-    # ---- EIP-7594 (src/eip7594/eip7594.h:35-57) ----
-    def compute_cells_and_kzg_proofs(self, blob, want_cells=True, want_proofs=True):
-        _check(len(blob) == BYTES_PER_BLOB, "blob")
-        cells = C.create_string_buffer(CELLS_PER_EXT_BLOB * BYTES_PER_CELL) if want_cells else None
-        proofs = C.create_string_buffer(CELLS_PER_EXT_BLOB * 48) if want_proofs else None
-        self._call("compute_cells_and_kzg_proofs", cells, proofs, bytes(blob), self.sp)
-        cl = [cells.raw[i * BYTES_PER_CELL:(i + 1) * BYTES_PER_CELL]
-              for i in range(CELLS_PER_EXT_BLOB)] if want_cells else None
-        pl = [proofs.raw[i * 48:(i + 1) * 48] for i in range(CELLS_PER_EXT_BLOB)] if want_proofs else None
-        return cl, pl
-
-    def compute_cells(self, blob):
-        # not a C symbol: bindings call compute_cells_and_kzg_proofs(cells, NULL, ..)
-        # (bindings/go/main.go:411-431)
-        return self.compute_cells_and_kzg_proofs(blob, True, False)[0]
-
-    def recover_cells_and_kzg_proofs(self, cell_indices, cells):
-        _check(len(cell_indices) == len(cells), "list lengths")
-        for c in cells:
-            _check(len(c) == BYTES_PER_CELL, "cell")
-        n = len(cells)
-        idx = (C.c_uint64 * max(n, 1))(*cell_indices)
-        rc = C.create_string_buffer(CELLS_PER_EXT_BLOB * BYTES_PER_CELL)
-        rp = C.create_string_buffer(CELLS_PER_EXT_BLOB * 48)
-        self._call("recover_cells_and_kzg_proofs", rc, rp, idx, b"".join(cells), C.c_uint64(n), self.sp)
-        return ([rc.raw[i * BYTES_PER_CELL:(i + 1) * BYTES_PER_CELL] for i in range(CELLS_PER_EXT_BLOB)],
-                [rp.raw[i * 48:(i + 1) * 48] for i in range(CELLS_PER_EXT_BLOB)])
-
-    def verify_cell_kzg_proof_batch(self, commitments, cell_indices, cells, proofs):
-        n = len(cells)
-        _check(len(commitments) == n and len(cell_indices) == n and len(proofs) == n, "list lengths")
-        for c in cells:
-            _check(len(c) == BYTES_PER_CELL, "cell")
-        for c in list(commitments) + list(proofs):
-            _check(len(c) == 48, "commitment/proof")
-        idx = (C.c_uint64 * max(n, 1))(*cell_indices)
-        ok = C.c_bool(False)
-        self._call("verify_cell_kzg_proof_batch", C.byref(ok), b"".join(commitments), idx,
-                   b"".join(cells), b"".join(proofs), C.c_uint64(n), self.sp)
-        return ok.value
