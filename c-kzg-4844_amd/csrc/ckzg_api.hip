@@ -254,6 +254,67 @@ extern "C" C_KZG_RET blob_to_kzg_commitment(KZGCommitment *out, const Blob *blob
     return ckzg_hip_blob_to_kzg_commitment_batch(out, &st, blob, 1, s);
 }
 
+// ------------------------------------------------------------------------------------------
+// compute_cells_and_kzg_proofs (src/eip7594/eip7594.c:61-157) and its batch forms
+// ------------------------------------------------------------------------------------------
+
+extern "C" C_KZG_RET ckzg_hip_compute_cells_and_kzg_proofs_batch_device(void *d_cells, void *d_proofs,
+                                                                        void *d_status,
+                                                                        const void *d_blobs, uint64_t n,
+                                                                        const KZGSettings *s) {
+    if (d_cells == NULL && d_proofs == NULL) return C_KZG_BADARGS;
+    dev::DeviceCtx *ctx = ctx_of(s);
+    if (!ctx) return C_KZG_ERROR;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (hipSetDevice(ctx->device) != hipSuccess) return C_KZG_ERROR;
+    return (C_KZG_RET)dev::cells_and_proofs_device(ctx, (uint8_t *)d_cells, (uint8_t *)d_proofs,
+                                                   (uint8_t *)d_status, (const uint8_t *)d_blobs, n);
+}
+
+extern "C" C_KZG_RET ckzg_hip_compute_cells_and_kzg_proofs_batch(Cell *cells, KZGProof *proofs,
+                                                                 uint8_t *status, const Blob *blobs,
+                                                                 uint64_t n, const KZGSettings *s) {
+    if (cells == NULL && proofs == NULL) return C_KZG_BADARGS;  // eip7594.c:72-74
+    dev::DeviceCtx *ctx = ctx_of(s);
+    if (!ctx) return C_KZG_ERROR;
+    if (n == 0) return C_KZG_OK;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (hipSetDevice(ctx->device) != hipSuccess) return C_KZG_ERROR;
+    const uint64_t CH = 256;
+    uint64_t m = n < CH ? n : CH;
+    const size_t cells_per = (size_t)CELLS_PER_EXT_BLOB * BYTES_PER_CELL, proofs_per = (size_t)CELLS_PER_EXT_BLOB * 48;
+    DeviceBuffer d_blobs, d_cells, d_proofs, d_status;
+    if (!d_blobs.alloc(m * BYTES_PER_BLOB) || !d_status.alloc(m)) return C_KZG_MALLOC;
+    if (cells && !d_cells.alloc(m * cells_per)) return C_KZG_MALLOC;
+    if (proofs && !d_proofs.alloc(m * proofs_per)) return C_KZG_MALLOC;
+    std::vector<uint8_t> st(m);
+    C_KZG_RET ret = C_KZG_OK;
+    for (uint64_t off = 0; off < n; off += CH) {
+        uint64_t k = n - off < CH ? n - off : CH;
+        if (hipMemcpyAsync(d_blobs.p, blobs + off, k * BYTES_PER_BLOB, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+            return C_KZG_ERROR;
+        int rc = dev::cells_and_proofs_device(ctx, (uint8_t *)d_cells.p, (uint8_t *)d_proofs.p,
+                                              (uint8_t *)d_status.p, (const uint8_t *)d_blobs.p, k);
+        if (rc) return (C_KZG_RET)rc;
+        if (cells && hipMemcpy(cells + off * CELLS_PER_EXT_BLOB, d_cells.p, k * cells_per, hipMemcpyDeviceToHost) != hipSuccess)
+            return C_KZG_ERROR;
+        if (proofs && hipMemcpy(proofs + off * CELLS_PER_EXT_BLOB, d_proofs.p, k * proofs_per, hipMemcpyDeviceToHost) != hipSuccess)
+            return C_KZG_ERROR;
+        if (hipMemcpy(st.data(), d_status.p, k, hipMemcpyDeviceToHost) != hipSuccess) return C_KZG_ERROR;
+        for (uint64_t i = 0; i < k; i++) {
+            if (status) status[off + i] = st[i];
+            if (st[i]) ret = C_KZG_BADARGS;
+        }
+    }
+    return ret;
+}
+
+extern "C" C_KZG_RET compute_cells_and_kzg_proofs(Cell *cells, KZGProof *proofs, const Blob *blob,
+                                                  const KZGSettings *s) {
+    uint8_t st = 0;
+    return ckzg_hip_compute_cells_and_kzg_proofs_batch(cells, proofs, &st, blob, 1, s);
+}
+
 extern "C" double ckzg_hip_last_kernel_ms(const KZGSettings *s, int which) {
     dev::DeviceCtx *ctx = ctx_of(s);
     if (!ctx || which < 0 || which > 3) return -1.0;

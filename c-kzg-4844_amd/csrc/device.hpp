@@ -46,6 +46,7 @@ struct DeviceCtx {
     // Fr tables for NTTs and evaluation (Montgomery form, 8 x u32)
     Fr *d_roots = nullptr;        // w^i, 8193 entries
     Fr *d_brp_roots = nullptr;    // 8192
+    uint32_t *d_roots_raw = nullptr;  // canonical limbs of w^i (scalars for the G1 FFT)
     // FK20
     FixedBaseTable fk20;          // over x_ext_fft columns: point index = col*64 + row
     G1Affine *d_xext = nullptr;   // [128][64] affine
@@ -76,6 +77,31 @@ int commit_blobs_device(DeviceCtx *ctx, uint8_t *d_out48, uint8_t *d_status, con
 // are already canonical little-endian 8xu32 integers in HBM ([n][4096][8]); writes n compressed
 // points.  Used by compute_kzg_proof (quotient polynomial) and friends.
 int msm_commit_table_raw_device(DeviceCtx *ctx, uint8_t *d_out48, const uint32_t *d_scalars, size_t n);
+
+int msm_small_vectors_device(DeviceCtx *ctx, const FixedBaseTable &t, G1XYZZ *d_out,
+                             const int16_t *d_digits, size_t nvec, uint32_t ppv,
+                             uint32_t vecs_per_group);
+
+// ntt.hip
+int fr_ntt_batch(DeviceCtx *ctx, Fr *d_data, size_t count, int logn, bool dif, bool inverse,
+                 bool scale_by_inv_n);
+int bytes_to_fr_batch(DeviceCtx *ctx, Fr *d_out, uint32_t *d_bad, const uint8_t *d_in, size_t total,
+                      uint32_t elems_per_unit);
+int fr_to_bytes_batch(DeviceCtx *ctx, uint8_t *d_out, const Fr *d_in, size_t total);
+int zero_extend_batch(DeviceCtx *ctx, Fr *d_dst, const Fr *d_src, size_t count, uint32_t n_src,
+                      uint32_t n_dst);
+
+// fk20.hip
+// x_ext_fft columns (setup.c:238-330) from the 4096 monomial points; fills ctx->d_xext
+// ([128][64] affine) and, if h_xext != nullptr, copies them to the host.
+int fk20_setup_device(DeviceCtx *ctx, const G1Affine *d_monomial, G1Affine *h_xext);
+// cells (n*128*2048 B) and/or proofs (n*128*48 B) for n blobs in HBM; either output may be null
+int cells_and_proofs_device(DeviceCtx *ctx, uint8_t *d_cells, uint8_t *d_proofs, uint8_t *d_status,
+                            const uint8_t *d_blobs, size_t n);
+// FK20 proofs from monomial coefficients already on the device ([n][4096] Fr, Montgomery)
+int fk20_proofs_device(DeviceCtx *ctx, uint8_t *d_proofs, const Fr *d_poly_monomial, size_t n);
+// generic helpers
+int batch_to_affine_device(DeviceCtx *ctx, G1Affine *d_out, const G1XYZZ *d_in, Fp *d_prefix, size_t n);
 
 }  // namespace dev
 }  // namespace ckzg

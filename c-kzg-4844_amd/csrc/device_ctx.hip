@@ -23,6 +23,7 @@ void destroy_device_ctx(dev::DeviceCtx *ctx) {
     if (ctx->d_xext) (void)hipFree(ctx->d_xext);
     if (ctx->d_roots) (void)hipFree(ctx->d_roots);
     if (ctx->d_brp_roots) (void)hipFree(ctx->d_brp_roots);
+    if (ctx->d_roots_raw) (void)hipFree(ctx->d_roots_raw);
     if (ctx->scratch.ptr) (void)hipFree(ctx->scratch.ptr);
     for (auto &e : ctx->ev) {
         if (e) (void)hipEventDestroy(e);
@@ -84,7 +85,45 @@ C_KZG_RET create_device_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affine,
             return (C_KZG_RET)rc;
         }
     }
-    (void)monomial_affine;
+    // FK20: x_ext_fft columns by 64 G1 FFTs on the GPU, mirrored into the host struct, then the
+    // fixed-base table over those 8192 points
+    {
+        DeviceBuffer d_mono;
+        if (!d_mono.alloc(NUM_G1_POINTS * sizeof(G1Affine))) {
+            destroy_device_ctx(ctx);
+            return C_KZG_MALLOC;
+        }
+        CTX_TRY(hipMemcpy(d_mono.p, monomial_affine, NUM_G1_POINTS * sizeof(G1Affine), hipMemcpyHostToDevice));
+        std::vector<G1Affine> h_xext((size_t)dev::N_CELLS_EXT * dev::N_CELL);
+        int rc = dev::fk20_setup_device(ctx, (const G1Affine *)d_mono.p, h_xext.data());
+        if (rc) {
+            destroy_device_ctx(ctx);
+            return (C_KZG_RET)rc;
+        }
+        s->x_ext_fft_columns = (g1_t **)calloc(dev::N_CELLS_EXT, sizeof(g1_t *));
+        if (!s->x_ext_fft_columns) {
+            destroy_device_ctx(ctx);
+            return C_KZG_MALLOC;
+        }
+        for (int j = 0; j < dev::N_CELLS_EXT; j++) {
+            s->x_ext_fft_columns[j] = (g1_t *)calloc(dev::N_CELL, sizeof(g1_t));
+            if (!s->x_ext_fft_columns[j]) {
+                destroy_device_ctx(ctx);
+                return C_KZG_MALLOC;
+            }
+            for (int i = 0; i < dev::N_CELL; i++) {
+                *as_g1(&s->x_ext_fft_columns[j][i]) = jac_from_affine(h_xext[(size_t)j * dev::N_CELL + i]);
+            }
+        }
+        int wbits = env_int("CKZG_HIP_FK20_WBITS", g_opts.fk20_wbits);
+        if (wbits == 0) wbits = s->wbits > 8 ? (s->wbits > 13 ? 13 : (int)s->wbits) : 8;
+        if (wbits < 4 || wbits > 15) wbits = 8;
+        rc = dev::build_fixed_base_table(ctx, &ctx->fk20, ctx->d_xext, dev::N_CELLS_EXT * dev::N_CELL, wbits);
+        if (rc) {
+            destroy_device_ctx(ctx);
+            return (C_KZG_RET)rc;
+        }
+    }
     header_of(s)->ctx = ctx;
     return C_KZG_OK;
 }

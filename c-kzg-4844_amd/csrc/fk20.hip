@@ -1,0 +1,371 @@
+// fk20.hip -- cells and FK20 cell proofs on the GPU.
+//
+// Replaces compute_cells_and_kzg_proofs (src/eip7594/eip7594.c:61-157), compute_fk20_cell_proofs
+// and circulant_coeffs_stride (src/eip7594/fk20.c:55-286), g1_fft / g1_ifft_unscaled
+// (src/eip7594/fft.c:164-240) and, at setup time, init_fk20_multi_settings / toeplitz_part_1
+// (src/setup/setup.c:197-330).
+//
+// Per blob:  bytes -> Fr -> DIT inverse NTT(4096) [blob order is already bit-reversed]
+//            -> cells:  zero-extend, DIF NTT(8192) [output order = cell order] -> bytes
+//            -> proofs: 64 circulant vectors -> DIF NTT(128) -> signed digits
+//                       -> 128 fixed-base MSMs of 64 points (table over x_ext_fft columns)
+//                       -> G1 DIF-FFT(128, w^-1) -> drop upper half -> G1 DIT-FFT(128)
+//                       -> bit-reverse, batch-normalise, compress.
+// The two G1 transforms use the DIF/DIT pair so that, as for Fr, no permutation pass exists.
+#include "device.hpp"
+#include "dev_inline.hpp"
+
+namespace ckzg {
+namespace dev {
+
+__device__ __forceinline__ uint32_t brp7(uint32_t v) { return __brev(v) >> 25; }
+
+__device__ __forceinline__ Fr ld_fr(const Fr *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 a = q[0], b = q[1];
+    Fr r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    return r;
+}
+
+__device__ __forceinline__ void st_fr(Fr *p, const Fr &v) {
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+
+// ------------------------------------------------------------------------------------------
+// scalar side
+// ------------------------------------------------------------------------------------------
+
+// circ[v][i][j], i = offset 0..63, j = 0..127  (fk20.c:55-78 with r = 64, l = 64, d = 4095):
+//   j == 0           -> poly[d - i]
+//   j = 128 - k, k in 1..62 -> poly[d - i - 64k]
+//   otherwise 0
+__global__ void k_fk20_circulant(Fr *circ, const Fr *poly, size_t total) {
+    size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    size_t v = g >> 13;
+    uint32_t i = (uint32_t)(g >> 7) & 63u, j = (uint32_t)g & 127u;
+    Fr x = Fr::zero();
+    const Fr *p = poly + v * N_BLOB;
+    if (j == 0) {
+        x = ld_fr(p + (N_BLOB - 1 - i));
+    } else {
+        uint32_t k = 128 - j;
+        if (k >= 1 && k <= 62) x = ld_fr(p + (N_BLOB - 1 - i - 64 * k));
+    }
+    st_fr(circ + g, x);
+}
+
+// cfft[v][i][p] holds (after the DIF NTT, already scaled by 1/128) the value for MSM column
+// j = brp7(p).  Recode it into digits[(v*128 + j)][w][i].
+__global__ void k_fk20_digits(int16_t *digits, const Fr *cfft, size_t total, int wbits, int nwin) {
+    size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    size_t v = g >> 13;
+    uint32_t i = (uint32_t)(g >> 7) & 63u, p = (uint32_t)g & 127u;
+    uint32_t j = brp7(p);
+    uint32_t s[8];
+    to_raw<FrParams>(s, ld_fr(cfft + g));
+    recode_signed(digits + ((v * 128 + j) * (size_t)nwin * 64) + i, 64, s, wbits, nwin);
+}
+
+// ------------------------------------------------------------------------------------------
+// G1 FFT of size 128: one 64-lane workgroup per transform, points in LDS (limb-major)
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ G1XYZZ pt_get(uint32_t (*sh)[128], int idx) {
+    G1XYZZ r;
+    uint32_t *d = reinterpret_cast<uint32_t *>(&r);
+#pragma unroll
+    for (int k = 0; k < 48; k++) d[k] = sh[k][idx];
+    return r;
+}
+
+__device__ __forceinline__ void pt_put(uint32_t (*sh)[128], int idx, const G1XYZZ &v) {
+    const uint32_t *s = reinterpret_cast<const uint32_t *>(&v);
+#pragma unroll
+    for (int k = 0; k < 48; k++) sh[k][idx] = s[k];
+}
+
+// [k]P for a 255-bit k (canonical little-endian limbs), fixed 4-bit windows: every lane executes
+// the same 4-doublings-then-add schedule, so lanes with different scalars do not diverge.
+__device__ __noinline__ G1XYZZ xyzz_mul_w4(const G1XYZZ &p, const uint32_t *k) {
+    G1XYZZ tbl[15];
+    tbl[0] = p;
+    tbl[1] = xyzz_dbl(p);
+    for (int i = 2; i < 15; i++) tbl[i] = xyzz_add(tbl[i - 1], p);
+    G1XYZZ acc = G1XYZZ::inf();
+    for (int w = 63; w >= 0; w--) {
+        if (w != 63) {
+            acc = xyzz_dbl(acc);
+            acc = xyzz_dbl(acc);
+            acc = xyzz_dbl(acc);
+            acc = xyzz_dbl(acc);
+        }
+        uint32_t d = (k[w >> 3] >> ((w & 7) * 4)) & 15u;
+        if (d) acc = xyzz_add(acc, tbl[d - 1]);
+    }
+    return acc;
+}
+
+// roots_raw[i] = canonical limbs of w^i, i = 0..8192.
+// DIF: natural in -> bit-reversed out; DIT: bit-reversed in -> natural out (fft.c:164-185 computes
+// the same butterflies recursively).  zero_odd: after a DIF, clear the odd positions, i.e. the
+// entries whose natural index is >= 64 (fk20.c:264-266).  out_brp: after a DIT, store element k
+// at position brp7(k) (eip7594.c:133).
+template <bool DIF>
+__global__ __launch_bounds__(64) void k_g1_fft128(G1XYZZ *data, const uint32_t *roots_raw,
+                                                  int inverse, int zero_odd, int out_brp) {
+    __shared__ uint32_t sh[48][128];
+    G1XYZZ *vec = data + (size_t)blockIdx.x * 128;
+    const int tid = threadIdx.x;
+    pt_put(sh, tid, vec[tid]);
+    pt_put(sh, tid + 64, vec[tid + 64]);
+    __syncthreads();
+    for (int st = 0; st < 7; st++) {
+        int s = DIF ? 7 - st : st + 1;
+        int half = 1 << (s - 1);
+        int j = tid & (half - 1);
+        int i0 = ((tid >> (s - 1)) << s) + j;
+        int i1 = i0 + half;
+        G1XYZZ u = pt_get(sh, i0), v = pt_get(sh, i1);
+        int ridx = j * (N_EXT / (2 * half));
+        if (inverse) ridx = N_EXT - ridx;
+        const uint32_t *k = roots_raw + (size_t)ridx * 8;
+        G1XYZZ x, y;
+        if (DIF) {
+            x = xyzz_add(u, v);
+            y = xyzz_add(u, xyzz_neg(v));
+            if (j != 0) y = xyzz_mul_w4(y, k);
+        } else {
+            if (j != 0) v = xyzz_mul_w4(v, k);
+            x = xyzz_add(u, v);
+            y = xyzz_add(u, xyzz_neg(v));
+        }
+        pt_put(sh, i0, x);
+        pt_put(sh, i1, y);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        int idx = tid + 64 * r;
+        G1XYZZ v = pt_get(sh, idx);
+        if (zero_odd && (idx & 1)) v = G1XYZZ::inf();
+        vec[out_brp ? brp7((uint32_t)idx) : idx] = v;
+    }
+}
+
+// Fr Montgomery -> canonical limbs (for scalar multiplication by roots of unity)
+__global__ void k_fr_to_raw(uint32_t *out, const Fr *in, size_t n) {
+    size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    uint32_t raw[8];
+    to_raw<FrParams>(raw, ld_fr(in + g));
+#pragma unroll
+    for (int k = 0; k < 8; k++) out[g * 8 + k] = raw[k];
+}
+
+__global__ void k_compress(uint8_t *out48, const G1Affine *in, size_t n) {
+    size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    uint8_t buf[48];
+    g1_compress_affine(buf, in[g]);
+    for (int k = 0; k < 48; k++) out48[g * 48 + k] = buf[k];
+}
+
+// ------------------------------------------------------------------------------------------
+// setup: x_ext_fft columns (setup.c:238-330)
+// ------------------------------------------------------------------------------------------
+
+// xin[off][k], off = 0..63: k < 63 -> monomial[4096 - 64 - 1 - off - 64k], else infinity
+__global__ void k_xext_gather(G1XYZZ *xin, const G1Affine *monomial) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= 64 * 128) return;
+    uint32_t off = g >> 7, k = g & 127u;
+    G1XYZZ v = G1XYZZ::inf();
+    if (k < 63) v = xyzz_from_affine(monomial[N_BLOB - N_CELL - 1 - off - 64 * k]);
+    xin[g] = v;
+}
+
+// xin[off][p] (DIF output: natural index j = brp7(p))  ->  cols[j*64 + off]
+__global__ void k_xext_transpose(G1XYZZ *cols, const G1XYZZ *xin) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= 64 * 128) return;
+    uint32_t off = g >> 7, p = g & 127u;
+    cols[brp7(p) * 64 + off] = xin[g];
+}
+
+static int ensure_roots_raw(DeviceCtx *ctx, uint32_t **out) {
+    // allocated lazily and kept for the life of the context
+    if (!ctx->d_roots_raw) {
+        HIP_TRY(hipMalloc(&ctx->d_roots_raw, (size_t)(N_EXT + 1) * 8 * sizeof(uint32_t)));
+        hipLaunchKernelGGL(k_fr_to_raw, dim3((N_EXT + 1 + 255) / 256), dim3(256), 0, ctx->stream,
+                           ctx->d_roots_raw, ctx->d_roots, (size_t)(N_EXT + 1));
+        HIP_TRY(hipGetLastError());
+    }
+    *out = ctx->d_roots_raw;
+    return 0;
+}
+
+int fk20_setup_device(DeviceCtx *ctx, const G1Affine *d_monomial, G1Affine *h_xext) {
+    uint32_t *d_rr = nullptr;
+    int rc = ensure_roots_raw(ctx, &d_rr);
+    if (rc) return rc;
+    G1XYZZ *d_xin = nullptr, *d_cols = nullptr;
+    Fp *d_prefix = nullptr;
+    const size_t npts = 64 * 128;
+    HIP_TRY(hipMalloc(&d_xin, npts * sizeof(G1XYZZ)));
+    HIP_TRY(hipMalloc(&d_cols, npts * sizeof(G1XYZZ)));
+    HIP_TRY(hipMalloc(&d_prefix, npts * sizeof(Fp)));
+    if (!ctx->d_xext) HIP_TRY(hipMalloc(&ctx->d_xext, npts * sizeof(G1Affine)));
+    hipLaunchKernelGGL(k_xext_gather, dim3(npts / 256), dim3(256), 0, ctx->stream, d_xin, d_monomial);
+    hipLaunchKernelGGL(k_g1_fft128<true>, dim3(64), dim3(64), 0, ctx->stream, d_xin, d_rr, 0, 0, 0);
+    hipLaunchKernelGGL(k_xext_transpose, dim3(npts / 256), dim3(256), 0, ctx->stream, d_cols, d_xin);
+    HIP_TRY(hipGetLastError());
+    rc = batch_to_affine_device(ctx, ctx->d_xext, d_cols, d_prefix, npts);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (h_xext) HIP_TRY(hipMemcpy(h_xext, ctx->d_xext, npts * sizeof(G1Affine), hipMemcpyDeviceToHost));
+    HIP_TRY(hipFree(d_xin));
+    HIP_TRY(hipFree(d_cols));
+    HIP_TRY(hipFree(d_prefix));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// proofs and cells
+// ------------------------------------------------------------------------------------------
+
+static size_t al(size_t v) { return (v + 255) / 256 * 256; }
+
+// Scratch layout for FK20 over n polynomials (offsets into ctx->scratch at `base`)
+struct Fk20Scratch {
+    Fr *circ;          // [n][64][128]
+    int16_t *digits;   // [n*128][nwin][64]
+    G1XYZZ *u;         // [n][128]
+    G1Affine *aff;     // [n][128]
+    Fp *prefix;        // [n][128]
+    size_t bytes;
+};
+
+static Fk20Scratch fk20_layout(uint8_t *base, size_t n, int nwin) {
+    Fk20Scratch s;
+    size_t off = 0;
+    s.circ = reinterpret_cast<Fr *>(base + off);
+    off += al(n * 8192 * sizeof(Fr));
+    s.digits = reinterpret_cast<int16_t *>(base + off);
+    off += al(n * 128 * (size_t)nwin * 64 * sizeof(int16_t));
+    s.u = reinterpret_cast<G1XYZZ *>(base + off);
+    off += al(n * 128 * sizeof(G1XYZZ));
+    s.aff = reinterpret_cast<G1Affine *>(base + off);
+    off += al(n * 128 * sizeof(G1Affine));
+    s.prefix = reinterpret_cast<Fp *>(base + off);
+    off += al(n * 128 * sizeof(Fp));
+    s.bytes = off;
+    return s;
+}
+
+// proofs from monomial coefficients, using scratch that the caller reserved at `base`
+static int fk20_run(DeviceCtx *ctx, uint8_t *d_proofs, const Fr *d_poly, size_t n, uint8_t *base) {
+    const FixedBaseTable &t = ctx->fk20;
+    if (!t.d_table) return 2;
+    uint32_t *d_rr = nullptr;
+    int rc = ensure_roots_raw(ctx, &d_rr);
+    if (rc) return rc;
+    Fk20Scratch s = fk20_layout(base, n, t.nwin);
+    size_t total = n * 8192;
+    hipLaunchKernelGGL(k_fk20_circulant, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       s.circ, d_poly, total);
+    HIP_TRY(hipGetLastError());
+    // 64 forward NTTs of size 128 per blob, each output * 1/128 (fk20.c:199-209)
+    rc = fr_ntt_batch(ctx, s.circ, n * 64, 7, /*dif=*/true, /*inverse=*/false, /*scale=*/true);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_fk20_digits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       s.digits, s.circ, total, t.wbits, t.nwin);
+    HIP_TRY(hipGetLastError());
+    rc = msm_small_vectors_device(ctx, t, s.u, s.digits, n * 128, 64, 128);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_g1_fft128<true>, dim3((unsigned)n), dim3(64), 0, ctx->stream, s.u, d_rr, 1, 1, 0);
+    hipLaunchKernelGGL(k_g1_fft128<false>, dim3((unsigned)n), dim3(64), 0, ctx->stream, s.u, d_rr, 0, 0, 1);
+    HIP_TRY(hipGetLastError());
+    rc = batch_to_affine_device(ctx, s.aff, s.u, s.prefix, n * 128);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_compress, dim3((unsigned)((n * 128 + 63) / 64)), dim3(64), 0, ctx->stream,
+                       d_proofs, s.aff, n * 128);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int fk20_proofs_device(DeviceCtx *ctx, uint8_t *d_proofs, const Fr *d_poly_monomial, size_t n) {
+    if (n == 0) return 0;
+    Fk20Scratch probe = fk20_layout(nullptr, n, ctx->fk20.nwin);
+    int rc = scratch_reserve(ctx, probe.bytes);
+    if (rc) return rc;
+    rc = fk20_run(ctx, d_proofs, d_poly_monomial, n, static_cast<uint8_t *>(ctx->scratch.ptr));
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+__global__ void k_bad_to_status(uint8_t *status, const uint32_t *bad, size_t n) {
+    size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (g < n) status[g] = bad[g] ? 1 : 0;
+}
+
+int cells_and_proofs_device(DeviceCtx *ctx, uint8_t *d_cells, uint8_t *d_proofs, uint8_t *d_status,
+                            const uint8_t *d_blobs, size_t n) {
+    if (n == 0) return 0;
+    // process in chunks so scratch stays bounded (about 1.2 MB per blob)
+    const size_t CH = 512;
+    size_t m = n < CH ? n : CH;
+    size_t poly_b = al(m * N_BLOB * sizeof(Fr)), ext_b = al(m * N_EXT * sizeof(Fr)), bad_b = al(m * 4);
+    Fk20Scratch probe = fk20_layout(nullptr, m, ctx->fk20.nwin);
+    int rc = scratch_reserve(ctx, poly_b + ext_b + bad_b + probe.bytes);
+    if (rc) return rc;
+    uint8_t *base = static_cast<uint8_t *>(ctx->scratch.ptr);
+    Fr *d_poly = reinterpret_cast<Fr *>(base);
+    Fr *d_ext = reinterpret_cast<Fr *>(base + poly_b);
+    uint32_t *d_bad = reinterpret_cast<uint32_t *>(base + poly_b + ext_b);
+    uint8_t *fk_base = base + poly_b + ext_b + bad_b;
+    HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+    for (size_t off = 0; off < n; off += CH) {
+        size_t k = n - off < CH ? n - off : CH;
+        HIP_TRY(hipMemsetAsync(d_bad, 0, k * 4, ctx->stream));
+        rc = bytes_to_fr_batch(ctx, d_poly, d_bad, d_blobs + off * (size_t)N_BLOB * 32, k * N_BLOB, N_BLOB);
+        if (rc) return rc;
+        // blob = evaluations in bit-reversed order: DIT inverse transform gives the coefficients
+        // (poly_lagrange_to_monomial, poly.c:58-80, without its permutation pass)
+        rc = fr_ntt_batch(ctx, d_poly, k, 12, /*dif=*/false, /*inverse=*/true, /*scale=*/true);
+        if (rc) return rc;
+        if (d_cells) {
+            rc = zero_extend_batch(ctx, d_ext, d_poly, k, N_BLOB, N_EXT);
+            if (rc) return rc;
+            rc = fr_ntt_batch(ctx, d_ext, k, 13, /*dif=*/true, /*inverse=*/false, /*scale=*/false);
+            if (rc) return rc;
+            rc = fr_to_bytes_batch(ctx, d_cells + off * (size_t)N_EXT * 32, d_ext, k * N_EXT);
+            if (rc) return rc;
+        }
+        if (d_proofs) {
+            rc = fk20_run(ctx, d_proofs + off * 128 * 48, d_poly, k, fk_base);
+            if (rc) return rc;
+        }
+        if (d_status) {
+            hipLaunchKernelGGL(k_bad_to_status, dim3((unsigned)((k + 63) / 64)), dim3(64), 0, ctx->stream,
+                               d_status + off, d_bad, k);
+        }
+    }
+    HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    float ms;
+    if (hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[4]) == hipSuccess) ctx->last_ms[3] = ms;
+    if (d_proofs && hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6]) == hipSuccess) ctx->last_ms[1] = ms;
+    (void)hipGetLastError();
+    return 0;
+}
+
+}  // namespace dev
+}  // namespace ckzg

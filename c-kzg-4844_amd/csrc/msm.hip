@@ -16,6 +16,7 @@
 // LDS tree to fold a workgroup, no buckets, no doublings, no atomics.  Arithmetic intensity is
 // ~3000 integer multiply-adds per 96-byte gather: the kernel is VALU-bound, not HBM-bound.
 #include "device.hpp"
+#include "dev_inline.hpp"
 
 namespace ckzg {
 namespace dev {
@@ -102,6 +103,17 @@ __global__ void k_batch_to_affine(G1Affine *out, const G1XYZZ *in, Fp *prefix, s
     }
 }
 
+int batch_to_affine_device(DeviceCtx *ctx, G1Affine *d_out, const G1XYZZ *d_in, Fp *d_prefix, size_t n) {
+    if (n == 0) return 0;
+    // short runs when there are few points (latency), long runs when there are many (throughput)
+    int L = n >= ((size_t)1 << 20) ? 128 : (n >= ((size_t)1 << 14) ? 16 : 4);
+    size_t threads = (n + L - 1) / L;
+    hipLaunchKernelGGL(k_batch_to_affine, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, ctx->stream,
+                       d_out, d_in, d_prefix, n, L);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int build_fixed_base_table(DeviceCtx *ctx, FixedBaseTable *t, const G1Affine *d_bases, int npoints,
                            int wbits) {
     if (wbits < 2 || wbits > 15) return 1;
@@ -140,38 +152,6 @@ int build_fixed_base_table(DeviceCtx *ctx, FixedBaseTable *t, const G1Affine *d_
 // scalar recoding
 // ------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ void load_be256(uint32_t s[8], const uint8_t *p) {
-    const uint4 *q = reinterpret_cast<const uint4 *>(p);
-    uint4 a = q[0], b = q[1];
-    s[7] = __builtin_bswap32(a.x);
-    s[6] = __builtin_bswap32(a.y);
-    s[5] = __builtin_bswap32(a.z);
-    s[4] = __builtin_bswap32(a.w);
-    s[3] = __builtin_bswap32(b.x);
-    s[2] = __builtin_bswap32(b.y);
-    s[1] = __builtin_bswap32(b.z);
-    s[0] = __builtin_bswap32(b.w);
-}
-
-// signed base-2^wbits digits of a 256-bit integer, digit w written at dst[w * stride]
-__device__ __forceinline__ void recode_signed(int16_t *dst, size_t stride, uint32_t s[8], int wbits,
-                                              int nwin) {
-    const uint32_t mask = (1u << wbits) - 1u, half = 1u << (wbits - 1);
-    uint32_t carry = 0;
-    for (int w = 0; w < nwin; w++) {
-        int d = (int)((s[0] & mask) + carry);
-#pragma unroll
-        for (int k = 0; k < 7; k++) s[k] = (s[k] >> wbits) | (s[k + 1] << (32 - wbits));
-        s[7] >>= wbits;
-        carry = 0;
-        if ((uint32_t)d > half) {
-            d -= (int)(mask + 1u);
-            carry = 1;
-        }
-        dst[(size_t)w * stride] = (int16_t)d;
-    }
-}
-
 // One thread per field element of the batch: big-endian bytes -> canonical check (blob.c:31-38 /
 // bytes.c:64-70: a value >= r makes the whole blob BADARGS) -> digits[blob][w][i].
 __global__ void k_blob_digits(int16_t *digits, uint32_t *bad, const uint8_t *blobs, size_t total,
@@ -207,13 +187,12 @@ __global__ void k_raw_digits(int16_t *digits, const uint32_t *scalars, size_t to
 // accumulate: the dominant kernel
 // ------------------------------------------------------------------------------------------
 
-constexpr int ACC_THREADS = 256;
-
-// Fold the 256 per-thread XYZZ accumulators of a workgroup into thread 0.  LDS is limb-major
-// ([48][128] u32, 24 KB) so that a wave's 64 lanes hit 64 consecutive banks.
-__device__ __forceinline__ void block_reduce_xyzz(G1XYZZ &acc, uint32_t (*sh)[ACC_THREADS / 2]) {
+// Fold the per-thread XYZZ accumulators of a workgroup into thread 0.  LDS is limb-major
+// ([48][THREADS/2] u32) so that a wave's 64 lanes hit 64 consecutive banks.
+template <int THREADS>
+__device__ __forceinline__ void block_reduce_xyzz(G1XYZZ &acc, uint32_t (*sh)[THREADS / 2]) {
     const int tid = threadIdx.x;
-    for (int s = ACC_THREADS / 2; s >= 1; s >>= 1) {
+    for (int s = THREADS / 2; s >= 1; s >>= 1) {
         if (tid >= s && tid < 2 * s) {
             const uint32_t *src = reinterpret_cast<const uint32_t *>(&acc);
 #pragma unroll
@@ -231,28 +210,36 @@ __device__ __forceinline__ void block_reduce_xyzz(G1XYZZ &acc, uint32_t (*sh)[AC
     }
 }
 
-// grid: nvec * blocks_per_vec workgroups.  Workgroup (v, c) sums the table entries selected by
-// digits[v][c*pairs_per_block .. +pairs_per_block) into partials[v*blocks_per_vec + c].
-// A "pair" index p = w*npoints + i addresses both the digit array and the table ([p][e]).
-__global__ __launch_bounds__(ACC_THREADS) void k_msm_accumulate(
+// grid: nvec * blocks_per_vec workgroups.  A "vector" is one MSM: ppv (points per vector) scalars
+// recoded to digits[vec][w][i], i < ppv.  Its bases are points voff..voff+ppv of a table over
+// npoints bases, voff = (vec % vecs_per_group) * ppv  (commitment: ppv = npoints = 4096, one
+// group; FK20: ppv = 64, 128 vectors per blob over the 8192 x_ext_fft points).
+// Workgroup (v, c) sums the table entries selected by pairs q in [c*ppb, (c+1)*ppb) of vector v,
+// q = w*ppv + i, into partials[v*blocks_per_vec + c].
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_msm_accumulate(
     G1XYZZ *partials, const G1Affine *table, const int16_t *digits, uint32_t pairs_per_vec,
-    uint32_t pairs_per_block, int half_shift, uint32_t blocks_per_vec) {
-    __shared__ uint32_t sh[48][ACC_THREADS / 2];
+    uint32_t pairs_per_block, int half_shift, uint32_t blocks_per_vec, uint32_t ppv,
+    uint32_t npoints, uint32_t vecs_per_group) {
+    __shared__ uint32_t sh[48][THREADS / 2];
     const uint32_t vec = blockIdx.x / blocks_per_vec, chunk = blockIdx.x % blocks_per_vec;
-    const uint32_t p0 = chunk * pairs_per_block;
-    const uint32_t p1 = p0 + pairs_per_block < pairs_per_vec ? p0 + pairs_per_block : pairs_per_vec;
+    const uint32_t q0 = chunk * pairs_per_block;
+    const uint32_t q1 = q0 + pairs_per_block < pairs_per_vec ? q0 + pairs_per_block : pairs_per_vec;
+    const uint32_t voff = (vec % vecs_per_group) * ppv;
     const int16_t *dg = digits + (size_t)vec * pairs_per_vec;
     G1XYZZ acc = G1XYZZ::inf();
-    for (uint32_t p = p0 + threadIdx.x; p < p1; p += ACC_THREADS) {
-        int d = dg[p];
+    for (uint32_t q = q0 + threadIdx.x; q < q1; q += THREADS) {
+        int d = dg[q];
         if (d != 0) {
+            uint32_t w = q / ppv, i = q - w * ppv;
+            size_t p = (size_t)w * npoints + voff + i;
             uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-            G1Affine pt = table[((size_t)p << half_shift) + (mag - 1)];
+            G1Affine pt = table[(p << half_shift) + (mag - 1)];
             if (d < 0) pt.y = neg(pt.y);
             xyzz_madd(acc, pt);
         }
     }
-    block_reduce_xyzz(acc, sh);
+    block_reduce_xyzz<THREADS>(acc, sh);
     if (threadIdx.x == 0) partials[blockIdx.x] = acc;
 }
 
@@ -288,9 +275,9 @@ static int run_msm(DeviceCtx *ctx, const FixedBaseTable &t, uint8_t *d_out48, ui
     uint32_t pairs_per_vec = (uint32_t)t.nwin * t.npoints;
     uint32_t bpv = (pairs_per_vec + ppb - 1) / ppb;
     HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
-    hipLaunchKernelGGL(k_msm_accumulate, dim3((unsigned)(nvec * bpv)), dim3(ACC_THREADS), 0,
-                       ctx->stream, d_partials, t.d_table, d_digits, pairs_per_vec, ppb, t.wbits - 1,
-                       bpv);
+    hipLaunchKernelGGL(k_msm_accumulate<256>, dim3((unsigned)(nvec * bpv)), dim3(256), 0, ctx->stream,
+                       d_partials, t.d_table, d_digits, pairs_per_vec, ppb, t.wbits - 1, bpv,
+                       (uint32_t)t.npoints, (uint32_t)t.npoints, 1u);
     HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
     hipLaunchKernelGGL(k_msm_finalize, dim3((unsigned)((nvec + 63) / 64)), dim3(64), 0, ctx->stream,
                        d_out48, d_status, d_partials, d_bad, bpv, nvec);
@@ -307,6 +294,22 @@ static void collect_times(DeviceCtx *ctx) {
     if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_ms[1] = ms;
     if (hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]) == hipSuccess) ctx->last_ms[2] = ms;
     if (hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[4]) == hipSuccess) ctx->last_ms[3] = ms;
+}
+
+// Many small MSMs against sub-ranges of one table (FK20: 128 vectors of 64 points per blob).
+// One 64-lane workgroup per vector; results stay in XYZZ form in d_out[nvec].
+int msm_small_vectors_device(DeviceCtx *ctx, const FixedBaseTable &t, G1XYZZ *d_out,
+                             const int16_t *d_digits, size_t nvec, uint32_t ppv,
+                             uint32_t vecs_per_group) {
+    if (nvec == 0) return 0;
+    uint32_t pairs_per_vec = (uint32_t)t.nwin * ppv;
+    HIP_TRY(hipEventRecord(ctx->ev[5], ctx->stream));
+    hipLaunchKernelGGL(k_msm_accumulate<64>, dim3((unsigned)nvec), dim3(64), 0, ctx->stream, d_out,
+                       t.d_table, d_digits, pairs_per_vec, pairs_per_vec, t.wbits - 1, 1u, ppv,
+                       (uint32_t)t.npoints, vecs_per_group);
+    HIP_TRY(hipEventRecord(ctx->ev[6], ctx->stream));
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 int commit_blobs_device(DeviceCtx *ctx, uint8_t *d_out48, uint8_t *d_status, const uint8_t *d_blobs,

@@ -1,0 +1,59 @@
+"""GPU parity for compute_cells_and_kzg_proofs (src/eip7594/eip7594.c:61-157) through the C-ABI:
+consensus-spec vectors, random blobs against the CPU oracle, batch == single."""
+import ctypes as C
+import hashlib
+
+import pytest
+
+import golden_util as G
+from test_gpu_commitment import rand_blob
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", G.case_names("compute_cells"))
+def test_golden_cells(hip, name):
+    got, exp = G.run_case(hip, "compute_cells", name)
+    assert got == exp
+
+
+@pytest.mark.parametrize("name", G.case_names("compute_cells_and_kzg_proofs"))
+def test_golden_cells_and_proofs(hip, name):
+    got, exp = G.run_case(hip, "compute_cells_and_kzg_proofs", name)
+    assert got == exp
+
+
+def test_random_vs_oracle(hip, oracle):
+    b = rand_blob(21, 0)
+    cells, proofs = hip.compute_cells_and_kzg_proofs(b)
+    ecells, eproofs = oracle.compute_cells_and_kzg_proofs(b)
+    assert cells == ecells
+    assert proofs == eproofs
+
+
+def test_proofs_only_and_cells_only(hip):
+    b = rand_blob(22, 1)
+    cells, proofs = hip.compute_cells_and_kzg_proofs(b)
+    c2, p2 = hip.compute_cells_and_kzg_proofs(b, True, False)
+    c3, p3 = hip.compute_cells_and_kzg_proofs(b, False, True)
+    assert c2 == cells and p2 is None and c3 is None and p3 == proofs
+
+
+def test_batch_matches_single(hip):
+    n = 5
+    blobs = [rand_blob(23, i) for i in range(n)]
+    bad = bytearray(blobs[3])
+    bad[0:32] = b"\xff" * 32
+    blobs[3] = bytes(bad)
+    cells = C.create_string_buffer(n * 128 * 2048)
+    proofs = C.create_string_buffer(n * 128 * 48)
+    status = C.create_string_buffer(n)
+    f = hip.lib.ckzg_hip_compute_cells_and_kzg_proofs_batch
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p]
+    ret = f(cells, proofs, status, b"".join(blobs), n, C.addressof(hip.s))
+    assert ret == 1 and list(status.raw) == [0, 0, 0, 1, 0]
+    for i in (0, 1, 2, 4):
+        c, p = hip.compute_cells_and_kzg_proofs(blobs[i])
+        assert b"".join(c) == cells.raw[i * 128 * 2048:(i + 1) * 128 * 2048]
+        assert b"".join(p) == proofs.raw[i * 128 * 48:(i + 1) * 128 * 48]
