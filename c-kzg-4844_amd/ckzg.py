@@ -175,3 +175,41 @@ class Kzg:
         self._call("verify_cell_kzg_proof_batch", C.byref(ok), b"".join(commitments), idx,
                    b"".join(cells), b"".join(proofs), C.c_uint64(n), self.sp)
         return ok.value
+
+    # ---- test-exposed internals (src/eip4844/eip4844.h:84, src/eip7594/eip7594.h:59-68) ----
+    def compute_challenge(self, blob, commitment):
+        _check(len(blob) == BYTES_PER_BLOB, "blob")
+        _check(len(commitment) == 48, "commitment")
+        g1 = C.create_string_buffer(144)
+        self._call("bytes_to_kzg_commitment", g1, bytes(commitment))
+        fr = C.create_string_buffer(32)
+        f = getattr(self.lib, self.prefix + "compute_challenge")
+        f.restype = None
+        f(fr, bytes(blob), g1)
+        out = C.create_string_buffer(32)
+        g = getattr(self.lib, self.prefix + "bytes_from_bls_field")
+        g.restype = None
+        g(out, fr)
+        return out.raw
+
+    def compute_verify_cell_kzg_proof_batch_challenge(self, commitments, commitment_indices, cell_indices,
+                                                      cells, proofs):
+        n = len(cells)
+        _check(len(commitment_indices) == n and len(cell_indices) == n and len(proofs) == n, "list lengths")
+        for c in cells:
+            _check(len(c) == BYTES_PER_CELL, "cell")
+        for c in list(commitments) + list(proofs):
+            _check(len(c) == 48, "commitment/proof")
+        fr = C.create_string_buffer(32)
+        ci = (C.c_uint64 * max(n, 1))(*commitment_indices)
+        xi = (C.c_uint64 * max(n, 1))(*cell_indices)
+        self._call("compute_verify_cell_kzg_proof_batch_challenge", fr, b"".join(commitments),
+                   C.c_uint64(len(commitments)), ci, xi, b"".join(cells), b"".join(proofs), C.c_uint64(n))
+        return self._fr_to_bytes(fr)
+
+    def _fr_to_bytes(self, fr):
+        out = C.create_string_buffer(32)
+        g = getattr(self.lib, self.prefix + "bytes_from_bls_field")
+        g.restype = None
+        g(out, fr)
+        return out.raw

@@ -1,0 +1,640 @@
+// ckzg_api2.hip -- C-ABI entry points for point proofs, verification and recovery
+// (src/eip4844/eip4844.c:313-844, src/eip7594/eip7594.c:177-974).  Host code here is protocol
+// glue (transcripts, argument checks, the final two-pairing check); every MSM, NTT, polynomial
+// evaluation and point validation is dispatched to the kernels in msm.hip / ntt.hip / fk20.hip /
+// verify.hip.
+#include <functional>
+#include <thread>
+
+#include "api_common.hpp"
+
+using namespace ckzg;
+using namespace ckzg::host;
+using namespace ckzg::api;
+
+namespace {
+
+template <class T>
+struct DBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    bool alloc(size_t count) {
+        n = count;
+        return hipMalloc((void **)&p, (count ? count : 1) * sizeof(T)) == hipSuccess;
+    }
+    bool up(const T *h, size_t count) { return hipMemcpy(p, h, count * sizeof(T), hipMemcpyHostToDevice) == hipSuccess; }
+    bool down(T *h, size_t count) const { return hipMemcpy(h, p, count * sizeof(T), hipMemcpyDeviceToHost) == hipSuccess; }
+    ~DBuf() {
+        if (p) (void)hipFree(p);
+    }
+};
+
+#define RC(expr)                          \
+    do {                                  \
+        int _rc = (expr);                 \
+        if (_rc) return (C_KZG_RET)_rc;   \
+    } while (0)
+#define OKB(expr)                         \
+    do {                                  \
+        if (!(expr)) return C_KZG_ERROR;  \
+    } while (0)
+#define OKM(expr)                         \
+    do {                                  \
+        if (!(expr)) return C_KZG_MALLOC; \
+    } while (0)
+
+struct RawScalar {
+    uint32_t l[8];
+};
+
+RawScalar raw_of(const Fr &a) {
+    RawScalar r;
+    to_raw<FrParams>(r.l, a);
+    return r;
+}
+
+G1Jac g1_mul_fr(const G1Jac &p, const Fr &k) {
+    RawScalar r = raw_of(k);
+    return jac_mul(p, r.l, 255);
+}
+
+// src/eip4844/eip4844.c:80-106
+bool fr_batch_inv(Fr *out, const Fr *a, size_t len) {
+    Fr acc = Fr::one();
+    for (size_t i = 0; i < len; i++) {
+        out[i] = acc;
+        acc = mul(acc, a[i]);
+    }
+    if (acc.is_zero()) return false;
+    acc = fr_inv(acc);
+    for (size_t i = len; i-- > 0;) {
+        out[i] = mul(out[i], acc);
+        acc = mul(acc, a[i]);
+    }
+    return true;
+}
+
+Fr fr_pow_u64(Fr a, uint64_t n) {
+    Fr out = Fr::one();
+    while (true) {
+        if (n & 1) out = mul(out, a);
+        if ((n >>= 1) == 0) break;
+        a = sqr(a);
+    }
+    return out;
+}
+
+// src/eip4844/blob.c:31-38
+C_KZG_RET blob_to_polynomial(Fr *p, const Blob *blob) {
+    for (size_t i = 0; i < FIELD_ELEMENTS_PER_BLOB; i++) {
+        if (!fr_from_bytes_canonical(p[i], blob->bytes + 32 * i)) return C_KZG_BADARGS;
+    }
+    return C_KZG_OK;
+}
+
+// src/eip4844/eip4844.c:192-240 (host form, used where the inverses are needed anyway)
+C_KZG_RET evaluate_host(Fr &out, const Fr *poly, const Fr &x, const KZGSettings *s) {
+    const size_t n = FIELD_ELEMENTS_PER_BLOB;
+    const Fr *dom = as_fr(s->brp_roots_of_unity);
+    std::vector<Fr> den(n), inv(n);
+    for (size_t i = 0; i < n; i++) {
+        if (x == dom[i]) {
+            out = poly[i];
+            return C_KZG_OK;
+        }
+        den[i] = sub(x, dom[i]);
+    }
+    if (!fr_batch_inv(inv.data(), den.data(), n)) return C_KZG_BADARGS;
+    Fr acc = Fr::zero();
+    for (size_t i = 0; i < n; i++) acc = add(acc, mul(mul(inv[i], dom[i]), poly[i]));
+    acc = mul(acc, fr_inv(fr_from_u64(n)));
+    out = mul(acc, sub(fr_pow_u64(x, n), Fr::one()));
+    return C_KZG_OK;
+}
+
+// "FSBLOBVERIFY_V1_" | u64be 0 | u64be 4096 | blob | commitment  (eip4844.c:147-178)
+Fr challenge_from_bytes(const uint8_t *blob, const uint8_t *commitment48) {
+    Sha256 h;
+    uint8_t head[32], out[32];
+    memcpy(head, "FSBLOBVERIFY_V1_", 16);
+    be64(head + 16, 0);
+    be64(head + 24, FIELD_ELEMENTS_PER_BLOB);
+    h.update(head, 32);
+    h.update(blob, BYTES_PER_BLOB);
+    h.update(commitment48, 48);
+    h.finish(out);
+    return fr_from_bytes_reduce(out);
+}
+
+// e(C - [y]G1, G2) == e(proof, [s]G2 - [z]G2)   (eip4844.c:359-383)
+bool verify_kzg_proof_impl(const G1Jac &commitment, const Fr &z, const Fr &y, const G1Jac &proof,
+                           const KZGSettings *s) {
+    RawScalar zr = raw_of(z);
+    G2Jac x_minus_z = g2_add(*as_g2(&s->g2_values_monomial[1]), g2_neg(g2_mul(g2_generator(), zr.l, 255)));
+    G1Jac p_minus_y = jac_add(commitment, jac_neg(g1_mul_fr(g1_generator(), y)));
+    return pairings_verify(p_minus_y, g2_generator(), proof, x_minus_z);
+}
+
+// quotient polynomial and its commitment (eip4844.c:417-494); the 4096-term MSM runs on the GPU
+C_KZG_RET compute_kzg_proof_impl(KZGProof *proof_out, Fr &y_out, const Fr *poly, const Fr &z,
+                                 const KZGSettings *s, dev::DeviceCtx *ctx) {
+    const size_t n = FIELD_ELEMENTS_PER_BLOB;
+    const Fr *dom = as_fr(s->brp_roots_of_unity);
+    C_KZG_RET ret = evaluate_host(y_out, poly, z, s);
+    if (ret != C_KZG_OK) return ret;
+    std::vector<Fr> den(n), inv(n), q(n);
+    size_t m = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (z == dom[i]) {
+            m = i + 1;
+            den[i] = Fr::one();
+            q[i] = Fr::zero();
+            continue;
+        }
+        q[i] = sub(poly[i], y_out);
+        den[i] = sub(dom[i], z);
+    }
+    if (!fr_batch_inv(inv.data(), den.data(), n)) return C_KZG_BADARGS;
+    for (size_t i = 0; i < n; i++) q[i] = mul(q[i], inv[i]);
+    if (m != 0) {
+        m--;
+        q[m] = Fr::zero();
+        for (size_t i = 0; i < n; i++) {
+            if (i == m) continue;
+            den[i] = mul(sub(z, dom[i]), z);
+        }
+        den[m] = Fr::one();
+        if (!fr_batch_inv(inv.data(), den.data(), n)) return C_KZG_BADARGS;
+        for (size_t i = 0; i < n; i++) {
+            if (i == m) continue;
+            q[m] = add(q[m], mul(mul(sub(poly[i], y_out), dom[i]), inv[i]));
+        }
+    }
+    std::vector<RawScalar> raw(n);
+    for (size_t i = 0; i < n; i++) raw[i] = raw_of(q[i]);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    OKB(hipSetDevice(ctx->device) == hipSuccess);
+    DBuf<RawScalar> d_sc;
+    DBuf<uint8_t> d_out;
+    OKM(d_sc.alloc(n) && d_out.alloc(48));
+    OKB(d_sc.up(raw.data(), n));
+    RC(dev::msm_commit_table_raw_device(ctx, d_out.p, (const uint32_t *)d_sc.p, 1));
+    OKB(d_out.down(proof_out->bytes, 48));
+    return C_KZG_OK;
+}
+
+void parallel_for(size_t n, const std::function<void(size_t)> &fn) {
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nt = hw ? hw : 4;
+    if (nt > 32) nt = 32;
+    if (nt > n) nt = n;
+    if (nt <= 1) {
+        for (size_t i = 0; i < n; i++) fn(i);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nt; t++) {
+        th.emplace_back([&, t]() {
+            for (size_t i = t; i < n; i += nt) fn(i);
+        });
+    }
+    for (auto &x : th) x.join();
+}
+
+G1Jac jac_of_affine_bytes(const G1Affine &a) { return jac_from_affine(a); }
+
+// One GPU lincomb: sum_i k_i P_i over points already on the device
+C_KZG_RET gpu_lincomb(dev::DeviceCtx *ctx, G1Jac &out, const G1Affine *d_pts, const std::vector<RawScalar> &k) {
+    size_t n = k.size();
+    DBuf<RawScalar> d_k;
+    DBuf<G1XYZZ> d_part;
+    DBuf<G1Affine> d_out;
+    OKM(d_k.alloc(n) && d_part.alloc((n + 63) / 64 + 1) && d_out.alloc(1));
+    OKB(d_k.up(k.data(), n));
+    RC(dev::lincomb_var_device(ctx, d_out.p, d_part.p, d_pts, (const uint32_t *)d_k.p, n));
+    G1Affine a;
+    OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
+    OKB(d_out.down(&a, 1));
+    out = jac_from_affine(a);
+    return C_KZG_OK;
+}
+
+// Shared core of verify_blob_kzg_proof and verify_blob_kzg_proof_batch (eip4844.c:537-595,
+// 697-844).  Per blob, on the GPU: point validation, bytes -> Fr, evaluation at the challenge;
+// then three lincombs over all blobs; host: transcripts and the pairing check
+//   e(sum r^i proof_i, [s]G2) == e(sum r^i (C_i - [y_i]G1) + sum r^i z_i proof_i, G2).
+C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, const Bytes48 *pb, uint64_t n,
+                            const KZGSettings *s, dev::DeviceCtx *ctx) {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    OKB(hipSetDevice(ctx->device) == hipSuccess);
+    DBuf<uint8_t> d_ptb, d_st, d_blobs;
+    DBuf<G1Affine> d_pts;
+    DBuf<Fr> d_poly, d_z, d_y;
+    DBuf<uint32_t> d_bad;
+    OKM(d_ptb.alloc(2 * n * 48) && d_st.alloc(2 * n) && d_pts.alloc(2 * n) && d_blobs.alloc(n * BYTES_PER_BLOB) &&
+        d_poly.alloc(n * FIELD_ELEMENTS_PER_BLOB) && d_z.alloc(n) && d_y.alloc(n) && d_bad.alloc(n));
+    // commitments [0,n), proofs [n,2n)
+    OKB(hipMemcpy(d_ptb.p, cb, n * 48, hipMemcpyHostToDevice) == hipSuccess);
+    OKB(hipMemcpy(d_ptb.p + n * 48, pb, n * 48, hipMemcpyHostToDevice) == hipSuccess);
+    RC(dev::validate_g1_batch_device(ctx, d_pts.p, d_st.p, d_ptb.p, 2 * n));
+    OKB(hipMemcpyAsync(d_blobs.p, blobs, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
+    OKB(hipMemsetAsync(d_bad.p, 0, n * 4, ctx->stream) == hipSuccess);
+    RC(dev::bytes_to_fr_batch(ctx, d_poly.p, d_bad.p, d_blobs.p, n * FIELD_ELEMENTS_PER_BLOB, FIELD_ELEMENTS_PER_BLOB));
+    // challenges on the host while the GPU validates and converts
+    std::vector<Fr> z(n), y(n);
+    parallel_for(n, [&](size_t i) { z[i] = challenge_from_bytes(blobs[i].bytes, cb[i].bytes); });
+    OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
+    std::vector<uint8_t> st(2 * n);
+    std::vector<uint32_t> bad(n);
+    OKB(d_st.down(st.data(), 2 * n) && d_bad.down(bad.data(), n));
+    for (size_t i = 0; i < 2 * n; i++) {
+        if (st[i]) return C_KZG_BADARGS;
+    }
+    for (size_t i = 0; i < n; i++) {
+        if (bad[i]) return C_KZG_BADARGS;
+    }
+    OKB(d_z.up(z.data(), n));
+    RC(dev::eval_poly_batch_device(ctx, d_y.p, d_poly.p, d_z.p, n));
+    OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
+    OKB(d_y.down(y.data(), n));
+    if (n == 1) {
+        // the single-blob form of the check (eip4844.c:537-595)
+        G1Affine pts[2];
+        OKB(d_pts.down(pts, 2));
+        *ok = verify_kzg_proof_impl(jac_from_affine(pts[0]), z[0], y[0], jac_from_affine(pts[1]), s);
+        return C_KZG_OK;
+    }
+    // r = H("RCKZGBATCH___V1_" | u64be 4096 | u64be n | (C_i | z_i | y_i | proof_i)*)  (eip4844.c:597-680);
+    // valid compressed encodings are canonical, so the input bytes are the re-compressed bytes
+    Sha256 h;
+    uint8_t head[32], zb[64], digest[32];
+    memcpy(head, "RCKZGBATCH___V1_", 16);
+    be64(head + 16, FIELD_ELEMENTS_PER_BLOB);
+    be64(head + 24, n);
+    h.update(head, 32);
+    for (size_t i = 0; i < n; i++) {
+        h.update(cb[i].bytes, 48);
+        fr_to_bytes(zb, z[i]);
+        fr_to_bytes(zb + 32, y[i]);
+        h.update(zb, 64);
+        h.update(pb[i].bytes, 48);
+    }
+    h.finish(digest);
+    Fr r = fr_from_bytes_reduce(digest);
+    std::vector<RawScalar> rp(n), rz(n);
+    Fr pw = Fr::one(), ysum = Fr::zero();
+    for (size_t i = 0; i < n; i++) {
+        rp[i] = raw_of(pw);
+        rz[i] = raw_of(mul(pw, z[i]));
+        ysum = add(ysum, mul(pw, y[i]));
+        pw = mul(pw, r);
+    }
+    G1Jac proof_lc, proof_z_lc, c_lc;
+    C_KZG_RET ret;
+    if ((ret = gpu_lincomb(ctx, proof_lc, d_pts.p + n, rp)) != C_KZG_OK) return ret;
+    if ((ret = gpu_lincomb(ctx, proof_z_lc, d_pts.p + n, rz)) != C_KZG_OK) return ret;
+    if ((ret = gpu_lincomb(ctx, c_lc, d_pts.p, rp)) != C_KZG_OK) return ret;
+    // sum r^i (C_i - [y_i]G) = sum r^i C_i - [sum r^i y_i]G
+    G1Jac rhs = jac_add(jac_add(c_lc, jac_neg(g1_mul_fr(g1_generator(), ysum))), proof_z_lc);
+    *ok = pairings_verify(proof_lc, *as_g2(&s->g2_values_monomial[1]), rhs, g2_generator());
+    return C_KZG_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// EIP-4844
+// ------------------------------------------------------------------------------------------
+
+extern "C" void compute_challenge(fr_t *eval_challenge_out, const Blob *blob, const g1_t *commitment) {
+    uint8_t c48[48];
+    g1_compress_affine(c48, jac_to_affine(*as_g1(commitment)));
+    *as_fr(eval_challenge_out) = challenge_from_bytes(blob->bytes, c48);
+}
+
+extern "C" C_KZG_RET compute_kzg_proof(KZGProof *proof_out, Bytes32 *y_out, const Blob *blob,
+                                       const Bytes32 *z_bytes, const KZGSettings *s) {
+    dev::DeviceCtx *ctx = ctx_of(s);
+    if (!ctx) return C_KZG_ERROR;
+    std::vector<Fr> poly(FIELD_ELEMENTS_PER_BLOB);
+    Fr z, y;
+    C_KZG_RET ret = blob_to_polynomial(poly.data(), blob);
+    if (ret != C_KZG_OK) return ret;
+    if (!fr_from_bytes_canonical(z, z_bytes->bytes)) return C_KZG_BADARGS;
+    ret = compute_kzg_proof_impl(proof_out, y, poly.data(), z, s, ctx);
+    if (ret != C_KZG_OK) return ret;
+    fr_to_bytes(y_out->bytes, y);
+    return C_KZG_OK;
+}
+
+extern "C" C_KZG_RET compute_blob_kzg_proof(KZGProof *out, const Blob *blob, const Bytes48 *commitment_bytes,
+                                            const KZGSettings *s) {
+    dev::DeviceCtx *ctx = ctx_of(s);
+    if (!ctx) return C_KZG_ERROR;
+    std::vector<Fr> poly(FIELD_ELEMENTS_PER_BLOB);
+    G1Jac c;
+    Fr y;
+    C_KZG_RET ret = validate_kzg_g1(c, commitment_bytes->bytes);
+    if (ret != C_KZG_OK) return ret;
+    ret = blob_to_polynomial(poly.data(), blob);
+    if (ret != C_KZG_OK) return ret;
+    Fr z = challenge_from_bytes(blob->bytes, commitment_bytes->bytes);
+    return compute_kzg_proof_impl(out, y, poly.data(), z, s, ctx);
+}
+
+extern "C" C_KZG_RET verify_kzg_proof(bool *ok, const Bytes48 *commitment_bytes, const Bytes32 *z_bytes,
+                                      const Bytes32 *y_bytes, const Bytes48 *proof_bytes,
+                                      const KZGSettings *s) {
+    G1Jac c, p;
+    Fr z, y;
+    *ok = false;
+    if (!header_of(s)) return C_KZG_ERROR;
+    if (validate_kzg_g1(c, commitment_bytes->bytes) != C_KZG_OK) return C_KZG_BADARGS;
+    if (!fr_from_bytes_canonical(z, z_bytes->bytes)) return C_KZG_BADARGS;
+    if (!fr_from_bytes_canonical(y, y_bytes->bytes)) return C_KZG_BADARGS;
+    if (validate_kzg_g1(p, proof_bytes->bytes) != C_KZG_OK) return C_KZG_BADARGS;
+    *ok = verify_kzg_proof_impl(c, z, y, p, s);
+    return C_KZG_OK;
+}
+
+extern "C" C_KZG_RET verify_blob_kzg_proof(bool *ok, const Blob *blob, const Bytes48 *commitment_bytes,
+                                           const Bytes48 *proof_bytes, const KZGSettings *s) {
+    *ok = false;
+    dev::DeviceCtx *ctx = ctx_of(s);
+    if (!ctx) return C_KZG_ERROR;
+    return verify_blobs_core(ok, blob, commitment_bytes, proof_bytes, 1, s, ctx);
+}
+
+extern "C" C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48 *commitments_bytes,
+                                                 const Bytes48 *proofs_bytes, uint64_t n,
+                                                 const KZGSettings *s) {
+    if (n == 0) {  // eip4844.c:791-794
+        *ok = true;
+        return C_KZG_OK;
+    }
+    if (n == 1) return verify_blob_kzg_proof(ok, blobs, commitments_bytes, proofs_bytes, s);
+    dev::DeviceCtx *ctx = ctx_of(s);
+    if (!ctx) return C_KZG_ERROR;
+    bool res = false;
+    C_KZG_RET ret = verify_blobs_core(&res, blobs, commitments_bytes, proofs_bytes, n, s, ctx);
+    if (ret == C_KZG_OK) *ok = res;
+    return ret;
+}
+
+// ------------------------------------------------------------------------------------------
+// EIP-7594: recovery
+// ------------------------------------------------------------------------------------------
+
+// (x - r_0)...(x - r_{n-1}), coefficients low to high  (recovery.c:46-75)
+static void vanishing_poly_from_roots(std::vector<Fr> &poly, const std::vector<Fr> &roots) {
+    size_t n = roots.size();
+    poly.assign(n + 1, Fr::zero());
+    poly[0] = neg(roots[0]);
+    for (size_t i = 1; i < n; i++) {
+        Fr nr = neg(roots[i]);
+        poly[i] = add(nr, poly[i - 1]);
+        for (size_t j = i - 1; j > 0; j--) poly[j] = add(mul(poly[j], nr), poly[j - 1]);
+        poly[0] = mul(poly[0], nr);
+    }
+    poly[n] = Fr::one();
+}
+
+// recover_cells (recovery.c:200-365) on the GPU.  d_e holds the 8192 values in cell (bit-reversed)
+// order with zeros at the missing cells and is overwritten with the recovered values, same order.
+static C_KZG_RET recover_cells_gpu(dev::DeviceCtx *ctx, Fr *d_e, const uint64_t *cell_indices, size_t num_cells,
+                                   const KZGSettings *s) {
+    const size_t n = FIELD_ELEMENTS_PER_EXT_BLOB;
+    std::vector<Fr> roots;
+    const Fr *rou = as_fr(s->roots_of_unity);
+    for (size_t i = 0; i < CELLS_PER_EXT_BLOB; i++) {
+        bool have = false;
+        for (size_t k = 0; k < num_cells; k++) have |= (cell_indices[k] == i);
+        if (!have) roots.push_back(rou[reverse_bits_limited(CELLS_PER_EXT_BLOB, i) * (n / CELLS_PER_EXT_BLOB)]);
+    }
+    if (roots.empty() || roots.size() >= CELLS_PER_EXT_BLOB) return C_KZG_BADARGS;  // recovery.c:103-106
+    std::vector<Fr> shortp, zc(n, Fr::zero());
+    vanishing_poly_from_roots(shortp, roots);
+    for (size_t i = 0; i < shortp.size(); i++) zc[i * FIELD_ELEMENTS_PER_CELL] = shortp[i];
+    DBuf<Fr> d_zc, d_zev;
+    OKM(d_zc.alloc(n) && d_zev.alloc(n));
+    OKB(d_zc.up(zc.data(), n));
+    OKB(hipMemcpyAsync(d_zev.p, d_zc.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess);
+    // Z over the domain, in bit-reversed order = the order of d_e
+    RC(dev::fr_ntt_batch(ctx, d_zev.p, 1, 13, true, false, false));
+    RC(dev::fr_mul_inplace_device(ctx, d_e, d_zev.p, n, n));          // (E * Z)(w^i)
+    RC(dev::fr_ntt_batch(ctx, d_e, 1, 13, false, true, true));        // -> coefficients
+    RC(dev::fr_mul_inplace_device(ctx, d_e, ctx->d_shift, n, n));     // coset_fft: scale by 7^i ...
+    RC(dev::fr_ntt_batch(ctx, d_e, 1, 13, true, false, false));       // ... and transform
+    RC(dev::fr_mul_inplace_device(ctx, d_zc.p, ctx->d_shift, n, n));
+    RC(dev::fr_ntt_batch(ctx, d_zc.p, 1, 13, true, false, false));
+    RC(dev::fr_div_inplace_device(ctx, d_e, d_zc.p, n));              // recovery.c:322-328
+    RC(dev::fr_ntt_batch(ctx, d_e, 1, 13, false, true, true));        // coset_ifft ...
+    RC(dev::fr_mul_inplace_device(ctx, d_e, ctx->d_unshift, n, n));   // ... unscale by 7^-i
+    RC(dev::fr_ntt_batch(ctx, d_e, 1, 13, true, false, false));       // evaluations, cell order
+    OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
+    return C_KZG_OK;
+}
+
+extern "C" C_KZG_RET recover_cells_and_kzg_proofs(Cell *recovered_cells, KZGProof *recovered_proofs,
+                                                  const uint64_t *cell_indices, const Cell *cells,
+                                                  uint64_t num_cells, const KZGSettings *s) {
+    // eip7594.c:177-304
+    if (num_cells > CELLS_PER_EXT_BLOB || num_cells < CELLS_PER_BLOB) return C_KZG_BADARGS;
+    for (size_t i = 0; i < num_cells; i++) {
+        if (cell_indices[i] >= CELLS_PER_EXT_BLOB) return C_KZG_BADARGS;
+        if (i > 0 && cell_indices[i] <= cell_indices[i - 1]) return C_KZG_BADARGS;
+    }
+    dev::DeviceCtx *ctx = ctx_of(s);
+    if (!ctx) return C_KZG_ERROR;
+    const size_t n = FIELD_ELEMENTS_PER_EXT_BLOB;
+    std::vector<uint8_t> image(n * 32, 0);
+    for (size_t i = 0; i < num_cells; i++) memcpy(&image[cell_indices[i] * BYTES_PER_CELL], cells[i].bytes, BYTES_PER_CELL);
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        OKB(hipSetDevice(ctx->device) == hipSuccess);
+        DBuf<uint8_t> d_img, d_proofs;
+        DBuf<Fr> d_e;
+        DBuf<uint32_t> d_bad;
+        OKM(d_img.alloc(n * 32) && d_e.alloc(n) && d_bad.alloc(1) && d_proofs.alloc(CELLS_PER_EXT_BLOB * 48));
+        OKB(d_img.up(image.data(), n * 32));
+        OKB(hipMemsetAsync(d_bad.p, 0, 4, ctx->stream) == hipSuccess);
+        RC(dev::bytes_to_fr_batch(ctx, d_e.p, d_bad.p, d_img.p, n, (uint32_t)n));
+        OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
+        uint32_t bad = 0;
+        OKB(d_bad.down(&bad, 1));
+        if (bad) return C_KZG_BADARGS;
+        if (num_cells == CELLS_PER_EXT_BLOB) {
+            for (size_t i = 0; i < CELLS_PER_EXT_BLOB; i++) recovered_cells[i] = cells[i];
+        } else {
+            C_KZG_RET ret = recover_cells_gpu(ctx, d_e.p, cell_indices, num_cells, s);
+            if (ret != C_KZG_OK) return ret;
+            RC(dev::fr_to_bytes_batch(ctx, d_img.p, d_e.p, n));
+            OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
+            OKB(hipMemcpy(recovered_cells, d_img.p, n * 32, hipMemcpyDeviceToHost) == hipSuccess);
+        }
+        if (recovered_proofs) {
+            // cell order is bit-reversed evaluation order: DIT inverse gives the coefficients
+            // (poly_lagrange_to_monomial over 8192 points, eip7594.c:270); FK20 reads the low 4096
+            RC(dev::fr_ntt_batch(ctx, d_e.p, 1, 13, false, true, true));
+            RC(dev::fk20_proofs_device(ctx, d_proofs.p, d_e.p, 1));
+            OKB(d_proofs.down((uint8_t *)recovered_proofs, CELLS_PER_EXT_BLOB * 48));
+        }
+    }
+    return C_KZG_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// EIP-7594: cell proof batch verification
+// ------------------------------------------------------------------------------------------
+
+extern "C" C_KZG_RET compute_verify_cell_kzg_proof_batch_challenge(
+    fr_t *challenge_out, const Bytes48 *commitments_bytes, uint64_t num_commitments,
+    const uint64_t *commitment_indices, const uint64_t *cell_indices, const Cell *cells,
+    const Bytes48 *proofs_bytes, uint64_t num_cells) {
+    // eip7594.c:390-482
+    Sha256 h;
+    uint8_t head[48], idx[16], digest[32];
+    memcpy(head, "RCKZGCBATCH__V1_", 16);
+    be64(head + 16, FIELD_ELEMENTS_PER_BLOB);
+    be64(head + 24, FIELD_ELEMENTS_PER_CELL);
+    be64(head + 32, num_commitments);
+    be64(head + 40, num_cells);
+    h.update(head, 48);
+    for (uint64_t i = 0; i < num_commitments; i++) h.update(commitments_bytes[i].bytes, 48);
+    for (uint64_t i = 0; i < num_cells; i++) {
+        be64(idx, commitment_indices[i]);
+        be64(idx + 8, cell_indices[i]);
+        h.update(idx, 16);
+        h.update(cells[i].bytes, BYTES_PER_CELL);
+        h.update(proofs_bytes[i].bytes, 48);
+    }
+    h.finish(digest);
+    *as_fr(challenge_out) = fr_from_bytes_reduce(digest);
+    return C_KZG_OK;
+}
+
+// interp[k] = sum_c col[c][k] * (h_c^-1)^k with h_c^-1 = w^(8192 - brp7(c))  (eip7594.c:549-566,
+// 713-752): one thread per coefficient k
+__global__ void k_interp_sum(Fr *interp, const Fr *cols, const Fr *roots) {
+    int k = threadIdx.x;
+    Fr acc = Fr::zero();
+    for (int c = 0; c < 128; c++) {
+        uint32_t rb = __brev((uint32_t)c) >> 25;
+        uint32_t idx = ((8192u - rb) * (uint32_t)k) & 8191u;
+        const uint4 *q = reinterpret_cast<const uint4 *>(cols + c * 64 + k);
+        const uint4 *w = reinterpret_cast<const uint4 *>(roots + idx);
+        uint4 a = q[0], b = q[1], wa = w[0], wb = w[1];
+        Fr v, r;
+        v.l[0] = a.x; v.l[1] = a.y; v.l[2] = a.z; v.l[3] = a.w; v.l[4] = b.x; v.l[5] = b.y; v.l[6] = b.z; v.l[7] = b.w;
+        r.l[0] = wa.x; r.l[1] = wa.y; r.l[2] = wa.z; r.l[3] = wa.w; r.l[4] = wb.x; r.l[5] = wb.y; r.l[6] = wb.z; r.l[7] = wb.w;
+        acc = add(acc, mul(v, r));
+    }
+    uint32_t raw[8];
+    to_raw<FrParams>(raw, acc);  // canonical limbs: this vector is used as MSM scalars
+    for (int i = 0; i < 8; i++) reinterpret_cast<uint32_t *>(interp + k)[i] = raw[i];
+}
+
+extern "C" C_KZG_RET verify_cell_kzg_proof_batch(bool *ok, const Bytes48 *commitments_bytes,
+                                                 const uint64_t *cell_indices, const Cell *cells,
+                                                 const Bytes48 *proofs_bytes, uint64_t num_cells,
+                                                 const KZGSettings *s) {
+    // eip7594.c:825-974
+    *ok = false;
+    if (num_cells == 0) {
+        *ok = true;
+        return C_KZG_OK;
+    }
+    for (size_t i = 0; i < num_cells; i++) {
+        if (cell_indices[i] >= CELLS_PER_EXT_BLOB) return C_KZG_BADARGS;
+    }
+    dev::DeviceCtx *ctx = ctx_of(s);
+    if (!ctx) return C_KZG_ERROR;
+    const size_t n = num_cells, l = FIELD_ELEMENTS_PER_CELL;
+    const Fr *rou = as_fr(s->roots_of_unity);
+    // deduplicate commitments (eip7594.c:345-376)
+    std::vector<Bytes48> uniq;
+    std::vector<uint64_t> cidx(n);
+    for (size_t i = 0; i < n; i++) {
+        size_t j;
+        for (j = 0; j < uniq.size(); j++) {
+            if (memcmp(uniq[j].bytes, commitments_bytes[i].bytes, 48) == 0) break;
+        }
+        if (j == uniq.size()) uniq.push_back(commitments_bytes[i]);
+        cidx[i] = j;
+    }
+    const size_t nc = uniq.size();
+    Fr r;
+    compute_verify_cell_kzg_proof_batch_challenge((fr_t *)&r, uniq.data(), nc, cidx.data(), cell_indices, cells,
+                                                  proofs_bytes, n);
+    std::vector<Fr> rp(n);
+    {
+        Fr pw = Fr::one();
+        for (size_t i = 0; i < n; i++) {
+            rp[i] = pw;
+            pw = mul(pw, r);
+        }
+    }
+    // aggregated column data: sum of r^i * cell_i per column (eip7594.c:661-683), host side
+    std::vector<Fr> agg((size_t)CELLS_PER_EXT_BLOB * l, Fr::zero());
+    for (size_t i = 0; i < n; i++) {
+        for (size_t j = 0; j < l; j++) {
+            Fr v;
+            if (!fr_from_bytes_canonical(v, cells[i].bytes + 32 * j)) return C_KZG_BADARGS;
+            Fr &dst = agg[cell_indices[i] * l + j];
+            dst = add(dst, mul(v, rp[i]));
+        }
+    }
+    std::vector<RawScalar> rp_raw(n), wrp_raw(n), wts_raw(nc);
+    {
+        std::vector<Fr> wts(nc, Fr::zero());
+        for (size_t i = 0; i < n; i++) {
+            rp_raw[i] = raw_of(rp[i]);
+            wts[cidx[i]] = add(wts[cidx[i]], rp[i]);
+            size_t rb = reverse_bits_limited(CELLS_PER_EXT_BLOB, cell_indices[i]);
+            wrp_raw[i] = raw_of(mul(rp[i], rou[rb * l]));  // r^i * h_k^64 (eip7594.c:784-812)
+        }
+        for (size_t j = 0; j < nc; j++) wts_raw[j] = raw_of(wts[j]);
+    }
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    OKB(hipSetDevice(ctx->device) == hipSuccess);
+    DBuf<uint8_t> d_ptb, d_st;
+    DBuf<G1Affine> d_pts;
+    DBuf<Fr> d_agg, d_interp;
+    OKM(d_ptb.alloc((n + nc) * 48) && d_st.alloc(n + nc) && d_pts.alloc(n + nc) && d_agg.alloc(agg.size()) &&
+        d_interp.alloc(l));
+    // proofs [0,n), unique commitments [n, n+nc)
+    OKB(hipMemcpy(d_ptb.p, proofs_bytes, n * 48, hipMemcpyHostToDevice) == hipSuccess);
+    OKB(hipMemcpy(d_ptb.p + n * 48, uniq.data(), nc * 48, hipMemcpyHostToDevice) == hipSuccess);
+    RC(dev::validate_g1_batch_device(ctx, d_pts.p, d_st.p, d_ptb.p, n + nc));
+    OKB(d_agg.up(agg.data(), agg.size()));
+    // per column: cell data is in bit-reversed order -> DIT inverse NTT(64) gives the interpolation
+    // polynomial over the coset; unused columns are all-zero and stay zero
+    RC(dev::fr_ntt_batch(ctx, d_agg.p, CELLS_PER_EXT_BLOB, 6, false, true, true));
+    hipLaunchKernelGGL(k_interp_sum, dim3(1), dim3(64), 0, ctx->stream, d_interp.p, d_agg.p, ctx->d_roots);
+    OKB(hipGetLastError() == hipSuccess);
+    OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
+    std::vector<uint8_t> st(n + nc);
+    OKB(d_st.down(st.data(), n + nc));
+    for (auto b : st) {
+        if (b) return C_KZG_BADARGS;
+    }
+    G1Jac proof_lc, csum, interp_commit, wsum;
+    C_KZG_RET ret;
+    if ((ret = gpu_lincomb(ctx, proof_lc, d_pts.p, rp_raw)) != C_KZG_OK) return ret;
+    if ((ret = gpu_lincomb(ctx, csum, d_pts.p + n, wts_raw)) != C_KZG_OK) return ret;
+    if ((ret = gpu_lincomb(ctx, wsum, d_pts.p, wrp_raw)) != C_KZG_OK) return ret;
+    {
+        // commitment to the aggregated interpolation polynomial: 64 monomial setup points
+        DBuf<G1XYZZ> d_part;
+        DBuf<G1Affine> d_out;
+        OKM(d_part.alloc(2) && d_out.alloc(1));
+        RC(dev::lincomb_var_device(ctx, d_out.p, d_part.p, ctx->d_mono, (const uint32_t *)d_interp.p, l));
+        OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
+        G1Affine a;
+        OKB(d_out.down(&a, 1));
+        interp_commit = jac_from_affine(a);
+    }
+    G1Jac final_sum = jac_add(jac_add(csum, jac_neg(interp_commit)), wsum);
+    *ok = pairings_verify(final_sum, g2_generator(), proof_lc, *as_g2(&s->g2_values_monomial[l]));
+    return C_KZG_OK;
+}

@@ -50,6 +50,9 @@ struct DeviceCtx {
     // FK20
     FixedBaseTable fk20;          // over x_ext_fft columns: point index = col*64 + row
     G1Affine *d_xext = nullptr;   // [128][64] affine
+    G1Affine *d_mono = nullptr;   // g1_values_monomial, affine, 4096
+    Fr *d_shift = nullptr;        // 7^i, i < 8192   (coset_fft, fft.c:257-279)
+    Fr *d_unshift = nullptr;      // 7^-i, i < 8192  (coset_ifft, fft.c:290-301)
 };
 
 #define HIP_TRY(expr)                                                                          \
@@ -100,6 +103,14 @@ int cells_and_proofs_device(DeviceCtx *ctx, uint8_t *d_cells, uint8_t *d_proofs,
                             const uint8_t *d_blobs, size_t n);
 // FK20 proofs from monomial coefficients already on the device ([n][4096] Fr, Montgomery)
 int fk20_proofs_device(DeviceCtx *ctx, uint8_t *d_proofs, const Fr *d_poly_monomial, size_t n);
+// verify.hip
+int eval_poly_batch_device(DeviceCtx *ctx, Fr *d_y, const Fr *d_poly, const Fr *d_z, size_t n);
+int validate_g1_batch_device(DeviceCtx *ctx, G1Affine *d_out, uint8_t *d_status, const uint8_t *d_in48,
+                             size_t n);
+int lincomb_var_device(DeviceCtx *ctx, G1Affine *d_out, G1XYZZ *d_partials, const G1Affine *d_pts,
+                       const uint32_t *d_scalars, size_t n);
+int fr_mul_inplace_device(DeviceCtx *ctx, Fr *d_a, const Fr *d_b, size_t n, size_t period);
+int fr_div_inplace_device(DeviceCtx *ctx, Fr *d_a, const Fr *d_b, size_t n);
 // generic helpers
 int batch_to_affine_device(DeviceCtx *ctx, G1Affine *d_out, const G1XYZZ *d_in, Fp *d_prefix, size_t n);
 

@@ -24,6 +24,9 @@ void destroy_device_ctx(dev::DeviceCtx *ctx) {
     if (ctx->d_roots) (void)hipFree(ctx->d_roots);
     if (ctx->d_brp_roots) (void)hipFree(ctx->d_brp_roots);
     if (ctx->d_roots_raw) (void)hipFree(ctx->d_roots_raw);
+    if (ctx->d_mono) (void)hipFree(ctx->d_mono);
+    if (ctx->d_shift) (void)hipFree(ctx->d_shift);
+    if (ctx->d_unshift) (void)hipFree(ctx->d_unshift);
     if (ctx->scratch.ptr) (void)hipFree(ctx->scratch.ptr);
     for (auto &e : ctx->ev) {
         if (e) (void)hipEventDestroy(e);
@@ -69,6 +72,25 @@ C_KZG_RET create_device_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affine,
     CTX_TRY(hipMemcpy(ctx->d_roots, s->roots_of_unity, (dev::N_EXT + 1) * sizeof(Fr), hipMemcpyHostToDevice));
     CTX_TRY(hipMemcpy(ctx->d_brp_roots, s->brp_roots_of_unity, dev::N_EXT * sizeof(Fr), hipMemcpyHostToDevice));
 
+    // coset shift factors for recovery: 7^i and 7^-i
+    {
+        std::vector<Fr> sh(dev::N_EXT), ush(dev::N_EXT);
+        Fr seven, seven_inv;
+        for (int i = 0; i < 8; i++) {
+            seven.l[i] = FR_SEVEN_MONT[i];
+            seven_inv.l[i] = FR_SEVEN_INV_MONT[i];
+        }
+        sh[0] = ush[0] = Fr::one();
+        for (int i = 1; i < dev::N_EXT; i++) {
+            sh[i] = mul(sh[i - 1], seven);
+            ush[i] = mul(ush[i - 1], seven_inv);
+        }
+        CTX_TRY(hipMalloc(&ctx->d_shift, dev::N_EXT * sizeof(Fr)));
+        CTX_TRY(hipMalloc(&ctx->d_unshift, dev::N_EXT * sizeof(Fr)));
+        CTX_TRY(hipMemcpy(ctx->d_shift, sh.data(), dev::N_EXT * sizeof(Fr), hipMemcpyHostToDevice));
+        CTX_TRY(hipMemcpy(ctx->d_unshift, ush.data(), dev::N_EXT * sizeof(Fr), hipMemcpyHostToDevice));
+    }
+
     // commitment table over the bit-reversed Lagrange points
     {
         int wbits = env_int("CKZG_HIP_COMMIT_WBITS", g_opts.commit_wbits);
@@ -88,14 +110,10 @@ C_KZG_RET create_device_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affine,
     // FK20: x_ext_fft columns by 64 G1 FFTs on the GPU, mirrored into the host struct, then the
     // fixed-base table over those 8192 points
     {
-        DeviceBuffer d_mono;
-        if (!d_mono.alloc(NUM_G1_POINTS * sizeof(G1Affine))) {
-            destroy_device_ctx(ctx);
-            return C_KZG_MALLOC;
-        }
-        CTX_TRY(hipMemcpy(d_mono.p, monomial_affine, NUM_G1_POINTS * sizeof(G1Affine), hipMemcpyHostToDevice));
+        CTX_TRY(hipMalloc(&ctx->d_mono, NUM_G1_POINTS * sizeof(G1Affine)));
+        CTX_TRY(hipMemcpy(ctx->d_mono, monomial_affine, NUM_G1_POINTS * sizeof(G1Affine), hipMemcpyHostToDevice));
         std::vector<G1Affine> h_xext((size_t)dev::N_CELLS_EXT * dev::N_CELL);
-        int rc = dev::fk20_setup_device(ctx, (const G1Affine *)d_mono.p, h_xext.data());
+        int rc = dev::fk20_setup_device(ctx, ctx->d_mono, h_xext.data());
         if (rc) {
             destroy_device_ctx(ctx);
             return (C_KZG_RET)rc;

@@ -1,0 +1,286 @@
+// verify.hip -- the data-parallel per-blob / per-point work of the verification and recovery
+// paths, batched on the GPU:
+//   * barycentric evaluation of a blob polynomial at a challenge point
+//     (evaluate_polynomial_in_evaluation_form + fr_batch_inv, src/eip4844/eip4844.c:80-106,192-240)
+//   * G1 point validation: decompress (Fp square root), curve and subgroup checks
+//     (validate_kzg_g1, src/common/bytes.c:81-95)
+//   * variable-base linear combinations sum_i k_i P_i (g1_lincomb_naive / g1_lincomb_fast over
+//     proofs and commitments, src/eip4844/eip4844.c:731-746, src/eip7594/eip7594.c:530,807,926)
+//   * element-wise Fr helpers used by recover_cells (src/eip7594/recovery.c:281,322-328)
+#include "device.hpp"
+#include "dev_inline.hpp"
+
+namespace ckzg {
+namespace dev {
+
+__device__ __forceinline__ Fr vld_fr(const Fr *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 a = q[0], b = q[1];
+    Fr r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    return r;
+}
+
+__device__ __forceinline__ void vst_fr(Fr *p, const Fr &v) {
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+
+__device__ __noinline__ Fr fr_inv_dev(const Fr &a) { return fr_inv(a); }
+
+// ------------------------------------------------------------------------------------------
+// barycentric evaluation: one 256-thread workgroup per polynomial
+//   y = (z^4096 - 1)/4096 * sum_i p_i w_i / (z - w_i),   or p_m if z == w_m
+// ------------------------------------------------------------------------------------------
+
+constexpr int EV_THREADS = 256;
+constexpr int EV_PER = N_BLOB / EV_THREADS;  // 16 terms per thread
+
+__global__ __launch_bounds__(EV_THREADS) void k_eval_barycentric(Fr *y_out, const Fr *poly,
+                                                                 const Fr *zs, const Fr *brp_roots) {
+    __shared__ uint32_t sh[8][EV_THREADS];
+    __shared__ int hit;
+    const int tid = threadIdx.x;
+    const Fr *p = poly + (size_t)blockIdx.x * N_BLOB;
+    const Fr z = vld_fr(zs + blockIdx.x);
+    if (tid == 0) hit = -1;
+    __syncthreads();
+    Fr den[EV_PER], pre[EV_PER];
+    Fr acc = Fr::one();
+#pragma unroll
+    for (int k = 0; k < EV_PER; k++) {
+        int i = tid + k * EV_THREADS;
+        den[k] = sub(z, vld_fr(brp_roots + i));
+        if (den[k].is_zero()) hit = i;  // at most one domain point equals z
+        pre[k] = acc;
+        acc = mul(acc, den[k]);
+    }
+    __syncthreads();
+    if (hit >= 0) {
+        if (tid == 0) vst_fr(y_out + blockIdx.x, vld_fr(p + hit));
+        return;
+    }
+    Fr inv = fr_inv_dev(acc);
+    Fr sum = Fr::zero();
+#pragma unroll
+    for (int k = EV_PER - 1; k >= 0; k--) {
+        int i = tid + k * EV_THREADS;
+        Fr di = mul(inv, pre[k]);  // 1/(z - w_i)
+        inv = mul(inv, den[k]);
+        sum = add(sum, mul(mul(di, vld_fr(brp_roots + i)), vld_fr(p + i)));
+    }
+    // workgroup sum
+    for (int s = EV_THREADS / 2; s >= 1; s >>= 1) {
+        if (tid >= s && tid < 2 * s) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) sh[k][tid - s] = sum.l[k];
+        }
+        __syncthreads();
+        if (tid < s) {
+            Fr o;
+#pragma unroll
+            for (int k = 0; k < 8; k++) o.l[k] = sh[k][tid];
+            sum = add(sum, o);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        Fr zn = z;
+        for (int k = 0; k < 12; k++) zn = sqr(zn);  // z^4096
+        Fr f = sub(zn, Fr::one());
+        Fr n_inv = Fr::one();                        // 1/4096 by halving
+        uint32_t m[8];
+        mod_limbs<FrParams>(m);
+        for (int k = 0; k < 12; k++) {
+            uint32_t t[9];
+            uint32_t c = 0;
+            if (n_inv.l[0] & 1u) {
+                c = limbs_add<8>(t, n_inv.l, m);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; i++) t[i] = n_inv.l[i];
+            }
+            t[8] = c;
+#pragma unroll
+            for (int i = 0; i < 8; i++) n_inv.l[i] = (t[i] >> 1) | (t[i + 1] << 31);
+        }
+        vst_fr(y_out + blockIdx.x, mul(mul(sum, n_inv), f));
+    }
+}
+
+int eval_poly_batch_device(DeviceCtx *ctx, Fr *d_y, const Fr *d_poly, const Fr *d_z, size_t n) {
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_eval_barycentric, dim3((unsigned)n), dim3(EV_THREADS), 0, ctx->stream, d_y,
+                       d_poly, d_z, ctx->d_brp_roots);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// G1 validation: one thread per 48-byte compressed point
+// status: 0 ok, 1 invalid (bad encoding / not on curve / not in the r-torsion subgroup)
+// ------------------------------------------------------------------------------------------
+
+__device__ __noinline__ G1XYZZ xyzz_mul_w4_dev(const G1XYZZ &p, const uint32_t *k) {
+    G1XYZZ tbl[15];
+    tbl[0] = p;
+    tbl[1] = xyzz_dbl(p);
+    for (int i = 2; i < 15; i++) tbl[i] = xyzz_add(tbl[i - 1], p);
+    G1XYZZ acc = G1XYZZ::inf();
+    for (int w = 63; w >= 0; w--) {
+        if (w != 63) {
+            acc = xyzz_dbl(acc);
+            acc = xyzz_dbl(acc);
+            acc = xyzz_dbl(acc);
+            acc = xyzz_dbl(acc);
+        }
+        uint32_t d = (k[w >> 3] >> ((w & 7) * 4)) & 15u;
+        if (d) acc = xyzz_add(acc, tbl[d - 1]);
+    }
+    return acc;
+}
+
+__global__ void k_validate_g1(G1Affine *out, uint8_t *status, const uint8_t *in48, size_t n) {
+    size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    uint8_t buf[48];
+    for (int k = 0; k < 48; k++) buf[k] = in48[g * 48 + k];
+    G1Affine a;
+    int rc = g1_uncompress(a, buf);
+    uint8_t st = rc ? 1 : 0;
+    if (!rc && !a.is_inf()) {
+        uint32_t r[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) r[k] = FR_R[k];
+        G1XYZZ t = xyzz_mul_w4_dev(xyzz_from_affine(a), r);
+        if (!t.is_inf()) st = 1;
+    }
+    if (st) a = G1Affine::inf();
+    out[g] = a;
+    status[g] = st;
+}
+
+int validate_g1_batch_device(DeviceCtx *ctx, G1Affine *d_out, uint8_t *d_status, const uint8_t *d_in48,
+                             size_t n) {
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_validate_g1, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, d_out,
+                       d_status, d_in48, n);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// variable-base linear combination: out = sum_i k_i * P_i  (k_i canonical 8 x u32)
+// ------------------------------------------------------------------------------------------
+
+constexpr int LC_THREADS = 64;
+
+__global__ __launch_bounds__(LC_THREADS) void k_lincomb_partial(G1XYZZ *partials, const G1Affine *pts,
+                                                                const uint32_t *scalars, size_t n) {
+    __shared__ uint32_t sh[48][LC_THREADS / 2];
+    size_t g = blockIdx.x * (size_t)LC_THREADS + threadIdx.x;
+    G1XYZZ acc = G1XYZZ::inf();
+    if (g < n) {
+        uint32_t k[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) k[i] = scalars[g * 8 + i];
+        G1Affine a = pts[g];
+        if (!a.is_inf()) acc = xyzz_mul_w4_dev(xyzz_from_affine(a), k);
+    }
+    const int tid = threadIdx.x;
+    for (int s = LC_THREADS / 2; s >= 1; s >>= 1) {
+        if (tid >= s && tid < 2 * s) {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(&acc);
+#pragma unroll
+            for (int k = 0; k < 48; k++) sh[k][tid - s] = src[k];
+        }
+        __syncthreads();
+        if (tid < s) {
+            G1XYZZ o;
+            uint32_t *dst = reinterpret_cast<uint32_t *>(&o);
+#pragma unroll
+            for (int k = 0; k < 48; k++) dst[k] = sh[k][tid];
+            acc = xyzz_add(acc, o);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) partials[blockIdx.x] = acc;
+}
+
+__global__ void k_lincomb_final(G1Affine *out, const G1XYZZ *partials, size_t nparts) {
+    if (blockIdx.x || threadIdx.x) return;
+    G1XYZZ acc = G1XYZZ::inf();
+    for (size_t i = 0; i < nparts; i++) acc = xyzz_add(acc, partials[i]);
+    *out = xyzz_to_affine(acc);
+}
+
+// d_out: one affine point; d_partials: scratch for ceil(n/64) XYZZ points
+int lincomb_var_device(DeviceCtx *ctx, G1Affine *d_out, G1XYZZ *d_partials, const G1Affine *d_pts,
+                       const uint32_t *d_scalars, size_t n) {
+    size_t nb = (n + LC_THREADS - 1) / LC_THREADS;
+    if (nb == 0) nb = 1;
+    hipLaunchKernelGGL(k_lincomb_partial, dim3((unsigned)nb), dim3(LC_THREADS), 0, ctx->stream, d_partials,
+                       d_pts, d_scalars, n);
+    hipLaunchKernelGGL(k_lincomb_final, dim3(1), dim3(1), 0, ctx->stream, d_out, d_partials, nb);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// element-wise Fr helpers
+// ------------------------------------------------------------------------------------------
+
+// a[i] *= b[i mod period]
+__global__ void k_fr_mul_inplace(Fr *a, const Fr *b, size_t n, size_t period) {
+    size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    vst_fr(a + g, mul(vld_fr(a + g), vld_fr(b + (g % period))));
+}
+
+// a[i] = a[i] / b[i] with Montgomery's trick inside each thread's run of 16 (recovery.c:322-328
+// does 8192 separate inversions; division by zero yields 0 like blst_fr_eucl_inverse)
+__global__ void k_fr_div_inplace(Fr *a, const Fr *b, size_t n) {
+    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    size_t base = t * 16;
+    if (base >= n) return;
+    Fr den[16], pre[16];
+    Fr acc = Fr::one();
+    int cnt = (int)(n - base < 16 ? n - base : 16);
+    for (int k = 0; k < cnt; k++) {
+        den[k] = vld_fr(b + base + k);
+        pre[k] = acc;
+        if (!den[k].is_zero()) acc = mul(acc, den[k]);
+    }
+    Fr inv = fr_inv_dev(acc);
+    for (int k = cnt - 1; k >= 0; k--) {
+        Fr q = Fr::zero();
+        if (!den[k].is_zero()) {
+            Fr di = mul(inv, pre[k]);
+            inv = mul(inv, den[k]);
+            q = mul(vld_fr(a + base + k), di);
+        }
+        vst_fr(a + base + k, q);
+    }
+}
+
+int fr_mul_inplace_device(DeviceCtx *ctx, Fr *d_a, const Fr *d_b, size_t n, size_t period) {
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_fr_mul_inplace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_a,
+                       d_b, n, period);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int fr_div_inplace_device(DeviceCtx *ctx, Fr *d_a, const Fr *d_b, size_t n) {
+    if (!n) return 0;
+    size_t threads = (n + 15) / 16;
+    hipLaunchKernelGGL(k_fr_div_inplace, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, ctx->stream,
+                       d_a, d_b, n);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace dev
+}  // namespace ckzg

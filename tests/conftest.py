@@ -26,8 +26,8 @@ def _ensure_oracle():
 @pytest.fixture(scope="session")
 def oracle():
     """CPU oracle (test infrastructure) with the mainnet trusted setup, precompute=0."""
-    from kzg_ctypes import Kzg
-    api = Kzg(_ensure_oracle(), "okzg_", precompute=0)
+    from oracle_binding import OracleKzg
+    api = OracleKzg(_ensure_oracle(), precompute=0)
     yield api
     api.close()
 

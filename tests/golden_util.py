@@ -87,6 +87,12 @@ def run_case(api, fn, name):
         elif fn == "verify_cell_kzg_proof_batch":
             got = api.verify_cell_kzg_proof_batch(inp["commitments"], inp["cell_indices"],
                                                   inp["cells"], inp["proofs"])
+        elif fn == "compute_challenge":
+            got = api.compute_challenge(inp["blob"], inp["commitment"])
+        elif fn == "compute_verify_cell_kzg_proof_batch_challenge":
+            cells = [b"".join(c) if isinstance(c, list) else c for c in inp["cosets_evals"]]
+            got = api.compute_verify_cell_kzg_proof_batch_challenge(
+                inp["commitments"], inp["commitment_indices"], inp["cell_indices"], cells, inp["proofs"])
         else:
             raise NotImplementedError(fn)
     except KzgError:
