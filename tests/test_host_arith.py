@@ -1,0 +1,169 @@
+"""The product's header-only arithmetic (c-kzg-4844_amd/csrc/field.hpp, g1.hpp, host_pairing.hpp),
+compiled for the host by g++ into libhost_shim.so, against the oracle limb for limb.  The same
+headers are what the HIP kernels inline, so this covers the device formulas without a GPU."""
+import ctypes as C
+import hashlib
+import os
+import random
+import subprocess
+
+import pytest
+
+from conftest import ORACLE_SO, ROOT, SHIM_SO
+
+P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+R = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+
+
+@pytest.fixture(scope="module")
+def libs():
+    if not os.path.exists(SHIM_SO):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "c-kzg-4844_amd"), "csrc/libhost_shim.so"])
+    if not os.path.exists(ORACLE_SO):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    o, h = C.CDLL(ORACLE_SO), C.CDLL(SHIM_SO)
+    o.og1_equal.restype = C.c_bool
+    o.og1_is_inf.restype = C.c_bool
+    return o, h
+
+
+def _buf(n):
+    return C.create_string_buffer(n)
+
+
+def test_field_ops_match(libs):
+    o, h = libs
+    rnd = random.Random(5)
+    for name, nbytes, mod in (("fp", 48, P), ("fr", 32, R)):
+        edge = [0, 1, mod - 1, mod - 2, (mod - 1) // 2]
+        for op in ("mul", "add", "sub"):
+            for k in range(300):
+                a = edge[k % 5] if k < 25 else rnd.randrange(mod)
+                b = edge[(k // 5) % 5] if k < 25 else rnd.randrange(mod)
+                ab, bb = a.to_bytes(nbytes, "little"), b.to_bytes(nbytes, "little")
+                r1, r2 = _buf(nbytes), _buf(nbytes)
+                getattr(o, "o%s_%s" % (name, op))(r1, ab, bb)
+                getattr(h, "hs_%s_%s" % (name, op))(r2, ab, bb)
+                assert r1.raw == r2.raw, (name, op, a, b)
+        for _ in range(4):
+            a = rnd.randrange(1, mod).to_bytes(nbytes, "little")
+            r1, r2 = _buf(nbytes), _buf(nbytes)
+            getattr(o, "o%s_inv" % name)(r1, a)
+            getattr(h, "hs_%s_inv" % name)(r2, a)
+            assert r1.raw == r2.raw
+
+
+def _omul(o, p, k):
+    r = _buf(144)
+    kk = (C.c_uint64 * 4)(*[(k >> (64 * i)) & (2 ** 64 - 1) for i in range(4)])
+    o.og1_mul_raw(r, p, kk, 255)
+    return r
+
+
+def test_g1_group_laws_match(libs):
+    o, h = libs
+    rnd = random.Random(7)
+    g = _buf(144)
+    h.hs_g1_generator(g)
+    inf = _buf(144)
+    for _ in range(6):
+        k1, k2 = rnd.randrange(R), rnd.randrange(R)
+        p1, p2 = _omul(o, g, k1), _omul(o, g, k2)
+        ref = _buf(144)
+        o.og1_add(ref, p1, p2)
+        a1, a2 = _buf(96), _buf(96)
+        o.og1_to_affine(a1, p1)
+        o.og1_to_affine(a2, p2)
+        for fn, arg in (("hs_g1_add_jac", p2), ("hs_g1_add_xyzz", p2), ("hs_g1_madd_xyzz", a2), ("hs_g1_madd_jac", a2)):
+            r = _buf(144)
+            getattr(h, fn)(r, p1, arg)
+            assert o.og1_equal(r, ref), fn
+        dbl = _buf(144)
+        o.og1_dbl(dbl, p1)
+        # the complete laws must take the doubling path when both inputs are the same point
+        for fn, arg in (("hs_g1_add_jac", p1), ("hs_g1_add_xyzz", p1), ("hs_g1_madd_xyzz", a1), ("hs_g1_madd_jac", a1)):
+            r = _buf(144)
+            getattr(h, fn)(r, p1, arg)
+            assert o.og1_equal(r, dbl), fn
+        for fn in ("hs_g1_dbl_jac", "hs_g1_dbl_xyzz"):
+            r = _buf(144)
+            getattr(h, fn)(r, p1)
+            assert o.og1_equal(r, dbl), fn
+        # P + (-P) = infinity, infinity + P = P
+        n1 = _buf(144)
+        o.og1_neg(n1, p1)
+        for fn in ("hs_g1_add_jac", "hs_g1_add_xyzz"):
+            r = _buf(144)
+            getattr(h, fn)(r, p1, n1)
+            assert o.og1_is_inf(r), fn
+            r = _buf(144)
+            getattr(h, fn)(r, inf, p1)
+            assert o.og1_equal(r, p1), fn
+        kk = (C.c_uint32 * 8)(*[(k2 >> (32 * i)) & 0xffffffff for i in range(8)])
+        r = _buf(144)
+        h.hs_g1_mul(r, p1, kk, 255)
+        ref3 = _omul(o, p1, k2)
+        assert o.og1_equal(r, ref3)
+        c1, c2 = _buf(48), _buf(48)
+        o.og1_compress(c1, ref3)
+        h.hs_g1_compress(c2, r)
+        assert c1.raw == c2.raw
+        u, a3 = _buf(96), _buf(96)
+        assert h.hs_g1_uncompress(u, c1.raw) == 0
+        o.og1_to_affine(a3, ref3)
+        assert u.raw == a3.raw
+
+
+# the 15 accept/reject encodings pinned by /root/reference/src/test/tests.c:551-747
+G1_ENCODING_KATS = [
+    ("a491d1b0ecd9bb917989f0e74f0dea0422eac4a873e5e2644f368dffb9a6e20fd6e10c1b77654d067c0618f6e5a7f79a", True),
+    ("8123456789abcdef0123456789abcdef0123456789abcdef0123456789abcdef0123456789abcdef0123456789abcdef", False),
+    ("8123456789abcdef0123456789abcdef0123456789abcdef0123456789abcdef0123456789abcdef0123456789abcde0", False),
+    ("9a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab", False),
+    ("9a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaac", False),
+    ("c0" + "00" * 47, True),
+    ("c01" + "0" * 93, False),
+    ("80" + "00" * 47, False),
+    ("0123456789abcdef0123456789abcdef0123456789abcdef0123456789abcdef0123456789abcdef0123456789abcdef", False),
+    ("c123456789abcdef0123456789abcdef0123456789abcdef0123456789abcdef0123456789abcdef0123456789abcdef", False),
+    ("e0" + "00" * 47, False),
+    ("e491d1b0ecd9bb917989f0e74f0dea0422eac4a873e5e2644f368dffb9a6e20fd6e10c1b77654d067c0618f6e5a7f79a", False),
+]
+
+
+def test_g1_encoding_kats_host_and_oracle(libs):
+    o, h = libs
+    o.og1_in_subgroup.restype = C.c_bool
+    for hx, ok in G1_ENCODING_KATS:
+        b = bytes.fromhex(hx)
+        for lib, fn in ((h, "hs_g1_uncompress"), (o, "og1_uncompress")):
+            a = _buf(96)
+            rc = getattr(lib, fn)(a, b)
+            valid = rc == 0
+            if valid:
+                j = _buf(144)
+                o.og1_from_affine(j, a)
+                valid = o.og1_is_inf(j) or o.og1_in_subgroup(j)
+            assert valid == ok, (hx[:8], fn)
+
+
+def test_pairing_and_sha(libs):
+    o, h = libs
+    g = _buf(144)
+    g2 = _buf(288)
+    h.hs_g1_generator(g)
+    h.hs_g2_generator(g2)
+    k = 0x1234567890abcdef1234567890abcdef % R
+    kk = (C.c_uint32 * 8)(*[(k >> (32 * i)) & 0xffffffff for i in range(8)])
+    kg1 = _omul(o, g, k)
+    kg2 = _buf(288)
+    h.hs_g2_mul(kg2, g2, kk, 255)
+    assert h.hs_pairings_verify(kg1, g2, g, kg2) == 1
+    assert h.hs_pairings_verify(kg1, g2, kg1, kg2) == 0
+    for n in (0, 1, 55, 56, 63, 64, 65, 119, 120, 1000, 131152):
+        m = os.urandom(n)
+        out = _buf(32)
+        h.hs_sha256(out, m, C.c_size_t(n))
+        assert out.raw == hashlib.sha256(m).digest()
+        o.osha256(out, m, C.c_size_t(n))
+        assert out.raw == hashlib.sha256(m).digest()
