@@ -128,6 +128,22 @@ def main():
             pcie_rate = BLOBS_PER_STEP / (t2 - t1)
             assert ho.raw == out.cpu().numpy().tobytes(), "host-pointer and device-pointer paths disagree"
 
+    # spot-check the timed kernel's output against the CPU oracle (checker only, untimed)
+    parity = None
+    if rank == 0:
+        try:
+            orc = mod.Kzg(os.path.join(ROOT, "oracle", "liboracle.so"), "okzg_")
+            hb_all = blobs.cpu().numpy()
+            ho_all = out.cpu().numpy()
+            parity = True
+            for i in (0, 1, 511, BLOBS_PER_STEP - 1):
+                parity &= orc.blob_to_kzg_commitment(hb_all[i].tobytes()) == ho_all[i].tobytes()
+            orc.close()
+        except Exception as e:
+            parity = "oracle unavailable: %s" % e
+        if parity is False:
+            raise SystemExit("bench: GPU commitments differ from the oracle -- number would be invalid")
+
     if rank == 0:
         total_blobs = BLOBS_PER_STEP * args.steps * world
         value = total_blobs / dt
@@ -148,6 +164,7 @@ def main():
                          "kernel": "k_msm_accumulate", "kernel_ms": round(avg_k * 1e3, 3),
                          "note": "integer-VALU-bound kernel (v_mad_u64_u32 chains); HBM fraction is small by nature"},
             "pcie_inclusive_blobs_per_s": None if pcie_rate is None else round(pcie_rate, 2),
+            "parity_spot_check_vs_oracle": parity,
         }
         if not args.no_cpu_baseline and world == 1:
             try:

@@ -1,0 +1,80 @@
+// g1_28.hpp -- XYZZ mixed addition on the 28-bit-limb field (fp28.hpp): the inner operation of
+// the MSM accumulate kernel.  Same madd-2008-s formulas as g1.hpp::xyzz_madd; the bounds in the
+// comments are what the F28<limb, value> types prove at compile time.
+#pragma once
+#include "fp28.hpp"
+#include "g1.hpp"
+
+namespace ckzg {
+
+struct XYZZ28 {
+    F28<1, 10> x;
+    F28<1, 6> y;
+    F28<1, 2> zz, zzz;
+};
+
+// doubling of an affine point (mdbl-2008-s-1), only reached when acc == pt
+HDNI inline void xyzz28_dbl_affine(XYZZ28 &acc, const F28<1, 1> &x2, const F28<4, 2> &y2) {
+    auto u = add(y2, y2);                       // <8,4>
+    auto un = norm(u);                          // <1,4>
+    auto v = sqr(un);                           // <1,2>
+    auto w = mul(un, v);                        // <1,2>
+    auto s = mul(x2, v);                        // <1,2>
+    auto x2s = sqr(x2);                         // <1,2>
+    auto m = add(add(x2s, x2s), x2s);           // <3,6>
+    auto mm = sqr(m);                           // <1,2>
+    acc.x = norm(sub(mm, add(s, s)));           // sub(<1,2>,<2,4>) = <5,10> -> <1,10>
+    auto d = sub(s, acc.x);                     // <4,18>
+    auto m1 = mul(m, d);                        // 14*12+15 ok, 6*18 ok
+    auto m2 = mul(w, y2);                       // <1,2>
+    acc.y = norm(sub(m1, m2));                  // <4,6> -> <1,6>
+    acc.zz = v;
+    acc.zzz = w;
+}
+
+// acc += (x2, y2); `inf` is the accumulator's infinity flag (kept outside the coordinates because
+// a lazily reduced ZZ cannot be tested for zero cheaply).  The point must not be infinity.
+HD void xyzz28_madd(XYZZ28 &acc, bool &inf, const F28<1, 1> &x2, const F28<4, 2> &y2) {
+    if (inf) {
+        acc.x = widen<1, 10>(x2);
+        acc.y = widen<1, 6>(norm(y2));
+        acc.zz = widen<1, 2>(f28_one());
+        acc.zzz = acc.zz;
+        inf = false;
+        return;
+    }
+    auto u2 = mul(x2, acc.zz);                  // <1,2>
+    auto s2 = mul(y2, acc.zzz);                 // <1,2>
+    auto p = sub(u2, acc.x);                    // <4,18>
+    auto r = sub(s2, acc.y);                    // <4,10>
+    auto pp = sqr(p);                           // 14*16+15 = 239 <= 255; 18*18 <= 2500
+    if (is_zero(pp)) {
+        // same x: either the same point (double) or its negative (result is infinity)
+        auto rr = mul(r, f28_one());
+        if (is_zero(rr)) {
+            xyzz28_dbl_affine(acc, x2, y2);
+        } else {
+            inf = true;
+        }
+        return;
+    }
+    auto ppp = mul(p, pp);                      // <1,2>
+    auto q = mul(acc.x, pp);                    // <1,2>
+    auto rr = sqr(r);                           // <1,2>
+    auto t1 = add(ppp, add(q, q));              // <3,6>
+    acc.x = norm(sub(rr, t1));                  // <6,10> -> <1,10>
+    auto d = sub(q, acc.x);                     // <4,18>
+    auto m1 = mul(r, d);                        // 14*16+15 ok; 10*18 ok
+    auto m2 = mul(acc.y, ppp);                  // <1,2>
+    acc.y = norm(sub(m1, m2));                  // <4,6> -> <1,6>
+    acc.zz = mul(acc.zz, pp);
+    acc.zzz = mul(acc.zzz, ppp);
+}
+
+// out of the 28-bit domain: fully reduced coordinates in the host/LDS representation
+HD G1XYZZ xyzz28_to_xyzz(const XYZZ28 &a, bool inf) {
+    if (inf) return G1XYZZ::inf();
+    return {f28_to_fp(a.x), f28_to_fp(a.y), f28_to_fp(a.zz), f28_to_fp(a.zzz)};
+}
+
+}  // namespace ckzg

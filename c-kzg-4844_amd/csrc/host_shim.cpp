@@ -48,3 +48,51 @@ void hs_sha256(uint8_t *out, const uint8_t *msg, size_t len) {
     s.finish(out);
 }
 }
+
+// ---- 28-bit-limb device arithmetic (fp28.hpp / g1_28.hpp), exercised on the host ----
+#include "g1_28.hpp"
+extern "C" {
+// r = a*b in the 2^384 domain, computed through the 2^392-domain multiplier
+void hs_fp28_mul(Fp *r, const Fp *a, const Fp *b) { *r = f28_to_fp(mul(f28_from_fp(*a), f28_from_fp(*b))); }
+void hs_fp28_roundtrip(Fp *r, const Fp *a) { *r = f28_to_fp(f28_from_fp(*a)); }
+void hs_fp28_sub(Fp *r, const Fp *a, const Fp *b) { *r = f28_to_fp(sub(f28_from_fp(*a), f28_from_fp(*b))); }
+void hs_fp28_addchain(Fp *r, const Fp *a, const Fp *b) {
+    auto x = f28_from_fp(*a), y = f28_from_fp(*b);
+    *r = f28_to_fp(norm(sub(add(add(x, y), x), add(y, y))));  // 2a - b
+}
+// r = (-a)*b through cneg_reduced (a must be fully reduced, as table coordinates are)
+void hs_fp28_cneg_mul(Fp *r, const Fp *a, const Fp *b, int negate) {
+    Fp k;
+    for (int i = 0; i < 12; i++) k.l[i] = FP_MONT_2POW8[i];
+    Fp t = mul(*a, k);  // a in the 2^392 domain, fully reduced, packed
+    *r = f28_to_fp(mul(cneg_reduced(f28_unpack<1>(t.l), negate != 0), f28_from_fp(*b)));
+}
+// table entries are stored as the 32-bit-domain product with 2^8, packed; emulate that path
+static F28<1, 1> table_coord(const Fp &v) {
+    Fp k;
+    for (int i = 0; i < 12; i++) k.l[i] = FP_MONT_2POW8[i];
+    Fp t = mul(v, k);
+    return f28_unpack<1>(t.l);
+}
+// acc (Jacobian, may be infinity) += +-pt (affine) through xyzz28_madd
+void hs_g1_madd28(G1Jac *r, const G1Jac *acc_in, const G1Affine *pt, int negate) {
+    XYZZ28 acc;
+    bool inf = acc_in->is_inf();
+    if (!inf) {
+        G1XYZZ a = xyzz_from_jac(*acc_in);
+        acc.x = widen<1, 10>(f28_from_fp(a.x));
+        acc.y = widen<1, 6>(f28_from_fp(a.y));
+        acc.zz = f28_from_fp(a.zz);
+        acc.zzz = f28_from_fp(a.zzz);
+    }
+    xyzz28_madd(acc, inf, table_coord(pt->x), cneg_reduced(table_coord(pt->y), negate != 0));
+    *r = jac_from_xyzz(xyzz28_to_xyzz(acc, inf));
+}
+// many additions in a row, to exercise the value-bound bookkeeping over a long chain
+void hs_g1_madd28_chain(G1Jac *r, const G1Affine *pts, int n) {
+    XYZZ28 acc;
+    bool inf = true;
+    for (int i = 0; i < n; i++) xyzz28_madd(acc, inf, table_coord(pts[i].x), cneg_reduced(table_coord(pts[i].y), (i & 1) != 0));
+    *r = jac_from_xyzz(xyzz28_to_xyzz(acc, inf));
+}
+}

@@ -17,6 +17,7 @@
 // ~3000 integer multiply-adds per 96-byte gather: the kernel is VALU-bound, not HBM-bound.
 #include "device.hpp"
 #include "dev_inline.hpp"
+#include "g1_28.hpp"
 
 namespace ckzg {
 namespace dev {
@@ -78,7 +79,10 @@ __global__ void k_table_chain(G1XYZZ *tmp, const G1XYZZ *wb, int npoints, size_t
 }
 
 // Montgomery simultaneous inversion: each thread normalises a run of L points
-__global__ void k_batch_to_affine(G1Affine *out, const G1XYZZ *in, Fp *prefix, size_t n, int L) {
+// to392: store the coordinates multiplied by 2^8, i.e. in the 2^392 Montgomery domain that the
+// 28-bit-limb accumulate kernel works in (fp28.hpp); used for table entries only.
+__global__ void k_batch_to_affine(G1Affine *out, const G1XYZZ *in, Fp *prefix, size_t n, int L,
+                                  int to392) {
     size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     size_t b = t * (size_t)L;
     if (b >= n) return;
@@ -99,7 +103,15 @@ __global__ void k_batch_to_affine(G1Affine *out, const G1XYZZ *in, Fp *prefix, s
         Fp ti = mul(inv, prefix[k]);  // 1/zzz_k
         inv = mul(inv, p.zzz);
         Fp u = mul(p.zz, ti);  // 1/z
-        out[k] = {mul(p.x, sqr(u)), mul(p.y, ti)};
+        Fp ax = mul(p.x, sqr(u)), ay = mul(p.y, ti);
+        if (to392) {
+            Fp k8;
+#pragma unroll
+            for (int i = 0; i < 12; i++) k8.l[i] = FP_MONT_2POW8[i];
+            ax = mul(ax, k8);
+            ay = mul(ay, k8);
+        }
+        out[k] = {ax, ay};
     }
 }
 
@@ -109,7 +121,7 @@ int batch_to_affine_device(DeviceCtx *ctx, G1Affine *d_out, const G1XYZZ *d_in, 
     int L = n >= ((size_t)1 << 20) ? 128 : (n >= ((size_t)1 << 14) ? 16 : 4);
     size_t threads = (n + L - 1) / L;
     hipLaunchKernelGGL(k_batch_to_affine, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, ctx->stream,
-                       d_out, d_in, d_prefix, n, L);
+                       d_out, d_in, d_prefix, n, L, 0);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -138,7 +150,7 @@ int build_fixed_base_table(DeviceCtx *ctx, FixedBaseTable *t, const G1Affine *d_
         hipLaunchKernelGGL(k_table_chain, dim3((unsigned)((chain_threads + 63) / 64)), dim3(64), 0,
                            ctx->stream, d_tmp, d_wb + (size_t)w * npoints, npoints, t->half);
         hipLaunchKernelGGL(k_batch_to_affine, dim3((unsigned)((aff_threads + 63) / 64)), dim3(64), 0,
-                           ctx->stream, t->d_table + (size_t)w * slab, d_tmp, d_prefix, slab, L);
+                           ctx->stream, t->d_table + (size_t)w * slab, d_tmp, d_prefix, slab, L, 1);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -227,18 +239,30 @@ __global__ __launch_bounds__(THREADS) void k_msm_accumulate(
     const uint32_t q1 = q0 + pairs_per_block < pairs_per_vec ? q0 + pairs_per_block : pairs_per_vec;
     const uint32_t voff = (vec % vecs_per_group) * ppv;
     const int16_t *dg = digits + (size_t)vec * pairs_per_vec;
-    G1XYZZ acc = G1XYZZ::inf();
+    // accumulator in the 28-bit-limb / 2^392 domain (fp28.hpp), infinity tracked by a flag
+    XYZZ28 acc28;
+    bool inf = true;
     for (uint32_t q = q0 + threadIdx.x; q < q1; q += THREADS) {
         int d = dg[q];
         if (d != 0) {
             uint32_t w = q / ppv, i = q - w * ppv;
             size_t p = (size_t)w * npoints + voff + i;
             uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-            G1Affine pt = table[(p << half_shift) + (mag - 1)];
-            if (d < 0) pt.y = neg(pt.y);
-            xyzz_madd(acc, pt);
+            const uint4 *src = reinterpret_cast<const uint4 *>(table + ((p << half_shift) + (mag - 1)));
+            uint32_t wd[24];
+            uint32_t any = 0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                uint4 v = src[k];
+                wd[4 * k] = v.x; wd[4 * k + 1] = v.y; wd[4 * k + 2] = v.z; wd[4 * k + 3] = v.w;
+                any |= v.x | v.y | v.z | v.w;
+            }
+            if (any != 0) {  // (0,0) encodes a table entry at infinity
+                xyzz28_madd(acc28, inf, f28_unpack<1>(wd), cneg_reduced(f28_unpack<1>(wd + 12), d < 0));
+            }
         }
     }
+    G1XYZZ acc = xyzz28_to_xyzz(acc28, inf);
     block_reduce_xyzz<THREADS>(acc, sh);
     if (threadIdx.x == 0) partials[blockIdx.x] = acc;
 }

@@ -167,3 +167,90 @@ def test_pairing_and_sha(libs):
         assert out.raw == hashlib.sha256(m).digest()
         o.osha256(out, m, C.c_size_t(n))
         assert out.raw == hashlib.sha256(m).digest()
+
+
+# ---- 28-bit-limb device arithmetic (fp28.hpp, g1_28.hpp), host-compiled ----
+
+def test_fp28_field_ops_match_oracle(libs):
+    o, h = libs
+    rnd = random.Random(9)
+    edge = [0, 1, P - 1, P - 2, (P - 1) // 2, 2 ** 380, P - 3]
+    for k in range(400):
+        a = edge[k % 7] if k < 49 else rnd.randrange(P)
+        b = edge[(k // 7) % 7] if k < 49 else rnd.randrange(P)
+        ab, bb = a.to_bytes(48, "little"), b.to_bytes(48, "little")
+        r1, r2 = _buf(48), _buf(48)
+        o.ofp_mul(r1, ab, bb)
+        h.hs_fp28_mul(r2, ab, bb)
+        assert r1.raw == r2.raw
+        h.hs_fp28_roundtrip(r2, ab)
+        assert r2.raw == ab
+        o.ofp_sub(r1, ab, bb)
+        h.hs_fp28_sub(r2, ab, bb)
+        assert r1.raw == r2.raw
+        o.ofp_add(r1, ab, ab)
+        o.ofp_sub(r1, r1, bb)
+        h.hs_fp28_addchain(r2, ab, bb)
+        assert r1.raw == r2.raw
+
+
+def test_fp28_conditional_negation_top_limb_edge(libs):
+    # regression: a stored coordinate whose top 28-bit limb equals p's must negate correctly
+    o, h = libs
+    rnd = random.Random(1)
+    r392, r384 = pow(2, 392, P), pow(2, 384, P)
+    for k in range(600):
+        if k < 400:
+            t = ((P >> 364 << 364) - rnd.randrange(1 << 300) - 1) if k % 2 else (P - 1 - rnd.randrange(1 << 360))
+            a = (t % P) * pow(r392, -1, P) % P
+        else:
+            a = rnd.randrange(P)
+        b = rnd.randrange(P)
+        am, bm = (a * r384 % P).to_bytes(48, "little"), (b * r384 % P).to_bytes(48, "little")
+        for neg in (0, 1):
+            r = _buf(48)
+            h.hs_fp28_cneg_mul(r, am, bm, neg)
+            assert int.from_bytes(r.raw, "little") == ((-a if neg else a) * b % P) * r384 % P
+
+
+def test_xyzz28_mixed_addition_matches_oracle(libs):
+    o, h = libs
+    rnd = random.Random(11)
+    g = _buf(144)
+    h.hs_g1_generator(g)
+    inf = _buf(144)
+    for _ in range(8):
+        p1, p2 = _omul(o, g, rnd.randrange(R)), _omul(o, g, rnd.randrange(R))
+        a1, a2 = _buf(96), _buf(96)
+        o.og1_to_affine(a1, p1)
+        o.og1_to_affine(a2, p2)
+        n2 = _buf(144)
+        o.og1_neg(n2, p2)
+        for neg, other in ((0, p2), (1, n2)):
+            ref, r = _buf(144), _buf(144)
+            o.og1_add(ref, p1, other)
+            h.hs_g1_madd28(r, p1, a2, neg)
+            assert o.og1_equal(r, ref)
+        r = _buf(144)
+        h.hs_g1_madd28(r, inf, a2, 1)           # accumulator at infinity, negated point
+        assert o.og1_equal(r, n2)
+        d, r = _buf(144), _buf(144)
+        o.og1_dbl(d, p1)
+        h.hs_g1_madd28(r, p1, a1, 0)            # same point: doubling path
+        assert o.og1_equal(r, d)
+        r = _buf(144)
+        h.hs_g1_madd28(r, p1, a1, 1)            # P + (-P)
+        assert o.og1_is_inf(r)
+    n = 200
+    pts, ref = _buf(96 * n), _buf(144)
+    for i in range(n):
+        p = _omul(o, g, rnd.randrange(R))
+        a = _buf(96)
+        o.og1_to_affine(a, p)
+        pts[96 * i:96 * i + 96] = a.raw
+        if i & 1:
+            o.og1_neg(p, p)
+        o.og1_add(ref, ref, p)
+    r = _buf(144)
+    h.hs_g1_madd28_chain(r, pts, n)
+    assert o.og1_equal(r, ref)
