@@ -29,6 +29,12 @@ extern "C" C_KZG_RET ckzg_hip_set_option(const char *key, int64_t value) {
     } else if (!strcmp(key, "fk20_wbits")) {
         if (value != 0 && (value < 4 || value > 15)) return C_KZG_BADARGS;
         g_opts.fk20_wbits = (int)value;
+    } else if (!strcmp(key, "proof_wbits")) {
+        if (value != 0 && (value < 4 || value > 15)) return C_KZG_BADARGS;
+        g_opts.proof_wbits = (int)value;
+    } else if (!strcmp(key, "direct_max")) {
+        if (value < 0 || value > 4096) return C_KZG_BADARGS;
+        g_opts.direct_max = (int)value;
     } else {
         return C_KZG_BADARGS;
     }
@@ -324,5 +330,5 @@ extern "C" double ckzg_hip_last_kernel_ms(const KZGSettings *s, int which) {
 extern "C" uint64_t ckzg_hip_table_bytes(const KZGSettings *s) {
     dev::DeviceCtx *ctx = ctx_of(s);
     if (!ctx) return 0;
-    return ctx->commit.bytes() + ctx->fk20.bytes();
+    return ctx->commit.bytes() + ctx->fk20.bytes() + ctx->mono.bytes();
 }

@@ -40,6 +40,8 @@ struct DeviceCtx {
     hipStream_t stream = nullptr;
     std::mutex mu;
     FixedBaseTable commit;        // over g1_values_lagrange_brp (4096 points)
+    FixedBaseTable mono;          // over g1_values_monomial (4096 points): low-latency cell proofs
+    int direct_max = 32;          // batches up to this many blobs use the direct proof path
     Scratch scratch;              // reused by every call under `mu`
     hipEvent_t ev[8] = {};        // timing events
     float last_ms[4] = {-1, -1, -1, -1};
@@ -81,6 +83,9 @@ int commit_blobs_device(DeviceCtx *ctx, uint8_t *d_out48, uint8_t *d_status, con
 // points.  Used by compute_kzg_proof (quotient polynomial) and friends.
 int msm_commit_table_raw_device(DeviceCtx *ctx, uint8_t *d_out48, const uint32_t *d_scalars, size_t n);
 
+size_t msm_partials_needed(const FixedBaseTable &t, size_t nvec);
+int msm_from_digits_device(DeviceCtx *ctx, const FixedBaseTable &t, uint8_t *d_out48,
+                           const int16_t *d_digits, G1XYZZ *d_partials, size_t nvec);
 int msm_small_vectors_device(DeviceCtx *ctx, const FixedBaseTable &t, G1XYZZ *d_out,
                              const int16_t *d_digits, size_t nvec, uint32_t ppv,
                              uint32_t vecs_per_group);

@@ -20,6 +20,7 @@ void destroy_device_ctx(dev::DeviceCtx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->commit.d_table) (void)hipFree(ctx->commit.d_table);
     if (ctx->fk20.d_table) (void)hipFree(ctx->fk20.d_table);
+    if (ctx->mono.d_table) (void)hipFree(ctx->mono.d_table);
     if (ctx->d_xext) (void)hipFree(ctx->d_xext);
     if (ctx->d_roots) (void)hipFree(ctx->d_roots);
     if (ctx->d_brp_roots) (void)hipFree(ctx->d_brp_roots);
@@ -140,6 +141,19 @@ C_KZG_RET create_device_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affine,
         if (rc) {
             destroy_device_ctx(ctx);
             return (C_KZG_RET)rc;
+        }
+    }
+    // table over the monomial points for the low-latency (direct) cell-proof path
+    {
+        int wbits = env_int("CKZG_HIP_PROOF_WBITS", g_opts.proof_wbits);
+        ctx->direct_max = env_int("CKZG_HIP_DIRECT_MAX", g_opts.direct_max);
+        if (wbits != 0 && ctx->direct_max > 0) {
+            if (wbits < 4 || wbits > 15) wbits = 8;
+            int rc = dev::build_fixed_base_table(ctx, &ctx->mono, ctx->d_mono, (int)NUM_G1_POINTS, wbits);
+            if (rc) {
+                destroy_device_ctx(ctx);
+                return (C_KZG_RET)rc;
+            }
         }
     }
     header_of(s)->ctx = ctx;

@@ -336,6 +336,23 @@ int msm_small_vectors_device(DeviceCtx *ctx, const FixedBaseTable &t, G1XYZZ *d_
     return 0;
 }
 
+// Full-size MSMs (ppv == npoints) for nvec digit vectors already in HBM; writes nvec compressed
+// points.  d_partials must hold msm_partials_needed() XYZZ points.
+size_t msm_partials_needed(const FixedBaseTable &t, size_t nvec) {
+    uint32_t pairs_per_vec = (uint32_t)t.nwin * t.npoints;
+    uint32_t ppb = pick_pairs_per_block(nvec, pairs_per_vec);
+    return nvec * ((pairs_per_vec + ppb - 1) / ppb);
+}
+
+int msm_from_digits_device(DeviceCtx *ctx, const FixedBaseTable &t, uint8_t *d_out48,
+                           const int16_t *d_digits, G1XYZZ *d_partials, size_t nvec) {
+    if (nvec == 0) return 0;
+    if (!t.d_table) return 2;
+    uint32_t pairs_per_vec = (uint32_t)t.nwin * t.npoints;
+    uint32_t ppb = pick_pairs_per_block(nvec, pairs_per_vec);
+    return run_msm(ctx, t, d_out48, nullptr, d_digits, nullptr, d_partials, nvec, ppb);
+}
+
 int commit_blobs_device(DeviceCtx *ctx, uint8_t *d_out48, uint8_t *d_status, const uint8_t *d_blobs,
                         size_t n) {
     if (n == 0) return 0;

@@ -41,3 +41,18 @@ def hip():
     api = Kzg(HIP_SO, "", precompute=0)
     yield api
     api.close()
+
+
+@pytest.fixture(scope="session")
+def hip_fk20():
+    """Same library, loaded with the low-latency proof path disabled so that every
+    compute_cells_and_kzg_proofs / recover call takes the FK20 (G1 FFT) path."""
+    from kzg_ctypes import Kzg
+    if not os.path.exists(HIP_SO):
+        pytest.fail("libckzg_hip.so is not built")
+    api = Kzg(HIP_SO, "", precompute=0, options={"direct_max": 0, "commit_wbits": 8})
+    # restore the defaults for settings loaded later in the session
+    api.lib.ckzg_hip_set_option(b"direct_max", 32)
+    api.lib.ckzg_hip_set_option(b"commit_wbits", 10)
+    yield api
+    api.close()

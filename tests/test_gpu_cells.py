@@ -57,3 +57,22 @@ def test_batch_matches_single(hip):
         c, p = hip.compute_cells_and_kzg_proofs(blobs[i])
         assert b"".join(c) == cells.raw[i * 128 * 2048:(i + 1) * 128 * 2048]
         assert b"".join(p) == proofs.raw[i * 128 * 48:(i + 1) * 128 * 48]
+
+
+# ---- the FK20 (throughput) path, forced by direct_max = 0 ----
+
+@pytest.mark.parametrize("name", [n for n in G.case_names("compute_cells_and_kzg_proofs") if "valid" in n])
+def test_golden_cells_and_proofs_fk20_path(hip_fk20, name):
+    got, exp = G.run_case(hip_fk20, "compute_cells_and_kzg_proofs", name)
+    assert got == exp
+
+
+@pytest.mark.parametrize("name", [n for n in G.case_names("recover_cells_and_kzg_proofs") if "valid" in n])
+def test_golden_recover_fk20_path(hip_fk20, name):
+    got, exp = G.run_case(hip_fk20, "recover_cells_and_kzg_proofs", name)
+    assert got == exp
+
+
+def test_direct_and_fk20_paths_agree(hip, hip_fk20):
+    b = rand_blob(31, 0)
+    assert hip.compute_cells_and_kzg_proofs(b) == hip_fk20.compute_cells_and_kzg_proofs(b)

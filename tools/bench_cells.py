@@ -15,7 +15,9 @@ def main():
     mod = ge.load_package()
     fk = int(os.environ.get("FK20_WBITS", "8"))
     t0 = time.perf_counter()
-    hip = mod.Kzg(mod.HIP_SO, options={"commit_wbits": 8, "fk20_wbits": fk})
+    pw = int(os.environ.get("PROOF_WBITS", "13"))
+    hip = mod.Kzg(mod.HIP_SO, options={"commit_wbits": 8, "fk20_wbits": fk, "proof_wbits": pw,
+                                       "direct_max": int(os.environ.get("DIRECT_MAX", "32"))})
     print("load_trusted_setup_file: %.2f s (fk20_wbits=%d)" % (time.perf_counter() - t0, fk))
     blob = b"".join(b"\x00" + hashlib.sha256(b"c%d" % j).digest()[:31] for j in range(4096))
     hip.compute_cells_and_kzg_proofs(blob)
@@ -30,7 +32,7 @@ def main():
     f = hip.lib.ckzg_hip_compute_cells_and_kzg_proofs_batch
     f.restype = C.c_int
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p]
-    for n in (16, 128, 512):
+    for n in (4, 16, 32, 64, 128, 512):
         blobs = blob * n
         cells = C.create_string_buffer(n * 128 * 2048)
         proofs = C.create_string_buffer(n * 128 * 48)
