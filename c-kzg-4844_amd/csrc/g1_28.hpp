@@ -71,6 +71,88 @@ HD void xyzz28_madd(XYZZ28 &acc, bool &inf, const F28<1, 1> &x2, const F28<4, 2>
     acc.zzz = mul(acc.zzz, ppp);
 }
 
+// general doubling (dbl-2008-s-1)
+HD void xyzz28_dbl(XYZZ28 &a) {
+    auto u = add(a.y, a.y);                     // <2,12>
+    auto v = sqr(u);                            // 14*4+15 ok; 144 ok
+    auto w = mul(u, v);
+    auto s = mul(a.x, v);
+    auto x2 = sqr(a.x);                         // 100 ok
+    auto m = add(add(x2, x2), x2);              // <3,6>
+    auto mm = sqr(m);
+    auto x3 = norm(sub(mm, add(s, s)));         // <1,10>
+    auto d = sub(s, x3);                        // <4,18>
+    auto y3 = norm(sub(mul(m, d), mul(w, a.y))); // <1,6>
+    a.zz = mul(v, a.zz);
+    a.zzz = mul(w, a.zzz);
+    a.x = x3;
+    a.y = y3;
+}
+
+// a += b (add-2008-s), complete; ainf/binf are the infinity flags
+HD void xyzz28_add(XYZZ28 &a, bool &ainf, const XYZZ28 &b, bool binf) {
+    if (binf) return;
+    if (ainf) {
+        a = b;
+        ainf = false;
+        return;
+    }
+    auto u1 = mul(a.x, b.zz);
+    auto u2 = mul(b.x, a.zz);
+    auto s1 = mul(a.y, b.zzz);
+    auto s2 = mul(b.y, a.zzz);
+    auto p = sub(u2, u1);                       // <4,6>
+    auto r = sub(s2, s1);                       // <4,6>
+    auto pp = sqr(p);
+    if (is_zero(pp)) {
+        if (is_zero(mul(r, f28_one()))) {
+            xyzz28_dbl(a);
+        } else {
+            ainf = true;
+        }
+        return;
+    }
+    auto ppp = mul(p, pp);
+    auto q = mul(u1, pp);
+    auto rr = sqr(r);
+    auto x3 = norm(sub(rr, add(ppp, add(q, q))));   // <1,10>
+    auto d = sub(q, x3);                            // <4,18>
+    auto y3 = norm(sub(mul(r, d), mul(s1, ppp)));   // <1,6>
+    a.zz = mul(mul(a.zz, b.zz), pp);
+    a.zzz = mul(mul(a.zzz, b.zzz), ppp);
+    a.x = x3;
+    a.y = y3;
+}
+
+// into the 28-bit domain from fully reduced 2^384-domain coordinates
+HD XYZZ28 xyzz28_from_xyzz(const G1XYZZ &p, bool &inf) {
+    XYZZ28 r;
+    inf = p.is_inf();
+    r.x = widen<1, 10>(f28_from_fp(p.x));
+    r.y = widen<1, 6>(f28_from_fp(p.y));
+    r.zz = f28_from_fp(p.zz);
+    r.zzz = f28_from_fp(p.zzz);
+    return r;
+}
+
+// a^(p-2); plain square-and-multiply over the public exponent
+HDNI inline F28<1, 2> f28_inv(const F28<1, 2> &a) {
+    F28<1, 2> acc = widen<1, 2>(f28_one());
+    for (int i = 380; i >= 0; i--) {
+        acc = sqr(acc);
+        if ((FP_INV_EXP[i >> 5] >> (i & 31)) & 1u) acc = mul(acc, a);
+    }
+    return acc;
+}
+
+// affine coordinates (fully reduced, 2^384 domain) of a point in the 28-bit domain
+HDNI inline G1Affine xyzz28_to_affine(const XYZZ28 &a, bool inf) {
+    if (inf) return G1Affine::inf();
+    auto t = f28_inv(a.zzz);   // 1/z^3
+    auto u = mul(a.zz, t);     // 1/z
+    return {f28_to_fp(mul(a.x, sqr(u))), f28_to_fp(mul(a.y, t))};
+}
+
 // out of the 28-bit domain: fully reduced coordinates in the host/LDS representation
 HD G1XYZZ xyzz28_to_xyzz(const XYZZ28 &a, bool inf) {
     if (inf) return G1XYZZ::inf();

@@ -88,6 +88,12 @@ void hs_g1_madd28(G1Jac *r, const G1Jac *acc_in, const G1Affine *pt, int negate)
     xyzz28_madd(acc, inf, table_coord(pt->x), cneg_reduced(table_coord(pt->y), negate != 0));
     *r = jac_from_xyzz(xyzz28_to_xyzz(acc, inf));
 }
+void hs_g1_add28(G1Jac *r, const G1Jac *a, const G1Jac *b) {
+    bool ai, bi;
+    XYZZ28 x = xyzz28_from_xyzz(xyzz_from_jac(*a), ai), y = xyzz28_from_xyzz(xyzz_from_jac(*b), bi);
+    xyzz28_add(x, ai, y, bi);
+    *r = jac_from_affine(xyzz28_to_affine(x, ai));
+}
 // many additions in a row, to exercise the value-bound bookkeeping over a long chain
 void hs_g1_madd28_chain(G1Jac *r, const G1Affine *pts, int n) {
     XYZZ28 acc;

@@ -199,24 +199,25 @@ __global__ void k_raw_digits(int16_t *digits, const uint32_t *scalars, size_t to
 // accumulate: the dominant kernel
 // ------------------------------------------------------------------------------------------
 
-// Fold the per-thread XYZZ accumulators of a workgroup into thread 0.  LDS is limb-major
-// ([48][THREADS/2] u32) so that a wave's 64 lanes hit 64 consecutive banks.
+// Fold the per-thread accumulators (28-bit domain) of a workgroup into thread 0.  LDS is
+// limb-major ([56 limbs + infinity flag][THREADS/2] u32) so a wave's lanes hit consecutive banks.
 template <int THREADS>
-__device__ __forceinline__ void block_reduce_xyzz(G1XYZZ &acc, uint32_t (*sh)[THREADS / 2]) {
+__device__ __forceinline__ void block_reduce_xyzz28(XYZZ28 &acc, bool &inf, uint32_t (*sh)[THREADS / 2]) {
     const int tid = threadIdx.x;
     for (int s = THREADS / 2; s >= 1; s >>= 1) {
         if (tid >= s && tid < 2 * s) {
             const uint32_t *src = reinterpret_cast<const uint32_t *>(&acc);
 #pragma unroll
-            for (int k = 0; k < 48; k++) sh[k][tid - s] = src[k];
+            for (int k = 0; k < 56; k++) sh[k][tid - s] = src[k];
+            sh[56][tid - s] = inf ? 1u : 0u;
         }
         __syncthreads();
         if (tid < s) {
-            G1XYZZ o;
+            XYZZ28 o;
             uint32_t *dst = reinterpret_cast<uint32_t *>(&o);
 #pragma unroll
-            for (int k = 0; k < 48; k++) dst[k] = sh[k][tid];
-            acc = xyzz_add(acc, o);
+            for (int k = 0; k < 56; k++) dst[k] = sh[k][tid];
+            xyzz28_add(acc, inf, o, sh[56][tid] != 0);
         }
         __syncthreads();
     }
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(THREADS) void k_msm_accumulate(
     G1XYZZ *partials, const G1Affine *table, const int16_t *digits, uint32_t pairs_per_vec,
     uint32_t pairs_per_block, int half_shift, uint32_t blocks_per_vec, uint32_t ppv,
     uint32_t npoints, uint32_t vecs_per_group) {
-    __shared__ uint32_t sh[48][THREADS / 2];
+    __shared__ uint32_t sh[57][THREADS / 2];
     const uint32_t vec = blockIdx.x / blocks_per_vec, chunk = blockIdx.x % blocks_per_vec;
     const uint32_t q0 = chunk * pairs_per_block;
     const uint32_t q1 = q0 + pairs_per_block < pairs_per_vec ? q0 + pairs_per_block : pairs_per_vec;
@@ -262,19 +263,45 @@ __global__ __launch_bounds__(THREADS) void k_msm_accumulate(
             }
         }
     }
-    G1XYZZ acc = xyzz28_to_xyzz(acc28, inf);
-    block_reduce_xyzz<THREADS>(acc, sh);
-    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+    block_reduce_xyzz28<THREADS>(acc28, inf, sh);
+    if (threadIdx.x == 0) partials[blockIdx.x] = xyzz28_to_xyzz(acc28, inf);
 }
 
-// One thread per vector: fold the per-workgroup partials, normalise, compress (bytes.c:42-44).
-__global__ void k_msm_finalize(uint8_t *out48, uint8_t *status, const G1XYZZ *partials,
-                               const uint32_t *bad, uint32_t blocks_per_vec, size_t n) {
+// Fold many per-workgroup partials of one vector into one: a 64-lane workgroup per vector,
+// lane-parallel accumulation then an LDS tree.  Only used when a vector has more than a few
+// partials (small batches that were split finely to fill the chip).
+__global__ __launch_bounds__(64) void k_msm_reduce_partials(G1XYZZ *sums, const G1XYZZ *partials,
+                                                           uint32_t blocks_per_vec) {
+    __shared__ uint32_t sh[57][32];
+    const size_t v = blockIdx.x;
+    const int tid = threadIdx.x;
+    XYZZ28 acc;
+    bool inf = true;
+    for (uint32_t j = tid; j < blocks_per_vec; j += 64) {
+        bool oinf;
+        XYZZ28 o = xyzz28_from_xyzz(partials[v * blocks_per_vec + j], oinf);
+        xyzz28_add(acc, inf, o, oinf);
+    }
+    block_reduce_xyzz28<64>(acc, inf, sh);
+    if (tid == 0) sums[v] = xyzz28_to_xyzz(acc, inf);
+}
+
+// One LANE per vector, packed into full waves: sum the (few) partials, normalise with a Fermat
+// inversion, compress (bytes.c:42-44).  Measured (tools/ubench/inv_bench.hip): 1024 inversions
+// take 0.80 ms as 16 dense waves but 1.8-3.1 ms as 1024 single-lane waves, so the inversions are
+// packed even though that serialises the short partial sum.
+__global__ __launch_bounds__(64) void k_msm_finalize(uint8_t *out48, uint8_t *status, const G1XYZZ *partials,
+                                                    const uint32_t *bad, uint32_t blocks_per_vec, size_t n) {
     size_t v = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (v >= n) return;
-    G1XYZZ acc = partials[v * blocks_per_vec];
-    for (uint32_t j = 1; j < blocks_per_vec; j++) acc = xyzz_add(acc, partials[v * blocks_per_vec + j]);
-    G1Affine a = xyzz_to_affine(acc);
+    XYZZ28 acc;
+    bool inf = true;
+    for (uint32_t j = 0; j < blocks_per_vec; j++) {
+        bool oinf;
+        XYZZ28 o = xyzz28_from_xyzz(partials[v * blocks_per_vec + j], oinf);
+        xyzz28_add(acc, inf, o, oinf);
+    }
+    G1Affine a = xyzz28_to_affine(acc, inf);
     uint8_t buf[48];
     g1_compress_affine(buf, a);
     for (int k = 0; k < 48; k++) out48[v * 48 + k] = buf[k];
@@ -303,8 +330,17 @@ static int run_msm(DeviceCtx *ctx, const FixedBaseTable &t, uint8_t *d_out48, ui
                        d_partials, t.d_table, d_digits, pairs_per_vec, ppb, t.wbits - 1, bpv,
                        (uint32_t)t.npoints, (uint32_t)t.npoints, 1u);
     HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
-    hipLaunchKernelGGL(k_msm_finalize, dim3((unsigned)((nvec + 63) / 64)), dim3(64), 0, ctx->stream,
-                       d_out48, d_status, d_partials, d_bad, bpv, nvec);
+    if (bpv > 8) {
+        // partials[nvec*bpv ..] is free: run_msm callers size d_partials for nvec*bpv + nvec
+        G1XYZZ *d_sums = d_partials + nvec * (size_t)bpv;
+        hipLaunchKernelGGL(k_msm_reduce_partials, dim3((unsigned)nvec), dim3(64), 0, ctx->stream, d_sums,
+                           d_partials, bpv);
+        hipLaunchKernelGGL(k_msm_finalize, dim3((unsigned)((nvec + 63) / 64)), dim3(64), 0, ctx->stream,
+                           d_out48, d_status, d_sums, d_bad, 1u, nvec);
+    } else {
+        hipLaunchKernelGGL(k_msm_finalize, dim3((unsigned)((nvec + 63) / 64)), dim3(64), 0, ctx->stream,
+                           d_out48, d_status, d_partials, d_bad, bpv, nvec);
+    }
     HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
     HIP_TRY(hipGetLastError());
     return 0;
@@ -341,7 +377,7 @@ int msm_small_vectors_device(DeviceCtx *ctx, const FixedBaseTable &t, G1XYZZ *d_
 size_t msm_partials_needed(const FixedBaseTable &t, size_t nvec) {
     uint32_t pairs_per_vec = (uint32_t)t.nwin * t.npoints;
     uint32_t ppb = pick_pairs_per_block(nvec, pairs_per_vec);
-    return nvec * ((pairs_per_vec + ppb - 1) / ppb);
+    return nvec * ((pairs_per_vec + ppb - 1) / ppb) + nvec;
 }
 
 int msm_from_digits_device(DeviceCtx *ctx, const FixedBaseTable &t, uint8_t *d_out48,
@@ -363,7 +399,7 @@ int commit_blobs_device(DeviceCtx *ctx, uint8_t *d_out48, uint8_t *d_status, con
     uint32_t bpv = (pairs_per_vec + ppb - 1) / ppb;
     size_t dig_bytes = align_up(n * (size_t)pairs_per_vec * sizeof(int16_t), 256);
     size_t bad_bytes = align_up(n * sizeof(uint32_t), 256);
-    size_t part_bytes = align_up(n * (size_t)bpv * sizeof(G1XYZZ), 256);
+    size_t part_bytes = align_up(n * ((size_t)bpv + 1) * sizeof(G1XYZZ), 256);
     int rc = scratch_reserve(ctx, dig_bytes + bad_bytes + part_bytes);
     if (rc) return rc;
     uint8_t *base = static_cast<uint8_t *>(ctx->scratch.ptr);
@@ -390,7 +426,7 @@ int msm_commit_table_raw_device(DeviceCtx *ctx, uint8_t *d_out48, const uint32_t
     uint32_t ppb = pick_pairs_per_block(n, pairs_per_vec);
     uint32_t bpv = (pairs_per_vec + ppb - 1) / ppb;
     size_t dig_bytes = align_up(n * (size_t)pairs_per_vec * sizeof(int16_t), 256);
-    size_t part_bytes = align_up(n * (size_t)bpv * sizeof(G1XYZZ), 256);
+    size_t part_bytes = align_up(n * ((size_t)bpv + 1) * sizeof(G1XYZZ), 256);
     int rc = scratch_reserve(ctx, dig_bytes + part_bytes);
     if (rc) return rc;
     uint8_t *base = static_cast<uint8_t *>(ctx->scratch.ptr);
