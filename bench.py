@@ -20,6 +20,10 @@ sys.path.insert(0, ROOT)
 BLOBS_PER_STEP = 1024
 ALGO_BYTES_PER_BLOB = 131072 + 48  # scalars in + commitment out
 HBM_PEAK_GBS = 8000.0
+# HBM bytes per k_msm_accumulate launch (1024 blobs) from rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
+# KB units), see profiles/README.md; keyed by table window width.  The traffic is the table gathers
+# themselves (nwin*4096 x 96 B per blob), not re-reads of the algorithmic bytes.
+PMC_TRAFFIC_BYTES = {13: (7658816 + 960) * 1024, 15: (6796321 + 960) * 1024}
 
 
 def cpu_baseline(seconds_budget=12.0):
@@ -51,8 +55,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--wbits", type=int, default=int(os.environ.get("CKZG_BENCH_WBITS", "13")))
+    ap.add_argument("--wbits", type=int, default=int(os.environ.get("CKZG_BENCH_WBITS", "15")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -68,7 +73,8 @@ def main():
 
     import __graft_entry__ as ge
     mod = ge.load_package()
-    hip = mod.Kzg(mod.HIP_SO, options={"device": local_rank, "commit_wbits": args.wbits})
+    hip = mod.Kzg(mod.HIP_SO, options={"device": local_rank, "commit_wbits": args.wbits, "proof_wbits": 13,
+                                       "fk20_wbits": 8})
     lib = hip.lib
     fn = lib.ckzg_hip_blob_to_kzg_commitment_batch_device
     fn.restype = C.c_int
@@ -144,6 +150,38 @@ def main():
         if parity is False:
             raise SystemExit("bench: GPU commitments differ from the oracle -- number would be invalid")
 
+    # secondary metric of BASELINE.json: compute_cells_and_kzg_proofs (configs[2]), rank 0 only
+    secondary = None
+    if rank == 0 and world == 1 and not args.no_secondary:
+        fc = lib.ckzg_hip_compute_cells_and_kzg_proofs_batch_device
+        fc.restype = C.c_int
+        fc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        nb = 512
+        cells = torch.empty((nb, 128, 2048), dtype=torch.uint8, device=dev)
+        proofs = torch.empty((nb, 128, 48), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+
+        def run(n):
+            rc = fc(cells.data_ptr(), proofs.data_ptr(), status.data_ptr(), blobs.data_ptr(), n, C.addressof(hip.s))
+            if rc != 0:
+                raise RuntimeError("cells+proofs failed rc=%d" % rc)
+
+        run(1)
+        ts = []
+        for _ in range(10):
+            t1 = time.perf_counter()
+            run(1)
+            ts.append(time.perf_counter() - t1)
+        ts.sort()
+        run(nb)
+        t1 = time.perf_counter()
+        run(nb)
+        tb = time.perf_counter() - t1
+        secondary = {"compute_cells_and_kzg_proofs_ms_per_call_1blob": round(ts[len(ts) // 2] * 1e3, 3),
+                     "compute_cells_and_kzg_proofs_batch512_blobs_per_s": round(nb / tb, 1),
+                     "note": "1 blob: low-latency path (128 fixed-base MSMs, no G1 FFT); batch: FK20 path; "
+                             "inputs/outputs resident in HBM"}
+
     if rank == 0:
         total_blobs = BLOBS_PER_STEP * args.steps * world
         value = total_blobs / dt
@@ -160,11 +198,12 @@ def main():
                        "table_wbits": args.wbits, "table_bytes": int(lib.ckzg_hip_table_bytes(C.addressof(hip.s))),
                        "parallelism": "independent blob shards per GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": PMC_TRAFFIC_BYTES.get(args.wbits),
                          "kernel": "k_msm_accumulate", "kernel_ms": round(avg_k * 1e3, 3),
                          "note": "integer-VALU-bound kernel (v_mad_u64_u32 chains); HBM fraction is small by nature"},
             "pcie_inclusive_blobs_per_s": None if pcie_rate is None else round(pcie_rate, 2),
             "parity_spot_check_vs_oracle": parity,
+            "secondary": secondary,
         }
         if not args.no_cpu_baseline and world == 1:
             try:
