@@ -41,7 +41,7 @@ struct DeviceCtx {
     std::mutex mu;
     FixedBaseTable commit;        // over g1_values_lagrange_brp (4096 points)
     FixedBaseTable mono;          // over g1_values_monomial (4096 points): low-latency cell proofs
-    int direct_max = 32;          // batches up to this many blobs use the direct proof path
+    int direct_max = 24;          // batches up to this many blobs use the direct proof path
     Scratch scratch;              // reused by every call under `mu`
     hipEvent_t ev[8] = {};        // timing events
     float last_ms[4] = {-1, -1, -1, -1};

@@ -14,6 +14,7 @@
 // The two G1 transforms use the DIF/DIT pair so that, as for Fr, no permutation pass exists.
 #include "device.hpp"
 #include "dev_inline.hpp"
+#include "g1_28.hpp"
 
 namespace ckzg {
 namespace dev {
@@ -76,54 +77,48 @@ __global__ void k_fk20_digits(int16_t *digits, const Fr *cfft, size_t total, int
 // G1 FFT of size 128: one 64-lane workgroup per transform, points in LDS (limb-major)
 // ------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ G1XYZZ pt_get(uint32_t (*sh)[128], int idx) {
-    G1XYZZ r;
+// points live in LDS in the 28-bit-limb domain: 56 limbs + an infinity flag, limb-major
+__device__ __forceinline__ XYZZ28 pt_get(uint32_t (*sh)[128], int idx, bool &inf) {
+    XYZZ28 r;
     uint32_t *d = reinterpret_cast<uint32_t *>(&r);
 #pragma unroll
-    for (int k = 0; k < 48; k++) d[k] = sh[k][idx];
+    for (int k = 0; k < 56; k++) d[k] = sh[k][idx];
+    inf = sh[56][idx] != 0;
     return r;
 }
 
-__device__ __forceinline__ void pt_put(uint32_t (*sh)[128], int idx, const G1XYZZ &v) {
+__device__ __forceinline__ void pt_put(uint32_t (*sh)[128], int idx, const XYZZ28 &v, bool inf) {
     const uint32_t *s = reinterpret_cast<const uint32_t *>(&v);
 #pragma unroll
-    for (int k = 0; k < 48; k++) sh[k][idx] = s[k];
+    for (int k = 0; k < 56; k++) sh[k][idx] = s[k];
+    sh[56][idx] = inf ? 1u : 0u;
 }
 
-// [k]P for a 255-bit k (canonical little-endian limbs), fixed 4-bit windows: every lane executes
-// the same 4-doublings-then-add schedule, so lanes with different scalars do not diverge.
-__device__ __noinline__ G1XYZZ xyzz_mul_w4(const G1XYZZ &p, const uint32_t *k) {
-    G1XYZZ tbl[15];
-    tbl[0] = p;
-    tbl[1] = xyzz_dbl(p);
-    for (int i = 2; i < 15; i++) tbl[i] = xyzz_add(tbl[i - 1], p);
-    G1XYZZ acc = G1XYZZ::inf();
-    for (int w = 63; w >= 0; w--) {
-        if (w != 63) {
-            acc = xyzz_dbl(acc);
-            acc = xyzz_dbl(acc);
-            acc = xyzz_dbl(acc);
-            acc = xyzz_dbl(acc);
-        }
-        uint32_t d = (k[w >> 3] >> ((w & 7) * 4)) & 15u;
-        if (d) acc = xyzz_add(acc, tbl[d - 1]);
-    }
-    return acc;
+__device__ __noinline__ void g1_mul_root(XYZZ28 &p, bool &inf, const uint32_t *k) {
+    XYZZ28 o;
+    bool oi;
+    xyzz28_mul_w4(o, oi, p, inf, k);
+    p = o;
+    inf = oi;
 }
 
 // roots_raw[i] = canonical limbs of w^i, i = 0..8192.
 // DIF: natural in -> bit-reversed out; DIT: bit-reversed in -> natural out (fft.c:164-185 computes
 // the same butterflies recursively).  zero_odd: after a DIF, clear the odd positions, i.e. the
 // entries whose natural index is >= 64 (fk20.c:264-266).  out_brp: after a DIT, store element k
-// at position brp7(k) (eip7594.c:133).
+// at position brp7(k) (eip7594.c:133).  Arithmetic: fp28.hpp / g1_28.hpp.
 template <bool DIF>
 __global__ __launch_bounds__(64) void k_g1_fft128(G1XYZZ *data, const uint32_t *roots_raw,
                                                   int inverse, int zero_odd, int out_brp) {
-    __shared__ uint32_t sh[48][128];
+    __shared__ uint32_t sh[57][128];
     G1XYZZ *vec = data + (size_t)blockIdx.x * 128;
     const int tid = threadIdx.x;
-    pt_put(sh, tid, vec[tid]);
-    pt_put(sh, tid + 64, vec[tid + 64]);
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        bool inf;
+        XYZZ28 p = xyzz28_from_xyzz(vec[tid + 64 * r], inf);
+        pt_put(sh, tid + 64 * r, p, inf);
+    }
     __syncthreads();
     for (int st = 0; st < 7; st++) {
         int s = DIF ? 7 - st : st + 1;
@@ -131,30 +126,28 @@ __global__ __launch_bounds__(64) void k_g1_fft128(G1XYZZ *data, const uint32_t *
         int j = tid & (half - 1);
         int i0 = ((tid >> (s - 1)) << s) + j;
         int i1 = i0 + half;
-        G1XYZZ u = pt_get(sh, i0), v = pt_get(sh, i1);
+        bool ui, vi;
+        XYZZ28 u = pt_get(sh, i0, ui), v = pt_get(sh, i1, vi);
         int ridx = j * (N_EXT / (2 * half));
         if (inverse) ridx = N_EXT - ridx;
         const uint32_t *k = roots_raw + (size_t)ridx * 8;
-        G1XYZZ x, y;
-        if (DIF) {
-            x = xyzz_add(u, v);
-            y = xyzz_add(u, xyzz_neg(v));
-            if (j != 0) y = xyzz_mul_w4(y, k);
-        } else {
-            if (j != 0) v = xyzz_mul_w4(v, k);
-            x = xyzz_add(u, v);
-            y = xyzz_add(u, xyzz_neg(v));
-        }
-        pt_put(sh, i0, x);
-        pt_put(sh, i1, y);
+        if (!DIF && j != 0) g1_mul_root(v, vi, k);
+        XYZZ28 x = u, y = u;
+        bool xi = ui, yi = ui;
+        xyzz28_add(x, xi, v, vi);
+        xyzz28_add(y, yi, xyzz28_neg(v), vi);
+        if (DIF && j != 0) g1_mul_root(y, yi, k);
+        pt_put(sh, i0, x, xi);
+        pt_put(sh, i1, y, yi);
         __syncthreads();
     }
 #pragma unroll
     for (int r = 0; r < 2; r++) {
         int idx = tid + 64 * r;
-        G1XYZZ v = pt_get(sh, idx);
-        if (zero_odd && (idx & 1)) v = G1XYZZ::inf();
-        vec[out_brp ? brp7((uint32_t)idx) : idx] = v;
+        bool inf;
+        XYZZ28 v = pt_get(sh, idx, inf);
+        if (zero_odd && (idx & 1)) inf = true;
+        vec[out_brp ? brp7((uint32_t)idx) : idx] = xyzz28_to_xyzz(v, inf);
     }
 }
 

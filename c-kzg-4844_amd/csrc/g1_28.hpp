@@ -135,6 +135,49 @@ HD XYZZ28 xyzz28_from_xyzz(const G1XYZZ &p, bool &inf) {
     return r;
 }
 
+// -a (one multiplication by -1: keeps the coordinate inside its value bound)
+HD XYZZ28 xyzz28_neg(const XYZZ28 &a) {
+    F28<1, 0> zero;
+#pragma unroll
+    for (int j = 0; j < 14; j++) zero.l[j] = 0;
+    auto minus_one = sub(zero, f28_one());      // <4,2>
+    XYZZ28 r = a;
+    r.y = widen<1, 6>(mul(a.y, minus_one));
+    return r;
+}
+
+// [k]P for a 255-bit k (canonical little-endian u32 limbs), fixed 4-bit windows: every lane runs
+// the same 4 doublings + 1 table addition per window, so lanes with different scalars stay in step.
+HDNI inline void xyzz28_mul_w4(XYZZ28 &out, bool &out_inf, const XYZZ28 &p, bool p_inf, const uint32_t *k) {
+    XYZZ28 tbl[15];
+    uint32_t tinf = 0;  // bit i: (i+1)*P is infinity (possible for untrusted points of small order)
+    XYZZ28 acc;
+    bool inf = true;
+    if (!p_inf) {
+        tbl[0] = p;
+        tbl[1] = p;
+        xyzz28_dbl(tbl[1]);  // E(Fp) has odd order: doubling a finite point never gives infinity
+        for (int i = 2; i < 15; i++) {
+            tbl[i] = tbl[i - 1];
+            bool ti = ((tinf >> (i - 1)) & 1u) != 0;
+            xyzz28_add(tbl[i], ti, p, false);
+            if (ti) tinf |= 1u << i;
+        }
+        for (int w = 63; w >= 0; w--) {
+            if (!inf) {
+                xyzz28_dbl(acc);
+                xyzz28_dbl(acc);
+                xyzz28_dbl(acc);
+                xyzz28_dbl(acc);
+            }
+            uint32_t d = (k[w >> 3] >> ((w & 7) * 4)) & 15u;
+            if (d) xyzz28_add(acc, inf, tbl[d - 1], ((tinf >> (d - 1)) & 1u) != 0);
+        }
+    }
+    out = acc;
+    out_inf = inf;
+}
+
 // a^(p-2); plain square-and-multiply over the public exponent
 HDNI inline F28<1, 2> f28_inv(const F28<1, 2> &a) {
     F28<1, 2> acc = widen<1, 2>(f28_one());

@@ -94,6 +94,17 @@ void hs_g1_add28(G1Jac *r, const G1Jac *a, const G1Jac *b) {
     xyzz28_add(x, ai, y, bi);
     *r = jac_from_affine(xyzz28_to_affine(x, ai));
 }
+void hs_g1_mul28(G1Jac *r, const G1Jac *a, const uint32_t *k) {
+    bool ai, oi;
+    XYZZ28 x = xyzz28_from_xyzz(xyzz_from_jac(*a), ai), o;
+    xyzz28_mul_w4(o, oi, x, ai, k);
+    *r = jac_from_affine(xyzz28_to_affine(o, oi));
+}
+void hs_g1_neg28(G1Jac *r, const G1Jac *a) {
+    bool ai;
+    XYZZ28 x = xyzz28_from_xyzz(xyzz_from_jac(*a), ai);
+    *r = jac_from_affine(xyzz28_to_affine(xyzz28_neg(x), ai));
+}
 // many additions in a row, to exercise the value-bound bookkeeping over a long chain
 void hs_g1_madd28_chain(G1Jac *r, const G1Affine *pts, int n) {
     XYZZ28 acc;

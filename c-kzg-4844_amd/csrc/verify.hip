@@ -9,6 +9,7 @@
 //   * element-wise Fr helpers used by recover_cells (src/eip7594/recovery.c:281,322-328)
 #include "device.hpp"
 #include "dev_inline.hpp"
+#include "g1_28.hpp"
 
 namespace ckzg {
 namespace dev {
@@ -123,23 +124,17 @@ int eval_poly_batch_device(DeviceCtx *ctx, Fr *d_y, const Fr *d_poly, const Fr *
 // status: 0 ok, 1 invalid (bad encoding / not on curve / not in the r-torsion subgroup)
 // ------------------------------------------------------------------------------------------
 
-__device__ __noinline__ G1XYZZ xyzz_mul_w4_dev(const G1XYZZ &p, const uint32_t *k) {
-    G1XYZZ tbl[15];
-    tbl[0] = p;
-    tbl[1] = xyzz_dbl(p);
-    for (int i = 2; i < 15; i++) tbl[i] = xyzz_add(tbl[i - 1], p);
-    G1XYZZ acc = G1XYZZ::inf();
-    for (int w = 63; w >= 0; w--) {
-        if (w != 63) {
-            acc = xyzz_dbl(acc);
-            acc = xyzz_dbl(acc);
-            acc = xyzz_dbl(acc);
-            acc = xyzz_dbl(acc);
-        }
-        uint32_t d = (k[w >> 3] >> ((w & 7) * 4)) & 15u;
-        if (d) acc = xyzz_add(acc, tbl[d - 1]);
-    }
-    return acc;
+// [k]P for an affine P through the 28-bit-limb windowed ladder (g1_28.hpp); result in the
+// fully reduced 2^384-domain XYZZ form
+__device__ __noinline__ G1XYZZ affine_mul_w4(const G1Affine &a, const uint32_t *k) {
+    XYZZ28 p, o;
+    bool oi;
+    p.x = widen<1, 10>(f28_from_fp(a.x));
+    p.y = widen<1, 6>(f28_from_fp(a.y));
+    p.zz = widen<1, 2>(f28_one());
+    p.zzz = p.zz;
+    xyzz28_mul_w4(o, oi, p, a.is_inf(), k);
+    return xyzz28_to_xyzz(o, oi);
 }
 
 __global__ void k_validate_g1(G1Affine *out, uint8_t *status, const uint8_t *in48, size_t n) {
@@ -154,7 +149,7 @@ __global__ void k_validate_g1(G1Affine *out, uint8_t *status, const uint8_t *in4
         uint32_t r[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) r[k] = FR_R[k];
-        G1XYZZ t = xyzz_mul_w4_dev(xyzz_from_affine(a), r);
+        G1XYZZ t = affine_mul_w4(a, r);
         if (!t.is_inf()) st = 1;
     }
     if (st) a = G1Affine::inf();
@@ -187,7 +182,7 @@ __global__ __launch_bounds__(LC_THREADS) void k_lincomb_partial(G1XYZZ *partials
 #pragma unroll
         for (int i = 0; i < 8; i++) k[i] = scalars[g * 8 + i];
         G1Affine a = pts[g];
-        if (!a.is_inf()) acc = xyzz_mul_w4_dev(xyzz_from_affine(a), k);
+        if (!a.is_inf()) acc = affine_mul_w4(a, k);
     }
     const int tid = threadIdx.x;
     for (int s = LC_THREADS / 2; s >= 1; s >>= 1) {

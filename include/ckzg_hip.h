@@ -27,7 +27,7 @@ extern "C" {
  *   "fk20_wbits"    window width of the FK20 fixed-base tables (8192 points); default: max(8, precompute)
  *   "proof_wbits"   window width of the table over the 4096 monomial points used by the low-latency
  *                   (no G1 FFT) cell-proof path; default 8 (1.6 GB), 0 disables the path
- *   "direct_max"    largest batch that takes the low-latency proof path (default 32; larger batches
+ *   "direct_max"    largest batch that takes the low-latency proof path (default 24; larger batches
  *                   use FK20, which does ~10x fewer point additions but has a long dependency chain)
  * Returns C_KZG_BADARGS for an unknown key or out-of-range value. */
 C_KZG_RET ckzg_hip_set_option(const char *key, int64_t value);
