@@ -61,6 +61,16 @@ inline dev::DeviceCtx *ctx_of(const KZGSettings *s) {
     return h->ctx;
 }
 
+// line tables of the three G2 constants that appear in verification equations
+struct PreparedG2 {
+    host::G2Prepared gen;     // [1]_2
+    host::G2Prepared s1;      // [s]_2      = g2_values_monomial[1]
+    host::G2Prepared s64;     // [s^64]_2   = g2_values_monomial[64]
+};
+inline const PreparedG2 *prepared_of(const dev::DeviceCtx *ctx) {
+    return static_cast<const PreparedG2 *>(ctx->host_prepared);
+}
+
 // implemented in device_ctx.hip
 C_KZG_RET create_device_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affine,
                             const G1Affine *monomial_affine);

@@ -3,6 +3,7 @@
 // glue (transcripts, argument checks, the final two-pairing check); every MSM, NTT, polynomial
 // evaluation and point validation is dispatched to the kernels in msm.hip / ntt.hip / fk20.hip /
 // verify.hip.
+#include <chrono>
 #include <functional>
 #include <thread>
 
@@ -13,6 +14,21 @@ using namespace ckzg::host;
 using namespace ckzg::api;
 
 namespace {
+
+// CKZG_HIP_TRACE=1 prints a per-phase wall-clock breakdown of the verification calls to stderr
+struct Trace {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    const char *what;
+    explicit Trace(const char *w) : on(getenv("CKZG_HIP_TRACE") != nullptr), t0(std::chrono::steady_clock::now()), what(w) {}
+    void mark(const char *phase) {
+        if (!on) return;
+        auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[ckzg-hip trace] %s: %s %.3f ms\n", what, phase,
+                std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 
 template <class T>
 struct DBuf {
@@ -126,13 +142,13 @@ Fr challenge_from_bytes(const uint8_t *blob, const uint8_t *commitment48) {
     return fr_from_bytes_reduce(out);
 }
 
-// e(C - [y]G1, G2) == e(proof, [s]G2 - [z]G2)   (eip4844.c:359-383)
+// The reference checks e(C - [y]G1, G2) == e(proof, [s]G2 - [z]G2) (eip4844.c:359-383).  Moving
+// [z]proof to the G1 side gives the equivalent e(C - [y]G1 + [z]proof, G2) == e(proof, [s]G2),
+// whose G2 arguments are setup constants with precomputed line tables (host_pairing.hpp).
 bool verify_kzg_proof_impl(const G1Jac &commitment, const Fr &z, const Fr &y, const G1Jac &proof,
-                           const KZGSettings *s) {
-    RawScalar zr = raw_of(z);
-    G2Jac x_minus_z = g2_add(*as_g2(&s->g2_values_monomial[1]), g2_neg(g2_mul(g2_generator(), zr.l, 255)));
-    G1Jac p_minus_y = jac_add(commitment, jac_neg(g1_mul_fr(g1_generator(), y)));
-    return pairings_verify(p_minus_y, g2_generator(), proof, x_minus_z);
+                           const PreparedG2 *pg) {
+    G1Jac lhs = jac_add(jac_add(commitment, jac_neg(g1_mul_fr(g1_generator(), y))), g1_mul_fr(proof, z));
+    return pairing_product_is_one(jac_to_affine(lhs), pg->gen, jac_to_affine(jac_neg(proof)), pg->s1);
 }
 
 // quotient polynomial and its commitment (eip4844.c:417-494); the 4096-term MSM runs on the GPU
@@ -203,21 +219,62 @@ void parallel_for(size_t n, const std::function<void(size_t)> &fn) {
 
 G1Jac jac_of_affine_bytes(const G1Affine &a) { return jac_from_affine(a); }
 
-// One GPU lincomb: sum_i k_i P_i over points already on the device
-C_KZG_RET gpu_lincomb(dev::DeviceCtx *ctx, G1Jac &out, const G1Affine *d_pts, const std::vector<RawScalar> &k) {
-    size_t n = k.size();
+// Several variable-base lincombs sum_i k_i P_i in ONE launch.  Job j takes n points starting at
+// d_pts + pt_off[j] and its own scalar vector; every job is padded to a multiple of 64 lanes so
+// that a workgroup's partial sum belongs to exactly one job.
+struct LincombJob {
+    const G1Affine *d_pts;
+    const std::vector<RawScalar> *k;
+};
+
+C_KZG_RET gpu_lincomb_multi(dev::DeviceCtx *ctx, G1Jac *outs, const LincombJob *jobs, int njobs) {
+    size_t total = 0;
+    std::vector<size_t> off(njobs), nb(njobs);
+    for (int j = 0; j < njobs; j++) {
+        off[j] = total;
+        nb[j] = (jobs[j].k->size() + 63) / 64;
+        if (nb[j] == 0) nb[j] = 1;
+        total += nb[j] * 64;
+    }
     DBuf<RawScalar> d_k;
+    DBuf<G1Affine> d_p, d_out;
     DBuf<G1XYZZ> d_part;
-    DBuf<G1Affine> d_out;
-    OKM(d_k.alloc(n) && d_part.alloc((n + 63) / 64 + 1) && d_out.alloc(1));
-    OKB(d_k.up(k.data(), n));
-    RC(dev::lincomb_var_device(ctx, d_out.p, d_part.p, d_pts, (const uint32_t *)d_k.p, n));
-    G1Affine a;
+    OKM(d_k.alloc(total) && d_p.alloc(total) && d_part.alloc(total / 64) && d_out.alloc(njobs));
+    OKB(hipMemsetAsync(d_p.p, 0, total * sizeof(G1Affine), ctx->stream) == hipSuccess);  // (0,0) = infinity
+    OKB(hipMemsetAsync(d_k.p, 0, total * sizeof(RawScalar), ctx->stream) == hipSuccess);
+    for (int j = 0; j < njobs; j++) {
+        size_t n = jobs[j].k->size();
+        OKB(hipMemcpyAsync(d_p.p + off[j], jobs[j].d_pts, n * sizeof(G1Affine), hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess);
+        OKB(hipMemcpyAsync(d_k.p + off[j], jobs[j].k->data(), n * sizeof(RawScalar), hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
+    }
+    std::vector<uint32_t> part_off(njobs + 1);
+    for (int j = 0; j < njobs; j++) part_off[j] = (uint32_t)(off[j] / 64);
+    part_off[njobs] = (uint32_t)(total / 64);
+    RC(dev::lincomb_multi_device(ctx, d_out.p, d_part.p, d_p.p, (const uint32_t *)d_k.p, total, part_off.data(), njobs));
     OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
-    OKB(d_out.down(&a, 1));
-    out = jac_from_affine(a);
+    std::vector<G1Affine> res(njobs);
+    OKB(d_out.down(res.data(), njobs));
+    for (int j = 0; j < njobs; j++) outs[j] = jac_from_affine(res[j]);
     return C_KZG_OK;
 }
+
+C_KZG_RET gpu_lincomb(dev::DeviceCtx *ctx, G1Jac &out, const G1Affine *d_pts, const std::vector<RawScalar> &k) {
+    LincombJob job{d_pts, &k};
+    return gpu_lincomb_multi(ctx, &out, &job, 1);
+}
+
+// sum_i k_i P_i on the host, for the handful of points of a small call
+G1Jac host_lincomb(const std::vector<G1Jac> &pts, const std::vector<Fr> &k) {
+    G1Jac acc = G1Jac::inf();
+    for (size_t i = 0; i < pts.size(); i++) acc = jac_add(acc, g1_mul_fr(pts[i], k[i]));
+    return acc;
+}
+
+// Below this many blobs the few G1 scalar multiplications of a verification (point validation,
+// random-linear-combination sums) stay on the host next to the pairing: a single 255-bit scalar
+// multiplication is ~0.25 ms on a CPU core but ~5 ms of dependent latency on one GPU lane.  The
+// data-parallel part (bytes -> Fr, 4096-term evaluation) runs on the GPU for every n.
+constexpr uint64_t SMALL_VERIFY_N = 8;
 
 // Shared core of verify_blob_kzg_proof and verify_blob_kzg_proof_batch (eip4844.c:537-595,
 // 697-844).  Per blob, on the GPU: point validation, bytes -> Fr, evaluation at the challenge;
@@ -225,31 +282,53 @@ C_KZG_RET gpu_lincomb(dev::DeviceCtx *ctx, G1Jac &out, const G1Affine *d_pts, co
 //   e(sum r^i proof_i, [s]G2) == e(sum r^i (C_i - [y_i]G1) + sum r^i z_i proof_i, G2).
 C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, const Bytes48 *pb, uint64_t n,
                             const KZGSettings *s, dev::DeviceCtx *ctx) {
+    const bool small = n <= SMALL_VERIFY_N;
+    Trace tr("verify_blobs");
+    std::vector<G1Jac> hc, hp;  // host copies of the validated points (small n)
+    if (small) {
+        hc.resize(n);
+        hp.resize(n);
+        for (size_t i = 0; i < n; i++) {
+            if (validate_kzg_g1(hc[i], cb[i].bytes) != C_KZG_OK) return C_KZG_BADARGS;
+            if (validate_kzg_g1(hp[i], pb[i].bytes) != C_KZG_OK) return C_KZG_BADARGS;
+        }
+    }
+    tr.mark("host point validation");
     std::lock_guard<std::mutex> lock(ctx->mu);
     OKB(hipSetDevice(ctx->device) == hipSuccess);
     DBuf<uint8_t> d_ptb, d_st, d_blobs;
     DBuf<G1Affine> d_pts;
     DBuf<Fr> d_poly, d_z, d_y;
     DBuf<uint32_t> d_bad;
-    OKM(d_ptb.alloc(2 * n * 48) && d_st.alloc(2 * n) && d_pts.alloc(2 * n) && d_blobs.alloc(n * BYTES_PER_BLOB) &&
-        d_poly.alloc(n * FIELD_ELEMENTS_PER_BLOB) && d_z.alloc(n) && d_y.alloc(n) && d_bad.alloc(n));
-    // commitments [0,n), proofs [n,2n)
-    OKB(hipMemcpy(d_ptb.p, cb, n * 48, hipMemcpyHostToDevice) == hipSuccess);
-    OKB(hipMemcpy(d_ptb.p + n * 48, pb, n * 48, hipMemcpyHostToDevice) == hipSuccess);
-    RC(dev::validate_g1_batch_device(ctx, d_pts.p, d_st.p, d_ptb.p, 2 * n));
+    OKM(d_blobs.alloc(n * BYTES_PER_BLOB) && d_poly.alloc(n * FIELD_ELEMENTS_PER_BLOB) && d_z.alloc(n) &&
+        d_y.alloc(n) && d_bad.alloc(n));
+    tr.mark("hipMalloc");
+    if (!small) {
+        // commitments [0,n), proofs [n,2n): decompress + subgroup-check on the GPU
+        OKM(d_ptb.alloc(2 * n * 48) && d_st.alloc(2 * n) && d_pts.alloc(2 * n));
+        OKB(hipMemcpyAsync(d_ptb.p, cb, n * 48, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
+        OKB(hipMemcpyAsync(d_ptb.p + n * 48, pb, n * 48, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
+        RC(dev::validate_g1_batch_device(ctx, d_pts.p, d_st.p, d_ptb.p, 2 * n));
+    }
     OKB(hipMemcpyAsync(d_blobs.p, blobs, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
     OKB(hipMemsetAsync(d_bad.p, 0, n * 4, ctx->stream) == hipSuccess);
     RC(dev::bytes_to_fr_batch(ctx, d_poly.p, d_bad.p, d_blobs.p, n * FIELD_ELEMENTS_PER_BLOB, FIELD_ELEMENTS_PER_BLOB));
     // challenges on the host while the GPU validates and converts
     std::vector<Fr> z(n), y(n);
+    tr.mark("enqueue H2D + bytes_to_fr (+ GPU validation)");
     parallel_for(n, [&](size_t i) { z[i] = challenge_from_bytes(blobs[i].bytes, cb[i].bytes); });
+    tr.mark("host SHA-256 challenges");
     OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
-    std::vector<uint8_t> st(2 * n);
-    std::vector<uint32_t> bad(n);
-    OKB(d_st.down(st.data(), 2 * n) && d_bad.down(bad.data(), n));
-    for (size_t i = 0; i < 2 * n; i++) {
-        if (st[i]) return C_KZG_BADARGS;
+    tr.mark("wait for GPU");
+    if (!small) {
+        std::vector<uint8_t> st(2 * n);
+        OKB(d_st.down(st.data(), 2 * n));
+        for (size_t i = 0; i < 2 * n; i++) {
+            if (st[i]) return C_KZG_BADARGS;
+        }
     }
+    std::vector<uint32_t> bad(n);
+    OKB(d_bad.down(bad.data(), n));
     for (size_t i = 0; i < n; i++) {
         if (bad[i]) return C_KZG_BADARGS;
     }
@@ -257,11 +336,11 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     RC(dev::eval_poly_batch_device(ctx, d_y.p, d_poly.p, d_z.p, n));
     OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
     OKB(d_y.down(y.data(), n));
+    tr.mark("GPU evaluation");
     if (n == 1) {
         // the single-blob form of the check (eip4844.c:537-595)
-        G1Affine pts[2];
-        OKB(d_pts.down(pts, 2));
-        *ok = verify_kzg_proof_impl(jac_from_affine(pts[0]), z[0], y[0], jac_from_affine(pts[1]), s);
+        *ok = verify_kzg_proof_impl(hc[0], z[0], y[0], hp[0], prepared_of(ctx));
+        tr.mark("scalar muls + pairing check");
         return C_KZG_OK;
     }
     // r = H("RCKZGBATCH___V1_" | u64be 4096 | u64be n | (C_i | z_i | y_i | proof_i)*)  (eip4844.c:597-680);
@@ -281,22 +360,36 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     }
     h.finish(digest);
     Fr r = fr_from_bytes_reduce(digest);
-    std::vector<RawScalar> rp(n), rz(n);
+    std::vector<Fr> rpf(n), rzf(n);
     Fr pw = Fr::one(), ysum = Fr::zero();
     for (size_t i = 0; i < n; i++) {
-        rp[i] = raw_of(pw);
-        rz[i] = raw_of(mul(pw, z[i]));
+        rpf[i] = pw;
+        rzf[i] = mul(pw, z[i]);
         ysum = add(ysum, mul(pw, y[i]));
         pw = mul(pw, r);
     }
-    G1Jac proof_lc, proof_z_lc, c_lc;
-    C_KZG_RET ret;
-    if ((ret = gpu_lincomb(ctx, proof_lc, d_pts.p + n, rp)) != C_KZG_OK) return ret;
-    if ((ret = gpu_lincomb(ctx, proof_z_lc, d_pts.p + n, rz)) != C_KZG_OK) return ret;
-    if ((ret = gpu_lincomb(ctx, c_lc, d_pts.p, rp)) != C_KZG_OK) return ret;
+    G1Jac lc[3];  // sum r^i proof_i, sum r^i z_i proof_i, sum r^i C_i
+    if (small) {
+        lc[0] = host_lincomb(hp, rpf);
+        lc[1] = host_lincomb(hp, rzf);
+        lc[2] = host_lincomb(hc, rpf);
+    } else {
+        std::vector<RawScalar> rp(n), rz(n);
+        for (size_t i = 0; i < n; i++) {
+            rp[i] = raw_of(rpf[i]);
+            rz[i] = raw_of(rzf[i]);
+        }
+        LincombJob jobs[3] = {{d_pts.p + n, &rp}, {d_pts.p + n, &rz}, {d_pts.p, &rp}};
+        C_KZG_RET ret = gpu_lincomb_multi(ctx, lc, jobs, 3);
+        if (ret != C_KZG_OK) return ret;
+    }
+    tr.mark("transcript + lincombs");
     // sum r^i (C_i - [y_i]G) = sum r^i C_i - [sum r^i y_i]G
-    G1Jac rhs = jac_add(jac_add(c_lc, jac_neg(g1_mul_fr(g1_generator(), ysum))), proof_z_lc);
-    *ok = pairings_verify(proof_lc, *as_g2(&s->g2_values_monomial[1]), rhs, g2_generator());
+    G1Jac rhs = jac_add(jac_add(lc[2], jac_neg(g1_mul_fr(g1_generator(), ysum))), lc[1]);
+    // e(sum r^i proof_i, [s]G2) == e(rhs, G2)
+    *ok = pairing_product_is_one(jac_to_affine(jac_neg(lc[0])), prepared_of(ctx)->s1, jac_to_affine(rhs),
+                                 prepared_of(ctx)->gen);
+    tr.mark("pairing check");
     return C_KZG_OK;
 }
 
@@ -348,12 +441,13 @@ extern "C" C_KZG_RET verify_kzg_proof(bool *ok, const Bytes48 *commitment_bytes,
     G1Jac c, p;
     Fr z, y;
     *ok = false;
-    if (!header_of(s)) return C_KZG_ERROR;
+    dev::DeviceCtx *ctx = ctx_of(s);
+    if (!ctx) return C_KZG_ERROR;
     if (validate_kzg_g1(c, commitment_bytes->bytes) != C_KZG_OK) return C_KZG_BADARGS;
     if (!fr_from_bytes_canonical(z, z_bytes->bytes)) return C_KZG_BADARGS;
     if (!fr_from_bytes_canonical(y, y_bytes->bytes)) return C_KZG_BADARGS;
     if (validate_kzg_g1(p, proof_bytes->bytes) != C_KZG_OK) return C_KZG_BADARGS;
-    *ok = verify_kzg_proof_impl(c, z, y, p, s);
+    *ok = verify_kzg_proof_impl(c, z, y, p, prepared_of(ctx));
     return C_KZG_OK;
 }
 
@@ -619,10 +713,16 @@ extern "C" C_KZG_RET verify_cell_kzg_proof_batch(bool *ok, const Bytes48 *commit
         if (b) return C_KZG_BADARGS;
     }
     G1Jac proof_lc, csum, interp_commit, wsum;
-    C_KZG_RET ret;
-    if ((ret = gpu_lincomb(ctx, proof_lc, d_pts.p, rp_raw)) != C_KZG_OK) return ret;
-    if ((ret = gpu_lincomb(ctx, csum, d_pts.p + n, wts_raw)) != C_KZG_OK) return ret;
-    if ((ret = gpu_lincomb(ctx, wsum, d_pts.p, wrp_raw)) != C_KZG_OK) return ret;
+    {
+        // three of the four lincombs (eip7594.c:926, :530, :807) in one launch
+        G1Jac lc[3];
+        LincombJob jobs[3] = {{d_pts.p, &rp_raw}, {d_pts.p + n, &wts_raw}, {d_pts.p, &wrp_raw}};
+        C_KZG_RET ret = gpu_lincomb_multi(ctx, lc, jobs, 3);
+        if (ret != C_KZG_OK) return ret;
+        proof_lc = lc[0];
+        csum = lc[1];
+        wsum = lc[2];
+    }
     {
         // commitment to the aggregated interpolation polynomial: 64 monomial setup points
         DBuf<G1XYZZ> d_part;
@@ -635,6 +735,8 @@ extern "C" C_KZG_RET verify_cell_kzg_proof_batch(bool *ok, const Bytes48 *commit
         interp_commit = jac_from_affine(a);
     }
     G1Jac final_sum = jac_add(jac_add(csum, jac_neg(interp_commit)), wsum);
-    *ok = pairings_verify(final_sum, g2_generator(), proof_lc, *as_g2(&s->g2_values_monomial[l]));
+    // e(final_sum, G2) == e(proof_lc, [s^64]G2)
+    *ok = pairing_product_is_one(jac_to_affine(final_sum), prepared_of(ctx)->gen, jac_to_affine(jac_neg(proof_lc)),
+                                 prepared_of(ctx)->s64);
     return C_KZG_OK;
 }

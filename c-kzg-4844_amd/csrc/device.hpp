@@ -55,6 +55,7 @@ struct DeviceCtx {
     G1Affine *d_mono = nullptr;   // g1_values_monomial, affine, 4096
     Fr *d_shift = nullptr;        // 7^i, i < 8192   (coset_fft, fft.c:257-279)
     Fr *d_unshift = nullptr;      // 7^-i, i < 8192  (coset_ifft, fft.c:290-301)
+    void *host_prepared = nullptr; // api::PreparedG2 (host-side line tables for the pairing checks)
 };
 
 #define HIP_TRY(expr)                                                                          \
@@ -114,6 +115,8 @@ int validate_g1_batch_device(DeviceCtx *ctx, G1Affine *d_out, uint8_t *d_status,
                              size_t n);
 int lincomb_var_device(DeviceCtx *ctx, G1Affine *d_out, G1XYZZ *d_partials, const G1Affine *d_pts,
                        const uint32_t *d_scalars, size_t n);
+int lincomb_multi_device(DeviceCtx *ctx, G1Affine *d_out, G1XYZZ *d_partials, const G1Affine *d_pts,
+                         const uint32_t *d_scalars, size_t total, const uint32_t *h_part_off, int njobs);
 int fr_mul_inplace_device(DeviceCtx *ctx, Fr *d_a, const Fr *d_b, size_t n, size_t period);
 int fr_div_inplace_device(DeviceCtx *ctx, Fr *d_a, const Fr *d_b, size_t n);
 // generic helpers

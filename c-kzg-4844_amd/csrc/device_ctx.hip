@@ -33,6 +33,7 @@ void destroy_device_ctx(dev::DeviceCtx *ctx) {
         if (e) (void)hipEventDestroy(e);
     }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete static_cast<PreparedG2 *>(ctx->host_prepared);
     delete ctx;
 }
 
@@ -155,6 +156,13 @@ C_KZG_RET create_device_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affine,
                 return (C_KZG_RET)rc;
             }
         }
+    }
+    {
+        PreparedG2 *pg = new PreparedG2();
+        host::g2_prepare(pg->gen, host::g2_to_affine(host::g2_generator()));
+        host::g2_prepare(pg->s1, host::g2_to_affine(*as_g2(&s->g2_values_monomial[1])));
+        host::g2_prepare(pg->s64, host::g2_to_affine(*as_g2(&s->g2_values_monomial[dev::N_CELL])));
+        ctx->host_prepared = pg;
     }
     header_of(s)->ctx = ctx;
     return C_KZG_OK;

@@ -154,6 +154,61 @@ HD Mont<P> dbl(const Mont<P> &a) {
 template <class P>
 HD Mont<P> mul(const Mont<P> &a, const Mont<P> &b) {
     constexpr int N = P::N;
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__SIZEOF_INT128__)
+    // Host code path (setup, pairing): same CIOS on 64-bit limbs -- the bytes are identical,
+    // only the word size differs.
+    constexpr int H = N / 2;
+    typedef unsigned __int128 u128;
+    uint64_t x[H], y[H], m[H], t[H + 2];
+    for (int i = 0; i < H; i++) {
+        x[i] = (uint64_t)a.l[2 * i] | ((uint64_t)a.l[2 * i + 1] << 32);
+        y[i] = (uint64_t)b.l[2 * i] | ((uint64_t)b.l[2 * i + 1] << 32);
+        m[i] = (uint64_t)P::mod(2 * i) | ((uint64_t)P::mod(2 * i + 1) << 32);
+    }
+    // -m^-1 mod 2^64 from the 32-bit constant by one Newton step
+    uint64_t ninv = (uint64_t)P::NINV;  // -m^-1 mod 2^32
+    {
+        uint64_t inv = (uint64_t)0 - ninv;        // m^-1 mod 2^32
+        inv *= 2 - m[0] * inv;                    // m^-1 mod 2^64
+        ninv = (uint64_t)0 - inv;
+    }
+    for (int i = 0; i < H + 2; i++) t[i] = 0;
+    for (int i = 0; i < H; i++) {
+        u128 c = 0;
+        for (int j = 0; j < H; j++) {
+            c += (u128)x[j] * y[i] + t[j];
+            t[j] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[H];
+        t[H] = (uint64_t)c;
+        t[H + 1] = (uint64_t)(c >> 64);
+        uint64_t q = t[0] * ninv;
+        c = ((u128)q * m[0] + t[0]) >> 64;
+        for (int j = 1; j < H; j++) {
+            c += (u128)q * m[j] + t[j];
+            t[j - 1] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[H];
+        t[H - 1] = (uint64_t)c;
+        t[H] = t[H + 1] + (uint64_t)(c >> 64);
+    }
+    uint64_t s64[H];
+    uint64_t br = 0;
+    for (int i = 0; i < H; i++) {
+        u128 d = (u128)t[i] - m[i] - br;
+        s64[i] = (uint64_t)d;
+        br = (uint64_t)(d >> 64) & 1;
+    }
+    Mont<P> r;
+    for (int i = 0; i < H; i++) {
+        uint64_t v = br ? t[i] : s64[i];
+        r.l[2 * i] = (uint32_t)v;
+        r.l[2 * i + 1] = (uint32_t)(v >> 32);
+    }
+    return r;
+#else
     uint32_t t[N + 2];
 #pragma unroll
     for (int i = 0; i < N + 2; i++) t[i] = 0;
@@ -190,6 +245,7 @@ HD Mont<P> mul(const Mont<P> &a, const Mont<P> &b) {
 #pragma unroll
     for (int i = 0; i < N; i++) r.l[i] = br ? t[i] : s[i];
     return r;
+#endif
 }
 
 template <class P>

@@ -281,14 +281,126 @@ inline Fp12 miller_loop(const G2Affine &q, const G1Affine &p) {
     return f;  // conjugation for x < 0 omitted: applied to both factors of the product or neither
 }
 
-inline Fp12 final_exp(const Fp12 &f) {
-    Fp12 a = mul(conj(f), inv(f));  // f^(p^6-1)
-    Fp12 acc = Fp12::one();
-    for (int i = FINAL_EXP_BITS - 1; i >= 0; i--) {
-        acc = mul(acc, acc);
-        if ((FINAL_EXP_P6P1_DIV_R[i >> 5] >> (i & 31)) & 1u) acc = mul(acc, a);
+// f^(p^k), k = 1..3: with f = sum a_i w^i (a_i in Fp2, w^6 = 1+u), the map is
+// a_i -> conj^k(a_i) * (1+u)^(i (p^k - 1)/6).  In the (c0, c1) layout a_0,a_2,a_4 are c0's and
+// a_1,a_3,a_5 are c1's coefficients.
+inline Fp2 frob_gamma(int k, int i) {
+    Fp2 g;
+    for (int j = 0; j < 12; j++) {
+        g.c0.l[j] = FROB_GAMMA[k - 1][i - 1][0][j];
+        g.c1.l[j] = FROB_GAMMA[k - 1][i - 1][1][j];
     }
-    return acc;
+    return g;
+}
+
+inline Fp12 frobenius(const Fp12 &f, int k) {
+    auto cj = [k](const Fp2 &a) { return (k & 1) ? Fp2{a.c0, neg(a.c1)} : a; };
+    Fp12 r;
+    r.c0.c0 = cj(f.c0.c0);
+    r.c1.c0 = mul(cj(f.c1.c0), frob_gamma(k, 1));
+    r.c0.c1 = mul(cj(f.c0.c1), frob_gamma(k, 2));
+    r.c1.c1 = mul(cj(f.c1.c1), frob_gamma(k, 3));
+    r.c0.c2 = mul(cj(f.c0.c2), frob_gamma(k, 4));
+    r.c1.c2 = mul(cj(f.c1.c2), frob_gamma(k, 5));
+    return r;
+}
+
+// g^x for the (negative) BLS parameter x, g in the cyclotomic subgroup (inverse = conjugate)
+inline Fp12 pow_x(const Fp12 &g) {
+    const uint64_t xabs = BLS_X_ABS;
+    Fp12 acc = g;
+    for (int i = 62; i >= 0; i--) {
+        acc = mul(acc, acc);
+        if ((xabs >> i) & 1) acc = mul(acc, g);
+    }
+    return conj(acc);
+}
+
+// f^((p^12-1)/r * 3).  Easy part (p^6-1)(p^2+1); hard part through
+//   3 (p^4 - p^2 + 1)/r = l0 + l1 p + l2 p^2 + l3 p^3,
+//   l3 = (x-1)^2, l2 = l3 x, l1 = l2 x - l3, l0 = l1 x + 3
+// (identity asserted in tools/gen_constants.py).  The extra factor 3 is harmless for an
+// "== 1" test: the result has order dividing r, and r is prime to 3.
+inline Fp12 final_exp(const Fp12 &f) {
+    Fp12 a = mul(conj(f), inv(f));    // f^(p^6-1): now unitary
+    a = mul(frobenius(a, 2), a);      // ^(p^2+1): now in the cyclotomic subgroup
+    Fp12 t = mul(pow_x(a), conj(a));  // a^(x-1)
+    Fp12 y3 = mul(pow_x(t), conj(t)); // a^((x-1)^2)
+    Fp12 y2 = pow_x(y3);
+    Fp12 y1 = mul(pow_x(y2), conj(y3));
+    Fp12 y0 = mul(pow_x(y1), mul(mul(a, a), a));
+    return mul(mul(y0, frobenius(y1, 1)), mul(frobenius(y2, 2), frobenius(y3, 3)));
+}
+
+// ---- fixed-argument pairing: the G2 inputs of every verification equation are one of three
+// setup constants ([1]_2, [s]_2, [s^64]_2), so the slope and intercept of each of the 68 line
+// functions are computed once at load time; a pairing then needs no G2 arithmetic and no
+// inversions, and the two Miller loops of a product check share their squarings. ----
+
+constexpr int MILLER_STEPS = 68;  // 63 doublings + 5 additions for |x| = 0xd201000000010000
+
+struct G2Prepared {
+    Fp2 lam[MILLER_STEPS];  // slope of the line at each step
+    Fp2 c[MILLER_STEPS];    // lam * x_T - y_T
+    bool inf = true;
+};
+
+inline void g2_prepare(G2Prepared &out, const G2Affine &q) {
+    out.inf = q.is_inf();
+    if (out.inf) return;
+    Fp2 tx = q.x, ty = q.y;
+    const uint64_t xabs = BLS_X_ABS;
+    int n = 0;
+    for (int i = 62; i >= 0; i--) {
+        Fp2 x2 = sqr(tx);
+        Fp2 lam = mul(add(dbl(x2), x2), inv(dbl(ty)));
+        out.lam[n] = lam;
+        out.c[n++] = sub(mul(lam, tx), ty);
+        Fp2 x3 = sub(sub(sqr(lam), tx), tx);
+        Fp2 y3 = sub(mul(lam, sub(tx, x3)), ty);
+        tx = x3;
+        ty = y3;
+        if ((xabs >> i) & 1) {
+            lam = mul(sub(q.y, ty), inv(sub(q.x, tx)));
+            out.lam[n] = lam;
+            out.c[n++] = sub(mul(lam, tx), ty);
+            x3 = sub(sub(sqr(lam), tx), q.x);
+            y3 = sub(mul(lam, sub(tx, x3)), ty);
+            tx = x3;
+            ty = y3;
+        }
+    }
+}
+
+// f * (c + (-lam*xp) v + yp v w): the line value is sparse, multiply it out directly
+inline Fp12 mul_by_prepared_line(const Fp12 &f, const Fp2 &lam, const Fp2 &c, const G1Affine &p) {
+    Fp12 l;
+    std::memset(&l, 0, sizeof l);
+    l.c0.c0 = c;
+    l.c0.c1 = neg(mul_fp(lam, p.x));
+    l.c1.c1.c0 = p.y;
+    return mul(f, l);
+}
+
+// e(p1, Q1) * e(p2, Q2) == 1 ?
+inline bool pairing_product_is_one(const G1Affine &p1, const G2Prepared &q1, const G1Affine &p2,
+                                   const G2Prepared &q2) {
+    const bool use1 = !p1.is_inf() && !q1.inf, use2 = !p2.is_inf() && !q2.inf;
+    Fp12 f = Fp12::one();
+    const uint64_t xabs = BLS_X_ABS;
+    int n = 0;
+    for (int i = 62; i >= 0; i--) {
+        f = mul(f, f);
+        if (use1) f = mul_by_prepared_line(f, q1.lam[n], q1.c[n], p1);
+        if (use2) f = mul_by_prepared_line(f, q2.lam[n], q2.c[n], p2);
+        n++;
+        if ((xabs >> i) & 1) {
+            if (use1) f = mul_by_prepared_line(f, q1.lam[n], q1.c[n], p1);
+            if (use2) f = mul_by_prepared_line(f, q2.lam[n], q2.c[n], p2);
+            n++;
+        }
+    }
+    return final_exp(f).is_one();
 }
 
 // e(a1, a2) == e(b1, b2)

@@ -113,3 +113,10 @@ void hs_g1_madd28_chain(G1Jac *r, const G1Affine *pts, int n) {
     *r = jac_from_xyzz(xyzz28_to_xyzz(acc, inf));
 }
 }
+
+extern "C" int hs_pairing_prepared(const G1Jac *a1, const G2Jac *q1, const G1Jac *a2, const G2Jac *q2) {
+    G2Prepared p1, p2;
+    g2_prepare(p1, g2_to_affine(*q1));
+    g2_prepare(p2, g2_to_affine(*q2));
+    return pairing_product_is_one(jac_to_affine(*a1), p1, jac_to_affine(*a2), p2) ? 1 : 0;
+}

@@ -204,11 +204,31 @@ __global__ __launch_bounds__(LC_THREADS) void k_lincomb_partial(G1XYZZ *partials
     if (tid == 0) partials[blockIdx.x] = acc;
 }
 
-__global__ void k_lincomb_final(G1Affine *out, const G1XYZZ *partials, size_t nparts) {
-    if (blockIdx.x || threadIdx.x) return;
+// job j owns partials[part_off[j] .. part_off[j+1]); one lane per job
+__global__ void k_lincomb_final(G1Affine *out, const G1XYZZ *partials, const uint32_t *part_off, int njobs) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= njobs) return;
     G1XYZZ acc = G1XYZZ::inf();
-    for (size_t i = 0; i < nparts; i++) acc = xyzz_add(acc, partials[i]);
-    *out = xyzz_to_affine(acc);
+    for (uint32_t i = part_off[j]; i < part_off[j + 1]; i++) acc = xyzz_add(acc, partials[i]);
+    bool inf;
+    XYZZ28 a = xyzz28_from_xyzz(acc, inf);
+    out[j] = xyzz28_to_affine(a, inf);
+}
+
+// `total` (a multiple of 64) points/scalars laid out job after job; h_part_off has njobs+1 entries
+int lincomb_multi_device(DeviceCtx *ctx, G1Affine *d_out, G1XYZZ *d_partials, const G1Affine *d_pts,
+                         const uint32_t *d_scalars, size_t total, const uint32_t *h_part_off, int njobs) {
+    uint32_t *d_off = nullptr;
+    HIP_TRY(hipMalloc(&d_off, (njobs + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpyAsync(d_off, h_part_off, (njobs + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_lincomb_partial, dim3((unsigned)(total / LC_THREADS)), dim3(LC_THREADS), 0, ctx->stream,
+                       d_partials, d_pts, d_scalars, total);
+    hipLaunchKernelGGL(k_lincomb_final, dim3((njobs + 63) / 64), dim3(64), 0, ctx->stream, d_out, d_partials,
+                       d_off, njobs);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(d_off));
+    return 0;
 }
 
 // d_out: one affine point; d_partials: scratch for ceil(n/64) XYZZ points
@@ -216,10 +236,16 @@ int lincomb_var_device(DeviceCtx *ctx, G1Affine *d_out, G1XYZZ *d_partials, cons
                        const uint32_t *d_scalars, size_t n) {
     size_t nb = (n + LC_THREADS - 1) / LC_THREADS;
     if (nb == 0) nb = 1;
+    uint32_t off[2] = {0, (uint32_t)nb};
+    uint32_t *d_off = nullptr;
+    HIP_TRY(hipMalloc(&d_off, sizeof off));
+    HIP_TRY(hipMemcpyAsync(d_off, off, sizeof off, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_lincomb_partial, dim3((unsigned)nb), dim3(LC_THREADS), 0, ctx->stream, d_partials,
                        d_pts, d_scalars, n);
-    hipLaunchKernelGGL(k_lincomb_final, dim3(1), dim3(1), 0, ctx->stream, d_out, d_partials, nb);
+    hipLaunchKernelGGL(k_lincomb_final, dim3(1), dim3(64), 0, ctx->stream, d_out, d_partials, d_off, 1);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(d_off));
     return 0;
 }
 
