@@ -74,7 +74,7 @@ def main():
     import __graft_entry__ as ge
     mod = ge.load_package()
     hip = mod.Kzg(mod.HIP_SO, options={"device": local_rank, "commit_wbits": args.wbits, "proof_wbits": 13,
-                                       "fk20_wbits": 8})
+                                       "fk20_wbits": 12})
     lib = hip.lib
     fn = lib.ckzg_hip_blob_to_kzg_commitment_batch_device
     fn.restype = C.c_int
@@ -156,13 +156,15 @@ def main():
         fc = lib.ckzg_hip_compute_cells_and_kzg_proofs_batch_device
         fc.restype = C.c_int
         fc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
-        nb = 512
+        nb = 2048
+        blobs2 = blobs.repeat(2, 1, 1)
+        status2 = torch.empty((nb,), dtype=torch.uint8, device=dev)
         cells = torch.empty((nb, 128, 2048), dtype=torch.uint8, device=dev)
         proofs = torch.empty((nb, 128, 48), dtype=torch.uint8, device=dev)
         torch.cuda.synchronize()
 
         def run(n):
-            rc = fc(cells.data_ptr(), proofs.data_ptr(), status.data_ptr(), blobs.data_ptr(), n, C.addressof(hip.s))
+            rc = fc(cells.data_ptr(), proofs.data_ptr(), status2.data_ptr(), blobs2.data_ptr(), n, C.addressof(hip.s))
             if rc != 0:
                 raise RuntimeError("cells+proofs failed rc=%d" % rc)
 
@@ -178,7 +180,7 @@ def main():
         run(nb)
         tb = time.perf_counter() - t1
         secondary = {"compute_cells_and_kzg_proofs_ms_per_call_1blob": round(ts[len(ts) // 2] * 1e3, 3),
-                     "compute_cells_and_kzg_proofs_batch512_blobs_per_s": round(nb / tb, 1),
+                     "compute_cells_and_kzg_proofs_batch2048_blobs_per_s": round(nb / tb, 1),
                      "note": "1 blob: low-latency path (128 fixed-base MSMs, no G1 FFT); batch: FK20 path; "
                              "inputs/outputs resident in HBM"}
 
@@ -201,6 +203,15 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": PMC_TRAFFIC_BYTES.get(args.wbits),
                          "kernel": "k_msm_accumulate", "kernel_ms": round(avg_k * 1e3, 3),
                          "note": "integer-VALU-bound kernel (v_mad_u64_u32 chains); HBM fraction is small by nature"},
+            # the physical bound of this kernel: integer multiply-add issue rate.  peak = measured
+            # v_mad_u64_u32 rate of the chip (tools/ubench/instr_rates.hip: 32.9e12 lane-ops/s);
+            # achieved counts only the 392 multiply-adds of each of the 10 field products per
+            # table addition (nwin*4096 additions per blob), not the ~25 % of other instructions.
+            "roofline_valu": {"bound": "v_mad_u64_u32 issue", "unit": "T lane-mad/s", "peak": 32.9,
+                              "achieved": round(BLOBS_PER_STEP * (255 // args.wbits + 1) * 4096 * 10 * 392 / avg_k / 1e12, 3),
+                              "frac": round(BLOBS_PER_STEP * (255 // args.wbits + 1) * 4096 * 10 * 392 / avg_k / 32.9e12, 4),
+                              "pmc": "profiles/r01_pmc_sq_k_msm_accumulate.json: 5.92e9 VALU wave-instructions per launch, "
+                                     "~95 % of the VALU issue slots at the sustained 2.1 GHz clock"},
             "pcie_inclusive_blobs_per_s": None if pcie_rate is None else round(pcie_rate, 2),
             "parity_spot_check_vs_oracle": parity,
             "secondary": secondary,

@@ -395,8 +395,9 @@ __global__ void k_bad_to_status(uint8_t *status, const uint32_t *bad, size_t n) 
 int cells_and_proofs_device(DeviceCtx *ctx, uint8_t *d_cells, uint8_t *d_proofs, uint8_t *d_status,
                             const uint8_t *d_blobs, size_t n) {
     if (n == 0) return 0;
-    // process in chunks so scratch stays bounded (about 1.2 MB per blob)
-    const size_t CH = 512;
+    // process in chunks so scratch stays bounded (about 1.2 MB per blob); the G1 FFT launches one
+    // wave per blob, so a chunk should be several times the chip's 1024 SIMDs to keep them busy
+    const size_t CH = 4096;
     size_t m = n < CH ? n : CH;
     size_t poly_b = al(m * N_BLOB * sizeof(Fr)), ext_b = al(m * N_EXT * sizeof(Fr)), bad_b = al(m * 4);
     const bool direct = d_proofs != nullptr && use_direct(ctx, n);

@@ -32,7 +32,7 @@ def main():
     f = hip.lib.ckzg_hip_compute_cells_and_kzg_proofs_batch
     f.restype = C.c_int
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p]
-    for n in (4, 16, 32, 64, 128, 512):
+    for n in (4, 16, 64, 512, 2048, 4096):
         blobs = blob * n
         cells = C.create_string_buffer(n * 128 * 2048)
         proofs = C.create_string_buffer(n * 128 * 48)
