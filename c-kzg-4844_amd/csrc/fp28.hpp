@@ -86,9 +86,41 @@ HD F28<1, 2> mul(const F28<LA, VA> &a, const F28<LB, VB> &b) {
     return r;
 }
 
+// Montgomery square: the 91 cross products are taken once against a doubled operand (105
+// multiply-adds for the product instead of 196), then the same 14-row reduction: 301 vs 392 mads.
 template <int LA, int VA>
 HD F28<1, 2> sqr(const F28<LA, VA> &a) {
-    return mul(a, a);
+    // product column k holds <= 7 doubled cross terms (< 2*LA^2*2^56) + one square + 14 q*p terms
+    static_assert(15 * LA * LA + 14 + 1 <= 255, "64-bit column accumulator would overflow");
+    static_assert(2 * LA <= 15, "doubled limb would overflow 32 bits");
+    static_assert(VA * VA <= 2500, "Montgomery product would not be < 2p");
+    uint64_t t[29];
+#pragma unroll
+    for (int k = 0; k < 29; k++) t[k] = 0;
+    uint32_t d[14];
+#pragma unroll
+    for (int j = 0; j < 14; j++) d[j] = a.l[j] << 1;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        t[2 * i] += (uint64_t)a.l[i] * a.l[i];
+#pragma unroll
+        for (int j = i + 1; j < 14; j++) t[i + j] += (uint64_t)a.l[i] * d[j];
+    }
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        const uint32_t q = ((uint32_t)t[i] * (uint32_t)FP28_NINV) & M28;
+#pragma unroll
+        for (int j = 0; j < 14; j++) t[i + j] += (uint64_t)q * FP28_P[j];
+        t[i + 1] += t[i] >> 28;
+    }
+    F28<1, 2> r;
+#pragma unroll
+    for (int j = 0; j < 13; j++) {
+        t[14 + j + 1] += t[14 + j] >> 28;
+        r.l[j] = (uint32_t)t[14 + j] & M28;
+    }
+    r.l[13] = (uint32_t)t[27];
+    return r;
 }
 
 template <int LA, int VA, int LB, int VB>

@@ -178,12 +178,32 @@ HDNI inline void xyzz28_mul_w4(XYZZ28 &out, bool &out_inf, const XYZZ28 &p, bool
     out_inf = inf;
 }
 
-// a^(p-2); plain square-and-multiply over the public exponent
+// a^(p-2) by a fixed 4-bit sliding window over the public exponent: 381 squarings and ~80
+// multiplications (odd powers a, a^3, ..., a^15 precomputed)
 HDNI inline F28<1, 2> f28_inv(const F28<1, 2> &a) {
+    F28<1, 2> odd[8];
+    odd[0] = a;
+    F28<1, 2> a2 = sqr(a);
+    for (int i = 1; i < 8; i++) odd[i] = mul(odd[i - 1], a2);
     F28<1, 2> acc = widen<1, 2>(f28_one());
-    for (int i = 380; i >= 0; i--) {
-        acc = sqr(acc);
-        if ((FP_INV_EXP[i >> 5] >> (i & 31)) & 1u) acc = mul(acc, a);
+    int i = 380;
+    while (i >= 0) {
+        if (!((FP_INV_EXP[i >> 5] >> (i & 31)) & 1u)) {
+            acc = sqr(acc);
+            i--;
+            continue;
+        }
+        // longest window [i, i-w+1], w <= 4, that ends in a set bit
+        int w = i >= 3 ? 4 : i + 1;
+        uint32_t bits = 0;
+        for (int k = 0; k < w; k++) bits = (bits << 1) | ((FP_INV_EXP[(i - k) >> 5] >> ((i - k) & 31)) & 1u);
+        while (!(bits & 1u)) {
+            bits >>= 1;
+            w--;
+        }
+        for (int k = 0; k < w; k++) acc = sqr(acc);
+        acc = mul(acc, odd[bits >> 1]);
+        i -= w;
     }
     return acc;
 }

@@ -120,3 +120,13 @@ extern "C" int hs_pairing_prepared(const G1Jac *a1, const G2Jac *q1, const G1Jac
     g2_prepare(p2, g2_to_affine(*q2));
     return pairing_product_is_one(jac_to_affine(*a1), p1, jac_to_affine(*a2), p2) ? 1 : 0;
 }
+
+extern "C" {
+void hs_fp28_sqr(Fp *r, const Fp *a) { *r = f28_to_fp(sqr(f28_from_fp(*a))); }
+// square of a lazily reduced operand (limbs up to 4 units, value up to 18p): (a - b)^2
+void hs_fp28_sqr_lazy(Fp *r, const Fp *a, const Fp *b) {
+    auto d = sub(f28_from_fp(*a), widen<1, 10>(f28_from_fp(*b)));  // <4,18>
+    *r = f28_to_fp(sqr(d));
+}
+void hs_fp28_inv(Fp *r, const Fp *a) { *r = f28_to_fp(f28_inv(f28_from_fp(*a))); }
+}

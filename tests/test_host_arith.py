@@ -254,3 +254,60 @@ def test_xyzz28_mixed_addition_matches_oracle(libs):
     r = _buf(144)
     h.hs_g1_madd28_chain(r, pts, n)
     assert o.og1_equal(r, ref)
+
+
+def test_fp28_square_and_inverse(libs):
+    o, h = libs
+    rnd = random.Random(13)
+    edge = [1, 2, P - 1, P - 2, (P - 1) // 2, 2 ** 380]
+    for k in range(300):
+        a = edge[k % 6] if k < 36 else rnd.randrange(1, P)
+        b = edge[(k // 6) % 6] if k < 36 else rnd.randrange(P)
+        ab, bb = a.to_bytes(48, "little"), b.to_bytes(48, "little")
+        r1, r2 = _buf(48), _buf(48)
+        o.ofp_sqr(r1, ab)
+        h.hs_fp28_sqr(r2, ab)
+        assert r1.raw == r2.raw
+        o.ofp_sub(r1, ab, bb)
+        o.ofp_sqr(r1, r1)
+        h.hs_fp28_sqr_lazy(r2, ab, bb)
+        assert r1.raw == r2.raw
+        if k < 40:
+            o.ofp_inv(r1, ab)
+            h.hs_fp28_inv(r2, ab)
+            assert r1.raw == r2.raw
+
+
+def test_xyzz28_full_add_mul_neg(libs):
+    o, h = libs
+    rnd = random.Random(17)
+    g = _buf(144)
+    h.hs_g1_generator(g)
+    inf = _buf(144)
+    for t in range(8):
+        p1, p2 = _omul(o, g, rnd.randrange(R)), _omul(o, g, rnd.randrange(R))
+        for a, b in ((p1, p2), (p1, p1), (inf, p2), (p1, inf)):
+            ref, r = _buf(144), _buf(144)
+            o.og1_add(ref, a, b)
+            h.hs_g1_add28(r, a, b)
+            assert o.og1_equal(r, ref)
+        n1, r = _buf(144), _buf(144)
+        o.og1_neg(n1, p1)
+        h.hs_g1_add28(r, p1, n1)
+        assert o.og1_is_inf(r)
+        h.hs_g1_neg28(r, p1)
+        assert o.og1_equal(r, n1)
+        k = [0, 1, 15, 16, R - 1, R][t] if t < 6 else rnd.randrange(R)
+        kk = (C.c_uint32 * 8)(*[(k >> (32 * i)) & 0xffffffff for i in range(8)])
+        h.hs_g1_mul28(r, p1, kk)
+        assert o.og1_equal(r, _omul(o, p1, k))
+    # a point of order 3 (x = 0, y = 2): the windowed ladder must track infinities in its table
+    r384 = pow(2, 384, P)
+    pt = _buf(144)
+    pt[48:96] = (2 * r384 % P).to_bytes(48, "little")
+    pt[96:144] = (r384 % P).to_bytes(48, "little")
+    for k in (3, 6, 7, R, R + 1, 4):
+        kk = (C.c_uint32 * 8)(*[(k >> (32 * i)) & 0xffffffff for i in range(8)])
+        r = _buf(144)
+        h.hs_g1_mul28(r, pt, kk)
+        assert o.og1_equal(r, _omul(o, pt, k))
