@@ -128,5 +128,7 @@ void hs_fp28_sqr_lazy(Fp *r, const Fp *a, const Fp *b) {
     auto d = sub(f28_from_fp(*a), widen<1, 10>(f28_from_fp(*b)));  // <4,18>
     *r = f28_to_fp(sqr(d));
 }
-void hs_fp28_inv(Fp *r, const Fp *a) { *r = f28_to_fp(f28_inv(f28_from_fp(*a))); }
+void hs_fp28_inv(Fp *r, const Fp *a) { *r = f28_to_fp(f28_inv_fermat(f28_from_fp(*a))); }
 }
+
+extern "C" void hs_fp28_inv_safegcd(Fp *r, const Fp *a) { *r = f28_to_fp(f28_inv_safegcd(f28_from_fp(*a))); }

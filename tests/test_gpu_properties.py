@@ -141,3 +141,32 @@ def test_full_batch_checksum_property(hip, oracle):
     for k in range(16):
         i = next(i for i in range(n) if (i * 7 + i // 16) % 16 == k)
         assert outs[i] == hip.blob_to_kzg_commitment(base[k])
+
+
+def test_concurrent_callers_share_one_settings(hip):
+    # the reference allows concurrent readers of one loaded KZGSettings (Rust marks it Send+Sync,
+    # bindings/rust/src/bindings/mod.rs:910-913; the Go benchmark fans out goroutines,
+    # bindings/go/main_test.go:953-971): calls from several threads must give the same bytes
+    import threading
+    blobs = [rand_blob(47, i) for i in range(6)]
+    expect_c = [hip.blob_to_kzg_commitment(b) for b in blobs]
+    expect_p = hip.compute_cells_and_kzg_proofs(blobs[0])
+    errors = []
+
+    def worker(tid):
+        try:
+            for k in range(4):
+                i = (tid + k) % 6
+                if hip.blob_to_kzg_commitment(blobs[i]) != expect_c[i]:
+                    errors.append(("commit", tid, i))
+            if tid % 2 == 0 and hip.compute_cells_and_kzg_proofs(blobs[0]) != expect_p:
+                errors.append(("cells", tid))
+        except Exception as e:  # noqa: BLE001
+            errors.append(("exc", tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors

@@ -311,3 +311,20 @@ def test_xyzz28_full_add_mul_neg(libs):
         r = _buf(144)
         h.hs_g1_mul28(r, pt, kk)
         assert o.og1_equal(r, _omul(o, pt, k))
+
+
+def test_safegcd_inverse_matches_fermat_and_python(libs):
+    o, h = libs
+    rnd = random.Random(19)
+    r384 = pow(2, 384, P)
+    vals = [0, 1, 2, P - 1, P - 2, (P - 1) // 2, 3, 7, 2 ** 380, 2 ** 381 - 1, P - 3]
+    vals += [rnd.randrange(P) for _ in range(1500)]
+    for a in vals:
+        ab = (a * r384 % P).to_bytes(48, "little")
+        r1, r2 = _buf(48), _buf(48)
+        h.hs_fp28_inv_safegcd(r1, ab)
+        got = int.from_bytes(r1.raw, "little") * pow(r384, -1, P) % P
+        assert got == (pow(a, -1, P) if a else 0)
+        if a < 2 ** 20 or a > P - 4:
+            h.hs_fp28_inv(r2, ab)  # sliding-window Fermat ladder
+            assert r1.raw == r2.raw
