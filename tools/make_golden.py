@@ -10,7 +10,7 @@ once in a content-addressed object file:
   tests/golden/objects.json  sha256-prefix -> [offset, length]
   tests/golden/cases.json    {function: {case: {"input": ..., "output": ...}}}; big values are
                              {"$obj": key}; small hex strings stay inline as "0x..".
-  tests/golden/trusted_setup.txt  the mainnet setup (data, sha256 d39b9f2d...26b7)
+  c-kzg-4844_amd/data/trusted_setup.txt  the mainnet setup (runtime data, sha256 d39b9f2d...26b7)
 
 Run in the build container only (reads /root/reference):  python tools/make_golden.py
 """
@@ -71,7 +71,8 @@ def main():
         json.dump(objects, f)
     with open(os.path.join(OUT, "cases.json"), "w") as f:
         json.dump(cases, f, separators=(",", ":"))
-    shutil.copyfile(os.path.join(REF, "src", "trusted_setup.txt"), os.path.join(OUT, "trusted_setup.txt"))
+    shutil.copyfile(os.path.join(REF, "src", "trusted_setup.txt"),
+                    os.path.join(OUT, "..", "..", "c-kzg-4844_amd", "data", "trusted_setup.txt"))
     print("cases:", total, "objects:", len(objects), "bytes:", len(blob))
 
 
