@@ -232,25 +232,74 @@ extern "C" C_KZG_RET ckzg_hip_blob_to_kzg_commitment_batch(KZGCommitment *out, u
     if (n == 0) return C_KZG_OK;
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (hipSetDevice(ctx->device) != hipSuccess) return C_KZG_ERROR;
-    // chunk so that blobs + digits stay within a bounded staging footprint
-    const uint64_t CH = 1024;
-    DeviceBuffer d_blobs, d_out, d_status;
-    uint64_t m = n < CH ? n : CH;
-    if (!d_blobs.alloc(m * BYTES_PER_BLOB) || !d_out.alloc(m * 48) || !d_status.alloc(m)) return C_KZG_MALLOC;
-    std::vector<uint8_t> st(m);
+    // Host buffers are pageable, and a pageable hipMemcpyAsync serialises with everything.  So chunk
+    // i+1 is memcpy'd by this thread into a pinned staging buffer and DMA'd on the copy stream while
+    // the kernels of chunk i execute on the compute stream.  Two staging/device buffers, events
+    // both ways.
+    const uint64_t CH = 128;
+    const uint64_t m = n < CH ? n : CH;
+    DeviceBuffer d_blobs[2], d_out, d_status;
+    hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
     C_KZG_RET ret = C_KZG_OK;
-    for (uint64_t off = 0; off < n; off += CH) {
-        uint64_t k = n - off < CH ? n - off : CH;
-        if (hipMemcpyAsync(d_blobs.p, blobs + off, k * BYTES_PER_BLOB, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-            return C_KZG_ERROR;
-        int rc = dev::commit_blobs_device(ctx, (uint8_t *)d_out.p, (uint8_t *)d_status.p, (const uint8_t *)d_blobs.p, k);
-        if (rc) return (C_KZG_RET)rc;
-        if (hipMemcpy(out + off, d_out.p, k * 48, hipMemcpyDeviceToHost) != hipSuccess) return C_KZG_ERROR;
-        if (hipMemcpy(st.data(), d_status.p, k, hipMemcpyDeviceToHost) != hipSuccess) return C_KZG_ERROR;
-        for (uint64_t i = 0; i < k; i++) {
-            if (status) status[off + i] = st[i];
-            if (st[i]) ret = C_KZG_BADARGS;
+    std::vector<uint8_t> st(n);
+    bool pending[2] = {false, false};
+    if (!d_blobs[0].alloc(m * BYTES_PER_BLOB) || (n > CH && !d_blobs[1].alloc(m * BYTES_PER_BLOB)) ||
+        !d_out.alloc(n * 48) || !d_status.alloc(n)) {
+        return C_KZG_MALLOC;
+    }
+    if (dev::scratch_reserve(ctx, dev::commit_scratch_bytes(ctx, m)) != 0) return C_KZG_MALLOC;
+    for (int i = 0; i < 2; i++) {
+        if (!ctx->h_stage[i] && hipHostMalloc(&ctx->h_stage[i], CH * BYTES_PER_BLOB, hipHostMallocDefault) != hipSuccess) {
+            ctx->h_stage[i] = nullptr;
+            return C_KZG_MALLOC;
         }
+    }
+    for (int i = 0; i < 2; i++) {
+        if (hipEventCreateWithFlags(&copied[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&consumed[i], hipEventDisableTiming) != hipSuccess) {
+            ret = C_KZG_ERROR;
+        }
+    }
+    uint64_t chunk = 0;
+    for (uint64_t off = 0; off < n && ret == C_KZG_OK; off += CH, chunk++) {
+        const int b = (int)(chunk & 1);
+        const uint64_t k = n - off < CH ? n - off : CH;
+        bool ok = true;
+        if (pending[b]) {
+            // the pinned buffer is free once its DMA finished; the device buffer once its kernels did
+            ok = ok && hipEventSynchronize(copied[b]) == hipSuccess;
+            ok = ok && hipStreamWaitEvent(ctx->copy_stream, consumed[b], 0) == hipSuccess;
+        }
+        memcpy(ctx->h_stage[b], blobs + off, k * BYTES_PER_BLOB);
+        ok = ok && hipMemcpyAsync(d_blobs[b].p, ctx->h_stage[b], k * BYTES_PER_BLOB, hipMemcpyHostToDevice,
+                                  ctx->copy_stream) == hipSuccess;
+        ok = ok && hipEventRecord(copied[b], ctx->copy_stream) == hipSuccess;
+        ok = ok && hipStreamWaitEvent(ctx->stream, copied[b], 0) == hipSuccess;
+        if (!ok) {
+            ret = C_KZG_ERROR;
+            break;
+        }
+        int rc = dev::commit_blobs_enqueue(ctx, (uint8_t *)d_out.p + off * 48, (uint8_t *)d_status.p + off,
+                                           (const uint8_t *)d_blobs[b].p, k);
+        if (rc) {
+            ret = (C_KZG_RET)rc;
+            break;
+        }
+        if (hipEventRecord(consumed[b], ctx->stream) != hipSuccess) ret = C_KZG_ERROR;
+        pending[b] = true;
+    }
+    if (hipStreamSynchronize(ctx->copy_stream) != hipSuccess) ret = ret == C_KZG_OK ? C_KZG_ERROR : ret;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) ret = ret == C_KZG_OK ? C_KZG_ERROR : ret;
+    for (int i = 0; i < 2; i++) {
+        if (copied[i]) (void)hipEventDestroy(copied[i]);
+        if (consumed[i]) (void)hipEventDestroy(consumed[i]);
+    }
+    if (ret != C_KZG_OK) return ret;
+    if (hipMemcpy(out, d_out.p, n * 48, hipMemcpyDeviceToHost) != hipSuccess) return C_KZG_ERROR;
+    if (hipMemcpy(st.data(), d_status.p, n, hipMemcpyDeviceToHost) != hipSuccess) return C_KZG_ERROR;
+    for (uint64_t i = 0; i < n; i++) {
+        if (status) status[i] = st[i];
+        if (st[i]) ret = C_KZG_BADARGS;
     }
     return ret;
 }

@@ -38,6 +38,8 @@ struct Scratch {
 struct DeviceCtx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;  // host-to-device staging, overlapped with `stream`
+    void *h_stage[2] = {nullptr, nullptr};  // pinned host staging buffers (allocated on first use)
     std::mutex mu;
     FixedBaseTable commit;        // over g1_values_lagrange_brp (4096 points)
     FixedBaseTable mono;          // over g1_values_monomial (4096 points): low-latency cell proofs
@@ -78,6 +80,11 @@ int build_fixed_base_table(DeviceCtx *ctx, FixedBaseTable *t, const G1Affine *d_
 // Commit n blobs resident in HBM: d_out48[n][48], d_status[n] (0 ok, 1 non-canonical element).
 int commit_blobs_device(DeviceCtx *ctx, uint8_t *d_out48, uint8_t *d_status, const uint8_t *d_blobs,
                         size_t n);
+
+// the same without the final wait, for callers that pipeline host-to-device copies against it
+size_t commit_scratch_bytes(const DeviceCtx *ctx, size_t n);
+int commit_blobs_enqueue(DeviceCtx *ctx, uint8_t *d_out48, uint8_t *d_status, const uint8_t *d_blobs,
+                         size_t n);
 
 // Generic: sum_i scalar_i * P_i over the ctx->commit table for n independent scalar vectors that
 // are already canonical little-endian 8xu32 integers in HBM ([n][4096][8]); writes n compressed

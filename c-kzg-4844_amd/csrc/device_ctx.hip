@@ -33,6 +33,10 @@ void destroy_device_ctx(dev::DeviceCtx *ctx) {
         if (e) (void)hipEventDestroy(e);
     }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    for (auto &h : ctx->h_stage) {
+        if (h) (void)hipHostFree(h);
+    }
     delete static_cast<PreparedG2 *>(ctx->host_prepared);
     delete ctx;
 }
@@ -66,6 +70,7 @@ C_KZG_RET create_device_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affine,
     ctx->device = device;
     CTX_TRY(hipSetDevice(device));
     CTX_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    CTX_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     for (auto &e : ctx->ev) CTX_TRY(hipEventCreate(&e));
 
     // Fr twiddles

@@ -389,8 +389,20 @@ int msm_from_digits_device(DeviceCtx *ctx, const FixedBaseTable &t, uint8_t *d_o
     return run_msm(ctx, t, d_out48, nullptr, d_digits, nullptr, d_partials, nvec, ppb);
 }
 
-int commit_blobs_device(DeviceCtx *ctx, uint8_t *d_out48, uint8_t *d_status, const uint8_t *d_blobs,
-                        size_t n) {
+// Enqueue digits + MSM + finalize for n blobs on the context stream without waiting.  The scratch
+// arena must already hold commit_scratch_bytes(n); successive enqueues may share it because the
+// stream executes them in order.
+size_t commit_scratch_bytes(const DeviceCtx *ctx, size_t n) {
+    const FixedBaseTable &t = ctx->commit;
+    uint32_t pairs_per_vec = (uint32_t)t.nwin * t.npoints;
+    uint32_t ppb = pick_pairs_per_block(n, pairs_per_vec);
+    uint32_t bpv = (pairs_per_vec + ppb - 1) / ppb;
+    return align_up(n * (size_t)pairs_per_vec * sizeof(int16_t), 256) + align_up(n * sizeof(uint32_t), 256) +
+           align_up(n * ((size_t)bpv + 1) * sizeof(G1XYZZ), 256);
+}
+
+int commit_blobs_enqueue(DeviceCtx *ctx, uint8_t *d_out48, uint8_t *d_status, const uint8_t *d_blobs,
+                         size_t n) {
     if (n == 0) return 0;
     const FixedBaseTable &t = ctx->commit;
     if (!t.d_table) return 2;
@@ -399,9 +411,7 @@ int commit_blobs_device(DeviceCtx *ctx, uint8_t *d_out48, uint8_t *d_status, con
     uint32_t bpv = (pairs_per_vec + ppb - 1) / ppb;
     size_t dig_bytes = align_up(n * (size_t)pairs_per_vec * sizeof(int16_t), 256);
     size_t bad_bytes = align_up(n * sizeof(uint32_t), 256);
-    size_t part_bytes = align_up(n * ((size_t)bpv + 1) * sizeof(G1XYZZ), 256);
-    int rc = scratch_reserve(ctx, dig_bytes + bad_bytes + part_bytes);
-    if (rc) return rc;
+    if (ctx->scratch.cap < dig_bytes + bad_bytes + align_up(n * ((size_t)bpv + 1) * sizeof(G1XYZZ), 256)) return 2;
     uint8_t *base = static_cast<uint8_t *>(ctx->scratch.ptr);
     int16_t *d_digits = reinterpret_cast<int16_t *>(base);
     uint32_t *d_bad = reinterpret_cast<uint32_t *>(base + dig_bytes);
@@ -411,7 +421,15 @@ int commit_blobs_device(DeviceCtx *ctx, uint8_t *d_out48, uint8_t *d_status, con
     size_t total = n * N_BLOB;
     hipLaunchKernelGGL(k_blob_digits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
                        d_digits, d_bad, d_blobs, total, t.wbits, t.nwin);
-    rc = run_msm(ctx, t, d_out48, d_status, d_digits, d_bad, d_partials, n, ppb);
+    return run_msm(ctx, t, d_out48, d_status, d_digits, d_bad, d_partials, n, ppb);
+}
+
+int commit_blobs_device(DeviceCtx *ctx, uint8_t *d_out48, uint8_t *d_status, const uint8_t *d_blobs,
+                        size_t n) {
+    if (n == 0) return 0;
+    int rc = scratch_reserve(ctx, commit_scratch_bytes(ctx, n));
+    if (rc) return rc;
+    rc = commit_blobs_enqueue(ctx, d_out48, d_status, d_blobs, n);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     collect_times(ctx);
