@@ -1,0 +1,53 @@
+"""Table-width options and the reference's `precompute` argument: every supported window width
+must give the same bytes (the table layout, digit recoding and window count all depend on it)."""
+import pytest
+
+import golden_util as G
+from kzg_ctypes import HIP_SO, Kzg
+from test_gpu_commitment import rand_blob
+
+pytestmark = pytest.mark.gpu
+
+
+def _restore(api):
+    for k, v in (("commit_wbits", 10), ("fk20_wbits", 0), ("proof_wbits", 8), ("direct_max", 24)):
+        api.lib.ckzg_hip_set_option(k.encode(), v)
+
+
+@pytest.mark.parametrize("wbits", [4, 5, 7, 9, 12])
+def test_commitment_for_every_table_width(hip, wbits):
+    api = Kzg(HIP_SO, "", precompute=0, options={"commit_wbits": wbits, "proof_wbits": 0})
+    _restore(api)
+    try:
+        for name in G.case_names("blob_to_kzg_commitment"):
+            got, exp = G.run_case(api, "blob_to_kzg_commitment", name)
+            assert got == exp, (wbits, name)
+        b = rand_blob(51, wbits)
+        assert api.blob_to_kzg_commitment(b) == hip.blob_to_kzg_commitment(b)
+    finally:
+        api.close()
+
+
+@pytest.mark.parametrize("precompute,direct", [(9, 0), (4, 0), (0, 24)])
+def test_cells_and_proofs_for_precompute_values(hip, precompute, direct):
+    # precompute > 8 widens the FK20 table (reference: src/setup/setup.c:411-422 -> wbits);
+    # proof_wbits 5 exercises a narrow table on the low-latency path
+    api = Kzg(HIP_SO, "", precompute=precompute,
+              options={"commit_wbits": 8, "direct_max": direct, "proof_wbits": 5 if direct else 0})
+    _restore(api)
+    try:
+        assert api.s.wbits == precompute
+        name = "compute_cells_and_kzg_proofs_case_valid_2"
+        names = [n for n in G.case_names("compute_cells_and_kzg_proofs") if "valid" in n]
+        got, exp = G.run_case(api, "compute_cells_and_kzg_proofs", names[2] if len(names) > 2 else names[0])
+        assert got == exp
+        b = rand_blob(52, precompute)
+        assert api.compute_cells_and_kzg_proofs(b) == hip.compute_cells_and_kzg_proofs(b)
+    finally:
+        api.close()
+
+
+def test_precompute_out_of_range_is_badargs():
+    from kzg_ctypes import KzgError
+    with pytest.raises(KzgError):
+        Kzg(HIP_SO, "", precompute=16)
