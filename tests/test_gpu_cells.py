@@ -76,3 +76,22 @@ def test_golden_recover_fk20_path(hip_fk20, name):
 def test_direct_and_fk20_paths_agree(hip, hip_fk20):
     b = rand_blob(31, 0)
     assert hip.compute_cells_and_kzg_proofs(b) == hip_fk20.compute_cells_and_kzg_proofs(b)
+
+
+def test_large_batch_takes_fk20_and_16_lane_msm_path(hip):
+    # 40 blobs > direct_max (24): FK20 path with 5120 small MSMs -> the 16-lanes-per-vector kernel
+    n = 40
+    base = [rand_blob(32, i) for i in range(4)]
+    blobs = [base[i % 4] for i in range(n)]
+    cells = C.create_string_buffer(n * 128 * 2048)
+    proofs = C.create_string_buffer(n * 128 * 48)
+    status = C.create_string_buffer(n)
+    f = hip.lib.ckzg_hip_compute_cells_and_kzg_proofs_batch
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p]
+    assert f(cells, proofs, status, b"".join(blobs), n, C.addressof(hip.s)) == 0
+    single = [hip.compute_cells_and_kzg_proofs(b) for b in base]  # low-latency path
+    for i in range(n):
+        c, p = single[i % 4]
+        assert b"".join(c) == cells.raw[i * 128 * 2048:(i + 1) * 128 * 2048]
+        assert b"".join(p) == proofs.raw[i * 128 * 48:(i + 1) * 128 * 48]
