@@ -435,6 +435,77 @@ extern "C" C_KZG_RET compute_blob_kzg_proof(KZGProof *out, const Blob *blob, con
     return compute_kzg_proof_impl(out, y, poly.data(), z, s, ctx);
 }
 
+// compute_blob_kzg_proof for a batch: challenges on the host (SHA-256), evaluation + quotient
+// polynomial and the 4096-term MSMs on the GPU.
+extern "C" C_KZG_RET ckzg_hip_compute_blob_kzg_proof_batch(KZGProof *proofs, uint8_t *status, const Blob *blobs,
+                                                           const Bytes48 *commitments_bytes, uint64_t n,
+                                                           const KZGSettings *s) {
+    dev::DeviceCtx *ctx = ctx_of(s);
+    if (!ctx) return C_KZG_ERROR;
+    if (n == 0) return C_KZG_OK;
+    C_KZG_RET ret = C_KZG_OK;
+    std::vector<uint8_t> st(n, 0);
+    std::vector<int> redo;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        OKB(hipSetDevice(ctx->device) == hipSuccess);
+        const uint64_t CH = 256;
+        const uint64_t m = n < CH ? n : CH;
+        DBuf<uint8_t> d_blobs, d_ptb, d_pst, d_out;
+        DBuf<G1Affine> d_pts;
+        DBuf<Fr> d_poly, d_z, d_y;
+        DBuf<uint32_t> d_bad, d_q;
+        DBuf<int> d_hit;
+        OKM(d_blobs.alloc(m * BYTES_PER_BLOB) && d_ptb.alloc(m * 48) && d_pst.alloc(m) && d_pts.alloc(m) &&
+            d_out.alloc(m * 48) && d_poly.alloc(m * FIELD_ELEMENTS_PER_BLOB) && d_z.alloc(m) && d_y.alloc(m) &&
+            d_bad.alloc(m) && d_q.alloc(m * FIELD_ELEMENTS_PER_BLOB * 8) && d_hit.alloc(m));
+        std::vector<Fr> z(m);
+        std::vector<uint8_t> pst(m);
+        std::vector<uint32_t> bad(m);
+        std::vector<int> hit(m);
+        for (uint64_t off = 0; off < n; off += CH) {
+            const uint64_t k = n - off < CH ? n - off : CH;
+            // commitments must be valid G1 points (bytes_to_kzg_commitment, eip4844.c:513)
+            if (k > SMALL_VERIFY_N) {
+                OKB(hipMemcpyAsync(d_ptb.p, commitments_bytes + off, k * 48, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
+                RC(dev::validate_g1_batch_device(ctx, d_pts.p, d_pst.p, d_ptb.p, k));
+            } else {
+                for (uint64_t i = 0; i < k; i++) {
+                    G1Jac c;
+                    pst[i] = validate_kzg_g1(c, commitments_bytes[off + i].bytes) == C_KZG_OK ? 0 : 1;
+                }
+            }
+            OKB(hipMemcpyAsync(d_blobs.p, blobs + off, k * BYTES_PER_BLOB, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
+            OKB(hipMemsetAsync(d_bad.p, 0, k * 4, ctx->stream) == hipSuccess);
+            RC(dev::bytes_to_fr_batch(ctx, d_poly.p, d_bad.p, d_blobs.p, k * FIELD_ELEMENTS_PER_BLOB, FIELD_ELEMENTS_PER_BLOB));
+            parallel_for(k, [&](size_t i) { z[i] = challenge_from_bytes(blobs[off + i].bytes, commitments_bytes[off + i].bytes); });
+            OKB(hipMemcpyAsync(d_z.p, z.data(), k * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
+            RC(dev::eval_quotient_batch_device(ctx, d_y.p, d_q.p, d_hit.p, d_poly.p, d_z.p, k));
+            RC(dev::msm_commit_table_raw_device(ctx, d_out.p, d_q.p, k));
+            if (k > SMALL_VERIFY_N) OKB(d_pst.down(pst.data(), k));
+            OKB(d_bad.down(bad.data(), k) && d_hit.down(hit.data(), k));
+            OKB(hipMemcpy(proofs + off, d_out.p, k * 48, hipMemcpyDeviceToHost) == hipSuccess);
+            for (uint64_t i = 0; i < k; i++) {
+                if (pst[i] || bad[i]) {
+                    st[off + i] = C_KZG_BADARGS;
+                    ret = C_KZG_BADARGS;
+                } else if (hit[i] >= 0) {
+                    redo.push_back((int)(off + i));  // challenge inside the domain: scalar path below
+                }
+            }
+        }
+    }
+    for (int i : redo) {
+        C_KZG_RET r = compute_blob_kzg_proof(&proofs[i], &blobs[i], &commitments_bytes[i], s);
+        if (r != C_KZG_OK) {
+            st[i] = (uint8_t)r;
+            ret = r;
+        }
+    }
+    if (status) memcpy(status, st.data(), n);
+    return ret;
+}
+
 extern "C" C_KZG_RET verify_kzg_proof(bool *ok, const Bytes48 *commitment_bytes, const Bytes32 *z_bytes,
                                       const Bytes32 *y_bytes, const Bytes48 *proof_bytes,
                                       const KZGSettings *s) {

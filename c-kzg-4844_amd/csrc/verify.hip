@@ -39,12 +39,20 @@ __device__ __noinline__ Fr fr_inv_dev(const Fr &a) { return fr_inv(a); }
 constexpr int EV_THREADS = 256;
 constexpr int EV_PER = N_BLOB / EV_THREADS;  // 16 terms per thread
 
-__global__ __launch_bounds__(EV_THREADS) void k_eval_barycentric(Fr *y_out, const Fr *poly,
-                                                                 const Fr *zs, const Fr *brp_roots) {
+// QUOT: additionally write the quotient polynomial of the KZG opening at z in evaluation form,
+//   q_i = (p_i - y)/(w_i - z) = (y - p_i) * 1/(z - w_i)          (eip4844.c:441-456)
+// as canonical little-endian scalars ready for the MSM recoding.  The inverses are parked in the
+// output buffer until y is known.  hit_out[blob] = index of the domain point equal to z, or -1;
+// for such a blob (eip4844.c:458-481) q is not produced here and the caller takes the scalar path.
+template <bool QUOT>
+__global__ __launch_bounds__(EV_THREADS) void k_eval_barycentric(Fr *y_out, uint32_t *q_raw, int *hit_out,
+                                                                 const Fr *poly, const Fr *zs,
+                                                                 const Fr *brp_roots) {
     __shared__ uint32_t sh[8][EV_THREADS];
     __shared__ int hit;
     const int tid = threadIdx.x;
     const Fr *p = poly + (size_t)blockIdx.x * N_BLOB;
+    Fr *qinv = reinterpret_cast<Fr *>(q_raw) + (size_t)blockIdx.x * N_BLOB;
     const Fr z = vld_fr(zs + blockIdx.x);
     if (tid == 0) hit = -1;
     __syncthreads();
@@ -60,9 +68,13 @@ __global__ __launch_bounds__(EV_THREADS) void k_eval_barycentric(Fr *y_out, cons
     }
     __syncthreads();
     if (hit >= 0) {
-        if (tid == 0) vst_fr(y_out + blockIdx.x, vld_fr(p + hit));
+        if (tid == 0) {
+            vst_fr(y_out + blockIdx.x, vld_fr(p + hit));
+            if (hit_out) hit_out[blockIdx.x] = hit;
+        }
         return;
     }
+    if (tid == 0 && hit_out) hit_out[blockIdx.x] = -1;
     Fr inv = fr_inv_dev(acc);
     Fr sum = Fr::zero();
 #pragma unroll
@@ -70,6 +82,7 @@ __global__ __launch_bounds__(EV_THREADS) void k_eval_barycentric(Fr *y_out, cons
         int i = tid + k * EV_THREADS;
         Fr di = mul(inv, pre[k]);  // 1/(z - w_i)
         inv = mul(inv, den[k]);
+        if (QUOT) vst_fr(qinv + i, di);
         sum = add(sum, mul(mul(di, vld_fr(brp_roots + i)), vld_fr(p + i)));
     }
     // workgroup sum
@@ -107,14 +120,46 @@ __global__ __launch_bounds__(EV_THREADS) void k_eval_barycentric(Fr *y_out, cons
 #pragma unroll
             for (int i = 0; i < 8; i++) n_inv.l[i] = (t[i] >> 1) | (t[i + 1] << 31);
         }
-        vst_fr(y_out + blockIdx.x, mul(mul(sum, n_inv), f));
+        Fr y = mul(mul(sum, n_inv), f);
+        vst_fr(y_out + blockIdx.x, y);
+        if (QUOT) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) sh[k][0] = y.l[k];
+        }
+    }
+    if (QUOT) {
+        __syncthreads();
+        Fr y;
+#pragma unroll
+        for (int k = 0; k < 8; k++) y.l[k] = sh[k][0];
+#pragma unroll
+        for (int k = 0; k < EV_PER; k++) {
+            int i = tid + k * EV_THREADS;
+            Fr q = mul(sub(y, vld_fr(p + i)), vld_fr(qinv + i));
+            uint32_t raw[8];
+            to_raw<FrParams>(raw, q);
+            uint4 *dst = reinterpret_cast<uint4 *>(q_raw + ((size_t)blockIdx.x * N_BLOB + i) * 8);
+            dst[0] = make_uint4(raw[0], raw[1], raw[2], raw[3]);
+            dst[1] = make_uint4(raw[4], raw[5], raw[6], raw[7]);
+        }
     }
 }
 
 int eval_poly_batch_device(DeviceCtx *ctx, Fr *d_y, const Fr *d_poly, const Fr *d_z, size_t n) {
     if (!n) return 0;
-    hipLaunchKernelGGL(k_eval_barycentric, dim3((unsigned)n), dim3(EV_THREADS), 0, ctx->stream, d_y,
-                       d_poly, d_z, ctx->d_brp_roots);
+    hipLaunchKernelGGL(k_eval_barycentric<false>, dim3((unsigned)n), dim3(EV_THREADS), 0, ctx->stream, d_y,
+                       (uint32_t *)nullptr, (int *)nullptr, d_poly, d_z, ctx->d_brp_roots);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// y_i = p_i(z_i) and the quotient scalars q (canonical limbs, [n][4096][8]); d_hit[i] >= 0 flags a
+// blob whose z lies in the evaluation domain
+int eval_quotient_batch_device(DeviceCtx *ctx, Fr *d_y, uint32_t *d_q_raw, int *d_hit, const Fr *d_poly,
+                               const Fr *d_z, size_t n) {
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_eval_barycentric<true>, dim3((unsigned)n), dim3(EV_THREADS), 0, ctx->stream, d_y,
+                       d_q_raw, d_hit, d_poly, d_z, ctx->d_brp_roots);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -57,6 +57,13 @@ C_KZG_RET ckzg_hip_compute_cells_and_kzg_proofs_batch_device(void *d_cells, void
                                                              void *d_status, const void *d_blobs,
                                                              uint64_t n, const KZGSettings *s);
 
+/* compute_blob_kzg_proof (src/eip4844/eip4844.c:496-535) over n blobs: proofs[i] opens blobs[i] at the
+ * Fiat-Shamir challenge derived from (blobs[i], commitments[i]).  Returns C_KZG_BADARGS if any blob
+ * or commitment is invalid (per-blob C_KZG_RET in status[i] when status != NULL). */
+C_KZG_RET ckzg_hip_compute_blob_kzg_proof_batch(KZGProof *proofs, uint8_t *status, const Blob *blobs,
+                                                const Bytes48 *commitments_bytes, uint64_t n,
+                                                const KZGSettings *s);
+
 /* Timing hook for bench.py: elapsed milliseconds of the named kernel family inside the last
  * batch call, measured with hipEvents on the stream the kernels were launched on.
  * which: 0 = scalar recoding, 1 = MSM bucket-free accumulate (dominant), 2 = reduce+compress,

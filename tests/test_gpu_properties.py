@@ -170,3 +170,41 @@ def test_concurrent_callers_share_one_settings(hip):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def _proof_batch(hip, blobs, commitments):
+    n = len(blobs)
+    out = C.create_string_buffer(48 * n)
+    status = C.create_string_buffer(n)
+    f = hip.lib.ckzg_hip_compute_blob_kzg_proof_batch
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p, C.c_uint64, C.c_void_p]
+    ret = f(out, status, b"".join(blobs), b"".join(commitments), n, C.addressof(hip.s))
+    return ret, [out.raw[48 * i:48 * i + 48] for i in range(n)], list(status.raw)
+
+
+@pytest.mark.parametrize("n", [1, 5, 20])
+def test_blob_proof_batch_matches_single_calls_and_oracle(hip, oracle, n):
+    # GPU evaluation + quotient kernel (k_eval_barycentric<true>) + 4096-term MSM per blob
+    blobs = [rand_blob(48, i) for i in range(n)]
+    cms = [hip.blob_to_kzg_commitment(b) for b in blobs]
+    ret, proofs, status = _proof_batch(hip, blobs, cms)
+    assert ret == 0 and not any(status)
+    for i in range(n):
+        assert proofs[i] == hip.compute_blob_kzg_proof(blobs[i], cms[i])
+    assert proofs[0] == oracle.compute_blob_kzg_proof(blobs[0], cms[0])
+    assert hip.verify_blob_kzg_proof_batch(blobs, cms, proofs) is True
+
+
+def test_blob_proof_batch_flags_bad_inputs(hip):
+    blobs = [rand_blob(49, i) for i in range(12)]
+    cms = [hip.blob_to_kzg_commitment(b) for b in blobs]
+    bad_blob = bytearray(blobs[4])
+    bad_blob[64:96] = b"\xff" * 32
+    blobs[4] = bytes(bad_blob)
+    cms[9] = bytes([0x80]) + bytes(47)  # on the curve, outside the subgroup
+    ret, proofs, status = _proof_batch(hip, blobs, cms)
+    assert ret == 1
+    assert [i for i, s in enumerate(status) if s] == [4, 9]
+    for i in (0, 3, 11):
+        assert proofs[i] == hip.compute_blob_kzg_proof(blobs[i], cms[i])

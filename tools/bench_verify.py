@@ -40,6 +40,19 @@ def main():
         print("verify_blob_kzg_proof_batch n=%d: %.1f ms -> %.0f blobs/s (ok=%s)" % (n, dt * 1e3, n / dt, ok))
     pr[3] = proofs[0]
     assert not hip.verify_blob_kzg_proof_batch(bl, cm, pr)
+    f = hip.lib.ckzg_hip_compute_blob_kzg_proof_batch
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p, C.c_uint64, C.c_void_p]
+    nb = 512
+    out = C.create_string_buffer(48 * nb)
+    stt = C.create_string_buffer(nb)
+    bb, cc = b"".join(uniq[i % 8] for i in range(nb)), b"".join(commits[i % 8] for i in range(nb))
+    f(out, stt, bb, cc, nb, C.addressof(hip.s))
+    t = time.perf_counter()
+    rc = f(out, stt, bb, cc, nb, C.addressof(hip.s))
+    dt = time.perf_counter() - t
+    print("compute_blob_kzg_proof batch n=%d: %.1f ms -> %.0f proofs/s (rc=%d)" % (nb, dt * 1e3, nb / dt, rc))
+    assert out.raw[:48] == proofs[0]
     cells, cproofs = hip.compute_cells_and_kzg_proofs(uniq[0])
     for name, idx in (("first half missing", list(range(64, 128))), ("every other cell", list(range(0, 128, 2)))):
         hip.recover_cells_and_kzg_proofs(idx, [cells[i] for i in idx])
