@@ -217,8 +217,6 @@ void parallel_for(size_t n, const std::function<void(size_t)> &fn) {
     for (auto &x : th) x.join();
 }
 
-G1Jac jac_of_affine_bytes(const G1Affine &a) { return jac_from_affine(a); }
-
 // Several variable-base lincombs sum_i k_i P_i in ONE launch.  Job j takes n points starting at
 // d_pts + pt_off[j] and its own scalar vector; every job is padded to a multiple of 64 lanes so
 // that a workgroup's partial sum belongs to exactly one job.
@@ -256,11 +254,6 @@ C_KZG_RET gpu_lincomb_multi(dev::DeviceCtx *ctx, G1Jac *outs, const LincombJob *
     OKB(d_out.down(res.data(), njobs));
     for (int j = 0; j < njobs; j++) outs[j] = jac_from_affine(res[j]);
     return C_KZG_OK;
-}
-
-C_KZG_RET gpu_lincomb(dev::DeviceCtx *ctx, G1Jac &out, const G1Affine *d_pts, const std::vector<RawScalar> &k) {
-    LincombJob job{d_pts, &k};
-    return gpu_lincomb_multi(ctx, &out, &job, 1);
 }
 
 // sum_i k_i P_i on the host, for the handful of points of a small call
