@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--wbits", type=int, default=int(os.environ.get("CKZG_BENCH_WBITS", "15")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the untimed host-pointer (PCIe-inclusive) leg")
     args = ap.parse_args()
 
     import torch
@@ -142,7 +143,7 @@ def main():
 
     # PCIe-inclusive rate (host pointers), one untimed-for-`value` call on rank 0
     pcie_rate = None
-    if rank == 0:
+    if rank == 0 and not args.no_pcie:
         hb = blobs.cpu().numpy().tobytes()
         ho = C.create_string_buffer(48 * BLOBS_PER_STEP)
         hs = C.create_string_buffer(BLOBS_PER_STEP)
