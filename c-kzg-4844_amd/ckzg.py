@@ -163,6 +163,26 @@ class Kzg:
         return ([rc.raw[i * BYTES_PER_CELL:(i + 1) * BYTES_PER_CELL] for i in range(CELLS_PER_EXT_BLOB)],
                 [rp.raw[i * 48:(i + 1) * 48] for i in range(CELLS_PER_EXT_BLOB)])
 
+    def recover_cells_and_kzg_proofs_batch(self, cell_indices, rows, want_cells=True, want_proofs=True):
+        """rows: one list of cells per blob, every row holding the columns `cell_indices` (additive
+        API ckzg_hip_recover_cells_and_kzg_proofs_batch).  Returns ([cells128 per row], [proofs128 per row])."""
+        nb, nc = len(rows), len(cell_indices)
+        for r in rows:
+            _check(len(r) == nc, "list lengths")
+            for c in r:
+                _check(len(c) == BYTES_PER_CELL, "cell")
+        idx = (C.c_uint64 * max(nc, 1))(*cell_indices)
+        rc = C.create_string_buffer(max(nb, 1) * CELLS_PER_EXT_BLOB * BYTES_PER_CELL) if want_cells else None
+        rp = C.create_string_buffer(max(nb, 1) * CELLS_PER_EXT_BLOB * 48) if want_proofs else None
+        self._call("ckzg_hip_recover_cells_and_kzg_proofs_batch", rc, rp, None, idx,
+                   b"".join(b"".join(r) for r in rows), C.c_uint64(nc), C.c_uint64(nb), self.sp)
+        cs = BYTES_PER_CELL * CELLS_PER_EXT_BLOB
+        out_c = [[rc.raw[b * cs + i * BYTES_PER_CELL: b * cs + (i + 1) * BYTES_PER_CELL]
+                  for i in range(CELLS_PER_EXT_BLOB)] for b in range(nb)] if want_cells else None
+        out_p = [[rp.raw[(b * CELLS_PER_EXT_BLOB + i) * 48:(b * CELLS_PER_EXT_BLOB + i + 1) * 48]
+                  for i in range(CELLS_PER_EXT_BLOB)] for b in range(nb)] if want_proofs else None
+        return out_c, out_p
+
     def verify_cell_kzg_proof_batch(self, commitments, cell_indices, cells, proofs):
         n = len(cells)
         _check(len(commitments) == n and len(cell_indices) == n and len(proofs) == n, "list lengths")

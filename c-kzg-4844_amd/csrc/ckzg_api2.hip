@@ -557,46 +557,66 @@ static void vanishing_poly_from_roots(std::vector<Fr> &poly, const std::vector<F
     poly[n] = Fr::one();
 }
 
-// recover_cells (recovery.c:200-365) on the GPU.  d_e holds the 8192 values in cell (bit-reversed)
-// order with zeros at the missing cells and is overwritten with the recovered values, same order.
-static C_KZG_RET recover_cells_gpu(dev::DeviceCtx *ctx, Fr *d_e, const uint64_t *cell_indices, size_t num_cells,
-                                   const KZGSettings *s) {
+// recover_cells (recovery.c:200-365) on the GPU for `count` extended blobs that miss the SAME
+// cells.  d_e holds count x 8192 values in cell (bit-reversed) order with zeros at the missing
+// cells and is overwritten with the recovered values, same order.  Everything that depends only
+// on the missing set (Z over the domain, 1/Z over the coset) is computed once.
+static C_KZG_RET recover_cells_gpu(dev::DeviceCtx *ctx, Fr *d_e, size_t count, const uint64_t *cell_indices,
+                                   size_t num_cells, const KZGSettings *s) {
     const size_t n = FIELD_ELEMENTS_PER_EXT_BLOB;
     std::vector<Fr> roots;
     const Fr *rou = as_fr(s->roots_of_unity);
-    for (size_t i = 0; i < CELLS_PER_EXT_BLOB; i++) {
-        bool have = false;
-        for (size_t k = 0; k < num_cells; k++) have |= (cell_indices[k] == i);
-        if (!have) roots.push_back(rou[reverse_bits_limited(CELLS_PER_EXT_BLOB, i) * (n / CELLS_PER_EXT_BLOB)]);
-    }
+    bool have[CELLS_PER_EXT_BLOB] = {false};
+    for (size_t k = 0; k < num_cells; k++) have[cell_indices[k]] = true;
+    for (size_t i = 0; i < CELLS_PER_EXT_BLOB; i++)
+        if (!have[i]) roots.push_back(rou[reverse_bits_limited(CELLS_PER_EXT_BLOB, i) * (n / CELLS_PER_EXT_BLOB)]);
     if (roots.empty() || roots.size() >= CELLS_PER_EXT_BLOB) return C_KZG_BADARGS;  // recovery.c:103-106
-    std::vector<Fr> shortp, zc(n, Fr::zero());
+    std::vector<Fr> shortp, zc(n, Fr::zero()), ones(n, Fr::one());
     vanishing_poly_from_roots(shortp, roots);
     for (size_t i = 0; i < shortp.size(); i++) zc[i * FIELD_ELEMENTS_PER_CELL] = shortp[i];
-    DBuf<Fr> d_zc, d_zev;
-    OKM(d_zc.alloc(n) && d_zev.alloc(n));
+    DBuf<Fr> d_zc, d_zev, d_zinv;
+    OKM(d_zc.alloc(n) && d_zev.alloc(n) && d_zinv.alloc(n));
     OKB(d_zc.up(zc.data(), n));
+    OKB(d_zinv.up(ones.data(), n));
     OKB(hipMemcpyAsync(d_zev.p, d_zc.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess);
     // Z over the domain, in bit-reversed order = the order of d_e
     RC(dev::fr_ntt_batch(ctx, d_zev.p, 1, 13, true, false, false));
-    RC(dev::fr_mul_inplace_device(ctx, d_e, d_zev.p, n, n));          // (E * Z)(w^i)
-    RC(dev::fr_ntt_batch(ctx, d_e, 1, 13, false, true, true));        // -> coefficients
-    RC(dev::fr_mul_inplace_device(ctx, d_e, ctx->d_shift, n, n));     // coset_fft: scale by 7^i ...
-    RC(dev::fr_ntt_batch(ctx, d_e, 1, 13, true, false, false));       // ... and transform
+    // 1 / Z over the coset (the divisor of recovery.c:322-328, inverted once for the whole batch)
     RC(dev::fr_mul_inplace_device(ctx, d_zc.p, ctx->d_shift, n, n));
     RC(dev::fr_ntt_batch(ctx, d_zc.p, 1, 13, true, false, false));
-    RC(dev::fr_div_inplace_device(ctx, d_e, d_zc.p, n));              // recovery.c:322-328
-    RC(dev::fr_ntt_batch(ctx, d_e, 1, 13, false, true, true));        // coset_ifft ...
-    RC(dev::fr_mul_inplace_device(ctx, d_e, ctx->d_unshift, n, n));   // ... unscale by 7^-i
-    RC(dev::fr_ntt_batch(ctx, d_e, 1, 13, true, false, false));       // evaluations, cell order
+    RC(dev::fr_div_inplace_device(ctx, d_zinv.p, d_zc.p, n));
+    const size_t tot = count * n;
+    RC(dev::fr_mul_inplace_device(ctx, d_e, d_zev.p, tot, n));           // (E * Z)(w^i)
+    RC(dev::fr_ntt_batch(ctx, d_e, count, 13, false, true, true));       // -> coefficients
+    RC(dev::fr_mul_inplace_device(ctx, d_e, ctx->d_shift, tot, n));      // coset_fft: scale by 7^i ...
+    RC(dev::fr_ntt_batch(ctx, d_e, count, 13, true, false, false));      // ... and transform
+    RC(dev::fr_mul_inplace_device(ctx, d_e, d_zinv.p, tot, n));          // recovery.c:322-328
+    RC(dev::fr_ntt_batch(ctx, d_e, count, 13, false, true, true));       // coset_ifft ...
+    RC(dev::fr_mul_inplace_device(ctx, d_e, ctx->d_unshift, tot, n));    // ... unscale by 7^-i
+    RC(dev::fr_ntt_batch(ctx, d_e, count, 13, true, false, false));      // evaluations, cell order
     OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
     return C_KZG_OK;
 }
 
-extern "C" C_KZG_RET recover_cells_and_kzg_proofs(Cell *recovered_cells, KZGProof *recovered_proofs,
-                                                  const uint64_t *cell_indices, const Cell *cells,
-                                                  uint64_t num_cells, const KZGSettings *s) {
-    // eip7594.c:177-304
+// cells[b][j] (2048 B each) -> image[b][cell_indices[j]]; the image is zero elsewhere
+__global__ void k_scatter_cells(uint4 *image, const uint4 *cells, const uint32_t *idx, uint32_t num_cells,
+                                size_t total_u4) {
+    size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (g >= total_u4) return;
+    constexpr uint32_t U4 = BYTES_PER_CELL / 16;
+    size_t cell = g / U4;
+    uint32_t w = (uint32_t)(g % U4);
+    size_t b = cell / num_cells;
+    uint32_t j = (uint32_t)(cell % num_cells);
+    image[(b * CELLS_PER_EXT_BLOB + idx[j]) * U4 + w] = cells[g];
+}
+
+extern "C" C_KZG_RET ckzg_hip_recover_cells_and_kzg_proofs_batch(Cell *recovered_cells, KZGProof *recovered_proofs,
+                                                                 uint8_t *status, const uint64_t *cell_indices,
+                                                                 const Cell *cells, uint64_t num_cells,
+                                                                 uint64_t num_blobs, const KZGSettings *s) {
+    // eip7594.c:177-304, for num_blobs rows that all hold the same num_cells columns
+    if (recovered_cells == NULL && recovered_proofs == NULL) return C_KZG_BADARGS;
     if (num_cells > CELLS_PER_EXT_BLOB || num_cells < CELLS_PER_BLOB) return C_KZG_BADARGS;
     for (size_t i = 0; i < num_cells; i++) {
         if (cell_indices[i] >= CELLS_PER_EXT_BLOB) return C_KZG_BADARGS;
@@ -604,41 +624,71 @@ extern "C" C_KZG_RET recover_cells_and_kzg_proofs(Cell *recovered_cells, KZGProo
     }
     dev::DeviceCtx *ctx = ctx_of(s);
     if (!ctx) return C_KZG_ERROR;
+    if (num_blobs == 0) return C_KZG_OK;
     const size_t n = FIELD_ELEMENTS_PER_EXT_BLOB;
-    std::vector<uint8_t> image(n * 32, 0);
-    for (size_t i = 0; i < num_cells; i++) memcpy(&image[cell_indices[i] * BYTES_PER_CELL], cells[i].bytes, BYTES_PER_CELL);
-    {
-        std::lock_guard<std::mutex> lock(ctx->mu);
-        OKB(hipSetDevice(ctx->device) == hipSuccess);
-        DBuf<uint8_t> d_img, d_proofs;
-        DBuf<Fr> d_e;
-        DBuf<uint32_t> d_bad;
-        OKM(d_img.alloc(n * 32) && d_e.alloc(n) && d_bad.alloc(1) && d_proofs.alloc(CELLS_PER_EXT_BLOB * 48));
-        OKB(d_img.up(image.data(), n * 32));
-        OKB(hipMemsetAsync(d_bad.p, 0, 4, ctx->stream) == hipSuccess);
-        RC(dev::bytes_to_fr_batch(ctx, d_e.p, d_bad.p, d_img.p, n, (uint32_t)n));
+    const size_t CH = 512;  // 512 rows: 128 MiB of byte image + 128 MiB of Fr + 64 MiB of coefficients
+    const size_t m = num_blobs < CH ? (size_t)num_blobs : CH;
+    std::vector<uint32_t> idx32(num_cells);
+    for (size_t i = 0; i < num_cells; i++) idx32[i] = (uint32_t)cell_indices[i];
+    std::vector<uint32_t> bad(m);
+    C_KZG_RET result = C_KZG_OK;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    OKB(hipSetDevice(ctx->device) == hipSuccess);
+    DBuf<uint8_t> d_img, d_in, d_proofs;
+    DBuf<Fr> d_e, d_poly;
+    DBuf<uint32_t> d_bad, d_idx;
+    OKM(d_img.alloc(m * n * 32) && d_in.alloc(m * num_cells * BYTES_PER_CELL) && d_e.alloc(m * n) &&
+        d_bad.alloc(m) && d_idx.alloc(num_cells));
+    if (recovered_proofs) OKM(d_proofs.alloc(m * CELLS_PER_EXT_BLOB * 48) && d_poly.alloc(m * FIELD_ELEMENTS_PER_BLOB));
+    OKB(d_idx.up(idx32.data(), num_cells));
+    for (size_t off = 0; off < num_blobs; off += CH) {
+        const size_t k = num_blobs - off < CH ? (size_t)(num_blobs - off) : CH;
+        const size_t in_bytes = k * num_cells * BYTES_PER_CELL;
+        OKB(hipMemcpyAsync(d_in.p, cells + off * num_cells, in_bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
+        OKB(hipMemsetAsync(d_img.p, 0, k * n * 32, ctx->stream) == hipSuccess);
+        OKB(hipMemsetAsync(d_bad.p, 0, k * 4, ctx->stream) == hipSuccess);
+        const size_t u4 = in_bytes / 16;
+        hipLaunchKernelGGL(k_scatter_cells, dim3((unsigned)((u4 + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (uint4 *)d_img.p, (const uint4 *)d_in.p, d_idx.p, (uint32_t)num_cells, u4);
+        OKB(hipGetLastError() == hipSuccess);
+        RC(dev::bytes_to_fr_batch(ctx, d_e.p, d_bad.p, d_img.p, k * n, (uint32_t)n));
         OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
-        uint32_t bad = 0;
-        OKB(d_bad.down(&bad, 1));
-        if (bad) return C_KZG_BADARGS;
-        if (num_cells == CELLS_PER_EXT_BLOB) {
-            for (size_t i = 0; i < CELLS_PER_EXT_BLOB; i++) recovered_cells[i] = cells[i];
-        } else {
-            C_KZG_RET ret = recover_cells_gpu(ctx, d_e.p, cell_indices, num_cells, s);
+        OKB(d_bad.down(bad.data(), k));
+        bool any_bad = false;
+        for (size_t i = 0; i < k; i++) {
+            if (status) status[off + i] = bad[i] ? (uint8_t)C_KZG_BADARGS : 0;
+            any_bad |= bad[i] != 0;
+        }
+        if (any_bad) result = C_KZG_BADARGS;  // rows flagged in status[] hold unspecified output
+        if (num_cells != CELLS_PER_EXT_BLOB) {
+            C_KZG_RET ret = recover_cells_gpu(ctx, d_e.p, k, cell_indices, num_cells, s);
             if (ret != C_KZG_OK) return ret;
-            RC(dev::fr_to_bytes_batch(ctx, d_img.p, d_e.p, n));
+            if (recovered_cells) RC(dev::fr_to_bytes_batch(ctx, d_img.p, d_e.p, k * n));
+        }
+        if (recovered_cells) {
             OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
-            OKB(hipMemcpy(recovered_cells, d_img.p, n * 32, hipMemcpyDeviceToHost) == hipSuccess);
+            OKB(hipMemcpy(recovered_cells + off * CELLS_PER_EXT_BLOB, d_img.p, k * n * 32, hipMemcpyDeviceToHost) == hipSuccess);
         }
         if (recovered_proofs) {
             // cell order is bit-reversed evaluation order: DIT inverse gives the coefficients
             // (poly_lagrange_to_monomial over 8192 points, eip7594.c:270); FK20 reads the low 4096
-            RC(dev::fr_ntt_batch(ctx, d_e.p, 1, 13, false, true, true));
-            RC(dev::fk20_proofs_device(ctx, d_proofs.p, d_e.p, 1));
-            OKB(d_proofs.down((uint8_t *)recovered_proofs, CELLS_PER_EXT_BLOB * 48));
+            RC(dev::fr_ntt_batch(ctx, d_e.p, k, 13, false, true, true));
+            OKB(hipMemcpy2DAsync(d_poly.p, FIELD_ELEMENTS_PER_BLOB * sizeof(Fr), d_e.p, n * sizeof(Fr),
+                                 FIELD_ELEMENTS_PER_BLOB * sizeof(Fr), k, hipMemcpyDeviceToDevice,
+                                 ctx->stream) == hipSuccess);
+            RC(dev::fk20_proofs_device(ctx, d_proofs.p, d_poly.p, k));
+            OKB(hipMemcpy(recovered_proofs + off * CELLS_PER_EXT_BLOB, d_proofs.p, k * CELLS_PER_EXT_BLOB * 48,
+                          hipMemcpyDeviceToHost) == hipSuccess);
         }
     }
-    return C_KZG_OK;
+    return result;
+}
+
+extern "C" C_KZG_RET recover_cells_and_kzg_proofs(Cell *recovered_cells, KZGProof *recovered_proofs,
+                                                  const uint64_t *cell_indices, const Cell *cells,
+                                                  uint64_t num_cells, const KZGSettings *s) {
+    return ckzg_hip_recover_cells_and_kzg_proofs_batch(recovered_cells, recovered_proofs, NULL, cell_indices,
+                                                       cells, num_cells, 1, s);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -64,6 +64,16 @@ C_KZG_RET ckzg_hip_compute_blob_kzg_proof_batch(KZGProof *proofs, uint8_t *statu
                                                 const Bytes48 *commitments_bytes, uint64_t n,
                                                 const KZGSettings *s);
 
+/* recover_cells_and_kzg_proofs (src/eip7594/eip7594.c:177-304) over num_blobs rows that all hold
+ * the SAME num_cells columns (the PeerDAS reconstruction case: a node has columns cell_indices[] of
+ * every blob in the block).  cells is [num_blobs][num_cells], outputs are [num_blobs][128]; either
+ * output may be NULL.  The vanishing polynomial of the missing set is built once for the batch.
+ * status[i] (optional) is C_KZG_BADARGS for a row with a non-canonical field element. */
+C_KZG_RET ckzg_hip_recover_cells_and_kzg_proofs_batch(Cell *recovered_cells, KZGProof *recovered_proofs,
+                                                      uint8_t *status, const uint64_t *cell_indices,
+                                                      const Cell *cells, uint64_t num_cells,
+                                                      uint64_t num_blobs, const KZGSettings *s);
+
 /* Timing hook for bench.py: elapsed milliseconds of the named kernel family inside the last
  * batch call, measured with hipEvents on the stream the kernels were launched on.
  * which: 0 = scalar recoding, 1 = MSM bucket-free accumulate (dominant), 2 = reduce+compress,
