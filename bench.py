@@ -23,7 +23,9 @@ HBM_PEAK_GBS = 8000.0
 # HBM bytes per k_msm_accumulate launch (1024 blobs) from rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
 # KB units), see profiles/README.md; keyed by table window width.  The traffic is the table gathers
 # themselves (nwin*4096 x 96 B per blob), not re-reads of the algorithmic bytes.
-PMC_TRAFFIC_BYTES = {13: (7658816 + 960) * 1024, 15: (6796321 + 960) * 1024}
+PMC_TRAFFIC_BYTES = {13: (7658816 + 960) * 1024, 15: (6796321 + 960) * 1024, 16: (6327172 + 768) * 1024}
+# SQ_INSTS_VALU per 1024-blob launch (profiles/r01_pmc_sq_k_msm_accumulate*.json)
+PMC_VALU_INSTS = {15: 5.92e9, 16: 5.49e9}
 
 
 def cpu_baseline(seconds_budget=12.0):
@@ -77,7 +79,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--wbits", type=int, default=int(os.environ.get("CKZG_BENCH_WBITS", "15")))
+    ap.add_argument("--wbits", type=int, default=int(os.environ.get("CKZG_BENCH_WBITS", "16")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the untimed host-pointer (PCIe-inclusive) leg")
@@ -96,9 +98,14 @@ def main():
 
     import __graft_entry__ as ge
     mod = ge.load_package()
-    hip = mod.Kzg(mod.HIP_SO, options={"device": local_rank, "commit_wbits": args.wbits, "proof_wbits": 13,
-                                       "fk20_wbits": 12})
+    # headline leg: the widest commitment table that fits (16-bit windows = 206 GB of the 288 GB);
+    # the cell-proof tables stay at their small defaults here and are widened for the secondary leg
+    hip = mod.Kzg(mod.HIP_SO, options={"device": local_rank, "commit_wbits": args.wbits, "proof_wbits": 8,
+                                       "fk20_wbits": 8})
     lib = hip.lib
+    lib.ckzg_hip_table_wbits.restype = C.c_int
+    lib.ckzg_hip_table_wbits.argtypes = [C.c_void_p, C.c_int]
+    wbits = int(lib.ckzg_hip_table_wbits(C.addressof(hip.s), 0))  # what was actually built
     fn = lib.ckzg_hip_blob_to_kzg_commitment_batch_device
     fn.restype = C.c_int
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
@@ -174,9 +181,14 @@ def main():
         if parity is False:
             raise SystemExit("bench: GPU commitments differ from the oracle -- number would be invalid")
 
-    # secondary metric of BASELINE.json: compute_cells_and_kzg_proofs (configs[2]), rank 0 only
+    table_bytes = int(lib.ckzg_hip_table_bytes(C.addressof(hip.s)))
+    # secondary metric of BASELINE.json: compute_cells_and_kzg_proofs (configs[2]), rank 0 only,
+    # on a second load with a narrow commitment table and wide cell-proof tables
     secondary = None
     if rank == 0 and world == 1 and not args.no_secondary:
+        hip.close()
+        hip = mod.Kzg(mod.HIP_SO, options={"device": local_rank, "commit_wbits": 10, "proof_wbits": 13,
+                                           "fk20_wbits": 12})
         fc = lib.ckzg_hip_compute_cells_and_kzg_proofs_batch_device
         fc.restype = C.c_int
         fc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
@@ -221,10 +233,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": "blob_to_kzg_commitment batch of 1024 blobs per GPU (4096-point G1 MSM per blob), "
                                    "inputs resident in HBM", "blobs_per_step_per_gpu": BLOBS_PER_STEP,
-                       "table_wbits": args.wbits, "table_bytes": int(lib.ckzg_hip_table_bytes(C.addressof(hip.s))),
+                       "table_wbits": wbits, "table_bytes": table_bytes,
                        "parallelism": "independent blob shards per GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": PMC_TRAFFIC_BYTES.get(args.wbits),
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": PMC_TRAFFIC_BYTES.get(wbits),
                          "kernel": "k_msm_accumulate", "kernel_ms": round(avg_k * 1e3, 3),
                          "note": "integer-VALU-bound kernel (v_mad_u64_u32 chains); HBM fraction is small by nature"},
             # the physical bound of this kernel: integer multiply-add issue rate.  peak = measured
@@ -232,10 +244,11 @@ def main():
             # achieved counts only the 392 multiply-adds of each of the 10 field products per
             # table addition (nwin*4096 additions per blob), not the ~25 % of other instructions.
             "roofline_valu": {"bound": "v_mad_u64_u32 issue", "unit": "T lane-mad/s", "peak": 32.9,
-                              "achieved": round(BLOBS_PER_STEP * (255 // args.wbits + 1) * 4096 * 10 * 392 / avg_k / 1e12, 3),
-                              "frac": round(BLOBS_PER_STEP * (255 // args.wbits + 1) * 4096 * 10 * 392 / avg_k / 32.9e12, 4),
-                              "pmc": "profiles/r01_pmc_sq_k_msm_accumulate.json: 5.92e9 VALU wave-instructions per launch, "
-                                     "~95 % of the VALU issue slots at the sustained 2.1 GHz clock"},
+                              "achieved": round(BLOBS_PER_STEP * (255 // wbits + 1) * 4096 * 10 * 392 / avg_k / 1e12, 3),
+                              "frac": round(BLOBS_PER_STEP * (255 // wbits + 1) * 4096 * 10 * 392 / avg_k / 32.9e12, 4),
+                              "valu_wave_insts_per_launch": PMC_VALU_INSTS.get(wbits),
+                              "pmc": "profiles/r01_pmc_sq_k_msm_accumulate*.json (SQ_INSTS_VALU, GRBM_GUI_ACTIVE): "
+                                     "~95 % of the VALU issue slots at the sustained ~2.1 GHz clock"},
             "pcie_inclusive_blobs_per_s": None if pcie_rate is None else round(pcie_rate, 2),
             "parity_spot_check_vs_oracle": parity,
             "secondary": secondary,

@@ -24,7 +24,7 @@ extern "C" C_KZG_RET ckzg_hip_set_option(const char *key, int64_t value) {
         if (value < -1 || value > 1023) return C_KZG_BADARGS;
         g_opts.device = (int)value;
     } else if (!strcmp(key, "commit_wbits")) {
-        if (value < 4 || value > 15) return C_KZG_BADARGS;
+        if (value < 4 || value > 16) return C_KZG_BADARGS;
         g_opts.commit_wbits = (int)value;
     } else if (!strcmp(key, "fk20_wbits")) {
         if (value != 0 && (value < 4 || value > 15)) return C_KZG_BADARGS;
@@ -380,4 +380,15 @@ extern "C" uint64_t ckzg_hip_table_bytes(const KZGSettings *s) {
     dev::DeviceCtx *ctx = ctx_of(s);
     if (!ctx) return 0;
     return ctx->commit.bytes() + ctx->fk20.bytes() + ctx->mono.bytes();
+}
+
+extern "C" int ckzg_hip_table_wbits(const KZGSettings *s, int which) {
+    dev::DeviceCtx *ctx = ctx_of(s);
+    if (!ctx) return -1;
+    switch (which) {
+        case 0: return ctx->commit.wbits;
+        case 1: return ctx->fk20.wbits;
+        case 2: return ctx->mono.d_table ? ctx->mono.wbits : 0;
+        default: return -1;
+    }
 }

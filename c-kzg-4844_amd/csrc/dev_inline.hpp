@@ -18,7 +18,10 @@ __device__ __forceinline__ void load_be256(uint32_t s[8], const uint8_t *p) {
     s[0] = __builtin_bswap32(b.w);
 }
 
-// signed base-2^wbits digits of a 256-bit integer, digit w written at dst[w * stride]
+// signed base-2^wbits digits of a 256-bit integer, digit w written at dst[w * stride].
+// Digits lie in [-2^(wbits-1), 2^(wbits-1) - 1], so they fit int16_t up to wbits = 16.  With
+// wbits in {4, 8, 16} the nwin windows cover exactly 256 bits: the top digit of a canonical scalar
+// (< r < 0.46 * 2^255) stays below 2^(wbits-1) and never carries out.
 __device__ __forceinline__ void recode_signed(int16_t *dst, size_t stride, uint32_t s[8], int wbits,
                                               int nwin) {
     const uint32_t mask = (1u << wbits) - 1u, half = 1u << (wbits - 1);
@@ -29,7 +32,7 @@ __device__ __forceinline__ void recode_signed(int16_t *dst, size_t stride, uint3
         for (int k = 0; k < 7; k++) s[k] = (s[k] >> wbits) | (s[k + 1] << (32 - wbits));
         s[7] >>= wbits;
         carry = 0;
-        if ((uint32_t)d > half) {
+        if ((uint32_t)d >= half) {
             d -= (int)(mask + 1u);
             carry = 1;
         }

@@ -14,6 +14,27 @@ static int env_int(const char *name, int dflt) {
     return atoi(v);
 }
 
+// Largest window width <= wbits (but >= floor_bits) whose table, plus the construction scratch of
+// build_fixed_base_table and a margin for per-call scratch, fits the HBM that is free right now.
+// A wide table is an optimisation, never a reason for load_trusted_setup to fail.
+static int fit_wbits(const char *what, int wbits, int floor_bits, int npoints) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return wbits;
+    const size_t margin = (size_t)6 << 30;
+    const int asked = wbits;
+    while (wbits > floor_bits) {
+        size_t nwin = 255 / wbits + 1, half = (size_t)1 << (wbits - 1), slab = (size_t)npoints * half;
+        size_t need = nwin * slab * sizeof(G1Affine) + nwin * npoints * sizeof(G1XYZZ) +
+                      slab * (sizeof(G1XYZZ) + sizeof(Fp)) + margin;
+        if (need <= free_b) break;
+        wbits--;
+    }
+    if (wbits != asked)
+        fprintf(stderr, "[ckzg-hip] %s table: window %d bits does not fit %.1f GB of free HBM, using %d bits\n",
+                what, asked, free_b / 1e9, wbits);
+    return wbits;
+}
+
 void destroy_device_ctx(dev::DeviceCtx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
@@ -101,7 +122,8 @@ C_KZG_RET create_device_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affine,
     // commitment table over the bit-reversed Lagrange points
     {
         int wbits = env_int("CKZG_HIP_COMMIT_WBITS", g_opts.commit_wbits);
-        if (wbits < 4 || wbits > 15) wbits = 10;
+        if (wbits < 4 || wbits > 16) wbits = 10;
+        wbits = fit_wbits("commit", wbits, 10, (int)NUM_G1_POINTS);
         DeviceBuffer d_bases;
         if (!d_bases.alloc(NUM_G1_POINTS * sizeof(G1Affine))) {
             destroy_device_ctx(ctx);
@@ -143,6 +165,7 @@ C_KZG_RET create_device_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affine,
         int wbits = env_int("CKZG_HIP_FK20_WBITS", g_opts.fk20_wbits);
         if (wbits == 0) wbits = s->wbits > 8 ? (s->wbits > 13 ? 13 : (int)s->wbits) : 8;
         if (wbits < 4 || wbits > 15) wbits = 8;
+        wbits = fit_wbits("fk20", wbits, 8, dev::N_CELLS_EXT * dev::N_CELL);
         rc = dev::build_fixed_base_table(ctx, &ctx->fk20, ctx->d_xext, dev::N_CELLS_EXT * dev::N_CELL, wbits);
         if (rc) {
             destroy_device_ctx(ctx);
@@ -155,6 +178,7 @@ C_KZG_RET create_device_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affine,
         ctx->direct_max = env_int("CKZG_HIP_DIRECT_MAX", g_opts.direct_max);
         if (wbits != 0 && ctx->direct_max > 0) {
             if (wbits < 4 || wbits > 15) wbits = 8;
+            wbits = fit_wbits("proof", wbits, 8, (int)NUM_G1_POINTS);
             int rc = dev::build_fixed_base_table(ctx, &ctx->mono, ctx->d_mono, (int)NUM_G1_POINTS, wbits);
             if (rc) {
                 destroy_device_ctx(ctx);

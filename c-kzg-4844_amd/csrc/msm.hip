@@ -128,7 +128,7 @@ int batch_to_affine_device(DeviceCtx *ctx, G1Affine *d_out, const G1XYZZ *d_in, 
 
 int build_fixed_base_table(DeviceCtx *ctx, FixedBaseTable *t, const G1Affine *d_bases, int npoints,
                            int wbits) {
-    if (wbits < 2 || wbits > 15) return 1;
+    if (wbits < 2 || wbits > 16) return 1;
     t->npoints = npoints;
     t->wbits = wbits;
     t->nwin = 255 / wbits + 1;

@@ -83,6 +83,11 @@ double ckzg_hip_last_kernel_ms(const KZGSettings *s, int which);
 /* Bytes of HBM held by the context's tables. */
 uint64_t ckzg_hip_table_bytes(const KZGSettings *s);
 
+/* Window width actually built for table `which` (0 = commitment, 1 = FK20, 2 = proof/monomial;
+ * 0 if that table is disabled): load_trusted_setup narrows a requested width that does not fit the
+ * free HBM instead of failing. */
+int ckzg_hip_table_wbits(const KZGSettings *s, int which);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,7 +58,8 @@ def test_options_are_validated(lib):
     f = lib.ckzg_hip_set_option
     f.restype = C.c_int
     f.argtypes = [C.c_char_p, C.c_int64]
-    assert f(b"commit_wbits", 16) == 1
+    assert f(b"commit_wbits", 17) == 1
+    assert f(b"fk20_wbits", 16) == 1
     assert f(b"commit_wbits", 3) == 1
     assert f(b"nonsense", 1) == 1
     assert f(b"commit_wbits", 10) == 0

@@ -14,7 +14,7 @@ def _restore(api):
         api.lib.ckzg_hip_set_option(k.encode(), v)
 
 
-@pytest.mark.parametrize("wbits", [4, 5, 7, 9, 12])
+@pytest.mark.parametrize("wbits", [4, 5, 7, 8, 9, 12, 16])
 def test_commitment_for_every_table_width(hip, wbits):
     api = Kzg(HIP_SO, "", precompute=0, options={"commit_wbits": wbits, "proof_wbits": 0})
     _restore(api)
@@ -24,6 +24,13 @@ def test_commitment_for_every_table_width(hip, wbits):
             assert got == exp, (wbits, name)
         b = rand_blob(51, wbits)
         assert api.blob_to_kzg_commitment(b) == hip.blob_to_kzg_commitment(b)
+        # every digit exactly +-2^(wbits-1) in some window: the edge of the signed recoding
+        v = sum(1 << (wbits * w + wbits - 1) for w in range(0, 250 // wbits, 2))
+        edge = (v.to_bytes(32, "big") + (v >> 1).to_bytes(32, "big")) * 2048
+        assert api.blob_to_kzg_commitment(edge) == hip.blob_to_kzg_commitment(edge)
+        if wbits == 16:  # 206 GB: really built at 16 bits, not silently narrowed
+            api.lib.ckzg_hip_table_bytes.restype = __import__("ctypes").c_uint64
+            assert api.lib.ckzg_hip_table_bytes(api.sp) >= 4096 * 16 * 32768 * 96
     finally:
         api.close()
 
