@@ -24,6 +24,9 @@ HBM_PEAK_GBS = 8000.0
 # KB units), see profiles/README.md; keyed by table window width.  The traffic is the table gathers
 # themselves (nwin*4096 x 96 B per blob), not re-reads of the algorithmic bytes.
 PMC_TRAFFIC_BYTES = {13: (7658816 + 960) * 1024, 15: (6796321 + 960) * 1024, 16: (6327172 + 768) * 1024}
+# v_mad_u64_u32 per mixed addition (g1_28.hpp: xyzz28_madd_alt): 6 products x 392, 2 squares x 301,
+# one fused two-product reduction x 588
+MADS_PER_ADDITION = 6 * 392 + 2 * 301 + 588
 # SQ_INSTS_VALU per 1024-blob launch (profiles/r01_pmc_sq_k_msm_accumulate*.json)
 PMC_VALU_INSTS = {15: 5.92e9, 16: 5.49e9}
 
@@ -241,11 +244,11 @@ def main():
                          "note": "integer-VALU-bound kernel (v_mad_u64_u32 chains); HBM fraction is small by nature"},
             # the physical bound of this kernel: integer multiply-add issue rate.  peak = measured
             # v_mad_u64_u32 rate of the chip (tools/ubench/instr_rates.hip: 32.9e12 lane-ops/s);
-            # achieved counts only the 392 multiply-adds of each of the 10 field products per
-            # table addition (nwin*4096 additions per blob), not the ~25 % of other instructions.
+            # achieved counts only the multiply-adds of the field products of each table addition
+            # (MADS_PER_ADDITION; nwin*4096 additions per blob), not the ~25 % of other instructions.
             "roofline_valu": {"bound": "v_mad_u64_u32 issue", "unit": "T lane-mad/s", "peak": 32.9,
-                              "achieved": round(BLOBS_PER_STEP * (255 // wbits + 1) * 4096 * 10 * 392 / avg_k / 1e12, 3),
-                              "frac": round(BLOBS_PER_STEP * (255 // wbits + 1) * 4096 * 10 * 392 / avg_k / 32.9e12, 4),
+                              "achieved": round(BLOBS_PER_STEP * (255 // wbits + 1) * 4096 * MADS_PER_ADDITION / avg_k / 1e12, 3),
+                              "frac": round(BLOBS_PER_STEP * (255 // wbits + 1) * 4096 * MADS_PER_ADDITION / avg_k / 32.9e12, 4),
                               "valu_wave_insts_per_launch": PMC_VALU_INSTS.get(wbits),
                               "pmc": "profiles/r01_pmc_sq_k_msm_accumulate*.json (SQ_INSTS_VALU, GRBM_GUI_ACTIVE): "
                                      "~95 % of the VALU issue slots at the sustained ~2.1 GHz clock"},

@@ -86,6 +86,41 @@ HD F28<1, 2> mul(const F28<LA, VA> &a, const F28<LB, VB> &b) {
     return r;
 }
 
+// (a*b + c*d)/2^392 mod p with ONE Montgomery reduction: 588 multiply-adds instead of 784 for two
+// products.  Same row structure as mul(): both partial products of a row land in the column
+// accumulators before the row's q*p is added.
+template <int LA, int VA, int LB, int VB, int LC, int VC, int LD, int VD>
+HD F28<1, 2> mul_add2(const F28<LA, VA> &a, const F28<LB, VB> &b, const F28<LC, VC> &c, const F28<LD, VD> &d) {
+    static_assert(14 * (LA * LB + LC * LD) + 14 + 1 <= 255, "64-bit column accumulator would overflow");
+    static_assert(VA * VB + VC * VD <= 2500, "Montgomery result would not be < 2p");
+    uint64_t t[15];
+#pragma unroll
+    for (int j = 0; j < 15; j++) t[j] = 0;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        const uint32_t bi = b.l[i], di = d.l[i];
+#pragma unroll
+        for (int j = 0; j < 14; j++) t[j] += (uint64_t)a.l[j] * bi;
+#pragma unroll
+        for (int j = 0; j < 14; j++) t[j] += (uint64_t)c.l[j] * di;
+        const uint32_t q = ((uint32_t)t[0] * (uint32_t)FP28_NINV) & M28;
+#pragma unroll
+        for (int j = 0; j < 14; j++) t[j] += (uint64_t)q * FP28_P[j];
+        t[1] += t[0] >> 28;
+#pragma unroll
+        for (int j = 0; j < 14; j++) t[j] = t[j + 1];
+        t[14] = 0;
+    }
+    F28<1, 2> r;
+#pragma unroll
+    for (int j = 0; j < 13; j++) {
+        t[j + 1] += t[j] >> 28;
+        r.l[j] = (uint32_t)t[j] & M28;
+    }
+    r.l[13] = (uint32_t)t[13];
+    return r;
+}
+
 // Montgomery square: the 91 cross products are taken once against a doubled operand (105
 // multiply-adds for the product instead of 196), then the same 14-row reduction: 301 vs 392 mads.
 template <int LA, int VA>

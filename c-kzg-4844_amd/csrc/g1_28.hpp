@@ -72,6 +72,66 @@ HD void xyzz28_madd(XYZZ28 &acc, bool &inf, const F28<1, 1> &x2, const F28<4, 2>
     acc.zzz = mul(acc.zzz, ppp);
 }
 
+// The accumulate kernels' form of the mixed addition: one field reduction fewer per addition.
+// The accumulator keeps W = +-Y (`yneg` says which).  With t = -+y2 chosen so that T = t*ZZZ has the
+// opposite sign, Rw = T + W = -+R is an addition, and the new W3 = Rw*(Q - X3) + W*PPP is a SUM of two
+// products (one shared Montgomery reduction, mul_add2) that equals -+Y3: the stored sign flips at
+// every addition, which costs nothing because the table point's sign is chosen per lane anyway.
+// (x2, y2) is the table entry, fully reduced; `dneg` asks for its negative.  Not infinity.
+HD void xyzz28_madd_alt(XYZZ28 &acc, bool &inf, bool &yneg, const F28<1, 1> &x2, const F28<1, 1> &y2, bool dneg) {
+    if (inf) yneg = false;
+    // yneg == false: stored +Y, want t = -(+-y2); yneg == true: stored -Y, want t = +(+-y2)
+    const F28<4, 2> t = cneg_reduced(y2, dneg != !yneg);
+    if (inf) {
+        acc.x = widen<1, 10>(x2);
+        acc.y = widen<1, 6>(norm(t));           // = -(the point's y): stored sign is "negative"
+        acc.zz = widen<1, 2>(f28_one());
+        acc.zzz = acc.zz;
+        inf = false;
+        yneg = true;
+        return;
+    }
+    auto u2 = mul(x2, acc.zz);                  // <1,2>
+    auto tt = mul(t, acc.zzz);                  // <1,2>   -+S2
+    auto p = sub(u2, acc.x);                    // <4,18>
+    auto r = add(tt, acc.y);                    // <2,8>    -+R
+    auto pp = sqr(p);                           // <1,2>
+    if (is_zero(pp)) {
+        // same x: either the same point (double) or its negative (result is infinity)
+        if (is_zero(mul(r, f28_one()))) {
+            xyzz28_dbl_affine(acc, x2, cneg_reduced(y2, dneg));
+        } else {
+            inf = true;
+        }
+        yneg = false;
+        return;
+    }
+    auto ppp = mul(p, pp);                      // <1,2>
+    auto q = mul(acc.x, pp);                    // <1,2>
+    auto rr = sqr(r);                           // 15*4+15 ok; 64 ok
+    auto t1 = add(ppp, add(q, q));              // <3,6>
+    acc.x = norm(sub(rr, t1));                  // <6,10> -> <1,10>
+    auto d = sub(q, acc.x);                     // <4,18>
+    // limbs 14*(2*4 + 1*1)+15 = 141 ok; values 8*18 + 6*2 = 156 ok
+    acc.y = widen<1, 6>(mul_add2(r, d, acc.y, ppp));
+    acc.zz = mul(acc.zz, pp);
+    acc.zzz = mul(acc.zzz, ppp);
+    yneg = !yneg;
+}
+
+// back to the plain representation (acc.y = +Y) after a run of xyzz28_madd_alt
+HD void xyzz28_fix_sign(XYZZ28 &acc, bool inf, bool &yneg) {
+    F28<1, 0> zero;
+#pragma unroll
+    for (int j = 0; j < 14; j++) zero.l[j] = 0;
+    auto n = norm(sub(zero, acc.y));            // <4,8> -> <1,8>: 8p - y
+    auto m = mul(n, f28_one());                 // back under the <1,6> bound of the struct
+    const bool flip = yneg && !inf;
+#pragma unroll
+    for (int j = 0; j < 14; j++) acc.y.l[j] = flip ? m.l[j] : acc.y.l[j];
+    yneg = false;
+}
+
 // general doubling (dbl-2008-s-1)
 HD void xyzz28_dbl(XYZZ28 &a) {
     auto u = add(a.y, a.y);                     // <2,12>

@@ -105,6 +105,23 @@ void hs_g1_neg28(G1Jac *r, const G1Jac *a) {
     XYZZ28 x = xyzz28_from_xyzz(xyzz_from_jac(*a), ai);
     *r = jac_from_affine(xyzz28_to_affine(xyzz28_neg(x), ai));
 }
+// r = a*b + c*d with one reduction, operands lazily reduced the way xyzz28_madd_alt feeds them:
+// (a + a) as <2,4>, (b - c) as <4,18>
+void hs_fp28_mul_add2(Fp *r, const Fp *a, const Fp *b, const Fp *c, const Fp *d) {
+    auto fa = f28_from_fp(*a), fb = f28_from_fp(*b), fc = f28_from_fp(*c), fd = f28_from_fp(*d);
+    auto a2 = add(fa, fa);                              // <2,4>
+    auto bc = sub(fb, widen<1, 10>(fc));                // <4,18>
+    *r = f28_to_fp(mul_add2(a2, bc, widen<1, 6>(fc), fd));  // 2a(b-c) + c*d
+}
+// chain through xyzz28_madd_alt (sign-alternating accumulator): signs[i] != 0 subtracts pts[i]
+void hs_g1_madd28_alt_chain(G1Jac *r, const G1Affine *pts, const uint8_t *signs, int n) {
+    XYZZ28 acc;
+    bool inf = true, yneg = false;
+    for (int i = 0; i < n; i++)
+        xyzz28_madd_alt(acc, inf, yneg, table_coord(pts[i].x), table_coord(pts[i].y), signs[i] != 0);
+    xyzz28_fix_sign(acc, inf, yneg);
+    *r = jac_from_xyzz(xyzz28_to_xyzz(acc, inf));
+}
 // many additions in a row, to exercise the value-bound bookkeeping over a long chain
 void hs_g1_madd28_chain(G1Jac *r, const G1Affine *pts, int n) {
     XYZZ28 acc;

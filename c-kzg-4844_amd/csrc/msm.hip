@@ -242,7 +242,11 @@ __global__ __launch_bounds__(THREADS) void k_msm_accumulate(
     const int16_t *dg = digits + (size_t)vec * pairs_per_vec;
     // accumulator in the 28-bit-limb / 2^392 domain (fp28.hpp), infinity tracked by a flag
     XYZZ28 acc28;
-    bool inf = true;
+    bool inf = true, yneg = false;  // yneg: acc28.y currently holds -Y (xyzz28_madd_alt)
+    // (Measured alternatives: requesting the next entry before the current addition -- 10.45 ms vs
+    // 10.32 ms, the second wave of the SIMD already hides the gather; unrolling by two -- 14.4 ms,
+    // two copies of the ~40 KB addition body thrash the instruction cache; capping VGPRs for 3 or
+    // 4 waves per SIMD -- 11.4 / 13.2 ms.)
     for (uint32_t q = q0 + threadIdx.x; q < q1; q += THREADS) {
         int d = dg[q];
         if (d != 0) {
@@ -259,10 +263,11 @@ __global__ __launch_bounds__(THREADS) void k_msm_accumulate(
                 any |= v.x | v.y | v.z | v.w;
             }
             if (any != 0) {  // (0,0) encodes a table entry at infinity
-                xyzz28_madd(acc28, inf, f28_unpack<1>(wd), cneg_reduced(f28_unpack<1>(wd + 12), d < 0));
+                xyzz28_madd_alt(acc28, inf, yneg, f28_unpack<1>(wd), f28_unpack<1>(wd + 12), d < 0);
             }
         }
     }
+    xyzz28_fix_sign(acc28, inf, yneg);
     block_reduce_xyzz28<THREADS>(acc28, inf, sh);
     if (threadIdx.x == 0) partials[blockIdx.x] = xyzz28_to_xyzz(acc28, inf);
 }
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(64) void k_msm_small(G1XYZZ *out, const G1Affine *t
     const int tid = threadIdx.x, grp = tid / LPV, l = tid % LPV;
     const uint32_t vec = blockIdx.x * GROUPS + grp;
     XYZZ28 acc28;
-    bool inf = true;
+    bool inf = true, yneg = false;
     if (vec < nvec) {
         const uint32_t voff = (vec % vecs_per_group) * ppv;
         const int16_t *dg = digits + (size_t)vec * pairs_per_vec;
@@ -299,10 +304,11 @@ __global__ __launch_bounds__(64) void k_msm_small(G1XYZZ *out, const G1Affine *t
                     wd[4 * k] = v.x; wd[4 * k + 1] = v.y; wd[4 * k + 2] = v.z; wd[4 * k + 3] = v.w;
                     any |= v.x | v.y | v.z | v.w;
                 }
-                if (any != 0) xyzz28_madd(acc28, inf, f28_unpack<1>(wd), cneg_reduced(f28_unpack<1>(wd + 12), d < 0));
+                if (any != 0) xyzz28_madd_alt(acc28, inf, yneg, f28_unpack<1>(wd), f28_unpack<1>(wd + 12), d < 0);
             }
         }
     }
+    xyzz28_fix_sign(acc28, inf, yneg);
     for (int s = LPV / 2; s >= 1; s >>= 1) {
         if (l >= s && l < 2 * s) {
             const uint32_t *src = reinterpret_cast<const uint32_t *>(&acc28);

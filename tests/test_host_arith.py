@@ -256,6 +256,76 @@ def test_xyzz28_mixed_addition_matches_oracle(libs):
     assert o.og1_equal(r, ref)
 
 
+def test_fp28_fused_two_product_reduction(libs):
+    o, h = libs
+    rnd = random.Random(19)
+    edge = [0, 1, P - 1, P - 2, (P - 1) // 2, 2 ** 380]
+    for k in range(400):
+        v = [edge[(k // 6 ** i) % 6] for i in range(4)] if k < 200 else [rnd.randrange(P) for _ in range(4)]
+        a, b, c, d = v
+        bufs = [x.to_bytes(48, "little") for x in v]
+        # operands are Montgomery residues on both sides: compare in that domain via the oracle
+        t1, t2, t3, r1, r2 = _buf(48), _buf(48), _buf(48), _buf(48), _buf(48)
+        o.ofp_sub(t1, bufs[1], bufs[2])
+        o.ofp_mul(t1, bufs[0], t1)
+        o.ofp_add(t1, t1, t1)            # 2a(b-c)
+        o.ofp_mul(t2, bufs[2], bufs[3])  # c*d
+        o.ofp_add(r1, t1, t2)
+        h.hs_fp28_mul_add2(r2, bufs[0], bufs[1], bufs[2], bufs[3])
+        assert r1.raw == r2.raw, k
+
+
+def test_xyzz28_sign_alternating_accumulation(libs):
+    """xyzz28_madd_alt keeps +-Y and flips the stored sign at every addition; chains with every
+    special case in the middle (first point, doubling, cancellation to infinity, restart)."""
+    o, h = libs
+    rnd = random.Random(23)
+    g = _buf(144)
+    h.hs_g1_generator(g)
+
+    def aff(p):
+        a = _buf(96)
+        o.og1_to_affine(a, p)
+        return a.raw
+
+    base = [_omul(o, g, rnd.randrange(R)) for _ in range(12)]
+    # (index into base, subtract?) scripts
+    scripts = [
+        [(0, 0)], [(0, 1)], [(0, 0), (1, 0)], [(0, 1), (1, 0)], [(0, 0), (1, 1), (2, 0)],
+        [(0, 0), (0, 0)], [(0, 1), (0, 1)],                       # doubling as 2nd addition (stored sign "-")
+        [(0, 0), (1, 0), (0, 0)],
+        [(0, 0), (0, 1)], [(0, 1), (0, 0), (3, 0)],               # cancel, then restart
+        [(0, 0), (1, 0), (1, 1), (0, 1), (2, 1), (3, 0)],         # cancel in the middle of a chain
+        [(i % 12, rnd.randrange(2)) for i in range(150)],
+        [(rnd.randrange(12), rnd.randrange(2)) for i in range(200)],
+    ]
+    # P + Q where P = acc exactly (doubling at a later, even/odd position)
+    for pos in (2, 3):
+        sc = [(i, 0) for i in range(pos)]
+        scripts.append(("dbl", sc))
+    for sc in scripts:
+        special = None
+        if isinstance(sc, tuple):
+            special, sc = sc
+        pts = b"".join(aff(base[i]) for i, _ in sc)
+        signs = bytes(s for _, s in sc)
+        ref = _buf(144)
+        for i, sgn in sc:
+            p = _buf(144)
+            p.raw = base[i].raw
+            if sgn:
+                o.og1_neg(p, p)
+            o.og1_add(ref, ref, p)
+        if special == "dbl":
+            # append the running sum itself as an affine point: forces the doubling path
+            pts += aff(ref)
+            signs += b"\x00"
+            o.og1_dbl(ref, ref)
+        r = _buf(144)
+        h.hs_g1_madd28_alt_chain(r, pts, signs, len(signs))
+        assert o.og1_equal(r, ref), sc
+
+
 def test_fp28_square_and_inverse(libs):
     o, h = libs
     rnd = random.Random(13)
