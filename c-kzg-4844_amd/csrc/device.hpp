@@ -50,7 +50,7 @@ struct DeviceCtx {
     // Fr tables for NTTs and evaluation (Montgomery form, 8 x u32)
     Fr *d_roots = nullptr;        // w^i, 8193 entries
     Fr *d_brp_roots = nullptr;    // 8192
-    uint32_t *d_roots_raw = nullptr;  // canonical limbs of w^i (scalars for the G1 FFT)
+    uint32_t *d_roots_raw = nullptr;  // GLV halves {k1, k2} of w^(64 i), i <= 128 (twiddles of the G1 FFT)
     // FK20
     FixedBaseTable fk20;          // over x_ext_fft columns: point index = col*64 + row
     G1Affine *d_xext = nullptr;   // [128][64] affine

@@ -94,21 +94,22 @@ __device__ __forceinline__ void pt_put(uint32_t (*sh)[128], int idx, const XYZZ2
     sh[56][idx] = inf ? 1u : 0u;
 }
 
+// k points at the GLV halves {k1[4], k2[4]} of the twiddle (g1_28.hpp: glv_split)
 __device__ __noinline__ void g1_mul_root(XYZZ28 &p, bool &inf, const uint32_t *k) {
     XYZZ28 o;
     bool oi;
-    xyzz28_mul_w4(o, oi, p, inf, k);
+    xyzz28_mul_glv_w4(o, oi, p, inf, k);
     p = o;
     inf = oi;
 }
 
-// roots_raw[i] = canonical limbs of w^i, i = 0..8192.
+// roots_glv[i] = GLV halves of w^(64 i), i = 0..128 (every twiddle of a size-128 transform).
 // DIF: natural in -> bit-reversed out; DIT: bit-reversed in -> natural out (fft.c:164-185 computes
 // the same butterflies recursively).  zero_odd: after a DIF, clear the odd positions, i.e. the
 // entries whose natural index is >= 64 (fk20.c:264-266).  out_brp: after a DIT, store element k
 // at position brp7(k) (eip7594.c:133).  Arithmetic: fp28.hpp / g1_28.hpp.
 template <bool DIF>
-__global__ __launch_bounds__(64) void k_g1_fft128(G1XYZZ *data, const uint32_t *roots_raw,
+__global__ __launch_bounds__(64) void k_g1_fft128(G1XYZZ *data, const uint32_t *roots_glv,
                                                   int inverse, int zero_odd, int out_brp) {
     __shared__ uint32_t sh[57][128];
     G1XYZZ *vec = data + (size_t)blockIdx.x * 128;
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(64) void k_g1_fft128(G1XYZZ *data, const uint32_t *
         XYZZ28 u = pt_get(sh, i0, ui), v = pt_get(sh, i1, vi);
         int ridx = j * (N_EXT / (2 * half));
         if (inverse) ridx = N_EXT - ridx;
-        const uint32_t *k = roots_raw + (size_t)ridx * 8;
+        const uint32_t *k = roots_glv + (size_t)(ridx / (N_EXT / 128)) * 8;
         if (!DIF && j != 0) g1_mul_root(v, vi, k);
         XYZZ28 x = u, y = u;
         bool xi = ui, yi = ui;
@@ -149,16 +150,6 @@ __global__ __launch_bounds__(64) void k_g1_fft128(G1XYZZ *data, const uint32_t *
         if (zero_odd && (idx & 1)) inf = true;
         vec[out_brp ? brp7((uint32_t)idx) : idx] = xyzz28_to_xyzz(v, inf);
     }
-}
-
-// Fr Montgomery -> canonical limbs (for scalar multiplication by roots of unity)
-__global__ void k_fr_to_raw(uint32_t *out, const Fr *in, size_t n) {
-    size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (g >= n) return;
-    uint32_t raw[8];
-    to_raw<FrParams>(raw, ld_fr(in + g));
-#pragma unroll
-    for (int k = 0; k < 8; k++) out[g * 8 + k] = raw[k];
 }
 
 __global__ void k_compress(uint8_t *out48, const G1Affine *in, size_t n) {
@@ -191,12 +182,25 @@ __global__ void k_xext_transpose(G1XYZZ *cols, const G1XYZZ *xin) {
     cols[brp7(p) * 64 + off] = xin[g];
 }
 
+// GLV halves of the 129 twiddles w^(64 i) of the size-128 G1 transforms
+__global__ void k_glv_roots(uint32_t *out, const Fr *roots) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > 128) return;
+    uint32_t raw[8], k1[4], k2[4];
+    to_raw<FrParams>(raw, ld_fr(roots + (size_t)g * (N_EXT / 128)));
+    glv_split(raw, k1, k2);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        out[g * 8 + k] = k1[k];
+        out[g * 8 + 4 + k] = k2[k];
+    }
+}
+
 static int ensure_roots_raw(DeviceCtx *ctx, uint32_t **out) {
     // allocated lazily and kept for the life of the context
     if (!ctx->d_roots_raw) {
-        HIP_TRY(hipMalloc(&ctx->d_roots_raw, (size_t)(N_EXT + 1) * 8 * sizeof(uint32_t)));
-        hipLaunchKernelGGL(k_fr_to_raw, dim3((N_EXT + 1 + 255) / 256), dim3(256), 0, ctx->stream,
-                           ctx->d_roots_raw, ctx->d_roots, (size_t)(N_EXT + 1));
+        HIP_TRY(hipMalloc(&ctx->d_roots_raw, (size_t)129 * 8 * sizeof(uint32_t)));
+        hipLaunchKernelGGL(k_glv_roots, dim3(3), dim3(64), 0, ctx->stream, ctx->d_roots_raw, ctx->d_roots);
         HIP_TRY(hipGetLastError());
     }
     *out = ctx->d_roots_raw;

@@ -100,6 +100,15 @@ void hs_g1_mul28(G1Jac *r, const G1Jac *a, const uint32_t *k) {
     xyzz28_mul_w4(o, oi, x, ai, k);
     *r = jac_from_affine(xyzz28_to_affine(o, oi));
 }
+void hs_glv_split(uint32_t *k1k2, const uint32_t *k) { glv_split(k, k1k2, k1k2 + 4); }
+void hs_g1_mul28_glv(G1Jac *r, const G1Jac *a, const uint32_t *k) {
+    uint32_t glv[8];
+    glv_split(k, glv, glv + 4);
+    bool ai, oi;
+    XYZZ28 x = xyzz28_from_xyzz(xyzz_from_jac(*a), ai), o;
+    xyzz28_mul_glv_w4(o, oi, x, ai, glv);
+    *r = jac_from_affine(xyzz28_to_affine(o, oi));
+}
 void hs_g1_neg28(G1Jac *r, const G1Jac *a) {
     bool ai;
     XYZZ28 x = xyzz28_from_xyzz(xyzz_from_jac(*a), ai);

@@ -383,6 +383,36 @@ def test_xyzz28_full_add_mul_neg(libs):
         assert o.og1_equal(r, _omul(o, pt, k))
 
 
+def test_glv_split_and_glv_scalar_mul(libs):
+    """k = k1 + k2*lambda with both halves < 2^128 (lambda = x^2 - 1), and the two-dimensional
+    ladder [k1]P + [k2]phi(P) of the G1 FFT equals [k]P for subgroup points."""
+    o, h = libs
+    rnd = random.Random(29)
+    lam = (0xd201000000010000 ** 2 - 1)
+    assert (lam * lam + lam + 1) == R
+    g = _buf(144)
+    h.hs_g1_generator(g)
+    w = pow(7, (R - 1) // 8192, R)
+    ks = [0, 1, lam - 1, lam, lam + 1, R - 1, R - 2, 2 ** 128, 2 ** 128 - 1, lam * lam, lam * lam + lam]
+    ks += [pow(w, 64 * i, R) for i in range(0, 129, 7)] + [rnd.randrange(R) for _ in range(40)]
+    p1 = _omul(o, g, rnd.randrange(1, R))
+    for n, k in enumerate(ks):
+        kk = (C.c_uint32 * 8)(*[(k >> (32 * i)) & 0xffffffff for i in range(8)])
+        out = (C.c_uint32 * 8)()
+        h.hs_glv_split(out, kk)
+        k1 = sum(out[i] << (32 * i) for i in range(4))
+        k2 = sum(out[4 + i] << (32 * i) for i in range(4))
+        assert k1 == k % lam and k2 == k // lam and k1 + k2 * lam == k
+        if n < 30:
+            r = _buf(144)
+            h.hs_g1_mul28_glv(r, p1, kk)
+            assert o.og1_equal(r, _omul(o, p1, k)), k
+    r = _buf(144)
+    kk = (C.c_uint32 * 8)(*[(ks[20] >> (32 * i)) & 0xffffffff for i in range(8)])
+    h.hs_g1_mul28_glv(r, _buf(144), kk)   # infinity in, infinity out
+    assert o.og1_is_inf(r)
+
+
 def test_safegcd_inverse_matches_fermat_and_python(libs):
     o, h = libs
     rnd = random.Random(19)
