@@ -143,7 +143,12 @@ HD void xyzz28_dbl(XYZZ28 &a) {
     auto mm = sqr(m);
     auto x3 = norm(sub(mm, add(s, s)));         // <1,10>
     auto d = sub(s, x3);                        // <4,18>
-    auto y3 = norm(sub(mul(m, d), mul(w, a.y))); // <1,6>
+    F28<1, 0> zero;
+#pragma unroll
+    for (int j = 0; j < 14; j++) zero.l[j] = 0;
+    auto yn = sub(zero, a.y);                   // <4,8>  = -y
+    // m*d - w*y with one reduction: limbs 14*(3*4 + 1*4)+15 = 239 ok; values 6*18 + 2*8 ok
+    auto y3 = widen<1, 6>(mul_add2(m, d, w, yn));
     a.zz = mul(v, a.zz);
     a.zzz = mul(w, a.zzz);
     a.x = x3;
@@ -178,7 +183,12 @@ HD void xyzz28_add(XYZZ28 &a, bool &ainf, const XYZZ28 &b, bool binf) {
     auto rr = sqr(r);
     auto x3 = norm(sub(rr, add(ppp, add(q, q))));   // <1,10>
     auto d = sub(q, x3);                            // <4,18>
-    auto y3 = norm(sub(mul(r, d), mul(s1, ppp)));   // <1,6>
+    F28<1, 0> zero;
+#pragma unroll
+    for (int j = 0; j < 14; j++) zero.l[j] = 0;
+    auto s1n = sub(zero, s1);                       // <4,4>  = -s1
+    // r*d - s1*ppp with one reduction: limbs 14*(1*4 + 4*1)+15 = 127 ok; values 6*18 + 4*2 ok
+    auto y3 = widen<1, 6>(mul_add2(norm(r), d, s1n, ppp));
     a.zz = mul(mul(a.zz, b.zz), pp);
     a.zzz = mul(mul(a.zzz, b.zzz), ppp);
     a.x = x3;
