@@ -23,12 +23,12 @@ HBM_PEAK_GBS = 8000.0
 # HBM bytes per k_msm_accumulate launch (1024 blobs) from rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
 # KB units), see profiles/README.md; keyed by table window width.  The traffic is the table gathers
 # themselves (nwin*4096 x 96 B per blob), not re-reads of the algorithmic bytes.
-PMC_TRAFFIC_BYTES = {13: (7658816 + 960) * 1024, 15: (6796321 + 960) * 1024, 16: (6327172 + 768) * 1024}
+PMC_TRAFFIC_BYTES = {13: (7658816 + 960) * 1024, 15: (6796321 + 960) * 1024, 16: (6328211 + 768) * 1024}
 # v_mad_u64_u32 per mixed addition (g1_28.hpp: xyzz28_madd_alt): 6 products x 392, 2 squares x 301,
 # one fused two-product reduction x 588
 MADS_PER_ADDITION = 6 * 392 + 2 * 301 + 588
-# SQ_INSTS_VALU per 1024-blob launch (profiles/r01_pmc_sq_k_msm_accumulate*.json)
-PMC_VALU_INSTS = {15: 5.92e9, 16: 5.49e9}
+# SQ_INSTS_VALU per 1024-blob launch (profiles/r01_c16_pmc_sq_k_msm_accumulate.json)
+PMC_VALU_INSTS = {16: 5.12e9}
 
 
 def cpu_baseline(seconds_budget=12.0):
@@ -191,7 +191,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_secondary:
         hip.close()
         hip = mod.Kzg(mod.HIP_SO, options={"device": local_rank, "commit_wbits": 10, "proof_wbits": 13,
-                                           "fk20_wbits": 12})
+                                           "fk20_wbits": 15})
         fc = lib.ckzg_hip_compute_cells_and_kzg_proofs_batch_device
         fc.restype = C.c_int
         fc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
@@ -220,6 +220,9 @@ def main():
         tb = time.perf_counter() - t1
         secondary = {"compute_cells_and_kzg_proofs_ms_per_call_1blob": round(ts[len(ts) // 2] * 1e3, 3),
                      "compute_cells_and_kzg_proofs_batch2048_blobs_per_s": round(nb / tb, 1),
+                     "tables": {"fk20_wbits": int(lib.ckzg_hip_table_wbits(C.addressof(hip.s), 1)),
+                                "proof_wbits": int(lib.ckzg_hip_table_wbits(C.addressof(hip.s), 2)),
+                                "bytes": int(lib.ckzg_hip_table_bytes(C.addressof(hip.s)))},
                      "note": "1 blob: low-latency path (128 fixed-base MSMs, no G1 FFT); batch: FK20 path; "
                              "inputs/outputs resident in HBM"}
 
@@ -250,7 +253,7 @@ def main():
                               "achieved": round(BLOBS_PER_STEP * (255 // wbits + 1) * 4096 * MADS_PER_ADDITION / avg_k / 1e12, 3),
                               "frac": round(BLOBS_PER_STEP * (255 // wbits + 1) * 4096 * MADS_PER_ADDITION / avg_k / 32.9e12, 4),
                               "valu_wave_insts_per_launch": PMC_VALU_INSTS.get(wbits),
-                              "pmc": "profiles/r01_pmc_sq_k_msm_accumulate*.json (SQ_INSTS_VALU, GRBM_GUI_ACTIVE): "
+                              "pmc": "profiles/r01_c16_pmc_sq_k_msm_accumulate.json (SQ_INSTS_VALU, GRBM_GUI_ACTIVE): "
                                      "~95 % of the VALU issue slots at the sustained ~2.1 GHz clock"},
             "pcie_inclusive_blobs_per_s": None if pcie_rate is None else round(pcie_rate, 2),
             "parity_spot_check_vs_oracle": parity,

@@ -2,7 +2,7 @@ import sys, os, hashlib, time, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 mod = ge.load_package()
-hip = mod.Kzg(mod.HIP_SO, options={"commit_wbits": 8, "proof_wbits": 0, "fk20_wbits": 12})
+hip = mod.Kzg(mod.HIP_SO, options={"commit_wbits": 8, "proof_wbits": 0, "fk20_wbits": int(sys.argv[1]) if len(sys.argv) > 1 else 12})
 n = 2048
 b = b"".join(b"\x00" + hashlib.sha256(b"f%d" % j).digest()[:31] for j in range(4096))
 f = hip.lib.ckzg_hip_compute_cells_and_kzg_proofs_batch
