@@ -126,6 +126,8 @@ int lincomb_var_device(DeviceCtx *ctx, G1Affine *d_out, G1XYZZ *d_partials, cons
                        const uint32_t *d_scalars, size_t n);
 int lincomb_multi_device(DeviceCtx *ctx, G1Affine *d_out, G1XYZZ *d_partials, const G1Affine *d_pts,
                          const uint32_t *d_scalars, size_t total, const uint32_t *h_part_off, int njobs);
+// z_i = hash_to_bls_field(SHA-256(domain | degree | blob_i | commitment_i)) for n blobs in HBM
+int sha256_challenges_device(DeviceCtx *ctx, Fr *d_z, const uint8_t *d_blobs, const uint8_t *d_commit48, size_t n);
 int fr_mul_inplace_device(DeviceCtx *ctx, Fr *d_a, const Fr *d_b, size_t n, size_t period);
 int fr_div_inplace_device(DeviceCtx *ctx, Fr *d_a, const Fr *d_b, size_t n);
 // generic helpers

@@ -339,6 +339,116 @@ int fr_mul_inplace_device(DeviceCtx *ctx, Fr *d_a, const Fr *d_b, size_t n, size
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// Fiat-Shamir challenges on the GPU: z_i = SHA-256("FSBLOBVERIFY_V1_" | u64be 0 | u64be 4096 |
+// blob_i | commitment_i) mod r  (compute_challenge, src/eip4844/eip4844.c:147-178).
+// SHA-256 is sequential per message, so a lane owns a blob: 2050 compressions of 64 bytes each,
+// the same for every lane (no divergence).  The 32-byte header shifts the blob by half a block, so
+// block b (1 <= b <= 2047) is the 64 contiguous, 32-byte aligned bytes blob[64b-32, 64b+32); the
+// next block's four 16-byte loads are issued before the current block is compressed.
+// ------------------------------------------------------------------------------------------
+
+__device__ __constant__ uint32_t SHA256_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+    0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+    0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+    0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+    0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+__device__ __forceinline__ uint32_t rotr32(uint32_t x, int n) { return __builtin_rotateright32(x, n); }
+
+// one compression; w[16] holds the block as big-endian words and is clobbered
+__device__ __forceinline__ void sha256_compress(uint32_t (&h)[8], uint32_t (&w)[16]) {
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
+    for (int t = 0; t < 64; t++) {
+        if (t >= 16) {
+            uint32_t w15 = w[(t + 1) & 15], w2 = w[(t + 14) & 15];
+            uint32_t s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
+            uint32_t s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+            w[t & 15] = w[t & 15] + s0 + w[(t + 9) & 15] + s1;
+        }
+        uint32_t S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
+        uint32_t ch = (e & f) ^ (~e & g);
+        uint32_t t1 = hh + S1 + ch + SHA256_K[t] + w[t & 15];
+        uint32_t S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
+        uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+        uint32_t t2 = S0 + mj;
+        hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+
+__device__ __forceinline__ void be_words(uint32_t *w, const uint4 &v) {
+    w[0] = __builtin_bswap32(v.x);
+    w[1] = __builtin_bswap32(v.y);
+    w[2] = __builtin_bswap32(v.z);
+    w[3] = __builtin_bswap32(v.w);
+}
+
+__global__ __launch_bounds__(64) void k_sha256_challenges(Fr *z_out, const uint8_t *blobs, const uint8_t *commit48,
+                                                          size_t n) {
+    size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const uint4 *bp = reinterpret_cast<const uint4 *>(blobs + g * (size_t)(N_BLOB * 32));
+    const uint32_t *cp = reinterpret_cast<const uint32_t *>(commit48 + g * 48);
+    uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    uint32_t w[16];
+    // block 0: "FSBLOBVERIFY_V1_" | 0^8 | u64be(4096) | blob[0,32)
+    w[0] = 0x4653424c; w[1] = 0x4f425645; w[2] = 0x52494659; w[3] = 0x5f56315f;
+    w[4] = 0; w[5] = 0; w[6] = 0; w[7] = N_BLOB;
+    uint4 n0 = bp[0], n1 = bp[1], n2, n3;
+    be_words(w + 8, n0);
+    be_words(w + 12, n1);
+    n0 = bp[2]; n1 = bp[3]; n2 = bp[4]; n3 = bp[5];
+    sha256_compress(h, w);
+    // blocks 1..2047: blob[64b-32, 64b+32) = uint4 index 4b-2 .. 4b+1
+    for (int b = 1; b < 2048; b++) {
+        be_words(w, n0);
+        be_words(w + 4, n1);
+        be_words(w + 8, n2);
+        be_words(w + 12, n3);
+        const int nb = 4 * (b + 1) - 2;  // next block; the last iteration prefetches the 32-byte tail
+        n0 = bp[nb];
+        n1 = bp[nb + 1];
+        if (b < 2047) {
+            n2 = bp[nb + 2];
+            n3 = bp[nb + 3];
+        }
+        sha256_compress(h, w);
+    }
+    // block 2048: blob[131040, 131072) | commitment[0, 32)
+    be_words(w, n0);
+    be_words(w + 4, n1);
+#pragma unroll
+    for (int k = 0; k < 8; k++) w[8 + k] = __builtin_bswap32(cp[k]);
+    sha256_compress(h, w);
+    // block 2049: commitment[32, 48) | 0x80 | zeros | bit length (131152 bytes)
+#pragma unroll
+    for (int k = 0; k < 4; k++) w[k] = __builtin_bswap32(cp[8 + k]);
+    w[4] = 0x80000000u;
+#pragma unroll
+    for (int k = 5; k < 15; k++) w[k] = 0;
+    w[15] = (uint32_t)((32 + N_BLOB * 32 + 48) * 8);
+    sha256_compress(h, w);
+    // digest as a big-endian 256-bit integer, reduced mod r (hash_to_bls_field, eip4844.c:121-127)
+    uint32_t raw[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) raw[k] = h[7 - k];
+    vst_fr(z_out + g, from_raw<FrParams>(raw));
+}
+
+int sha256_challenges_device(DeviceCtx *ctx, Fr *d_z, const uint8_t *d_blobs, const uint8_t *d_commit48, size_t n) {
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_sha256_challenges, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, d_z,
+                       d_blobs, d_commit48, n);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int fr_div_inplace_device(DeviceCtx *ctx, Fr *d_a, const Fr *d_b, size_t n) {
     if (!n) return 0;
     size_t threads = (n + 15) / 16;

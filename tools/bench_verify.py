@@ -29,15 +29,23 @@ def main():
     for b, c, p in zip(uniq, commits, proofs):
         assert hip.verify_blob_kzg_proof(b, c, p)
     print("verify_blob_kzg_proof: %.2f ms/call" % ((time.perf_counter() - t) / 8 * 1e3))
-    for n in (8, 64, nmax):
+    fv = hip.lib.verify_blob_kzg_proof_batch
+    fv.restype = C.c_int
+    fv.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64, C.c_void_p]
+    for n in (8, 64, 512, nmax):
         bl = [uniq[i % 8] for i in range(n)]
         cm = [commits[i % 8] for i in range(n)]
         pr = [proofs[i % 8] for i in range(n)]
-        hip.verify_blob_kzg_proof_batch(bl[:2], cm[:2], pr[:2])
-        t = time.perf_counter()
-        ok = hip.verify_blob_kzg_proof_batch(bl, cm, pr)
-        dt = time.perf_counter() - t
-        print("verify_blob_kzg_proof_batch n=%d: %.1f ms -> %.0f blobs/s (ok=%s)" % (n, dt * 1e3, n / dt, ok))
+        # time the C call itself (the ctypes wrapper's b"".join of n blobs is harness overhead)
+        bb, cc, pp = b"".join(bl), b"".join(cm), b"".join(pr)
+        okv = C.c_bool(False)
+        fv(C.byref(okv), bb, cc, pp, min(n, 2), C.addressof(hip.s))
+        best = 1e9
+        for _ in range(3):
+            t = time.perf_counter()
+            rc = fv(C.byref(okv), bb, cc, pp, n, C.addressof(hip.s))
+            best = min(best, time.perf_counter() - t)
+        print("verify_blob_kzg_proof_batch n=%d: %.1f ms -> %.0f blobs/s (rc=%d ok=%s)" % (n, best * 1e3, n / best, rc, okv.value))
     pr[3] = proofs[0]
     assert not hip.verify_blob_kzg_proof_batch(bl, cm, pr)
     f = hip.lib.ckzg_hip_compute_blob_kzg_proof_batch
