@@ -1,6 +1,7 @@
 // dev_inline.hpp -- small device-only helpers shared by the .hip translation units.
 #pragma once
 #include "device.hpp"
+#include "g1_28.hpp"
 
 namespace ckzg {
 namespace dev {
@@ -37,6 +38,30 @@ __device__ __forceinline__ void recode_signed(int16_t *dst, size_t stride, uint3
             carry = 1;
         }
         dst[(size_t)w * stride] = (int16_t)d;
+    }
+}
+
+// Fold the per-thread accumulators (28-bit domain) of a workgroup into thread 0.  LDS is
+// limb-major ([56 limbs + infinity flag][THREADS/2] u32) so a wave's lanes hit consecutive banks.
+template <int THREADS>
+__device__ __forceinline__ void block_reduce_xyzz28(XYZZ28 &acc, bool &inf, uint32_t (*sh)[THREADS / 2]) {
+    const int tid = threadIdx.x;
+    for (int s = THREADS / 2; s >= 1; s >>= 1) {
+        if (tid >= s && tid < 2 * s) {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(&acc);
+#pragma unroll
+            for (int k = 0; k < 56; k++) sh[k][tid - s] = src[k];
+            sh[56][tid - s] = inf ? 1u : 0u;
+        }
+        __syncthreads();
+        if (tid < s) {
+            XYZZ28 o;
+            uint32_t *dst = reinterpret_cast<uint32_t *>(&o);
+#pragma unroll
+            for (int k = 0; k < 56; k++) dst[k] = sh[k][tid];
+            xyzz28_add(acc, inf, o, sh[56][tid] != 0);
+        }
+        __syncthreads();
     }
 }
 

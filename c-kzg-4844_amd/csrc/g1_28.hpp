@@ -315,18 +315,17 @@ HDNI inline void xyzz28_mul_glv_w4(XYZZ28 &out, bool &out_inf, const XYZZ28 &p, 
     out_inf = inf;
 }
 
-// a^(p-2) by a fixed 4-bit sliding window over the public exponent: 381 squarings and ~80
-// multiplications (odd powers a, a^3, ..., a^15 precomputed).  Kept as the independent
-// cross-check of the safegcd inverse (tests/test_host_arith.py).
-HDNI inline F28<1, 2> f28_inv_fermat(const F28<1, 2> &a) {
+// a^e for a public exponent e (little-endian limbs, nbits bits) by a 4-bit sliding window: nbits
+// squarings and ~nbits/5 multiplications (odd powers a, a^3, ..., a^15 precomputed).
+HDNI inline F28<1, 2> f28_pow_public(const F28<1, 2> &a, const uint32_t *e, int nbits) {
     F28<1, 2> odd[8];
     odd[0] = a;
     F28<1, 2> a2 = sqr(a);
     for (int i = 1; i < 8; i++) odd[i] = mul(odd[i - 1], a2);
     F28<1, 2> acc = widen<1, 2>(f28_one());
-    int i = 380;
+    int i = nbits - 1;
     while (i >= 0) {
-        if (!((FP_INV_EXP[i >> 5] >> (i & 31)) & 1u)) {
+        if (!((e[i >> 5] >> (i & 31)) & 1u)) {
             acc = sqr(acc);
             i--;
             continue;
@@ -334,7 +333,7 @@ HDNI inline F28<1, 2> f28_inv_fermat(const F28<1, 2> &a) {
         // longest window [i, i-w+1], w <= 4, that ends in a set bit
         int w = i >= 3 ? 4 : i + 1;
         uint32_t bits = 0;
-        for (int k = 0; k < w; k++) bits = (bits << 1) | ((FP_INV_EXP[(i - k) >> 5] >> ((i - k) & 31)) & 1u);
+        for (int k = 0; k < w; k++) bits = (bits << 1) | ((e[(i - k) >> 5] >> ((i - k) & 31)) & 1u);
         while (!(bits & 1u)) {
             bits >>= 1;
             w--;
@@ -344,6 +343,68 @@ HDNI inline F28<1, 2> f28_inv_fermat(const F28<1, 2> &a) {
         i -= w;
     }
     return acc;
+}
+
+// a^(p-2): 381 squarings and ~80 multiplications.  Kept as the independent cross-check of the
+// safegcd inverse (tests/test_host_arith.py).
+HDNI inline F28<1, 2> f28_inv_fermat(const F28<1, 2> &a) {
+    uint32_t e[12];
+    for (int i = 0; i < 12; i++) e[i] = FP_INV_EXP[i];
+    return f28_pow_public(a, e, 381);
+}
+
+// candidate square root a^((p+1)/4) (p = 3 mod 4); the caller checks the square
+HDNI inline F28<1, 2> f28_sqrt_candidate(const F28<1, 2> &a) {
+    uint32_t e[12];
+    for (int i = 0; i < 12; i++) e[i] = FP_SQRT_EXP[i];
+    return f28_pow_public(a, e, 381);
+}
+
+// a == b mod p for lazily reduced operands
+template <int LA, int VA, int LB, int VB>
+HD bool f28_equal(const F28<LA, VA> &a, const F28<LB, VB> &b) {
+    return is_zero(mul(sub(a, b), f28_one()));
+}
+
+// y with y^2 = x^3 + 4, or false if x is not the abscissa of a curve point
+HDNI inline bool g1_28_solve_y(F28<1, 2> &y, const F28<1, 2> &x) {
+    auto rhs = mul(add(mul(sqr(x), x), f28_const<1, 1>(FP28_FOUR)), f28_one());  // <1,2>
+    y = f28_sqrt_candidate(rhs);
+    return f28_equal(sqr(y), rhs);
+}
+
+// [|x|]P for the BLS parameter |x| = 0xd201000000010000 = 2^63 + 2^62 + 2^60 + 2^57 + 2^48 + 2^16:
+// 63 doublings and 5 additions, the same for every lane
+HDNI inline void xyzz28_mul_bls_x(XYZZ28 &out, bool &out_inf, const XYZZ28 &p, bool p_inf) {
+    XYZZ28 acc = p;
+    bool inf = p_inf;
+    for (int b = 62; b >= 0; b--) {
+        if (!inf) xyzz28_dbl(acc);
+        if (b == 62 || b == 60 || b == 57 || b == 48 || b == 16) xyzz28_add(acc, inf, p, p_inf);
+    }
+    out = acc;
+    out_inf = inf;
+}
+
+// Subgroup test for a finite curve point (x, y): P is in G1 iff phi2(P) = [-x^2]P with
+// phi2(X, Y) = (beta^2 X, Y), i.e. iff [x^2]P = (beta^2 X, -Y).  Exact: E(Fp) = G1 x T with the
+// exponent of T dividing x - 1, so on T the right side is -T' while phi2^2 + phi2 + 1 = 0 forces
+// phi2(T') = -T' only for T' = 0.  126 doublings + 10 additions instead of a 255-bit ladder by r
+// (the reference's blst performs an endomorphism-based test of the same kind).
+HDNI inline bool g1_28_in_subgroup(const F28<1, 2> &x, const F28<1, 2> &y) {
+    XYZZ28 p, q1, q;
+    p.x = widen<1, 10>(x);
+    p.y = widen<1, 6>(y);
+    p.zz = widen<1, 2>(f28_one());
+    p.zzz = p.zz;
+    bool i1, i2;
+    xyzz28_mul_bls_x(q1, i1, p, false);
+    xyzz28_mul_bls_x(q, i2, q1, i1);
+    if (i2) return false;
+    auto bx = mul(x, f28_const<1, 1>(FP28_BETA_LAMBDA2));
+    if (!f28_equal(q.x, mul(bx, q.zz))) return false;
+    // q.y == -y * q.zzz  <=>  q.y + y * q.zzz == 0
+    return is_zero(mul(add(q.y, mul(y, q.zzz)), f28_one()));
 }
 
 // the inversion used by the kernels: safegcd (fp28_inv.hpp), ~12x fewer instructions than the ladder

@@ -100,6 +100,14 @@ void hs_g1_mul28(G1Jac *r, const G1Jac *a, const uint32_t *k) {
     xyzz28_mul_w4(o, oi, x, ai, k);
     *r = jac_from_affine(xyzz28_to_affine(o, oi));
 }
+// subgroup test and square root of the device validation path; returns 1 in / 0 out / 2 not on curve
+int hs_g1_in_subgroup28(const G1Affine *pt) {
+    auto x = f28_from_fp(pt->x), y = f28_from_fp(pt->y);
+    F28<1, 2> yy;
+    if (!g1_28_solve_y(yy, x)) return 2;
+    if (!f28_equal(yy, y) && !is_zero(mul(add(yy, y), f28_one()))) return 3;  // sqrt must be +-y
+    return g1_28_in_subgroup(x, y) ? 1 : 0;
+}
 void hs_glv_split(uint32_t *k1k2, const uint32_t *k) { glv_split(k, k1k2, k1k2 + 4); }
 void hs_g1_mul28_glv(G1Jac *r, const G1Jac *a, const uint32_t *k) {
     uint32_t glv[8];

@@ -199,30 +199,6 @@ __global__ void k_raw_digits(int16_t *digits, const uint32_t *scalars, size_t to
 // accumulate: the dominant kernel
 // ------------------------------------------------------------------------------------------
 
-// Fold the per-thread accumulators (28-bit domain) of a workgroup into thread 0.  LDS is
-// limb-major ([56 limbs + infinity flag][THREADS/2] u32) so a wave's lanes hit consecutive banks.
-template <int THREADS>
-__device__ __forceinline__ void block_reduce_xyzz28(XYZZ28 &acc, bool &inf, uint32_t (*sh)[THREADS / 2]) {
-    const int tid = threadIdx.x;
-    for (int s = THREADS / 2; s >= 1; s >>= 1) {
-        if (tid >= s && tid < 2 * s) {
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(&acc);
-#pragma unroll
-            for (int k = 0; k < 56; k++) sh[k][tid - s] = src[k];
-            sh[56][tid - s] = inf ? 1u : 0u;
-        }
-        __syncthreads();
-        if (tid < s) {
-            XYZZ28 o;
-            uint32_t *dst = reinterpret_cast<uint32_t *>(&o);
-#pragma unroll
-            for (int k = 0; k < 56; k++) dst[k] = sh[k][tid];
-            xyzz28_add(acc, inf, o, sh[56][tid] != 0);
-        }
-        __syncthreads();
-    }
-}
-
 // grid: nvec * blocks_per_vec workgroups.  A "vector" is one MSM: ppv (points per vector) scalars
 // recoded to digits[vec][w][i], i < ppv.  Its bases are points voff..voff+ppv of a table over
 // npoints bases, voff = (vec % vecs_per_group) * ppv  (commitment: ppv = npoints = 4096, one

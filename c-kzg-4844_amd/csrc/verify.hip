@@ -182,22 +182,52 @@ __device__ __noinline__ G1XYZZ affine_mul_w4(const G1Affine &a, const uint32_t *
     return xyzz28_to_xyzz(o, oi);
 }
 
+// Same decisions as g1_uncompress (g1.hpp) + a subgroup check, but on the 28-bit-limb arithmetic:
+// the square root is a sliding-window power (381 squarings + ~80 products) and the subgroup test
+// the endomorphism identity [x^2]P = (beta^2 X, -Y) (g1_28.hpp: 126 doublings + 10 additions)
+// instead of a 255-bit ladder by r -- about 3x fewer instructions per point.
 __global__ void k_validate_g1(G1Affine *out, uint8_t *status, const uint8_t *in48, size_t n) {
     size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (g >= n) return;
-    uint8_t buf[48];
-    for (int k = 0; k < 48; k++) buf[k] = in48[g * 48 + k];
-    G1Affine a;
-    int rc = g1_uncompress(a, buf);
-    uint8_t st = rc ? 1 : 0;
-    if (!rc && !a.is_inf()) {
-        uint32_t r[8];
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(in48 + g * 48);
+    uint32_t raw[12];
 #pragma unroll
-        for (int k = 0; k < 8; k++) r[k] = FR_R[k];
-        G1XYZZ t = affine_mul_w4(a, r);
-        if (!t.is_inf()) st = 1;
+    for (int i = 0; i < 12; i++) raw[i] = __builtin_bswap32(src[11 - i]);  // big-endian bytes -> LE limbs
+    const uint32_t b0 = raw[11] >> 24;
+    G1Affine a = G1Affine::inf();
+    uint8_t st = 0;
+    if (!(b0 & 0x80)) {
+        st = 1;  // uncompressed form is not accepted
+    } else if (b0 & 0x40) {
+        uint32_t rest = raw[11] & 0x3fffffffu;
+#pragma unroll
+        for (int i = 0; i < 11; i++) rest |= raw[i];
+        if (rest) st = 1;  // infinity must be exactly 0xc0 00 .. 00
+    } else {
+        raw[11] &= 0x1fffffffu;
+        uint32_t m[12];
+        mod_limbs<FpParams>(m);
+        if (limbs_geq<12>(raw, m)) {
+            st = 1;
+        } else {
+            Fp x = from_raw<FpParams>(raw);
+            F28<1, 2> x28 = f28_from_fp(x), y28;
+            if (!g1_28_solve_y(y28, x28)) {
+                st = 1;  // not on the curve
+            } else {
+                Fp y = f28_to_fp(y28);
+                if (fp_is_lex_largest(y) != ((b0 & 0x20) != 0)) {
+                    y = neg(y);
+                    y28 = f28_from_fp(y);
+                }
+                if (!g1_28_in_subgroup(x28, y28)) {
+                    st = 1;
+                } else {
+                    a = {x, y};
+                }
+            }
+        }
     }
-    if (st) a = G1Affine::inf();
     out[g] = a;
     status[g] = st;
 }
@@ -217,47 +247,48 @@ int validate_g1_batch_device(DeviceCtx *ctx, G1Affine *d_out, uint8_t *d_status,
 
 constexpr int LC_THREADS = 64;
 
+// One lane per term: split the scalar (GLV, the points were subgroup-checked), run the
+// two-dimensional ladder, then fold the workgroup's 64 products in LDS (28-bit-limb domain).
 __global__ __launch_bounds__(LC_THREADS) void k_lincomb_partial(G1XYZZ *partials, const G1Affine *pts,
                                                                 const uint32_t *scalars, size_t n) {
-    __shared__ uint32_t sh[48][LC_THREADS / 2];
+    __shared__ uint32_t sh[57][LC_THREADS / 2];
     size_t g = blockIdx.x * (size_t)LC_THREADS + threadIdx.x;
-    G1XYZZ acc = G1XYZZ::inf();
+    XYZZ28 acc;
+    bool inf = true;
     if (g < n) {
-        uint32_t k[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) k[i] = scalars[g * 8 + i];
         G1Affine a = pts[g];
-        if (!a.is_inf()) acc = affine_mul_w4(a, k);
-    }
-    const int tid = threadIdx.x;
-    for (int s = LC_THREADS / 2; s >= 1; s >>= 1) {
-        if (tid >= s && tid < 2 * s) {
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(&acc);
+        if (!a.is_inf()) {
+            uint32_t k[8], glv[8];
 #pragma unroll
-            for (int k = 0; k < 48; k++) sh[k][tid - s] = src[k];
+            for (int i = 0; i < 8; i++) k[i] = scalars[g * 8 + i];
+            glv_split(k, glv, glv + 4);
+            XYZZ28 p;
+            p.x = widen<1, 10>(f28_from_fp(a.x));
+            p.y = widen<1, 6>(f28_from_fp(a.y));
+            p.zz = widen<1, 2>(f28_one());
+            p.zzz = p.zz;
+            xyzz28_mul_glv_w4(acc, inf, p, false, glv);
         }
-        __syncthreads();
-        if (tid < s) {
-            G1XYZZ o;
-            uint32_t *dst = reinterpret_cast<uint32_t *>(&o);
-#pragma unroll
-            for (int k = 0; k < 48; k++) dst[k] = sh[k][tid];
-            acc = xyzz_add(acc, o);
-        }
-        __syncthreads();
     }
-    if (tid == 0) partials[blockIdx.x] = acc;
+    block_reduce_xyzz28<LC_THREADS>(acc, inf, sh);
+    if (threadIdx.x == 0) partials[blockIdx.x] = xyzz28_to_xyzz(acc, inf);
 }
 
-// job j owns partials[part_off[j] .. part_off[j+1]); one lane per job
-__global__ void k_lincomb_final(G1Affine *out, const G1XYZZ *partials, const uint32_t *part_off, int njobs) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= njobs) return;
-    G1XYZZ acc = G1XYZZ::inf();
-    for (uint32_t i = part_off[j]; i < part_off[j + 1]; i++) acc = xyzz_add(acc, partials[i]);
-    bool inf;
-    XYZZ28 a = xyzz28_from_xyzz(acc, inf);
-    out[j] = xyzz28_to_affine(a, inf);
+// job j owns partials[part_off[j] .. part_off[j+1]): one 64-lane workgroup per job folds them
+// (lane-strided partial sums, then the LDS tree) and normalises the result
+__global__ __launch_bounds__(64) void k_lincomb_final(G1Affine *out, const G1XYZZ *partials,
+                                                     const uint32_t *part_off, int njobs) {
+    __shared__ uint32_t sh[57][32];
+    const int j = blockIdx.x;
+    XYZZ28 acc;
+    bool inf = true;
+    for (uint32_t i = part_off[j] + threadIdx.x; i < part_off[j + 1]; i += 64) {
+        bool oinf;
+        XYZZ28 o = xyzz28_from_xyzz(partials[i], oinf);
+        xyzz28_add(acc, inf, o, oinf);
+    }
+    block_reduce_xyzz28<64>(acc, inf, sh);
+    if (threadIdx.x == 0) out[j] = xyzz28_to_affine(acc, inf);
 }
 
 // `total` (a multiple of 64) points/scalars laid out job after job; h_part_off has njobs+1 entries
@@ -268,8 +299,7 @@ int lincomb_multi_device(DeviceCtx *ctx, G1Affine *d_out, G1XYZZ *d_partials, co
     HIP_TRY(hipMemcpyAsync(d_off, h_part_off, (njobs + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_lincomb_partial, dim3((unsigned)(total / LC_THREADS)), dim3(LC_THREADS), 0, ctx->stream,
                        d_partials, d_pts, d_scalars, total);
-    hipLaunchKernelGGL(k_lincomb_final, dim3((njobs + 63) / 64), dim3(64), 0, ctx->stream, d_out, d_partials,
-                       d_off, njobs);
+    hipLaunchKernelGGL(k_lincomb_final, dim3(njobs), dim3(64), 0, ctx->stream, d_out, d_partials, d_off, njobs);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipFree(d_off));

@@ -413,6 +413,53 @@ def test_glv_split_and_glv_scalar_mul(libs):
     assert o.og1_is_inf(r)
 
 
+def test_endomorphism_subgroup_test_is_exact(libs):
+    """g1_28_in_subgroup ([x^2]P == (beta^2 X, -Y)) against the oracle's [r]P == inf on points of
+    G1, of the cofactor subgroup, mixed points, the order-3 point and random curve points."""
+    o, h = libs
+    rnd = random.Random(31)
+    r384 = pow(2, 384, P)
+
+    def curve_point(x0):
+        x = x0
+        while True:
+            rhs = (x * x * x + 4) % P
+            y = pow(rhs, (P + 1) // 4, P)
+            if y * y % P == rhs:
+                pt = _buf(144)
+                pt[0:48] = (x * r384 % P).to_bytes(48, "little")
+                pt[48:96] = (y * r384 % P).to_bytes(48, "little")
+                pt[96:144] = (r384 % P).to_bytes(48, "little")
+                return pt
+            x += 1
+
+    def check(pt, expect=None):
+        a = _buf(96)
+        o.og1_to_affine(a, pt)
+        want = bool(o.og1_in_subgroup(pt))
+        if expect is not None:
+            assert want == expect
+        assert h.hs_g1_in_subgroup28(a) == (1 if want else 0)
+
+    o.og1_in_subgroup.restype = C.c_bool
+    g = _buf(144)
+    h.hs_g1_generator(g)
+    rk = (C.c_uint64 * 4)(*[(R >> (64 * i)) & (2 ** 64 - 1) for i in range(4)])
+    for t in range(6):
+        check(_omul(o, g, rnd.randrange(1, R)), True)
+    check(curve_point(0), False)                      # (0, 2): order 3
+    for t in range(6):
+        pt = curve_point(rnd.randrange(P))
+        check(pt, False)                              # a random curve point is outside G1
+        tors = _buf(144)
+        o.og1_mul_raw(tors, pt, rk, 255)              # [r]P: in the cofactor subgroup, not in G1
+        assert not o.og1_is_inf(tors)
+        check(tors, False)
+        mixed = _buf(144)
+        o.og1_add(mixed, tors, _omul(o, g, rnd.randrange(1, R)))
+        check(mixed, False)
+
+
 def test_safegcd_inverse_matches_fermat_and_python(libs):
     o, h = libs
     rnd = random.Random(19)
