@@ -226,7 +226,10 @@ void parallel_for(size_t n, const std::function<void(size_t)> &fn) {
 // that a workgroup's partial sum belongs to exactly one job.
 struct LincombJob {
     const G1Affine *d_pts;
-    const std::vector<RawScalar> *k;
+    const std::vector<RawScalar> *k;       // scalars on the host, or ...
+    const RawScalar *d_k = nullptr;        // ... already in HBM (k == nullptr), n_dev of them
+    size_t n_dev = 0;
+    size_t size() const { return k ? k->size() : n_dev; }
 };
 
 C_KZG_RET gpu_lincomb_multi(dev::DeviceCtx *ctx, G1Jac *outs, const LincombJob *jobs, int njobs) {
@@ -234,7 +237,7 @@ C_KZG_RET gpu_lincomb_multi(dev::DeviceCtx *ctx, G1Jac *outs, const LincombJob *
     std::vector<size_t> off(njobs), nb(njobs);
     for (int j = 0; j < njobs; j++) {
         off[j] = total;
-        nb[j] = (jobs[j].k->size() + 63) / 64;
+        nb[j] = (jobs[j].size() + 63) / 64;
         if (nb[j] == 0) nb[j] = 1;
         total += nb[j] * 64;
     }
@@ -245,9 +248,13 @@ C_KZG_RET gpu_lincomb_multi(dev::DeviceCtx *ctx, G1Jac *outs, const LincombJob *
     OKB(hipMemsetAsync(d_p.p, 0, total * sizeof(G1Affine), ctx->stream) == hipSuccess);  // (0,0) = infinity
     OKB(hipMemsetAsync(d_k.p, 0, total * sizeof(RawScalar), ctx->stream) == hipSuccess);
     for (int j = 0; j < njobs; j++) {
-        size_t n = jobs[j].k->size();
+        size_t n = jobs[j].size();
         OKB(hipMemcpyAsync(d_p.p + off[j], jobs[j].d_pts, n * sizeof(G1Affine), hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess);
-        OKB(hipMemcpyAsync(d_k.p + off[j], jobs[j].k->data(), n * sizeof(RawScalar), hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
+        if (jobs[j].k) {
+            OKB(hipMemcpyAsync(d_k.p + off[j], jobs[j].k->data(), n * sizeof(RawScalar), hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
+        } else {
+            OKB(hipMemcpyAsync(d_k.p + off[j], jobs[j].d_k, n * sizeof(RawScalar), hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess);
+        }
     }
     std::vector<uint32_t> part_off(njobs + 1);
     for (int j = 0; j < njobs; j++) part_off[j] = (uint32_t)(off[j] / 64);
@@ -770,6 +777,7 @@ extern "C" C_KZG_RET verify_cell_kzg_proof_batch(bool *ok, const Bytes48 *commit
     dev::DeviceCtx *ctx = ctx_of(s);
     if (!ctx) return C_KZG_ERROR;
     const size_t n = num_cells, l = FIELD_ELEMENTS_PER_CELL;
+    Trace tr("verify_cells");
     const Fr *rou = as_fr(s->roots_of_unity);
     // deduplicate commitments (eip7594.c:345-376)
     std::vector<Bytes48> uniq;
@@ -783,9 +791,23 @@ extern "C" C_KZG_RET verify_cell_kzg_proof_batch(bool *ok, const Bytes48 *commit
         cidx[i] = j;
     }
     const size_t nc = uniq.size();
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    OKB(hipSetDevice(ctx->device) == hipSuccess);
+    DBuf<uint8_t> d_ptb, d_st;
+    DBuf<G1Affine> d_pts;
+    DBuf<Fr> d_agg, d_interp;
+    OKM(d_ptb.alloc((n + nc) * 48) && d_st.alloc(n + nc) && d_pts.alloc(n + nc) &&
+        d_agg.alloc((size_t)CELLS_PER_EXT_BLOB * l) && d_interp.alloc(l));
+    // proofs [0,n), unique commitments [n, n+nc): decompression and subgroup checks start on the GPU
+    // while the host hashes the transcript and aggregates the cells
+    OKB(hipMemcpyAsync(d_ptb.p, proofs_bytes, n * 48, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
+    OKB(hipMemcpyAsync(d_ptb.p + n * 48, uniq.data(), nc * 48, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
+    RC(dev::validate_g1_batch_device(ctx, d_pts.p, d_st.p, d_ptb.p, n + nc));
+    tr.mark("dedup + enqueue validation");
     Fr r;
     compute_verify_cell_kzg_proof_batch_challenge((fr_t *)&r, uniq.data(), nc, cidx.data(), cell_indices, cells,
                                                   proofs_bytes, n);
+    tr.mark("transcript hash");
     std::vector<Fr> rp(n);
     {
         Fr pw = Fr::one();
@@ -799,7 +821,10 @@ extern "C" C_KZG_RET verify_cell_kzg_proof_batch(bool *ok, const Bytes48 *commit
     for (size_t i = 0; i < n; i++) {
         for (size_t j = 0; j < l; j++) {
             Fr v;
-            if (!fr_from_bytes_canonical(v, cells[i].bytes + 32 * j)) return C_KZG_BADARGS;
+            if (!fr_from_bytes_canonical(v, cells[i].bytes + 32 * j)) {
+                (void)hipStreamSynchronize(ctx->stream);
+                return C_KZG_BADARGS;
+            }
             Fr &dst = agg[cell_indices[i] * l + j];
             dst = add(dst, mul(v, rp[i]));
         }
@@ -815,54 +840,33 @@ extern "C" C_KZG_RET verify_cell_kzg_proof_batch(bool *ok, const Bytes48 *commit
         }
         for (size_t j = 0; j < nc; j++) wts_raw[j] = raw_of(wts[j]);
     }
-    std::lock_guard<std::mutex> lock(ctx->mu);
-    OKB(hipSetDevice(ctx->device) == hipSuccess);
-    DBuf<uint8_t> d_ptb, d_st;
-    DBuf<G1Affine> d_pts;
-    DBuf<Fr> d_agg, d_interp;
-    OKM(d_ptb.alloc((n + nc) * 48) && d_st.alloc(n + nc) && d_pts.alloc(n + nc) && d_agg.alloc(agg.size()) &&
-        d_interp.alloc(l));
-    // proofs [0,n), unique commitments [n, n+nc)
-    OKB(hipMemcpy(d_ptb.p, proofs_bytes, n * 48, hipMemcpyHostToDevice) == hipSuccess);
-    OKB(hipMemcpy(d_ptb.p + n * 48, uniq.data(), nc * 48, hipMemcpyHostToDevice) == hipSuccess);
-    RC(dev::validate_g1_batch_device(ctx, d_pts.p, d_st.p, d_ptb.p, n + nc));
-    OKB(d_agg.up(agg.data(), agg.size()));
+    tr.mark("host aggregation + weights");
+    OKB(hipMemcpyAsync(d_agg.p, agg.data(), agg.size() * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
     // per column: cell data is in bit-reversed order -> DIT inverse NTT(64) gives the interpolation
     // polynomial over the coset; unused columns are all-zero and stay zero
     RC(dev::fr_ntt_batch(ctx, d_agg.p, CELLS_PER_EXT_BLOB, 6, false, true, true));
     hipLaunchKernelGGL(k_interp_sum, dim3(1), dim3(64), 0, ctx->stream, d_interp.p, d_agg.p, ctx->d_roots);
     OKB(hipGetLastError() == hipSuccess);
-    OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
+    // all four lincombs (eip7594.c:926, :530, :807 and the commitment to the aggregated interpolation
+    // polynomial over the first 64 monomial setup points, :758) in one launch
+    G1Jac lc[4];
+    {
+        LincombJob jobs[4] = {{d_pts.p, &rp_raw}, {d_pts.p + n, &wts_raw}, {d_pts.p, &wrp_raw},
+                              {ctx->d_mono, nullptr, (const RawScalar *)d_interp.p, l}};
+        C_KZG_RET ret = gpu_lincomb_multi(ctx, lc, jobs, 4);
+        if (ret != C_KZG_OK) return ret;
+    }
     std::vector<uint8_t> st(n + nc);
     OKB(d_st.down(st.data(), n + nc));
     for (auto b : st) {
-        if (b) return C_KZG_BADARGS;
+        if (b) return C_KZG_BADARGS;  // rejected points were replaced by infinity: the sums above are discarded
     }
-    G1Jac proof_lc, csum, interp_commit, wsum;
-    {
-        // three of the four lincombs (eip7594.c:926, :530, :807) in one launch
-        G1Jac lc[3];
-        LincombJob jobs[3] = {{d_pts.p, &rp_raw}, {d_pts.p + n, &wts_raw}, {d_pts.p, &wrp_raw}};
-        C_KZG_RET ret = gpu_lincomb_multi(ctx, lc, jobs, 3);
-        if (ret != C_KZG_OK) return ret;
-        proof_lc = lc[0];
-        csum = lc[1];
-        wsum = lc[2];
-    }
-    {
-        // commitment to the aggregated interpolation polynomial: 64 monomial setup points
-        DBuf<G1XYZZ> d_part;
-        DBuf<G1Affine> d_out;
-        OKM(d_part.alloc(2) && d_out.alloc(1));
-        RC(dev::lincomb_var_device(ctx, d_out.p, d_part.p, ctx->d_mono, (const uint32_t *)d_interp.p, l));
-        OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
-        G1Affine a;
-        OKB(d_out.down(&a, 1));
-        interp_commit = jac_from_affine(a);
-    }
+    tr.mark("IFFTs + four lincombs");
+    const G1Jac &proof_lc = lc[0], &csum = lc[1], &wsum = lc[2], &interp_commit = lc[3];
     G1Jac final_sum = jac_add(jac_add(csum, jac_neg(interp_commit)), wsum);
     // e(final_sum, G2) == e(proof_lc, [s^64]G2)
     *ok = pairing_product_is_one(jac_to_affine(final_sum), prepared_of(ctx)->gen, jac_to_affine(jac_neg(proof_lc)),
                                  prepared_of(ctx)->s64);
+    tr.mark("pairing check");
     return C_KZG_OK;
 }

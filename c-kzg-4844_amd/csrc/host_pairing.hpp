@@ -444,6 +444,81 @@ inline void sha256_block(uint32_t h[8], const uint8_t *blk) {
     h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
 }
 
+// x86 SHA extensions: four rounds per instruction pair, ~4x the portable loop.  Compiled only into
+// the host pass and chosen at run time from CPUID (leaf 7, EBX bit 29).
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+#define CKZG_HAVE_SHANI 1
+}  // namespace host
+}  // namespace ckzg
+#include <cpuid.h>
+#include <immintrin.h>
+namespace ckzg {
+namespace host {
+inline bool cpu_has_sha_ni() {
+    static const int has = []() {
+        unsigned a = 0, b = 0, c = 0, d = 0;
+        if (!__get_cpuid_count(7, 0, &a, &b, &c, &d)) return 0;
+        unsigned a1 = 0, b1 = 0, c1 = 0, d1 = 0;
+        if (!__get_cpuid(1, &a1, &b1, &c1, &d1)) return 0;
+        const bool sse41 = (c1 >> 19) & 1u, ssse3 = (c1 >> 9) & 1u;
+        return (int)(((b >> 29) & 1u) && sse41 && ssse3);
+    }();
+    return has != 0;
+}
+
+__attribute__((target("sha,sse4.1,ssse3"))) inline void sha256_blocks_shani(uint32_t h[8], const uint8_t *p, size_t nblocks) {
+    alignas(16) static const uint32_t K[64] = {
+        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+        0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+        0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+        0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+        0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+        0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+        0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+        0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+    const __m128i bswap = _mm_set_epi64x(0x0c0d0e0f08090a0bLL, 0x0405060700010203LL);
+    // the instructions want the state as (A,B,E,F) and (C,D,G,H)
+    __m128i t = _mm_shuffle_epi32(_mm_loadu_si128((const __m128i *)&h[0]), 0xB1);   // C D A B
+    __m128i s1 = _mm_shuffle_epi32(_mm_loadu_si128((const __m128i *)&h[4]), 0x1B);  // E F G H
+    __m128i s0 = _mm_alignr_epi8(t, s1, 8);                                          // A B E F
+    s1 = _mm_blend_epi16(s1, t, 0xF0);                                               // C D G H
+    while (nblocks--) {
+        const __m128i save0 = s0, save1 = s1;
+        __m128i m[4];
+        for (int i = 0; i < 16; i++) {
+            if (i < 4) {
+                m[i] = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i *)(p + 16 * i)), bswap);
+            } else {
+                // W[4i..4i+3] = msg2(msg1(W[4i-16..], W[4i-12..]) + W[4i-7..4i-4], W[4i-4..4i-1])
+                __m128i x = _mm_sha256msg1_epu32(m[i & 3], m[(i + 1) & 3]);
+                x = _mm_add_epi32(x, _mm_alignr_epi8(m[(i + 3) & 3], m[(i + 2) & 3], 4));
+                m[i & 3] = _mm_sha256msg2_epu32(x, m[(i + 3) & 3]);
+            }
+            __m128i wk = _mm_add_epi32(m[i & 3], _mm_load_si128((const __m128i *)&K[4 * i]));
+            s1 = _mm_sha256rnds2_epu32(s1, s0, wk);
+            s0 = _mm_sha256rnds2_epu32(s0, s1, _mm_shuffle_epi32(wk, 0x0E));
+        }
+        s0 = _mm_add_epi32(s0, save0);
+        s1 = _mm_add_epi32(s1, save1);
+        p += 64;
+    }
+    t = _mm_shuffle_epi32(s0, 0x1B);                 // F E B A
+    s1 = _mm_shuffle_epi32(s1, 0xB1);                // D C H G
+    _mm_storeu_si128((__m128i *)&h[0], _mm_blend_epi16(t, s1, 0xF0));  // A B C D (memory order)
+    _mm_storeu_si128((__m128i *)&h[4], _mm_alignr_epi8(s1, t, 8));     // E F G H
+}
+#endif
+
+inline void sha256_blocks(uint32_t h[8], const uint8_t *p, size_t nblocks) {
+#ifdef CKZG_HAVE_SHANI
+    if (cpu_has_sha_ni()) {
+        sha256_blocks_shani(h, p, nblocks);
+        return;
+    }
+#endif
+    for (size_t i = 0; i < nblocks; i++) sha256_block(h, p + 64 * i);
+}
+
 // incremental interface so transcripts need not be copied into one buffer
 struct Sha256 {
     uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
@@ -456,9 +531,9 @@ struct Sha256 {
             size_t take = 64 - fill < n ? 64 - fill : n;
             std::memcpy(buf + fill, p, take);
             fill += take; p += take; n -= take;
-            if (fill == 64) { sha256_block(h, buf); fill = 0; }
+            if (fill == 64) { sha256_blocks(h, buf, 1); fill = 0; }
         }
-        while (n >= 64) { sha256_block(h, p); p += 64; n -= 64; }
+        if (n >= 64) { size_t nb = n / 64; sha256_blocks(h, p, nb); p += 64 * nb; n -= 64 * nb; }
         if (n) { std::memcpy(buf, p, n); fill = n; }
     }
     void finish(uint8_t out[32]) {

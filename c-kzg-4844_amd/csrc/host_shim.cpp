@@ -39,6 +39,31 @@ int hs_pairings_verify(const G1Jac *a1, const G2Jac *a2, const G1Jac *b1, const 
 void hs_g2_mul(G2Jac *r, const G2Jac *a, const uint32_t *k, int nbits) { *r = g2_mul(*a, k, nbits); }
 void hs_g2_generator(G2Jac *r) { *r = g2_generator(); }
 void hs_g1_generator(G1Jac *r) { *r = g1_generator(); }
+// portable compression loop only (the dispatching Sha256 picks SHA-NI when the CPU has it)
+void hs_sha256_portable(uint8_t *out, const uint8_t *msg, size_t len) {
+    uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    size_t nb = len / 64;
+    for (size_t i = 0; i < nb; i++) sha256_block(h, msg + 64 * i);
+    uint8_t tail[128] = {0};
+    size_t rem = len - 64 * nb;
+    memcpy(tail, msg + 64 * nb, rem);
+    tail[rem] = 0x80;
+    size_t tl = rem < 56 ? 64 : 128;
+    uint64_t bits = (uint64_t)len * 8;
+    for (int i = 0; i < 8; i++) tail[tl - 1 - i] = (uint8_t)(bits >> (8 * i));
+    for (size_t i = 0; i < tl / 64; i++) sha256_block(h, tail + 64 * i);
+    for (int i = 0; i < 8; i++) {
+        out[4 * i] = (uint8_t)(h[i] >> 24); out[4 * i + 1] = (uint8_t)(h[i] >> 16);
+        out[4 * i + 2] = (uint8_t)(h[i] >> 8); out[4 * i + 3] = (uint8_t)h[i];
+    }
+}
+int hs_cpu_has_sha_ni() {
+#ifdef CKZG_HAVE_SHANI
+    return cpu_has_sha_ni() ? 1 : 0;
+#else
+    return 0;
+#endif
+}
 void hs_sha256(uint8_t *out, const uint8_t *msg, size_t len) {
     Sha256 s;
     // feed in awkward pieces to exercise the buffering

@@ -167,6 +167,10 @@ def test_pairing_and_sha(libs):
         assert out.raw == hashlib.sha256(m).digest()
         o.osha256(out, m, C.c_size_t(n))
         assert out.raw == hashlib.sha256(m).digest()
+        h.hs_sha256_portable(out, m, C.c_size_t(n))   # the non-SHA-NI compression loop
+        assert out.raw == hashlib.sha256(m).digest()
+    # incremental updates with odd split points go through the same (SHA-NI or portable) block function
+    assert h.hs_cpu_has_sha_ni() in (0, 1)
 
 
 # ---- 28-bit-limb device arithmetic (fp28.hpp, g1_28.hpp), host-compiled ----
