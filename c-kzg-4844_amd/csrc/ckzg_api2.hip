@@ -45,6 +45,26 @@ struct DBuf {
     }
 };
 
+// the same interface over a slice of a persistent arena (device.hpp: Arena): no hipMalloc/hipFree
+template <class T>
+struct ABuf {
+    T *p;
+    ABuf(dev::Arena &a, size_t count) : p(a.get<T>(count)) {}
+    bool up(const T *h, size_t count) { return hipMemcpy(p, h, count * sizeof(T), hipMemcpyHostToDevice) == hipSuccess; }
+    bool down(T *h, size_t count) const { return hipMemcpy(h, p, count * sizeof(T), hipMemcpyDeviceToHost) == hipSuccess; }
+};
+using dev::Arena;
+
+// a very large batch must not pin its temporaries in HBM for ever: blocks above 1 GiB are returned
+// when the call ends (one hipFree per such call), smaller ones stay for the next call
+struct ArenaTrim {
+    Arena &a;
+    explicit ArenaTrim(Arena &ar) : a(ar) {}
+    ~ArenaTrim() {
+        if (a.cap > ((size_t)1 << 30)) a.release();
+    }
+};
+
 #define RC(expr)                          \
     do {                                  \
         int _rc = (expr);                 \
@@ -241,10 +261,14 @@ C_KZG_RET gpu_lincomb_multi(dev::DeviceCtx *ctx, G1Jac *outs, const LincombJob *
         if (nb[j] == 0) nb[j] = 1;
         total += nb[j] * 64;
     }
-    DBuf<RawScalar> d_k;
-    DBuf<G1Affine> d_p, d_out;
-    DBuf<G1XYZZ> d_part;
-    OKM(d_k.alloc(total) && d_p.alloc(total) && d_part.alloc(total / 64) && d_out.alloc(njobs));
+    Arena &ar = ctx->lc_arena;
+    OKM(ar.begin(total * (sizeof(RawScalar) + sizeof(G1Affine)) + (total / 64) * sizeof(G1XYZZ) +
+                 njobs * sizeof(G1Affine) + (njobs + 1) * 4));
+    struct { RawScalar *p; } d_k = {ar.get<RawScalar>(total)};
+    struct { G1Affine *p; } d_p = {ar.get<G1Affine>(total)}, d_out = {ar.get<G1Affine>(njobs)};
+    struct { G1XYZZ *p; } d_part = {ar.get<G1XYZZ>(total / 64)};
+    uint32_t *d_off = ar.get<uint32_t>(njobs + 1);
+    OKM(d_k.p && d_p.p && d_out.p && d_part.p && d_off);
     OKB(hipMemsetAsync(d_p.p, 0, total * sizeof(G1Affine), ctx->stream) == hipSuccess);  // (0,0) = infinity
     OKB(hipMemsetAsync(d_k.p, 0, total * sizeof(RawScalar), ctx->stream) == hipSuccess);
     for (int j = 0; j < njobs; j++) {
@@ -259,10 +283,9 @@ C_KZG_RET gpu_lincomb_multi(dev::DeviceCtx *ctx, G1Jac *outs, const LincombJob *
     std::vector<uint32_t> part_off(njobs + 1);
     for (int j = 0; j < njobs; j++) part_off[j] = (uint32_t)(off[j] / 64);
     part_off[njobs] = (uint32_t)(total / 64);
-    RC(dev::lincomb_multi_device(ctx, d_out.p, d_part.p, d_p.p, (const uint32_t *)d_k.p, total, part_off.data(), njobs));
-    OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
+    RC(dev::lincomb_multi_device(ctx, d_out.p, d_part.p, d_off, d_p.p, (const uint32_t *)d_k.p, total, part_off.data(), njobs));
     std::vector<G1Affine> res(njobs);
-    OKB(d_out.down(res.data(), njobs));
+    OKB(hipMemcpy(res.data(), d_out.p, njobs * sizeof(G1Affine), hipMemcpyDeviceToHost) == hipSuccess);
     for (int j = 0; j < njobs; j++) outs[j] = jac_from_affine(res[j]);
     return C_KZG_OK;
 }
@@ -300,16 +323,18 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     tr.mark("host point validation");
     std::lock_guard<std::mutex> lock(ctx->mu);
     OKB(hipSetDevice(ctx->device) == hipSuccess);
-    DBuf<uint8_t> d_ptb, d_st, d_blobs;
-    DBuf<G1Affine> d_pts;
-    DBuf<Fr> d_poly, d_z, d_y;
-    DBuf<uint32_t> d_bad;
-    OKM(d_blobs.alloc(n * BYTES_PER_BLOB) && d_poly.alloc(n * FIELD_ELEMENTS_PER_BLOB) && d_z.alloc(n) &&
-        d_y.alloc(n) && d_bad.alloc(n));
-    tr.mark("hipMalloc");
+    Arena &ar = ctx->api_arena;
+    OKM(ar.begin(n * BYTES_PER_BLOB + (n * FIELD_ELEMENTS_PER_BLOB + 2 * n) * sizeof(Fr) + n * 4 +
+                 2 * n * (48 + 1 + sizeof(G1Affine))));
+    ABuf<uint8_t> d_ptb(ar, 2 * n * 48), d_st(ar, 2 * n), d_blobs(ar, n * BYTES_PER_BLOB);
+    ABuf<G1Affine> d_pts(ar, 2 * n);
+    ABuf<Fr> d_poly(ar, n * FIELD_ELEMENTS_PER_BLOB), d_z(ar, n), d_y(ar, n);
+    ABuf<uint32_t> d_bad(ar, n);
+    OKM(d_ptb.p && d_st.p && d_blobs.p && d_pts.p && d_poly.p && d_z.p && d_y.p && d_bad.p);
+    ArenaTrim trim(ar);
+    tr.mark("arena");
     if (!small) {
         // commitments [0,n), proofs [n,2n): decompress + subgroup-check on the GPU
-        OKM(d_ptb.alloc(2 * n * 48) && d_st.alloc(2 * n) && d_pts.alloc(2 * n));
         OKB(hipMemcpyAsync(d_ptb.p, cb, n * 48, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
         OKB(hipMemcpyAsync(d_ptb.p + n * 48, pb, n * 48, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
         RC(dev::validate_g1_batch_device(ctx, d_pts.p, d_st.p, d_ptb.p, 2 * n));
@@ -761,6 +786,28 @@ __global__ void k_interp_sum(Fr *interp, const Fr *cols, const Fr *roots) {
     for (int i = 0; i < 8; i++) reinterpret_cast<uint32_t *>(interp + k)[i] = raw[i];
 }
 
+// agg[c][j] = sum over the cells i of column c of r^i * cell_i[j]  (eip7594.c:661-683).
+// order[col_start[c] .. col_start[c+1]) lists the cells of column c; thread = (c, j).
+__global__ void k_cell_aggregate(Fr *agg, const Fr *cell_fr, const Fr *rp, const uint32_t *col_start,
+                                 const uint32_t *order) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;  // < 128 * 64
+    const uint32_t c = g >> 6, j = g & 63u;
+    Fr acc = Fr::zero();
+    for (uint32_t t = col_start[c]; t < col_start[c + 1]; t++) {
+        const uint32_t i = order[t];
+        const uint4 *q = reinterpret_cast<const uint4 *>(cell_fr + (size_t)i * 64 + j);
+        const uint4 *w = reinterpret_cast<const uint4 *>(rp + i);
+        uint4 a = q[0], b = q[1], wa = w[0], wb = w[1];
+        Fr v, r;
+        v.l[0] = a.x; v.l[1] = a.y; v.l[2] = a.z; v.l[3] = a.w; v.l[4] = b.x; v.l[5] = b.y; v.l[6] = b.z; v.l[7] = b.w;
+        r.l[0] = wa.x; r.l[1] = wa.y; r.l[2] = wa.z; r.l[3] = wa.w; r.l[4] = wb.x; r.l[5] = wb.y; r.l[6] = wb.z; r.l[7] = wb.w;
+        acc = add(acc, mul(v, r));
+    }
+    uint4 *o = reinterpret_cast<uint4 *>(agg + g);
+    o[0] = make_uint4(acc.l[0], acc.l[1], acc.l[2], acc.l[3]);
+    o[1] = make_uint4(acc.l[4], acc.l[5], acc.l[6], acc.l[7]);
+}
+
 extern "C" C_KZG_RET verify_cell_kzg_proof_batch(bool *ok, const Bytes48 *commitments_bytes,
                                                  const uint64_t *cell_indices, const Cell *cells,
                                                  const Bytes48 *proofs_bytes, uint64_t num_cells,
@@ -793,15 +840,24 @@ extern "C" C_KZG_RET verify_cell_kzg_proof_batch(bool *ok, const Bytes48 *commit
     const size_t nc = uniq.size();
     std::lock_guard<std::mutex> lock(ctx->mu);
     OKB(hipSetDevice(ctx->device) == hipSuccess);
-    DBuf<uint8_t> d_ptb, d_st;
-    DBuf<G1Affine> d_pts;
-    DBuf<Fr> d_agg, d_interp;
-    OKM(d_ptb.alloc((n + nc) * 48) && d_st.alloc(n + nc) && d_pts.alloc(n + nc) &&
-        d_agg.alloc((size_t)CELLS_PER_EXT_BLOB * l) && d_interp.alloc(l));
-    // proofs [0,n), unique commitments [n, n+nc): decompression and subgroup checks start on the GPU
-    // while the host hashes the transcript and aggregates the cells
+    Arena &ar = ctx->api_arena;
+    OKM(ar.begin((n + nc) * (48 + 1 + sizeof(G1Affine)) + ((size_t)CELLS_PER_EXT_BLOB * l + l + n * l + n) * sizeof(Fr) +
+                 n * BYTES_PER_CELL + (n + CELLS_PER_EXT_BLOB + 1 + n) * 4));
+    ABuf<uint8_t> d_ptb(ar, (n + nc) * 48), d_st(ar, n + nc), d_cells(ar, n * BYTES_PER_CELL);
+    ABuf<G1Affine> d_pts(ar, n + nc);
+    ABuf<Fr> d_agg(ar, (size_t)CELLS_PER_EXT_BLOB * l), d_interp(ar, l), d_cellfr(ar, n * l), d_rp(ar, n);
+    ABuf<uint32_t> d_bad(ar, n), d_csr(ar, CELLS_PER_EXT_BLOB + 1 + n);
+    OKM(d_ptb.p && d_st.p && d_cells.p && d_pts.p && d_agg.p && d_interp.p && d_cellfr.p && d_rp.p && d_bad.p && d_csr.p);
+    ArenaTrim trim(ar);
+    // proofs [0,n), unique commitments [n, n+nc): decompression and subgroup checks start on the GPU,
+    // followed by the cells' bytes -> Fr conversion, while the host hashes the transcript
+    // (all copies from pageable memory first: such a copy returns only when it is done, so it must not
+    // queue behind the validation kernel)
     OKB(hipMemcpyAsync(d_ptb.p, proofs_bytes, n * 48, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
     OKB(hipMemcpyAsync(d_ptb.p + n * 48, uniq.data(), nc * 48, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
+    OKB(hipMemcpyAsync(d_cells.p, cells, n * BYTES_PER_CELL, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
+    OKB(hipMemsetAsync(d_bad.p, 0, n * 4, ctx->stream) == hipSuccess);
+    RC(dev::bytes_to_fr_batch(ctx, d_cellfr.p, d_bad.p, d_cells.p, n * l, (uint32_t)l));
     RC(dev::validate_g1_batch_device(ctx, d_pts.p, d_st.p, d_ptb.p, n + nc));
     tr.mark("dedup + enqueue validation");
     Fr r;
@@ -816,18 +872,13 @@ extern "C" C_KZG_RET verify_cell_kzg_proof_batch(bool *ok, const Bytes48 *commit
             pw = mul(pw, r);
         }
     }
-    // aggregated column data: sum of r^i * cell_i per column (eip7594.c:661-683), host side
-    std::vector<Fr> agg((size_t)CELLS_PER_EXT_BLOB * l, Fr::zero());
-    for (size_t i = 0; i < n; i++) {
-        for (size_t j = 0; j < l; j++) {
-            Fr v;
-            if (!fr_from_bytes_canonical(v, cells[i].bytes + 32 * j)) {
-                (void)hipStreamSynchronize(ctx->stream);
-                return C_KZG_BADARGS;
-            }
-            Fr &dst = agg[cell_indices[i] * l + j];
-            dst = add(dst, mul(v, rp[i]));
-        }
+    // cells grouped by column (counting sort) for the aggregation kernel
+    std::vector<uint32_t> csr(CELLS_PER_EXT_BLOB + 1 + n, 0);
+    for (size_t i = 0; i < n; i++) csr[cell_indices[i] + 1]++;
+    for (size_t c = 0; c < CELLS_PER_EXT_BLOB; c++) csr[c + 1] += csr[c];
+    {
+        std::vector<uint32_t> fill(csr.begin(), csr.begin() + CELLS_PER_EXT_BLOB);
+        for (size_t i = 0; i < n; i++) csr[CELLS_PER_EXT_BLOB + 1 + fill[cell_indices[i]]++] = (uint32_t)i;
     }
     std::vector<RawScalar> rp_raw(n), wrp_raw(n), wts_raw(nc);
     {
@@ -840,8 +891,13 @@ extern "C" C_KZG_RET verify_cell_kzg_proof_batch(bool *ok, const Bytes48 *commit
         }
         for (size_t j = 0; j < nc; j++) wts_raw[j] = raw_of(wts[j]);
     }
-    tr.mark("host aggregation + weights");
-    OKB(hipMemcpyAsync(d_agg.p, agg.data(), agg.size() * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
+    tr.mark("powers of r + weights");
+    OKB(hipMemcpyAsync(d_rp.p, rp.data(), n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
+    OKB(hipMemcpyAsync(d_csr.p, csr.data(), csr.size() * 4, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
+    // aggregated column data: sum of r^i * cell_i per column (eip7594.c:661-683)
+    hipLaunchKernelGGL(k_cell_aggregate, dim3(CELLS_PER_EXT_BLOB * l / 256), dim3(256), 0, ctx->stream, d_agg.p,
+                       d_cellfr.p, d_rp.p, d_csr.p, d_csr.p + CELLS_PER_EXT_BLOB + 1);
+    OKB(hipGetLastError() == hipSuccess);
     // per column: cell data is in bit-reversed order -> DIT inverse NTT(64) gives the interpolation
     // polynomial over the coset; unused columns are all-zero and stay zero
     RC(dev::fr_ntt_batch(ctx, d_agg.p, CELLS_PER_EXT_BLOB, 6, false, true, true));
@@ -861,7 +917,14 @@ extern "C" C_KZG_RET verify_cell_kzg_proof_batch(bool *ok, const Bytes48 *commit
     for (auto b : st) {
         if (b) return C_KZG_BADARGS;  // rejected points were replaced by infinity: the sums above are discarded
     }
-    tr.mark("IFFTs + four lincombs");
+    {
+        std::vector<uint32_t> bad(n);
+        OKB(d_bad.down(bad.data(), n));
+        for (auto b : bad) {
+            if (b) return C_KZG_BADARGS;  // a non-canonical field element in a cell (bytes.c:67)
+        }
+    }
+    tr.mark("aggregation + IFFTs + four lincombs");
     const G1Jac &proof_lc = lc[0], &csum = lc[1], &wsum = lc[2], &interp_commit = lc[3];
     G1Jac final_sum = jac_add(jac_add(csum, jac_neg(interp_commit)), wsum);
     // e(final_sum, G2) == e(proof_lc, [s^64]G2)

@@ -35,6 +35,38 @@ struct Scratch {
     size_t cap = 0;
 };
 
+// Bump allocator over one persistent HBM block: the verification entry points need a dozen small
+// temporaries per call, and hipMalloc/hipFree (which synchronises) cost more than their kernels.
+struct Arena {
+    void *base = nullptr;
+    size_t cap = 0, used = 0;
+    // start a call: make room for `bytes` (plus alignment slack) and forget earlier contents
+    bool begin(size_t bytes) {
+        bytes += 64 * 256;
+        used = 0;
+        if (cap >= bytes) return true;
+        if (base) (void)hipFree(base);
+        base = nullptr;
+        cap = 0;
+        size_t want = bytes + (bytes >> 1);
+        if (hipMalloc(&base, want) != hipSuccess) return false;
+        cap = want;
+        return true;
+    }
+    template <class T>
+    T *get(size_t count) {
+        size_t off = (used + 255) & ~(size_t)255, bytes = (count ? count : 1) * sizeof(T);
+        if (!base || off + bytes > cap) return nullptr;
+        used = off + bytes;
+        return reinterpret_cast<T *>(static_cast<uint8_t *>(base) + off);
+    }
+    void release() {
+        if (base) (void)hipFree(base);
+        base = nullptr;
+        cap = used = 0;
+    }
+};
+
 struct DeviceCtx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -45,6 +77,7 @@ struct DeviceCtx {
     FixedBaseTable mono;          // over g1_values_monomial (4096 points): low-latency cell proofs
     int direct_max = 24;          // batches up to this many blobs use the direct proof path
     Scratch scratch;              // reused by every call under `mu`
+    Arena api_arena, lc_arena;    // temporaries of the verification entry points / of gpu_lincomb_multi
     hipEvent_t ev[8] = {};        // timing events
     float last_ms[4] = {-1, -1, -1, -1};
     // Fr tables for NTTs and evaluation (Montgomery form, 8 x u32)
@@ -122,9 +155,8 @@ int eval_quotient_batch_device(DeviceCtx *ctx, Fr *d_y, uint32_t *d_q_raw, int *
                                const Fr *d_z, size_t n);
 int validate_g1_batch_device(DeviceCtx *ctx, G1Affine *d_out, uint8_t *d_status, const uint8_t *d_in48,
                              size_t n);
-int lincomb_var_device(DeviceCtx *ctx, G1Affine *d_out, G1XYZZ *d_partials, const G1Affine *d_pts,
-                       const uint32_t *d_scalars, size_t n);
-int lincomb_multi_device(DeviceCtx *ctx, G1Affine *d_out, G1XYZZ *d_partials, const G1Affine *d_pts,
+// d_off: njobs + 1 words of device scratch
+int lincomb_multi_device(DeviceCtx *ctx, G1Affine *d_out, G1XYZZ *d_partials, uint32_t *d_off, const G1Affine *d_pts,
                          const uint32_t *d_scalars, size_t total, const uint32_t *h_part_off, int njobs);
 // z_i = hash_to_bls_field(SHA-256(domain | degree | blob_i | commitment_i)) for n blobs in HBM
 int sha256_challenges_device(DeviceCtx *ctx, Fr *d_z, const uint8_t *d_blobs, const uint8_t *d_commit48, size_t n);

@@ -50,6 +50,8 @@ void destroy_device_ctx(dev::DeviceCtx *ctx) {
     if (ctx->d_shift) (void)hipFree(ctx->d_shift);
     if (ctx->d_unshift) (void)hipFree(ctx->d_unshift);
     if (ctx->scratch.ptr) (void)hipFree(ctx->scratch.ptr);
+    ctx->api_arena.release();
+    ctx->lc_arena.release();
     for (auto &e : ctx->ev) {
         if (e) (void)hipEventDestroy(e);
     }

@@ -292,35 +292,14 @@ __global__ __launch_bounds__(64) void k_lincomb_final(G1Affine *out, const G1XYZ
 }
 
 // `total` (a multiple of 64) points/scalars laid out job after job; h_part_off has njobs+1 entries
-int lincomb_multi_device(DeviceCtx *ctx, G1Affine *d_out, G1XYZZ *d_partials, const G1Affine *d_pts,
+int lincomb_multi_device(DeviceCtx *ctx, G1Affine *d_out, G1XYZZ *d_partials, uint32_t *d_off, const G1Affine *d_pts,
                          const uint32_t *d_scalars, size_t total, const uint32_t *h_part_off, int njobs) {
-    uint32_t *d_off = nullptr;
-    HIP_TRY(hipMalloc(&d_off, (njobs + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMemcpyAsync(d_off, h_part_off, (njobs + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_lincomb_partial, dim3((unsigned)(total / LC_THREADS)), dim3(LC_THREADS), 0, ctx->stream,
                        d_partials, d_pts, d_scalars, total);
     hipLaunchKernelGGL(k_lincomb_final, dim3(njobs), dim3(64), 0, ctx->stream, d_out, d_partials, d_off, njobs);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipFree(d_off));
-    return 0;
-}
-
-// d_out: one affine point; d_partials: scratch for ceil(n/64) XYZZ points
-int lincomb_var_device(DeviceCtx *ctx, G1Affine *d_out, G1XYZZ *d_partials, const G1Affine *d_pts,
-                       const uint32_t *d_scalars, size_t n) {
-    size_t nb = (n + LC_THREADS - 1) / LC_THREADS;
-    if (nb == 0) nb = 1;
-    uint32_t off[2] = {0, (uint32_t)nb};
-    uint32_t *d_off = nullptr;
-    HIP_TRY(hipMalloc(&d_off, sizeof off));
-    HIP_TRY(hipMemcpyAsync(d_off, off, sizeof off, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_lincomb_partial, dim3((unsigned)nb), dim3(LC_THREADS), 0, ctx->stream, d_partials,
-                       d_pts, d_scalars, n);
-    hipLaunchKernelGGL(k_lincomb_final, dim3(1), dim3(64), 0, ctx->stream, d_out, d_partials, d_off, 1);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipFree(d_off));
     return 0;
 }
 
