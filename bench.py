@@ -77,6 +77,75 @@ def cpu_baseline(seconds_budget=12.0):
                           "sample": "%d threads x %d commitments" % (nthreads, per_thread)}}
 
 
+def verify_and_recover_rows(hip, lib, base):
+    """verify_blob_kzg_proof_batch over 4096 blobs (this GPU's view of configs[3]: the whole batch on one
+    GPU), verify_cell_kzg_proof_batch over 8192 cells, and a 256-row recover batch (configs[4]),
+    timed at the C-ABI with host buffers; inputs are 8 distinct valid blobs repeated."""
+    ub = [base[i].tobytes() for i in range(8)]
+    cm = [hip.blob_to_kzg_commitment(b) for b in ub]
+    pr = [hip.compute_blob_kzg_proof(b, c) for b, c in zip(ub, cm)]
+    out = {}
+    sp = C.addressof(hip.s)
+    n = 4096
+    bb = b"".join(ub[i % 8] for i in range(n))
+    cc = b"".join(cm[i % 8] for i in range(n))
+    pp = b"".join(pr[i % 8] for i in range(n))
+    fv = lib.verify_blob_kzg_proof_batch
+    fv.restype = C.c_int
+    fv.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64, C.c_void_p]
+    ok = C.c_bool(False)
+    for k in (512, n):
+        fv(C.byref(ok), bb, cc, pp, k, sp)
+        best = 1e9
+        for _ in range(3):
+            t = time.perf_counter()
+            rc = fv(C.byref(ok), bb, cc, pp, k, sp)
+            best = min(best, time.perf_counter() - t)
+        if rc != 0 or not ok.value:
+            raise RuntimeError("verify_blob_kzg_proof_batch rc=%d ok=%s" % (rc, ok.value))
+        out["verify_blob_kzg_proof_batch_n%d_blobs_per_s" % k] = round(k / best, 1)
+    del bb
+    cp = [hip.compute_cells_and_kzg_proofs(b) for b in ub]
+    n = 8192
+    rows = [(i // 128) % 8 for i in range(n)]
+    cols = [i % 128 for i in range(n)]
+    ccm = b"".join(cm[r] for r in rows)
+    idx = (C.c_uint64 * n)(*cols)
+    cells = b"".join(cp[r][0][c] for r, c in zip(rows, cols))
+    cprf = b"".join(cp[r][1][c] for r, c in zip(rows, cols))
+    fc = lib.verify_cell_kzg_proof_batch
+    fc.restype = C.c_int
+    fc.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_char_p, C.c_char_p, C.c_uint64, C.c_void_p]
+    for k in (128, n):
+        fc(C.byref(ok), ccm, idx, cells, cprf, k, sp)
+        best = 1e9
+        for _ in range(3):
+            t = time.perf_counter()
+            rc = fc(C.byref(ok), ccm, idx, cells, cprf, k, sp)
+            best = min(best, time.perf_counter() - t)
+        if rc != 0 or not ok.value:
+            raise RuntimeError("verify_cell_kzg_proof_batch rc=%d ok=%s" % (rc, ok.value))
+        out["verify_cell_kzg_proof_batch_n%d_ms" % k] = round(best * 1e3, 3)
+    nb = 256
+    keep = list(range(0, 128, 2))
+    fr = lib.ckzg_hip_recover_cells_and_kzg_proofs_batch
+    fr.restype = C.c_int
+    data = b"".join(b"".join(cp[b % 8][0][i] for i in keep) for b in range(nb))
+    kidx = (C.c_uint64 * len(keep))(*keep)
+    rc_buf = C.create_string_buffer(nb * 128 * 2048)
+    rp_buf = C.create_string_buffer(nb * 128 * 48)
+    args = (rc_buf, rp_buf, None, kidx, data, C.c_uint64(len(keep)), C.c_uint64(nb), C.c_void_p(sp))
+    fr(*args)
+    t = time.perf_counter()
+    rc = fr(*args)
+    dt = time.perf_counter() - t
+    if rc != 0 or rp_buf.raw[:128 * 48] != b"".join(cp[0][1]):
+        raise RuntimeError("recover batch rc=%d or wrong proofs" % rc)
+    out["recover_cells_and_kzg_proofs_batch256_rows_per_s"] = round(nb / dt, 1)
+    out["recover_note"] = "64 of 128 cells per row, same columns in every row; cells and proofs out"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -225,6 +294,11 @@ def main():
                                 "bytes": int(lib.ckzg_hip_table_bytes(C.addressof(hip.s)))},
                      "note": "1 blob: low-latency path (128 fixed-base MSMs, no G1 FFT); batch: FK20 path; "
                              "inputs/outputs resident in HBM"}
+        # the other two rows of the path (BASELINE configs 4 and 5), host pointers at the C-ABI
+        try:
+            secondary.update(verify_and_recover_rows(hip, lib, blobs[:8].cpu().numpy()))
+        except Exception as e:  # reported, never fatal for the headline
+            secondary["verify_recover_error"] = str(e)
 
     if rank == 0:
         total_blobs = BLOBS_PER_STEP * args.steps * world
