@@ -348,15 +348,32 @@ __global__ __launch_bounds__(64) void k_msm_finalize(uint8_t *out48, uint8_t *st
     if (status) status[v] = (bad && bad[v]) ? 1 : 0;
 }
 
+// How many (window, point) pairs one 256-thread workgroup of k_msm_accumulate sums.  The chip holds
+// 512 such workgroups at once (2 per CU at ~200 VGPRs); a launch is `rounds` waves of resident
+// workgroups, each costing its threads' additions plus the 8-level LDS tree, so the choice trades
+// tail effect against tree overhead:  cost = rounds * (pairs_per_thread * ADD + TREE).
 static uint32_t pick_pairs_per_block(size_t nvec, uint32_t pairs_per_vec) {
-    // big chunks amortise the workgroup reduction; small batches need more workgroups to fill
-    // 256 CUs x 4 resident workgroups
-    const uint32_t cands[] = {16384, 8192, 4096, 2048, 1024, 512};
-    for (uint32_t c : cands) {
-        size_t blocks = nvec * ((pairs_per_vec + c - 1) / c);
-        if (blocks >= 2048) return c;
+    static const long forced = []() {
+        const char *v = getenv("CKZG_HIP_PPB");
+        return v && *v ? atol(v) : 0L;
+    }();
+    if (forced >= 256) return (uint32_t)forced;
+    const double ADD = 3542.0, TREE = 8 * 5110.0 * 0.5;  // the tree overlaps with the CU's other workgroup
+    const size_t resident = 512;
+    uint32_t best_ppb = pairs_per_vec;
+    double best = 1e300;
+    for (uint32_t bpv = 1; bpv <= 512; bpv++) {
+        uint32_t ppb = ((pairs_per_vec + bpv - 1) / bpv + 255) / 256 * 256;
+        if (ppb < 512 && bpv > 1) break;
+        uint32_t real_bpv = (pairs_per_vec + ppb - 1) / ppb;
+        size_t rounds = (nvec * real_bpv + resident - 1) / resident;
+        double cost = (double)rounds * ((double)(ppb / 256) * ADD + TREE) + real_bpv * 300.0;
+        if (cost < best) {
+            best = cost;
+            best_ppb = ppb;
+        }
     }
-    return 256;
+    return best_ppb;
 }
 
 // digits already in scratch; runs accumulate + finalize.  Scratch layout is owned by callers.
