@@ -30,7 +30,7 @@ extern "C" C_KZG_RET ckzg_hip_set_option(const char *key, int64_t value) {
         if (value != 0 && (value < 4 || value > 15)) return C_KZG_BADARGS;
         g_opts.fk20_wbits = (int)value;
     } else if (!strcmp(key, "proof_wbits")) {
-        if (value != 0 && (value < 4 || value > 15)) return C_KZG_BADARGS;
+        if (value != 0 && (value < 4 || value > 16)) return C_KZG_BADARGS;
         g_opts.proof_wbits = (int)value;
     } else if (!strcmp(key, "direct_max")) {
         if (value < 0 || value > 4096) return C_KZG_BADARGS;

@@ -179,7 +179,7 @@ C_KZG_RET create_device_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affine,
         int wbits = env_int("CKZG_HIP_PROOF_WBITS", g_opts.proof_wbits);
         ctx->direct_max = env_int("CKZG_HIP_DIRECT_MAX", g_opts.direct_max);
         if (wbits != 0 && ctx->direct_max > 0) {
-            if (wbits < 4 || wbits > 15) wbits = 8;
+            if (wbits < 4 || wbits > 16) wbits = 8;
             wbits = fit_wbits("proof", wbits, 8, (int)NUM_G1_POINTS);
             int rc = dev::build_fixed_base_table(ctx, &ctx->mono, ctx->d_mono, (int)NUM_G1_POINTS, wbits);
             if (rc) {

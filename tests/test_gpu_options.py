@@ -54,6 +54,24 @@ def test_cells_and_proofs_for_precompute_values(hip, precompute, direct):
         api.close()
 
 
+def test_low_latency_proofs_with_the_widest_monomial_table(hip):
+    # proof_wbits = 16: 206 GB table over the monomial points, 16 windows, int16 digits at their limit
+    api = Kzg(HIP_SO, "", precompute=0, options={"commit_wbits": 8, "direct_max": 24, "proof_wbits": 16})
+    _restore(api)
+    try:
+        import ctypes
+        api.lib.ckzg_hip_table_wbits.restype = ctypes.c_int
+        assert api.lib.ckzg_hip_table_wbits(api.sp, 2) == 16
+        names = [n for n in G.case_names("compute_cells_and_kzg_proofs") if "valid" in n]
+        for name in names[:3]:
+            got, exp = G.run_case(api, "compute_cells_and_kzg_proofs", name)
+            assert got == exp
+        b = rand_blob(53, 16)
+        assert api.compute_cells_and_kzg_proofs(b) == hip.compute_cells_and_kzg_proofs(b)
+    finally:
+        api.close()
+
+
 def test_precompute_out_of_range_is_badargs():
     from kzg_ctypes import KzgError
     with pytest.raises(KzgError):
