@@ -173,6 +173,56 @@ void hs_g1_madd28_chain(G1Jac *r, const G1Affine *pts, int n) {
 }
 }
 
+// Consistency of the fast Fp12 routines with the generic product, on pseudo-random inputs derived
+// from `seed`: bit 0 complex squaring, bit 1 sparse line product, bit 2 cyclotomic squaring (on an
+// element of the cyclotomic subgroup), bit 3 cyclotomic squaring must DIFFER on a generic element
+// (guards against a test that cannot fail).  Returns 0 when everything agrees.
+extern "C" int hs_fp12_selftest(uint32_t seed) {
+    auto rnd_fp = [&](uint32_t i) {
+        uint8_t in[8], d[64];
+        memcpy(in, &seed, 4);
+        memcpy(in + 4, &i, 4);
+        Sha256 a;
+        a.update(in, 8);
+        a.finish(d);
+        Sha256 b;
+        b.update(d, 32);
+        b.finish(d + 32);
+        uint32_t raw[12];
+        memcpy(raw, d, 48);
+        raw[11] &= 0x0fffffffu;  // < p
+        return from_raw<FpParams>(raw);
+    };
+    uint32_t ctr = 0;
+    auto rnd_fp2 = [&]() { Fp2 r = {rnd_fp(ctr), rnd_fp(ctr + 1)}; ctr += 2; return r; };
+    auto rnd_fp12 = [&]() {
+        Fp12 f;
+        f.c0 = {rnd_fp2(), rnd_fp2(), rnd_fp2()};
+        f.c1 = {rnd_fp2(), rnd_fp2(), rnd_fp2()};
+        return f;
+    };
+    auto same = [](const Fp12 &a, const Fp12 &b) { return std::memcmp(&a, &b, sizeof a) == 0; };
+    int bad = 0;
+    Fp12 f = rnd_fp12();
+    if (!same(sqr(f), mul(f, f))) bad |= 1;
+    {
+        Fp2 lam = rnd_fp2(), c = rnd_fp2();
+        G1Affine p = {rnd_fp(ctr), rnd_fp(ctr + 1)};
+        ctr += 2;
+        Fp12 l;
+        std::memset(&l, 0, sizeof l);
+        l.c0.c0 = c;
+        l.c0.c1 = neg(mul_fp(lam, p.x));
+        l.c1.c1.c0 = p.y;
+        if (!same(mul_by_prepared_line(f, lam, c, p), mul(f, l))) bad |= 2;
+    }
+    Fp12 a = mul(conj(f), inv(f));
+    a = mul(frobenius(a, 2), a);  // in the cyclotomic subgroup
+    if (!same(cyclotomic_sqr(a), mul(a, a))) bad |= 4;
+    if (same(cyclotomic_sqr(f), mul(f, f))) bad |= 8;
+    return bad;
+}
+
 extern "C" int hs_pairing_prepared(const G1Jac *a1, const G2Jac *q1, const G1Jac *a2, const G2Jac *q2) {
     G2Prepared p1, p2;
     g2_prepare(p1, g2_to_affine(*q1));

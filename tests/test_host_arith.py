@@ -173,6 +173,14 @@ def test_pairing_and_sha(libs):
     assert h.hs_cpu_has_sha_ni() in (0, 1)
 
 
+def test_fast_fp12_routines_match_the_generic_product(libs):
+    """complex squaring, sparse line multiplication and cyclotomic squaring of the verification
+    pairing (host_pairing.hpp) against the plain Karatsuba product"""
+    o, h = libs
+    for seed in range(40):
+        assert h.hs_fp12_selftest(C.c_uint32(seed)) == 0, seed
+
+
 # ---- 28-bit-limb device arithmetic (fp28.hpp, g1_28.hpp), host-compiled ----
 
 def test_fp28_field_ops_match_oracle(libs):
