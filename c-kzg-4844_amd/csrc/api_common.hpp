@@ -159,10 +159,7 @@ inline C_KZG_RET validate_kzg_g1(G1Jac &out, const uint8_t *b) {
     G1Affine a;
     if (g1_uncompress(a, b) != 0) return C_KZG_BADARGS;
     out = jac_from_affine(a);
-    if (out.is_inf()) return C_KZG_OK;
-    uint32_t r[8];
-    mod_limbs<FrParams>(r);
-    return jac_mul(out, r, 255).is_inf() ? C_KZG_OK : C_KZG_BADARGS;
+    return host::g1_in_subgroup_host(a) ? C_KZG_OK : C_KZG_BADARGS;
 }
 
 }  // namespace api

@@ -9,6 +9,7 @@
 #pragma once
 #include <cstring>
 #include "g1.hpp"
+#include "g1_28.hpp"
 
 namespace ckzg {
 namespace host {
@@ -372,6 +373,53 @@ inline Fp12 final_exp(const Fp12 &f) {
     Fp12 y1 = mul(pow_x(y2), conj(y3));
     Fp12 y0 = mul(pow_x(y1), mul(cyclotomic_sqr(a), a));
     return mul(mul(y0, frobenius(y1, 1)), mul(frobenius(y2, 2), frobenius(y3, 3)));
+}
+
+// ---- G1 helpers of the host-side (small-batch) verification path ----
+
+// [|x|]P for the BLS parameter |x| = 2^63 + 2^62 + 2^60 + 2^57 + 2^48 + 2^16
+inline G1Jac jac_mul_bls_x(const G1Jac &p) {
+    G1Jac acc = p;
+    for (int b = 62; b >= 0; b--) {
+        acc = jac_dbl(acc);
+        if (b == 62 || b == 60 || b == 57 || b == 48 || b == 16) acc = jac_add(acc, p);
+    }
+    return acc;
+}
+
+// P in G1  <=>  [x^2]P = (beta^2 X, -Y): the endomorphism test of g1_28.hpp (g1_28_in_subgroup, where
+// its exactness is argued) on the host's Jacobian arithmetic; 126 doublings + 10 additions
+inline bool g1_in_subgroup_host(const G1Affine &a) {
+    if (a.is_inf()) return true;
+    G1Jac q = jac_mul_bls_x(jac_mul_bls_x(jac_from_affine(a)));
+    if (q.is_inf()) return false;
+    Fp b2;
+    for (int i = 0; i < 12; i++) b2.l[i] = FP_BETA_LAMBDA2_MONT[i];
+    Fp z2 = sqr(q.z);
+    if (q.x != mul(mul(a.x, b2), z2)) return false;
+    return add(q.y, mul(a.y, mul(z2, q.z))).is_zero();
+}
+
+// [k]P for P in G1 through the GLV split (g1_28.hpp: glv_split): k = k1 + k2 lambda with 128-bit halves,
+// phi(P) = (beta X, Y, Z); joint double-and-add over (P, phi(P), P + phi(P)): 128 doublings and ~96
+// additions instead of 255 and ~128
+inline G1Jac g1_mul_glv_host(const G1Jac &p, const uint32_t *k) {
+    if (p.is_inf()) return p;
+    uint32_t k1[4], k2[4];
+    glv_split(k, k1, k2);
+    Fp b1;
+    for (int i = 0; i < 12; i++) b1.l[i] = FP_BETA_LAMBDA_MONT[i];
+    const G1Jac q = {mul(p.x, b1), p.y, p.z};
+    const G1Jac pq = jac_add(p, q);
+    G1Jac acc = G1Jac::inf();
+    for (int i = 127; i >= 0; i--) {
+        acc = jac_dbl(acc);
+        const uint32_t b = ((k1[i >> 5] >> (i & 31)) & 1u) | (((k2[i >> 5] >> (i & 31)) & 1u) << 1);
+        if (b == 1) acc = jac_add(acc, p);
+        else if (b == 2) acc = jac_add(acc, q);
+        else if (b == 3) acc = jac_add(acc, pq);
+    }
+    return acc;
 }
 
 // ---- fixed-argument pairing: the G2 inputs of every verification equation are one of three

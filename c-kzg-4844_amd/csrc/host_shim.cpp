@@ -177,6 +177,9 @@ void hs_g1_madd28_chain(G1Jac *r, const G1Affine *pts, int n) {
 // from `seed`: bit 0 complex squaring, bit 1 sparse line product, bit 2 cyclotomic squaring (on an
 // element of the cyclotomic subgroup), bit 3 cyclotomic squaring must DIFFER on a generic element
 // (guards against a test that cannot fail).  Returns 0 when everything agrees.
+extern "C" int hs_g1_in_subgroup_host(const G1Affine *a) { return g1_in_subgroup_host(*a) ? 1 : 0; }
+extern "C" void hs_g1_mul_glv_host(G1Jac *r, const G1Jac *p, const uint32_t *k) { *r = g1_mul_glv_host(*p, k); }
+
 extern "C" int hs_fp12_selftest(uint32_t seed) {
     auto rnd_fp = [&](uint32_t i) {
         uint8_t in[8], d[64];

@@ -419,6 +419,8 @@ def test_glv_split_and_glv_scalar_mul(libs):
             r = _buf(144)
             h.hs_g1_mul28_glv(r, p1, kk)
             assert o.og1_equal(r, _omul(o, p1, k)), k
+            h.hs_g1_mul_glv_host(r, p1, kk)      # joint double-and-add of the host verification path
+            assert o.og1_equal(r, _omul(o, p1, k)), k
     r = _buf(144)
     kk = (C.c_uint32 * 8)(*[(ks[20] >> (32 * i)) & 0xffffffff for i in range(8)])
     h.hs_g1_mul28_glv(r, _buf(144), kk)   # infinity in, infinity out
@@ -452,6 +454,7 @@ def test_endomorphism_subgroup_test_is_exact(libs):
         if expect is not None:
             assert want == expect
         assert h.hs_g1_in_subgroup28(a) == (1 if want else 0)
+        assert h.hs_g1_in_subgroup_host(a) == (1 if want else 0)   # same test on the host's Jacobian code
 
     o.og1_in_subgroup.restype = C.c_bool
     g = _buf(144)
