@@ -2,6 +2,9 @@
 // extensions).  Host-side protocol logic lives here; every MSM / NTT goes to the HIP kernels via
 // device.hpp.  There is no CPU fallback for the hot path: if no GPU context is attached to the
 // KZGSettings (or the HIP runtime fails) the call returns C_KZG_ERROR and says why on stderr.
+#include <atomic>
+#include <thread>
+
 #include "api_common.hpp"
 
 using namespace ckzg;
@@ -130,14 +133,30 @@ extern "C" C_KZG_RET load_trusted_setup(KZGSettings *out, const uint8_t *g1_mono
         goto fail;
     }
     // The file is trusted: curve membership only, no subgroup check (setup.c:447-477)
-    for (size_t i = 0; i < NUM_G1_POINTS; i++) {
-        if (g1_uncompress(mono_affine[i], g1_monomial_bytes + 48 * i) != 0 ||
-            g1_uncompress(lagr_affine[i], g1_lagrange_bytes + 48 * i) != 0) {
+    // (8192 square roots: ~0.25 s on one core, spread over up to 16 threads)
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        const size_t nt = hw >= 16 ? 16 : (hw ? hw : 1);
+        std::atomic<int> bad(0);
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nt; t++) {
+            th.emplace_back([&, t]() {
+                for (size_t i = t; i < NUM_G1_POINTS; i += nt) {
+                    if (g1_uncompress(mono_affine[i], g1_monomial_bytes + 48 * i) != 0 ||
+                        g1_uncompress(lagr_affine[i], g1_lagrange_bytes + 48 * i) != 0) {
+                        bad.store(1);
+                        return;
+                    }
+                    *as_g1(&out->g1_values_monomial[i]) = jac_from_affine(mono_affine[i]);
+                    *as_g1(&out->g1_values_lagrange_brp[i]) = jac_from_affine(lagr_affine[i]);
+                }
+            });
+        }
+        for (auto &x : th) x.join();
+        if (bad.load()) {
             ret = C_KZG_BADARGS;
             goto fail;
         }
-        *as_g1(&out->g1_values_monomial[i]) = jac_from_affine(mono_affine[i]);
-        *as_g1(&out->g1_values_lagrange_brp[i]) = jac_from_affine(lagr_affine[i]);
     }
     for (size_t i = 0; i < NUM_G2_POINTS; i++) {
         G2Affine a;
