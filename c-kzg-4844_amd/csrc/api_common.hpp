@@ -3,6 +3,7 @@
 // KZGSettings to its GPU context, small host helpers.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <cinttypes>
 #include <cstdio>
 #include <cstdlib>
@@ -29,6 +30,21 @@ inline const Fr *as_fr(const fr_t *p) { return reinterpret_cast<const Fr *>(p); 
 inline G1Jac *as_g1(g1_t *p) { return reinterpret_cast<G1Jac *>(p); }
 inline const G1Jac *as_g1(const g1_t *p) { return reinterpret_cast<const G1Jac *>(p); }
 inline const host::G2Jac *as_g2(const g2_t *p) { return reinterpret_cast<const host::G2Jac *>(p); }
+
+// CKZG_HIP_TRACE=1 prints a per-phase wall-clock breakdown of the host-pointer entry points to stderr
+struct Trace {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    const char *what;
+    explicit Trace(const char *w) : on(getenv("CKZG_HIP_TRACE") != nullptr), t0(std::chrono::steady_clock::now()), what(w) {}
+    void mark(const char *phase) {
+        if (!on) return;
+        auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[ckzg-hip trace] %s: %s %.3f ms\n", what, phase,
+                std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 
 struct Options {
     int device = -1;        // -1: env CKZG_HIP_DEVICE, else LOCAL_RANK, else 0

@@ -15,21 +15,6 @@ using namespace ckzg::api;
 
 namespace {
 
-// CKZG_HIP_TRACE=1 prints a per-phase wall-clock breakdown of the verification calls to stderr
-struct Trace {
-    bool on;
-    std::chrono::steady_clock::time_point t0;
-    const char *what;
-    explicit Trace(const char *w) : on(getenv("CKZG_HIP_TRACE") != nullptr), t0(std::chrono::steady_clock::now()), what(w) {}
-    void mark(const char *phase) {
-        if (!on) return;
-        auto t1 = std::chrono::steady_clock::now();
-        fprintf(stderr, "[ckzg-hip trace] %s: %s %.3f ms\n", what, phase,
-                std::chrono::duration<double, std::milli>(t1 - t0).count());
-        t0 = t1;
-    }
-};
-
 template <class T>
 struct DBuf {
     T *p = nullptr;
