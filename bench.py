@@ -164,9 +164,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # "nccl" is RCCL on ROCm.  CKZG_BENCH_BACKEND=gloo + CKZG_BENCH_ONE_GPU=1 exist only to exercise
+        # this file's multi-rank control flow on a one-GPU box (all ranks share device 0).
+        dist.init_process_group(os.environ.get("CKZG_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+    if os.environ.get("CKZG_BENCH_ONE_GPU"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = dev if (world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")
 
     import __graft_entry__ as ge
     mod = ge.load_package()
@@ -216,7 +221,7 @@ def main():
     dt = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
