@@ -387,7 +387,7 @@ extern "C" C_KZG_RET ckzg_hip_compute_cells_and_kzg_proofs_batch(Cell *cells, KZ
     if (n == 0) return C_KZG_OK;
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (hipSetDevice(ctx->device) != hipSuccess) return C_KZG_ERROR;
-    const uint64_t CH = 1024;
+    const uint64_t CH = 2048;  // >= 2 waves of G1-FFT butterflies per SIMD per stage launch
     uint64_t m = n < CH ? n : CH;
     const size_t cells_per = (size_t)CELLS_PER_EXT_BLOB * BYTES_PER_CELL, proofs_per = (size_t)CELLS_PER_EXT_BLOB * 48;
     DeviceBuffer d_blobs, d_cells, d_proofs, d_status;

@@ -74,25 +74,15 @@ __global__ void k_fk20_digits(int16_t *digits, const Fr *cfft, size_t total, int
 }
 
 // ------------------------------------------------------------------------------------------
-// G1 FFT of size 128: one 64-lane workgroup per transform, points in LDS (limb-major)
+// G1 FFT of size 128 over a batch of vectors: one launch per butterfly stage
+//
+// A butterfly is one 255-bit scalar multiplication (~0.8 M multiply-adds) and two additions; the
+// points it touches are 2 x 192 B.  So the stages go through global memory and the kernel keeps
+// nothing but the ladder alive: no LDS, ~200 VGPRs, two waves per SIMD.  Lanes are ordered
+// transform-fastest (lane = butterfly * nfft + transform), so a wave works on the SAME butterfly of
+// 64 different transforms: one twiddle per wave (window digits uniform, no divergence) and the
+// butterflies whose twiddle is 1 form whole waves that skip the ladder instead of idling in it.
 // ------------------------------------------------------------------------------------------
-
-// points live in LDS in the 28-bit-limb domain: 56 limbs + an infinity flag, limb-major
-__device__ __forceinline__ XYZZ28 pt_get(uint32_t (*sh)[128], int idx, bool &inf) {
-    XYZZ28 r;
-    uint32_t *d = reinterpret_cast<uint32_t *>(&r);
-#pragma unroll
-    for (int k = 0; k < 56; k++) d[k] = sh[k][idx];
-    inf = sh[56][idx] != 0;
-    return r;
-}
-
-__device__ __forceinline__ void pt_put(uint32_t (*sh)[128], int idx, const XYZZ28 &v, bool inf) {
-    const uint32_t *s = reinterpret_cast<const uint32_t *>(&v);
-#pragma unroll
-    for (int k = 0; k < 56; k++) sh[k][idx] = s[k];
-    sh[56][idx] = inf ? 1u : 0u;
-}
 
 // k points at the GLV halves {k1[4], k2[4]} of the twiddle (g1_28.hpp: glv_split)
 __device__ __noinline__ void g1_mul_root(XYZZ28 &p, bool &inf, const uint32_t *k) {
@@ -104,60 +94,84 @@ __device__ __noinline__ void g1_mul_root(XYZZ28 &p, bool &inf, const uint32_t *k
 }
 
 // roots_glv[i] = GLV halves of w^(64 i), i = 0..128 (every twiddle of a size-128 transform).
-// DIF: natural in -> bit-reversed out; DIT: bit-reversed in -> natural out (fft.c:164-185 computes
-// the same butterflies recursively).  zero_odd: after a DIF, clear the odd positions, i.e. the
-// entries whose natural index is >= 64 (fk20.c:264-266).  out_brp: after a DIT, store element k
-// at position brp7(k) (eip7594.c:133).  Arithmetic: fp28.hpp / g1_28.hpp.
+// Stage s (butterfly span 2^s).  DIF: x = u + v, y = (u - v) w; DIT: v' = v w, x = u + v', y = u - v'
+// (fft.c:164-185 computes the same butterflies recursively).  A DIF pass runs s = 7..1 (natural in,
+// bit-reversed out), a DIT pass s = 1..7 (bit-reversed in, natural out).
 template <bool DIF>
-__global__ __launch_bounds__(64) void k_g1_fft128(G1XYZZ *data, const uint32_t *roots_glv,
-                                                  int inverse, int zero_odd, int out_brp) {
-    __shared__ uint32_t sh[57][128];
-    G1XYZZ *vec = data + (size_t)blockIdx.x * 128;
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
-        bool inf;
-        XYZZ28 p = xyzz28_from_xyzz(vec[tid + 64 * r], inf);
-        pt_put(sh, tid + 64 * r, p, inf);
-    }
-    __syncthreads();
-    for (int st = 0; st < 7; st++) {
-        int s = DIF ? 7 - st : st + 1;
-        int half = 1 << (s - 1);
-        int j = tid & (half - 1);
-        int i0 = ((tid >> (s - 1)) << s) + j;
-        int i1 = i0 + half;
+__global__ __launch_bounds__(64) void k_g1_fft_stage(G1XYZZ *data, const uint32_t *roots_glv, uint32_t nfft,
+                                                     int s, int inverse) {
+    const size_t g = blockIdx.x * (size_t)64 + threadIdx.x;
+    if (g >= (size_t)nfft * 64) return;
+    const uint32_t bf = (uint32_t)(g / nfft), f = (uint32_t)(g - (size_t)bf * nfft);
+    const int half = 1 << (s - 1);
+    const int j = (int)bf & (half - 1);
+    const int i0 = (((int)bf >> (s - 1)) << s) + j, i1 = i0 + half;
+    G1XYZZ *vec = data + (size_t)f * 128;
+    int ridx = j * (N_EXT / (2 * half));
+    if (inverse) ridx = N_EXT - ridx;
+    const uint32_t *k = roots_glv + (size_t)(ridx / (N_EXT / 128)) * 8;
+    if (DIF) {
         bool ui, vi;
-        XYZZ28 u = pt_get(sh, i0, ui), v = pt_get(sh, i1, vi);
-        int ridx = j * (N_EXT / (2 * half));
-        if (inverse) ridx = N_EXT - ridx;
-        const uint32_t *k = roots_glv + (size_t)(ridx / (N_EXT / 128)) * 8;
-        if (!DIF && j != 0) g1_mul_root(v, vi, k);
-        XYZZ28 x = u, y = u;
-        bool xi = ui, yi = ui;
+        XYZZ28 u = xyzz28_from_xyzz(vec[i0], ui), v = xyzz28_from_xyzz(vec[i1], vi);
+        XYZZ28 x = u;
+        bool xi = ui;
         xyzz28_add(x, xi, v, vi);
-        xyzz28_add(y, yi, xyzz28_neg(v), vi);
-        if (DIF && j != 0) g1_mul_root(y, yi, k);
-        pt_put(sh, i0, x, xi);
-        pt_put(sh, i1, y, yi);
-        __syncthreads();
-    }
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
-        int idx = tid + 64 * r;
-        bool inf;
-        XYZZ28 v = pt_get(sh, idx, inf);
-        if (zero_odd && (idx & 1)) inf = true;
-        vec[out_brp ? brp7((uint32_t)idx) : idx] = xyzz28_to_xyzz(v, inf);
+        vec[i0] = xyzz28_to_xyzz(x, xi);
+        xyzz28_add(u, ui, xyzz28_neg(v), vi);
+        if (j != 0) g1_mul_root(u, ui, k);
+        vec[i1] = xyzz28_to_xyzz(u, ui);
+    } else {
+        bool ui, vi;
+        XYZZ28 v = xyzz28_from_xyzz(vec[i1], vi);
+        if (j != 0) g1_mul_root(v, vi, k);
+        XYZZ28 u = xyzz28_from_xyzz(vec[i0], ui);
+        XYZZ28 x = u;
+        bool xi = ui;
+        xyzz28_add(x, xi, v, vi);
+        vec[i0] = xyzz28_to_xyzz(x, xi);
+        xyzz28_add(u, ui, xyzz28_neg(v), vi);
+        vec[i1] = xyzz28_to_xyzz(u, ui);
     }
 }
 
-__global__ void k_compress(uint8_t *out48, const G1Affine *in, size_t n) {
+// The last DIF stage, the truncation h[64..127] = 0 (fk20.c:264-266: in bit-reversed order these are
+// the odd positions) and the first DIT stage fused: both slots of a pair receive u + v.
+__global__ void k_g1_fft_fold(G1XYZZ *data, size_t npairs) {
+    const size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (g >= npairs) return;
+    bool ui, vi;
+    XYZZ28 u = xyzz28_from_xyzz(data[2 * g], ui), v = xyzz28_from_xyzz(data[2 * g + 1], vi);
+    xyzz28_add(u, ui, v, vi);
+    G1XYZZ r = xyzz28_to_xyzz(u, ui);
+    data[2 * g] = r;
+    data[2 * g + 1] = r;
+}
+
+static int g1_fft_stages(DeviceCtx *ctx, G1XYZZ *d_data, const uint32_t *d_glv, size_t nfft, bool dif,
+                         int s_from, int s_to, int inverse) {
+    // dif: s runs downwards from s_from to s_to; dit: upwards
+    for (int s = s_from; dif ? s >= s_to : s <= s_to; s += dif ? -1 : 1) {
+        if (dif) {
+            hipLaunchKernelGGL(k_g1_fft_stage<true>, dim3((unsigned)nfft), dim3(64), 0, ctx->stream, d_data, d_glv,
+                               (uint32_t)nfft, s, inverse);
+        } else {
+            hipLaunchKernelGGL(k_g1_fft_stage<false>, dim3((unsigned)nfft), dim3(64), 0, ctx->stream, d_data, d_glv,
+                               (uint32_t)nfft, s, inverse);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// out48[v][brp7(k)] (or [k]) = compress(in[v][k])
+__global__ void k_compress(uint8_t *out48, const G1Affine *in, size_t n, int out_brp) {
     size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (g >= n) return;
     uint8_t buf[48];
     g1_compress_affine(buf, in[g]);
-    for (int k = 0; k < 48; k++) out48[g * 48 + k] = buf[k];
+    // eip7594.c:133: the proofs leave in bit-reversed order within each blob
+    const size_t o = out_brp ? ((g & ~(size_t)127) | brp7((uint32_t)g & 127u)) : g;
+    for (int k = 0; k < 48; k++) out48[o * 48 + k] = buf[k];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -219,7 +233,8 @@ int fk20_setup_device(DeviceCtx *ctx, const G1Affine *d_monomial, G1Affine *h_xe
     HIP_TRY(hipMalloc(&d_prefix, npts * sizeof(Fp)));
     if (!ctx->d_xext) HIP_TRY(hipMalloc(&ctx->d_xext, npts * sizeof(G1Affine)));
     hipLaunchKernelGGL(k_xext_gather, dim3(npts / 256), dim3(256), 0, ctx->stream, d_xin, d_monomial);
-    hipLaunchKernelGGL(k_g1_fft128<true>, dim3(64), dim3(64), 0, ctx->stream, d_xin, d_rr, 0, 0, 0);
+    rc = g1_fft_stages(ctx, d_xin, d_rr, 64, /*dif=*/true, 7, 1, /*inverse=*/0);
+    if (rc) return rc;
     hipLaunchKernelGGL(k_xext_transpose, dim3(npts / 256), dim3(256), 0, ctx->stream, d_cols, d_xin);
     HIP_TRY(hipGetLastError());
     rc = batch_to_affine_device(ctx, ctx->d_xext, d_cols, d_prefix, npts);
@@ -285,13 +300,17 @@ static int fk20_run(DeviceCtx *ctx, uint8_t *d_proofs, const Fr *d_poly, size_t 
     HIP_TRY(hipGetLastError());
     rc = msm_small_vectors_device(ctx, t, s.u, s.digits, n * 128, 64, 128);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_g1_fft128<true>, dim3((unsigned)n), dim3(64), 0, ctx->stream, s.u, d_rr, 1, 1, 0);
-    hipLaunchKernelGGL(k_g1_fft128<false>, dim3((unsigned)n), dim3(64), 0, ctx->stream, s.u, d_rr, 0, 0, 1);
-    HIP_TRY(hipGetLastError());
+    // h = IFFT(u) truncated to its first 64 entries, proofs = FFT(h) (fk20.c:257-269): inverse DIF
+    // stages 7..2, the fused stage pair around the truncation, forward DIT stages 2..7
+    rc = g1_fft_stages(ctx, s.u, d_rr, n, /*dif=*/true, 7, 2, /*inverse=*/1);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_g1_fft_fold, dim3((unsigned)((n * 64 + 63) / 64)), dim3(64), 0, ctx->stream, s.u, n * 64);
+    rc = g1_fft_stages(ctx, s.u, d_rr, n, /*dif=*/false, 2, 7, /*inverse=*/0);
+    if (rc) return rc;
     rc = batch_to_affine_device(ctx, s.aff, s.u, s.prefix, n * 128);
     if (rc) return rc;
     hipLaunchKernelGGL(k_compress, dim3((unsigned)((n * 128 + 63) / 64)), dim3(64), 0, ctx->stream,
-                       d_proofs, s.aff, n * 128);
+                       d_proofs, s.aff, n * 128, 1);
     HIP_TRY(hipGetLastError());
     return 0;
 }
