@@ -84,11 +84,15 @@ __global__ void k_fk20_digits(int16_t *digits, const Fr *cfft, size_t total, int
 // butterflies whose twiddle is 1 form whole waves that skip the ladder instead of idling in it.
 // ------------------------------------------------------------------------------------------
 
-// k points at the GLV halves {k1[4], k2[4]} of the twiddle (g1_28.hpp: glv_split)
-__device__ __noinline__ void g1_mul_root(XYZZ28 &p, bool &inf, const uint32_t *k) {
+// One record per twiddle w^(64 i), i = 0..128: the GLV halves {k1[4], k2[4]} (g1_28.hpp: glv_split)
+// followed by their width-4 NAF digit strings (wnaf4_128), built once per context by k_glv_roots.
+constexpr int TW_REC_WORDS = 8 + 2 * (GLV_NAF_LEN / 4);
+
+__device__ __noinline__ void g1_mul_root(XYZZ28 &p, bool &inf, const uint32_t *rec) {
     XYZZ28 o;
     bool oi;
-    xyzz28_mul_glv_w4(o, oi, p, inf, k);
+    const int8_t *naf = reinterpret_cast<const int8_t *>(rec + 8);
+    xyzz28_mul_glv_naf(o, oi, p, inf, naf, naf + GLV_NAF_LEN);
     p = o;
     inf = oi;
 }
@@ -96,47 +100,58 @@ __device__ __noinline__ void g1_mul_root(XYZZ28 &p, bool &inf, const uint32_t *k
 // roots_glv[i] = GLV halves of w^(64 i), i = 0..128 (every twiddle of a size-128 transform).
 // Stage s (butterfly span 2^s).  DIF: x = u + v, y = (u - v) w; DIT: v' = v w, x = u + v', y = u - v'
 // (fft.c:164-185 computes the same butterflies recursively).  A DIF pass runs s = 7..1 (natural in,
-// bit-reversed out), a DIT pass s = 1..7 (bit-reversed in, natural out).
-template <bool DIF>
-__global__ __launch_bounds__(64) void k_g1_fft_stage(G1XYZZ *data, const uint32_t *roots_glv, uint32_t nfft,
-                                                     int s, int inverse) {
-    const size_t g = blockIdx.x * (size_t)64 + threadIdx.x;
-    if (g >= (size_t)nfft * 64) return;
-    const uint32_t bf = (uint32_t)(g / nfft), f = (uint32_t)(g - (size_t)bf * nfft);
+// bit-reversed out), a DIT pass s = 1..7 (bit-reversed in, natural out).  Each stage is two launches,
+// so that the ladder kernel holds nothing but its own state: k_g1_fft_twiddle multiplies slot i1 of
+// every butterfly whose twiddle is not 1, k_g1_fft_addsub replaces (u, v) by (u + v, u - v); DIF runs
+// addsub then twiddle, DIT twiddle then addsub.
+// lane g -> (butterfly bf, transform f), transform-fastest over nfft rounded up to a multiple of 64 so
+// that every wave belongs to exactly one butterfly (lanes with f >= nfft are idle)
+__device__ __forceinline__ void butterfly_index(size_t g, uint32_t nfft, int s, uint32_t &f, int &j, int &i0, int &i1) {
+    const uint32_t pad = (nfft + 63u) & ~63u;
+    const uint32_t bf = (uint32_t)(g / pad);
+    f = (uint32_t)(g - (size_t)bf * pad);
     const int half = 1 << (s - 1);
-    const int j = (int)bf & (half - 1);
-    const int i0 = (((int)bf >> (s - 1)) << s) + j, i1 = i0 + half;
-    G1XYZZ *vec = data + (size_t)f * 128;
-    int ridx = j * (N_EXT / (2 * half));
+    j = (int)bf & (half - 1);
+    i0 = (((int)bf >> (s - 1)) << s) + j;
+    i1 = i0 + half;
+}
+
+__global__ __launch_bounds__(64) void k_g1_fft_twiddle(G1XYZZ *data, const uint32_t *roots_glv, uint32_t nfft, int s,
+                                                       int inverse) {
+    const size_t g = blockIdx.x * (size_t)64 + threadIdx.x;
+    uint32_t f;
+    int j, i0, i1;
+    butterfly_index(g, nfft, s, f, j, i0, i1);
+    if (f >= nfft || j == 0) return;
+    int ridx = j * (N_EXT / (2 << (s - 1)));
     if (inverse) ridx = N_EXT - ridx;
-    const uint32_t *k = roots_glv + (size_t)(ridx / (N_EXT / 128)) * 8;
-    if (DIF) {
-        bool ui, vi;
-        XYZZ28 u = xyzz28_from_xyzz(vec[i0], ui), v = xyzz28_from_xyzz(vec[i1], vi);
-        XYZZ28 x = u;
-        bool xi = ui;
-        xyzz28_add(x, xi, v, vi);
-        vec[i0] = xyzz28_to_xyzz(x, xi);
-        xyzz28_add(u, ui, xyzz28_neg(v), vi);
-        if (j != 0) g1_mul_root(u, ui, k);
-        vec[i1] = xyzz28_to_xyzz(u, ui);
-    } else {
-        bool ui, vi;
-        XYZZ28 v = xyzz28_from_xyzz(vec[i1], vi);
-        if (j != 0) g1_mul_root(v, vi, k);
-        XYZZ28 u = xyzz28_from_xyzz(vec[i0], ui);
-        XYZZ28 x = u;
-        bool xi = ui;
-        xyzz28_add(x, xi, v, vi);
-        vec[i0] = xyzz28_to_xyzz(x, xi);
-        xyzz28_add(u, ui, xyzz28_neg(v), vi);
-        vec[i1] = xyzz28_to_xyzz(u, ui);
-    }
+    G1XYZZ *slot = data + (size_t)f * 128 + i1;
+    bool vi;
+    XYZZ28 v = xyzz28_from_xyzz(*slot, vi);
+    g1_mul_root(v, vi, roots_glv + (size_t)(ridx / (N_EXT / 128)) * TW_REC_WORDS);
+    *slot = xyzz28_to_xyzz(v, vi);
+}
+
+__global__ __launch_bounds__(64) void k_g1_fft_addsub(G1XYZZ *data, uint32_t nfft, int s) {
+    const size_t g = blockIdx.x * (size_t)64 + threadIdx.x;
+    uint32_t f;
+    int j, i0, i1;
+    butterfly_index(g, nfft, s, f, j, i0, i1);
+    if (f >= nfft) return;
+    G1XYZZ *vec = data + (size_t)f * 128;
+    bool ui, vi;
+    XYZZ28 u = xyzz28_from_xyzz(vec[i0], ui), v = xyzz28_from_xyzz(vec[i1], vi);
+    XYZZ28 x = u;
+    bool xi = ui;
+    xyzz28_add(x, xi, v, vi);
+    vec[i0] = xyzz28_to_xyzz(x, xi);
+    xyzz28_add(u, ui, xyzz28_neg(v), vi);
+    vec[i1] = xyzz28_to_xyzz(u, ui);
 }
 
 // The last DIF stage, the truncation h[64..127] = 0 (fk20.c:264-266: in bit-reversed order these are
 // the odd positions) and the first DIT stage fused: both slots of a pair receive u + v.
-__global__ void k_g1_fft_fold(G1XYZZ *data, size_t npairs) {
+__global__ __launch_bounds__(64) void k_g1_fft_fold(G1XYZZ *data, size_t npairs) {
     const size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (g >= npairs) return;
     bool ui, vi;
@@ -150,14 +165,12 @@ __global__ void k_g1_fft_fold(G1XYZZ *data, size_t npairs) {
 static int g1_fft_stages(DeviceCtx *ctx, G1XYZZ *d_data, const uint32_t *d_glv, size_t nfft, bool dif,
                          int s_from, int s_to, int inverse) {
     // dif: s runs downwards from s_from to s_to; dit: upwards
+    const dim3 grid((unsigned)((nfft + 63) / 64 * 64)), block(64);  // 64 butterflies x padded transforms / 64 lanes
     for (int s = s_from; dif ? s >= s_to : s <= s_to; s += dif ? -1 : 1) {
-        if (dif) {
-            hipLaunchKernelGGL(k_g1_fft_stage<true>, dim3((unsigned)nfft), dim3(64), 0, ctx->stream, d_data, d_glv,
-                               (uint32_t)nfft, s, inverse);
-        } else {
-            hipLaunchKernelGGL(k_g1_fft_stage<false>, dim3((unsigned)nfft), dim3(64), 0, ctx->stream, d_data, d_glv,
-                               (uint32_t)nfft, s, inverse);
-        }
+        if (dif) hipLaunchKernelGGL(k_g1_fft_addsub, grid, block, 0, ctx->stream, d_data, (uint32_t)nfft, s);
+        if (s > 1)
+            hipLaunchKernelGGL(k_g1_fft_twiddle, grid, block, 0, ctx->stream, d_data, d_glv, (uint32_t)nfft, s, inverse);
+        if (!dif) hipLaunchKernelGGL(k_g1_fft_addsub, grid, block, 0, ctx->stream, d_data, (uint32_t)nfft, s);
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -196,24 +209,28 @@ __global__ void k_xext_transpose(G1XYZZ *cols, const G1XYZZ *xin) {
     cols[brp7(p) * 64 + off] = xin[g];
 }
 
-// GLV halves of the 129 twiddles w^(64 i) of the size-128 G1 transforms
+// twiddle records (GLV halves + NAF digits) of the 129 twiddles w^(64 i) of the size-128 G1 transforms
 __global__ void k_glv_roots(uint32_t *out, const Fr *roots) {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g > 128) return;
     uint32_t raw[8], k1[4], k2[4];
     to_raw<FrParams>(raw, ld_fr(roots + (size_t)g * (N_EXT / 128)));
     glv_split(raw, k1, k2);
+    uint32_t *rec = out + (size_t)g * TW_REC_WORDS;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        out[g * 8 + k] = k1[k];
-        out[g * 8 + 4 + k] = k2[k];
+        rec[k] = k1[k];
+        rec[4 + k] = k2[k];
     }
+    int8_t *naf = reinterpret_cast<int8_t *>(rec + 8);
+    wnaf4_128(naf, k1);
+    wnaf4_128(naf + GLV_NAF_LEN, k2);
 }
 
 static int ensure_roots_raw(DeviceCtx *ctx, uint32_t **out) {
     // allocated lazily and kept for the life of the context
     if (!ctx->d_roots_raw) {
-        HIP_TRY(hipMalloc(&ctx->d_roots_raw, (size_t)129 * 8 * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&ctx->d_roots_raw, (size_t)129 * TW_REC_WORDS * sizeof(uint32_t)));
         hipLaunchKernelGGL(k_glv_roots, dim3(3), dim3(64), 0, ctx->stream, ctx->d_roots_raw, ctx->d_roots);
         HIP_TRY(hipGetLastError());
     }

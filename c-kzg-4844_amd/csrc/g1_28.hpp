@@ -315,6 +315,74 @@ HDNI inline void xyzz28_mul_glv_w4(XYZZ28 &out, bool &out_inf, const XYZZ28 &p, 
     out_inf = inf;
 }
 
+// Width-4 non-adjacent form of a 128-bit k: digits in {0, +-1, +-3, +-5, +-7}, digit i has weight 2^i,
+// at most one non-zero digit in any 4 consecutive positions (density 1/5).  out has GLV_NAF_LEN entries.
+constexpr int GLV_NAF_LEN = 132;
+HDNI inline void wnaf4_128(int8_t *out, const uint32_t *k) {
+    uint32_t v[5] = {k[0], k[1], k[2], k[3], 0};
+    for (int i = 0; i < GLV_NAF_LEN; i++) {
+        int d = 0;
+        if (v[0] & 1u) {
+            d = (int)(v[0] & 15u);
+            if (d >= 8) d -= 16;
+            // v -= d
+            if (d > 0) {
+                uint64_t br = (uint64_t)d;
+                for (int j = 0; j < 5 && br; j++) {
+                    uint64_t t = (uint64_t)v[j] - br;
+                    v[j] = (uint32_t)t;
+                    br = (t >> 32) & 1u;
+                }
+            } else {
+                uint64_t c = (uint64_t)(-d);
+                for (int j = 0; j < 5 && c; j++) {
+                    uint64_t t = (uint64_t)v[j] + c;
+                    v[j] = (uint32_t)t;
+                    c = t >> 32;
+                }
+            }
+        }
+        out[i] = (int8_t)d;
+        for (int j = 0; j < 4; j++) v[j] = (v[j] >> 1) | (v[j + 1] << 31);
+        v[4] >>= 1;
+    }
+}
+
+// [k]P = [k1]P + [k2]phi(P) with both halves given in width-4 NAF (wnaf4_128): 131 doublings at most
+// and ~52 additions from the table {+-P, +-3P, +-5P, +-7P} (phi applied on the fly).  The schedule
+// depends on the digits, so it is meant for callers whose lanes share the scalar: the G1 FFT stage
+// kernels, where a wave works on one twiddle.  Only for points of the prime-order subgroup.
+HDNI inline void xyzz28_mul_glv_naf(XYZZ28 &out, bool &out_inf, const XYZZ28 &p, bool p_inf, const int8_t *naf1,
+                                    const int8_t *naf2) {
+    XYZZ28 tbl[8];  // [2m] = (2m+1)P, [2m+1] = -(2m+1)P
+    XYZZ28 acc;
+    bool inf = true;
+    if (!p_inf) {
+        const F28<1, 1> beta = f28_const<1, 1>(FP28_BETA_LAMBDA);
+        XYZZ28 p2 = p;
+        xyzz28_dbl(p2);
+        tbl[0] = p;
+        for (int m = 1; m < 4; m++) {
+            tbl[2 * m] = tbl[2 * m - 2];
+            bool ti = false;
+            xyzz28_add(tbl[2 * m], ti, p2, false);  // a subgroup point: (2m+1)P is finite
+        }
+        for (int m = 0; m < 4; m++) tbl[2 * m + 1] = xyzz28_neg(tbl[2 * m]);
+        for (int i = GLV_NAF_LEN - 1; i >= 0; i--) {
+            if (!inf) xyzz28_dbl(acc);
+            const int d1 = naf1[i], d2 = naf2[i];
+            if (d1) xyzz28_add(acc, inf, tbl[(d1 > 0 ? d1 - 1 : -d1)], false);
+            if (d2) {
+                XYZZ28 e = tbl[(d2 > 0 ? d2 - 1 : -d2)];
+                e.x = widen<1, 10>(mul(e.x, beta));
+                xyzz28_add(acc, inf, e, false);
+            }
+        }
+    }
+    out = acc;
+    out_inf = inf;
+}
+
 // a^e for a public exponent e (little-endian limbs, nbits bits) by a 4-bit sliding window: nbits
 // squarings and ~nbits/5 multiplications (odd powers a, a^3, ..., a^15 precomputed).
 HDNI inline F28<1, 2> f28_pow_public(const F28<1, 2> &a, const uint32_t *e, int nbits) {

@@ -142,6 +142,18 @@ void hs_g1_mul28_glv(G1Jac *r, const G1Jac *a, const uint32_t *k) {
     xyzz28_mul_glv_w4(o, oi, x, ai, glv);
     *r = jac_from_affine(xyzz28_to_affine(o, oi));
 }
+void hs_wnaf4_128(int8_t *out, const uint32_t *k) { wnaf4_128(out, k); }
+void hs_g1_mul28_glv_naf(G1Jac *r, const G1Jac *a, const uint32_t *k) {
+    uint32_t glv[8];
+    glv_split(k, glv, glv + 4);
+    int8_t naf[2 * GLV_NAF_LEN];
+    wnaf4_128(naf, glv);
+    wnaf4_128(naf + GLV_NAF_LEN, glv + 4);
+    bool ai, oi;
+    XYZZ28 x = xyzz28_from_xyzz(xyzz_from_jac(*a), ai), o;
+    xyzz28_mul_glv_naf(o, oi, x, ai, naf, naf + GLV_NAF_LEN);
+    *r = jac_from_affine(xyzz28_to_affine(o, oi));
+}
 void hs_g1_neg28(G1Jac *r, const G1Jac *a) {
     bool ai;
     XYZZ28 x = xyzz28_from_xyzz(xyzz_from_jac(*a), ai);

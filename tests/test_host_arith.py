@@ -421,6 +421,13 @@ def test_glv_split_and_glv_scalar_mul(libs):
             assert o.og1_equal(r, _omul(o, p1, k)), k
             h.hs_g1_mul_glv_host(r, p1, kk)      # joint double-and-add of the host verification path
             assert o.og1_equal(r, _omul(o, p1, k)), k
+            h.hs_g1_mul28_glv_naf(r, p1, kk)     # width-4 NAF ladder of the G1 FFT twiddles
+            assert o.og1_equal(r, _omul(o, p1, k)), k
+        naf = (C.c_int8 * 132)()
+        h.hs_wnaf4_128(naf, (C.c_uint32 * 4)(*[(k1 >> (32 * i)) & 0xffffffff for i in range(4)]))
+        assert sum(int(naf[i]) << i for i in range(132)) == k1
+        assert all(d == 0 or (d % 2 and abs(d) <= 7) for d in naf)
+        assert all(sum(1 for d in naf[i:i + 4] if d) <= 1 for i in range(129))
     r = _buf(144)
     kk = (C.c_uint32 * 8)(*[(ks[20] >> (32 * i)) & 0xffffffff for i in range(8)])
     h.hs_g1_mul28_glv(r, _buf(144), kk)   # infinity in, infinity out
