@@ -628,19 +628,6 @@ static C_KZG_RET recover_cells_gpu(dev::DeviceCtx *ctx, Fr *d_e, size_t count, c
     return C_KZG_OK;
 }
 
-// cells[b][j] (2048 B each) -> image[b][cell_indices[j]]; the image is zero elsewhere
-__global__ void k_scatter_cells(uint4 *image, const uint4 *cells, const uint32_t *idx, uint32_t num_cells,
-                                size_t total_u4) {
-    size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (g >= total_u4) return;
-    constexpr uint32_t U4 = BYTES_PER_CELL / 16;
-    size_t cell = g / U4;
-    uint32_t w = (uint32_t)(g % U4);
-    size_t b = cell / num_cells;
-    uint32_t j = (uint32_t)(cell % num_cells);
-    image[(b * CELLS_PER_EXT_BLOB + idx[j]) * U4 + w] = cells[g];
-}
-
 extern "C" C_KZG_RET ckzg_hip_recover_cells_and_kzg_proofs_batch(Cell *recovered_cells, KZGProof *recovered_proofs,
                                                                  uint8_t *status, const uint64_t *cell_indices,
                                                                  const Cell *cells, uint64_t num_cells,
@@ -677,10 +664,7 @@ extern "C" C_KZG_RET ckzg_hip_recover_cells_and_kzg_proofs_batch(Cell *recovered
         OKB(hipMemcpyAsync(d_in.p, cells + off * num_cells, in_bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
         OKB(hipMemsetAsync(d_img.p, 0, k * n * 32, ctx->stream) == hipSuccess);
         OKB(hipMemsetAsync(d_bad.p, 0, k * 4, ctx->stream) == hipSuccess);
-        const size_t u4 = in_bytes / 16;
-        hipLaunchKernelGGL(k_scatter_cells, dim3((unsigned)((u4 + 255) / 256)), dim3(256), 0, ctx->stream,
-                           (uint4 *)d_img.p, (const uint4 *)d_in.p, d_idx.p, (uint32_t)num_cells, u4);
-        OKB(hipGetLastError() == hipSuccess);
+        RC(dev::scatter_cells_device(ctx, d_img.p, d_in.p, d_idx.p, (uint32_t)num_cells, k));
         RC(dev::bytes_to_fr_batch(ctx, d_e.p, d_bad.p, d_img.p, k * n, (uint32_t)n));
         OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
         OKB(d_bad.down(bad.data(), k));
@@ -749,49 +733,6 @@ extern "C" C_KZG_RET compute_verify_cell_kzg_proof_batch_challenge(
     h.finish(digest);
     *as_fr(challenge_out) = fr_from_bytes_reduce(digest);
     return C_KZG_OK;
-}
-
-// interp[k] = sum_c col[c][k] * (h_c^-1)^k with h_c^-1 = w^(8192 - brp7(c))  (eip7594.c:549-566,
-// 713-752): one thread per coefficient k
-__global__ void k_interp_sum(Fr *interp, const Fr *cols, const Fr *roots) {
-    int k = threadIdx.x;
-    Fr acc = Fr::zero();
-    for (int c = 0; c < 128; c++) {
-        uint32_t rb = __brev((uint32_t)c) >> 25;
-        uint32_t idx = ((8192u - rb) * (uint32_t)k) & 8191u;
-        const uint4 *q = reinterpret_cast<const uint4 *>(cols + c * 64 + k);
-        const uint4 *w = reinterpret_cast<const uint4 *>(roots + idx);
-        uint4 a = q[0], b = q[1], wa = w[0], wb = w[1];
-        Fr v, r;
-        v.l[0] = a.x; v.l[1] = a.y; v.l[2] = a.z; v.l[3] = a.w; v.l[4] = b.x; v.l[5] = b.y; v.l[6] = b.z; v.l[7] = b.w;
-        r.l[0] = wa.x; r.l[1] = wa.y; r.l[2] = wa.z; r.l[3] = wa.w; r.l[4] = wb.x; r.l[5] = wb.y; r.l[6] = wb.z; r.l[7] = wb.w;
-        acc = add(acc, mul(v, r));
-    }
-    uint32_t raw[8];
-    to_raw<FrParams>(raw, acc);  // canonical limbs: this vector is used as MSM scalars
-    for (int i = 0; i < 8; i++) reinterpret_cast<uint32_t *>(interp + k)[i] = raw[i];
-}
-
-// agg[c][j] = sum over the cells i of column c of r^i * cell_i[j]  (eip7594.c:661-683).
-// order[col_start[c] .. col_start[c+1]) lists the cells of column c; thread = (c, j).
-__global__ void k_cell_aggregate(Fr *agg, const Fr *cell_fr, const Fr *rp, const uint32_t *col_start,
-                                 const uint32_t *order) {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;  // < 128 * 64
-    const uint32_t c = g >> 6, j = g & 63u;
-    Fr acc = Fr::zero();
-    for (uint32_t t = col_start[c]; t < col_start[c + 1]; t++) {
-        const uint32_t i = order[t];
-        const uint4 *q = reinterpret_cast<const uint4 *>(cell_fr + (size_t)i * 64 + j);
-        const uint4 *w = reinterpret_cast<const uint4 *>(rp + i);
-        uint4 a = q[0], b = q[1], wa = w[0], wb = w[1];
-        Fr v, r;
-        v.l[0] = a.x; v.l[1] = a.y; v.l[2] = a.z; v.l[3] = a.w; v.l[4] = b.x; v.l[5] = b.y; v.l[6] = b.z; v.l[7] = b.w;
-        r.l[0] = wa.x; r.l[1] = wa.y; r.l[2] = wa.z; r.l[3] = wa.w; r.l[4] = wb.x; r.l[5] = wb.y; r.l[6] = wb.z; r.l[7] = wb.w;
-        acc = add(acc, mul(v, r));
-    }
-    uint4 *o = reinterpret_cast<uint4 *>(agg + g);
-    o[0] = make_uint4(acc.l[0], acc.l[1], acc.l[2], acc.l[3]);
-    o[1] = make_uint4(acc.l[4], acc.l[5], acc.l[6], acc.l[7]);
 }
 
 extern "C" C_KZG_RET verify_cell_kzg_proof_batch(bool *ok, const Bytes48 *commitments_bytes,
@@ -881,14 +822,11 @@ extern "C" C_KZG_RET verify_cell_kzg_proof_batch(bool *ok, const Bytes48 *commit
     OKB(hipMemcpyAsync(d_rp.p, rp.data(), n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
     OKB(hipMemcpyAsync(d_csr.p, csr.data(), csr.size() * 4, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
     // aggregated column data: sum of r^i * cell_i per column (eip7594.c:661-683)
-    hipLaunchKernelGGL(k_cell_aggregate, dim3(CELLS_PER_EXT_BLOB * l / 256), dim3(256), 0, ctx->stream, d_agg.p,
-                       d_cellfr.p, d_rp.p, d_csr.p, d_csr.p + CELLS_PER_EXT_BLOB + 1);
-    OKB(hipGetLastError() == hipSuccess);
+    RC(dev::cell_aggregate_device(ctx, d_agg.p, d_cellfr.p, d_rp.p, d_csr.p, d_csr.p + CELLS_PER_EXT_BLOB + 1));
     // per column: cell data is in bit-reversed order -> DIT inverse NTT(64) gives the interpolation
     // polynomial over the coset; unused columns are all-zero and stay zero
     RC(dev::fr_ntt_batch(ctx, d_agg.p, CELLS_PER_EXT_BLOB, 6, false, true, true));
-    hipLaunchKernelGGL(k_interp_sum, dim3(1), dim3(64), 0, ctx->stream, d_interp.p, d_agg.p, ctx->d_roots);
-    OKB(hipGetLastError() == hipSuccess);
+    RC(dev::interp_sum_device(ctx, d_interp.p, d_agg.p));
     // all four lincombs (eip7594.c:926, :530, :807 and the commitment to the aggregated interpolation
     // polynomial over the first 64 monomial setup points, :758) in one launch
     G1Jac lc[4];

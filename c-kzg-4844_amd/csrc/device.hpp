@@ -160,6 +160,14 @@ int lincomb_multi_device(DeviceCtx *ctx, G1Affine *d_out, G1XYZZ *d_partials, ui
                          const uint32_t *d_scalars, size_t total, const uint32_t *h_part_off, int njobs);
 // z_i = hash_to_bls_field(SHA-256(domain | degree | blob_i | commitment_i)) for n blobs in HBM
 int sha256_challenges_device(DeviceCtx *ctx, Fr *d_z, const uint8_t *d_blobs, const uint8_t *d_commit48, size_t n);
+// cells[b][j] (2048 B each) -> image[b][idx[j]] (128 x 2048 B per row, zero-filled by the caller)
+int scatter_cells_device(DeviceCtx *ctx, uint8_t *d_image, const uint8_t *d_cells, const uint32_t *d_idx,
+                         uint32_t num_cells, size_t num_rows);
+// agg[c][j] = sum over the cells i of column c (CSR: col_start[129], order[n]) of rp[i] * cell_fr[i][j]
+int cell_aggregate_device(DeviceCtx *ctx, Fr *d_agg, const Fr *d_cell_fr, const Fr *d_rp, const uint32_t *d_col_start,
+                          const uint32_t *d_order);
+// interpolation-polynomial coefficients summed over the 128 columns, as canonical MSM scalars
+int interp_sum_device(DeviceCtx *ctx, Fr *d_interp, const Fr *d_cols);
 int fr_mul_inplace_device(DeviceCtx *ctx, Fr *d_a, const Fr *d_b, size_t n, size_t period);
 int fr_div_inplace_device(DeviceCtx *ctx, Fr *d_a, const Fr *d_b, size_t n);
 // generic helpers

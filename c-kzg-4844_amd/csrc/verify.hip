@@ -304,6 +304,90 @@ int lincomb_multi_device(DeviceCtx *ctx, G1Affine *d_out, G1XYZZ *d_partials, ui
 }
 
 // ------------------------------------------------------------------------------------------
+// cell helpers of recover_cells_and_kzg_proofs / verify_cell_kzg_proof_batch
+// ------------------------------------------------------------------------------------------
+
+// cells[b][j] (2048 B each) -> image[b][cell_indices[j]]; the image is zero elsewhere
+__global__ void k_scatter_cells(uint4 *image, const uint4 *cells, const uint32_t *idx, uint32_t num_cells,
+                                size_t total_u4) {
+    size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (g >= total_u4) return;
+    constexpr uint32_t U4 = 2048 / 16;
+    size_t cell = g / U4;
+    uint32_t w = (uint32_t)(g % U4);
+    size_t b = cell / num_cells;
+    uint32_t j = (uint32_t)(cell % num_cells);
+    image[(b * 128 + idx[j]) * U4 + w] = cells[g];
+}
+
+// interp[k] = sum_c col[c][k] * (h_c^-1)^k with h_c^-1 = w^(8192 - brp7(c))  (eip7594.c:549-566,
+// 713-752): one thread per coefficient k
+__global__ void k_interp_sum(Fr *interp, const Fr *cols, const Fr *roots) {
+    int k = threadIdx.x;
+    Fr acc = Fr::zero();
+    for (int c = 0; c < 128; c++) {
+        uint32_t rb = __brev((uint32_t)c) >> 25;
+        uint32_t idx = ((8192u - rb) * (uint32_t)k) & 8191u;
+        const uint4 *q = reinterpret_cast<const uint4 *>(cols + c * 64 + k);
+        const uint4 *w = reinterpret_cast<const uint4 *>(roots + idx);
+        uint4 a = q[0], b = q[1], wa = w[0], wb = w[1];
+        Fr v, r;
+        v.l[0] = a.x; v.l[1] = a.y; v.l[2] = a.z; v.l[3] = a.w; v.l[4] = b.x; v.l[5] = b.y; v.l[6] = b.z; v.l[7] = b.w;
+        r.l[0] = wa.x; r.l[1] = wa.y; r.l[2] = wa.z; r.l[3] = wa.w; r.l[4] = wb.x; r.l[5] = wb.y; r.l[6] = wb.z; r.l[7] = wb.w;
+        acc = add(acc, mul(v, r));
+    }
+    uint32_t raw[8];
+    to_raw<FrParams>(raw, acc);  // canonical limbs: this vector is used as MSM scalars
+    for (int i = 0; i < 8; i++) reinterpret_cast<uint32_t *>(interp + k)[i] = raw[i];
+}
+
+// agg[c][j] = sum over the cells i of column c of r^i * cell_i[j]  (eip7594.c:661-683).
+// order[col_start[c] .. col_start[c+1]) lists the cells of column c; thread = (c, j).
+__global__ void k_cell_aggregate(Fr *agg, const Fr *cell_fr, const Fr *rp, const uint32_t *col_start,
+                                 const uint32_t *order) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;  // < 128 * 64
+    const uint32_t c = g >> 6, j = g & 63u;
+    Fr acc = Fr::zero();
+    for (uint32_t t = col_start[c]; t < col_start[c + 1]; t++) {
+        const uint32_t i = order[t];
+        const uint4 *q = reinterpret_cast<const uint4 *>(cell_fr + (size_t)i * 64 + j);
+        const uint4 *w = reinterpret_cast<const uint4 *>(rp + i);
+        uint4 a = q[0], b = q[1], wa = w[0], wb = w[1];
+        Fr v, r;
+        v.l[0] = a.x; v.l[1] = a.y; v.l[2] = a.z; v.l[3] = a.w; v.l[4] = b.x; v.l[5] = b.y; v.l[6] = b.z; v.l[7] = b.w;
+        r.l[0] = wa.x; r.l[1] = wa.y; r.l[2] = wa.z; r.l[3] = wa.w; r.l[4] = wb.x; r.l[5] = wb.y; r.l[6] = wb.z; r.l[7] = wb.w;
+        acc = add(acc, mul(v, r));
+    }
+    uint4 *o = reinterpret_cast<uint4 *>(agg + g);
+    o[0] = make_uint4(acc.l[0], acc.l[1], acc.l[2], acc.l[3]);
+    o[1] = make_uint4(acc.l[4], acc.l[5], acc.l[6], acc.l[7]);
+}
+
+int scatter_cells_device(DeviceCtx *ctx, uint8_t *d_image, const uint8_t *d_cells, const uint32_t *d_idx,
+                         uint32_t num_cells, size_t num_rows) {
+    const size_t u4 = num_rows * num_cells * (2048 / 16);
+    if (!u4) return 0;
+    hipLaunchKernelGGL(k_scatter_cells, dim3((unsigned)((u4 + 255) / 256)), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<uint4 *>(d_image), reinterpret_cast<const uint4 *>(d_cells), d_idx, num_cells, u4);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int cell_aggregate_device(DeviceCtx *ctx, Fr *d_agg, const Fr *d_cell_fr, const Fr *d_rp, const uint32_t *d_col_start,
+                          const uint32_t *d_order) {
+    hipLaunchKernelGGL(k_cell_aggregate, dim3(128 * 64 / 256), dim3(256), 0, ctx->stream, d_agg, d_cell_fr, d_rp,
+                       d_col_start, d_order);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int interp_sum_device(DeviceCtx *ctx, Fr *d_interp, const Fr *d_cols) {
+    hipLaunchKernelGGL(k_interp_sum, dim3(1), dim3(64), 0, ctx->stream, d_interp, d_cols, ctx->d_roots);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // element-wise Fr helpers
 // ------------------------------------------------------------------------------------------
 
