@@ -116,7 +116,7 @@ __device__ __forceinline__ void butterfly_index(size_t g, uint32_t nfft, int s, 
     i1 = i0 + half;
 }
 
-__global__ __launch_bounds__(64) void k_g1_fft_twiddle(G1XYZZ *data, const uint32_t *roots_glv, uint32_t nfft, int s,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_g1_fft_twiddle(G1XYZZ *data, const uint32_t *roots_glv, uint32_t nfft, int s,
                                                        int inverse) {
     const size_t g = blockIdx.x * (size_t)64 + threadIdx.x;
     uint32_t f;

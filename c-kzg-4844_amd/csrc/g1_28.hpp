@@ -274,47 +274,6 @@ HDNI inline void glv_split(const uint32_t *k, uint32_t *k1, uint32_t *k2) {
     }
 }
 
-// [k]P = [k1]P + [k2]phi(P), phi(X, Y, ZZ, ZZZ) = (beta*X, Y, ZZ, ZZZ) = [lambda]P for P in G1:
-// 128 doublings instead of 256 for the same number of table additions.  Same uniform 4-bit window
-// schedule as xyzz28_mul_w4 (lanes with different scalars stay in step); glv = {k1[4], k2[4]}.
-// Only for points of the prime-order subgroup (the endomorphism is [lambda] only there).
-HDNI inline void xyzz28_mul_glv_w4(XYZZ28 &out, bool &out_inf, const XYZZ28 &p, bool p_inf, const uint32_t *glv) {
-    XYZZ28 tbl[15];
-    uint32_t tinf = 0;
-    XYZZ28 acc;
-    bool inf = true;
-    if (!p_inf) {
-        const F28<1, 1> beta = f28_const<1, 1>(FP28_BETA_LAMBDA);
-        tbl[0] = p;
-        tbl[1] = p;
-        xyzz28_dbl(tbl[1]);
-        for (int i = 2; i < 15; i++) {
-            tbl[i] = tbl[i - 1];
-            bool ti = ((tinf >> (i - 1)) & 1u) != 0;
-            xyzz28_add(tbl[i], ti, p, false);
-            if (ti) tinf |= 1u << i;
-        }
-        for (int w = 31; w >= 0; w--) {
-            if (!inf) {
-                xyzz28_dbl(acc);
-                xyzz28_dbl(acc);
-                xyzz28_dbl(acc);
-                xyzz28_dbl(acc);
-            }
-            uint32_t d1 = (glv[w >> 3] >> ((w & 7) * 4)) & 15u;
-            if (d1) xyzz28_add(acc, inf, tbl[d1 - 1], ((tinf >> (d1 - 1)) & 1u) != 0);
-            uint32_t d2 = (glv[4 + (w >> 3)] >> ((w & 7) * 4)) & 15u;
-            if (d2) {
-                XYZZ28 e = tbl[d2 - 1];
-                e.x = widen<1, 10>(mul(e.x, beta));
-                xyzz28_add(acc, inf, e, ((tinf >> (d2 - 1)) & 1u) != 0);
-            }
-        }
-    }
-    out = acc;
-    out_inf = inf;
-}
-
 // Width-4 non-adjacent form of a 128-bit k: digits in {0, +-1, +-3, +-5, +-7}, digit i has weight 2^i,
 // at most one non-zero digit in any 4 consecutive positions (density 1/5).  out has GLV_NAF_LEN entries.
 constexpr int GLV_NAF_LEN = 132;
@@ -348,38 +307,198 @@ HDNI inline void wnaf4_128(int8_t *out, const uint32_t *k) {
     }
 }
 
+// ---- Jacobian coordinates on the 28-bit-limb field, for doubling-heavy ladders ----
+// A doubling costs 3M + 4S here against 6M + 3S in XYZZ (2,380 vs 3,059 multiply-adds); an addition
+// with a table entry that caches Z^2 and Z^3 costs the same as the XYZZ addition.  So the scalar
+// ladders (G1 FFT twiddles, subgroup test, variable-base sums) run in Jacobian form and convert at
+// the ends: (X, Y, ZZ, ZZZ) -> (X*ZZ, Y*ZZZ, ZZ) is a valid Jacobian triple (Z = ZZ), and
+// (X, Y, Z) -> (X, Y, Z^2, Z^3) the way back.
+struct JAC28 {
+    F28<1, 34> x, y;
+    F28<2, 4> z;
+};
+// table entry: the point plus Z^2, Z^3; y may be a lazily negated value
+struct JACT28 {
+    F28<1, 34> x;
+    F28<1, 64> y;
+    F28<2, 4> z;
+    F28<1, 2> zz, zzz;
+};
+
+HD JAC28 jac28_from_xyzz(const XYZZ28 &p) {
+    JAC28 r;
+    r.x = widen<1, 34>(mul(p.x, p.zz));
+    r.y = widen<1, 34>(mul(p.y, p.zzz));
+    r.z = widen<2, 4>(p.zz);
+    return r;
+}
+HD XYZZ28 jac28_to_xyzz(const JAC28 &p) {
+    XYZZ28 r;
+    r.zz = sqr(p.z);
+    r.zzz = mul(p.z, r.zz);
+    r.x = widen<1, 10>(mul(p.x, f28_one()));   // back under the XYZZ28 bounds
+    r.y = widen<1, 6>(mul(p.y, f28_one()));
+    return r;
+}
+HD JACT28 jac28_table_entry(const JAC28 &p) {
+    JACT28 t;
+    t.x = p.x;
+    t.y = widen<1, 64>(p.y);
+    t.z = p.z;
+    t.zz = sqr(p.z);
+    t.zzz = mul(p.z, t.zz);
+    return t;
+}
+HD JACT28 jact28_neg(const JACT28 &t) {
+    F28<1, 0> zero;
+#pragma unroll
+    for (int j = 0; j < 14; j++) zero.l[j] = 0;
+    JACT28 r = t;
+    // only ever applied to entries whose y is still under the <1,34> bound of a JAC28
+    F28<1, 34> y;
+#pragma unroll
+    for (int j = 0; j < 14; j++) y.l[j] = t.y.l[j];
+    r.y = norm(sub(zero, y));                   // <4,64> -> <1,64>
+    return r;
+}
+
+// dbl-2009-l for a = 0 with D = 4 X Y^2 taken as a product (keeps the value bounds small)
+HD void jac28_dbl(JAC28 &a) {
+    auto A = sqr(a.x);                          // 34^2 = 1156 ok
+    auto B = sqr(a.y);
+    auto C = sqr(B);
+    auto XB = mul(a.x, B);                      // 34*2 ok
+    auto XB2 = add(XB, XB);
+    auto D = add(XB2, XB2);                     // <4,8>   = 4 X Y^2
+    auto E = add(add(A, A), A);                 // <3,6>   = 3 X^2
+    auto F = sqr(E);                            // 15*9+15 ok
+    auto X3 = norm(sub(F, add(D, D)));          // sub(<1,2>,<8,16>) = <11,34> -> <1,34>
+    auto dx = norm(sub(D, X3));                 // <7,72> -> <1,72>
+    auto C2 = add(C, C);
+    auto C4 = add(C2, C2);
+    auto C8 = add(C4, C4);                      // <8,16>
+    auto Y3 = norm(sub(mul(E, dx), C8));        // mul: 14*3+15 ok, 6*72 ok; sub -> <11,34> -> <1,34>
+    auto YZ = mul(a.y, a.z);                    // 14*2+15 ok, 34*4 ok
+    a.x = X3;
+    a.y = Y3;
+    a.z = add(YZ, YZ);                          // <2,4>
+}
+
+// a += b (add-2007-bl with the second operand's Z^2, Z^3 cached), complete; b is finite
+HD void jac28_add(JAC28 &a, bool &ainf, const JACT28 &b) {
+    if (ainf) {
+        a.x = b.x;
+        a.y = widen<1, 34>(mul(b.y, f28_one()));
+        a.z = b.z;
+        ainf = false;
+        return;
+    }
+    auto z1z1 = sqr(a.z);                       // 15*4+15 ok, 16 ok
+    auto u1 = mul(a.x, b.zz);                   // 34*2 ok
+    auto u2 = mul(b.x, z1z1);
+    auto s1 = mul(a.y, b.zzz);
+    auto s2 = mul(b.y, mul(a.z, z1z1));         // inner 14*2+15 ok, 4*2 ok; outer 64*2 ok
+    auto h = sub(u2, u1);                       // <4,6>
+    auto r = sub(s2, s1);                       // <4,6>
+    auto hh = sqr(h);                           // 15*16+15 = 255 ok, 36 ok
+    if (is_zero(hh)) {
+        if (is_zero(mul(r, f28_one()))) {
+            jac28_dbl(a);
+        } else {
+            ainf = true;
+        }
+        return;
+    }
+    auto hhh = mul(h, hh);
+    auto v = mul(u1, hh);
+    auto rr = sqr(r);
+    auto x3 = norm(sub(rr, add(hhh, add(v, v))));   // <6,10> -> <1,10>
+    auto dv = sub(v, x3);                           // <4,18>
+    F28<1, 0> zero;
+#pragma unroll
+    for (int j = 0; j < 14; j++) zero.l[j] = 0;
+    auto s1n = sub(zero, s1);                       // <4,4>
+    // r*dv - s1*hhh with one reduction: limbs 14*(1*4 + 4*1)+15 = 127 ok; values 6*18 + 4*2 ok
+    auto y3 = mul_add2(norm(r), dv, s1n, hhh);
+    auto z3 = mul(mul(a.z, b.z), h);                // 14*4+15 ok, 16 ok; 14*4+15 ok, 2*6 ok
+    a.x = widen<1, 34>(x3);
+    a.y = widen<1, 34>(y3);
+    a.z = widen<2, 4>(z3);
+}
+
 // [k]P = [k1]P + [k2]phi(P) with both halves given in width-4 NAF (wnaf4_128): 131 doublings at most
-// and ~52 additions from the table {+-P, +-3P, +-5P, +-7P} (phi applied on the fly).  The schedule
-// depends on the digits, so it is meant for callers whose lanes share the scalar: the G1 FFT stage
-// kernels, where a wave works on one twiddle.  Only for points of the prime-order subgroup.
+// and ~52 additions from the table {+-P, +-3P, +-5P, +-7P} (phi applied on the fly), in Jacobian
+// coordinates.  The schedule depends on the digits, so it is meant for callers whose lanes share the
+// scalar: the G1 FFT stage kernels, where a wave works on one twiddle.  Only for points of the
+// prime-order subgroup.
 HDNI inline void xyzz28_mul_glv_naf(XYZZ28 &out, bool &out_inf, const XYZZ28 &p, bool p_inf, const int8_t *naf1,
                                     const int8_t *naf2) {
-    XYZZ28 tbl[8];  // [2m] = (2m+1)P, [2m+1] = -(2m+1)P
-    XYZZ28 acc;
+    JACT28 tbl[8];  // [2m] = (2m+1)P, [2m+1] = -(2m+1)P
+    JAC28 acc;
     bool inf = true;
     if (!p_inf) {
         const F28<1, 1> beta = f28_const<1, 1>(FP28_BETA_LAMBDA);
-        XYZZ28 p2 = p;
-        xyzz28_dbl(p2);
-        tbl[0] = p;
+        JAC28 cur = jac28_from_xyzz(p), p2 = cur;
+        jac28_dbl(p2);
+        const JACT28 p2t = jac28_table_entry(p2);
+        tbl[0] = jac28_table_entry(cur);
         for (int m = 1; m < 4; m++) {
-            tbl[2 * m] = tbl[2 * m - 2];
-            bool ti = false;
-            xyzz28_add(tbl[2 * m], ti, p2, false);  // a subgroup point: (2m+1)P is finite
+            bool ci = false;
+            jac28_add(cur, ci, p2t);                // a subgroup point: (2m+1)P is finite
+            tbl[2 * m] = jac28_table_entry(cur);
         }
-        for (int m = 0; m < 4; m++) tbl[2 * m + 1] = xyzz28_neg(tbl[2 * m]);
+        for (int m = 0; m < 4; m++) tbl[2 * m + 1] = jact28_neg(tbl[2 * m]);
         for (int i = GLV_NAF_LEN - 1; i >= 0; i--) {
-            if (!inf) xyzz28_dbl(acc);
+            if (!inf) jac28_dbl(acc);
             const int d1 = naf1[i], d2 = naf2[i];
-            if (d1) xyzz28_add(acc, inf, tbl[(d1 > 0 ? d1 - 1 : -d1)], false);
+            if (d1) jac28_add(acc, inf, tbl[(d1 > 0 ? d1 - 1 : -d1)]);
             if (d2) {
-                XYZZ28 e = tbl[(d2 > 0 ? d2 - 1 : -d2)];
-                e.x = widen<1, 10>(mul(e.x, beta));
-                xyzz28_add(acc, inf, e, false);
+                JACT28 e = tbl[(d2 > 0 ? d2 - 1 : -d2)];
+                e.x = widen<1, 34>(mul(e.x, beta));
+                jac28_add(acc, inf, e);
             }
         }
     }
-    out = acc;
+    if (!inf) out = jac28_to_xyzz(acc);
+    out_inf = inf;
+}
+
+// [k]P = [k1]P + [k2]phi(P), phi(X, Y, Z) = (beta*X, Y, Z) = [lambda]P for P in G1, for lanes with
+// DIFFERENT scalars: a uniform 4-bit window schedule (4 doublings, then one table addition per half) so
+// that the lanes stay in step; 128 doublings instead of 256.  glv = {k1[4], k2[4]} (glv_split).
+// Jacobian coordinates inside.  Only for points of the prime-order subgroup (the endomorphism is
+// [lambda] only there, and every multiple 1..15 of such a point is finite).
+HDNI inline void xyzz28_mul_glv_w4(XYZZ28 &out, bool &out_inf, const XYZZ28 &p, bool p_inf, const uint32_t *glv) {
+    JACT28 tbl[15];
+    JAC28 acc;
+    bool inf = true;
+    if (!p_inf) {
+        const F28<1, 1> beta = f28_const<1, 1>(FP28_BETA_LAMBDA);
+        JAC28 cur = jac28_from_xyzz(p);
+        tbl[0] = jac28_table_entry(cur);
+        for (int i = 1; i < 15; i++) {
+            bool ci = false;
+            jac28_add(cur, ci, tbl[0]);
+            tbl[i] = jac28_table_entry(cur);
+        }
+        for (int w = 31; w >= 0; w--) {
+            if (!inf) {
+                jac28_dbl(acc);
+                jac28_dbl(acc);
+                jac28_dbl(acc);
+                jac28_dbl(acc);
+            }
+            uint32_t d1 = (glv[w >> 3] >> ((w & 7) * 4)) & 15u;
+            if (d1) jac28_add(acc, inf, tbl[d1 - 1]);
+            uint32_t d2 = (glv[4 + (w >> 3)] >> ((w & 7) * 4)) & 15u;
+            if (d2) {
+                JACT28 e = tbl[d2 - 1];
+                e.x = widen<1, 34>(mul(e.x, beta));
+                jac28_add(acc, inf, e);
+            }
+        }
+    }
+    if (!inf) out = jac28_to_xyzz(acc);
     out_inf = inf;
 }
 
@@ -442,13 +561,16 @@ HDNI inline bool g1_28_solve_y(F28<1, 2> &y, const F28<1, 2> &x) {
 }
 
 // [|x|]P for the BLS parameter |x| = 0xd201000000010000 = 2^63 + 2^62 + 2^60 + 2^57 + 2^48 + 2^16:
-// 63 doublings and 5 additions, the same for every lane
-HDNI inline void xyzz28_mul_bls_x(XYZZ28 &out, bool &out_inf, const XYZZ28 &p, bool p_inf) {
-    XYZZ28 acc = p;
+// 63 doublings and 5 additions, the same for every lane (Jacobian coordinates)
+HDNI inline void jac28_mul_bls_x(JAC28 &out, bool &out_inf, const JAC28 &p, bool p_inf) {
+    JAC28 acc = p;
     bool inf = p_inf;
-    for (int b = 62; b >= 0; b--) {
-        if (!inf) xyzz28_dbl(acc);
-        if (b == 62 || b == 60 || b == 57 || b == 48 || b == 16) xyzz28_add(acc, inf, p, p_inf);
+    if (!p_inf) {
+        const JACT28 pt = jac28_table_entry(p);
+        for (int b = 62; b >= 0; b--) {
+            if (!inf) jac28_dbl(acc);
+            if (b == 62 || b == 60 || b == 57 || b == 48 || b == 16) jac28_add(acc, inf, pt);
+        }
     }
     out = acc;
     out_inf = inf;
@@ -460,19 +582,19 @@ HDNI inline void xyzz28_mul_bls_x(XYZZ28 &out, bool &out_inf, const XYZZ28 &p, b
 // phi2(T') = -T' only for T' = 0.  126 doublings + 10 additions instead of a 255-bit ladder by r
 // (the reference's blst performs an endomorphism-based test of the same kind).
 HDNI inline bool g1_28_in_subgroup(const F28<1, 2> &x, const F28<1, 2> &y) {
-    XYZZ28 p, q1, q;
-    p.x = widen<1, 10>(x);
-    p.y = widen<1, 6>(y);
-    p.zz = widen<1, 2>(f28_one());
-    p.zzz = p.zz;
+    JAC28 p, q1, q;
+    p.x = widen<1, 34>(x);
+    p.y = widen<1, 34>(y);
+    p.z = widen<2, 4>(f28_one());
     bool i1, i2;
-    xyzz28_mul_bls_x(q1, i1, p, false);
-    xyzz28_mul_bls_x(q, i2, q1, i1);
+    jac28_mul_bls_x(q1, i1, p, false);
+    jac28_mul_bls_x(q, i2, q1, i1);
     if (i2) return false;
+    auto zz = sqr(q.z);
     auto bx = mul(x, f28_const<1, 1>(FP28_BETA_LAMBDA2));
-    if (!f28_equal(q.x, mul(bx, q.zz))) return false;
-    // q.y == -y * q.zzz  <=>  q.y + y * q.zzz == 0
-    return is_zero(mul(add(q.y, mul(y, q.zzz)), f28_one()));
+    if (!f28_equal(q.x, mul(bx, zz))) return false;
+    // q.y == -y * z^3  <=>  q.y + y * z^3 == 0
+    return is_zero(mul(add(q.y, mul(y, mul(q.z, zz))), f28_one()));
 }
 
 // the inversion used by the kernels: safegcd (fp28_inv.hpp), ~12x fewer instructions than the ladder

@@ -154,6 +154,26 @@ void hs_g1_mul28_glv_naf(G1Jac *r, const G1Jac *a, const uint32_t *k) {
     xyzz28_mul_glv_naf(o, oi, x, ai, naf, naf + GLV_NAF_LEN);
     *r = jac_from_affine(xyzz28_to_affine(o, oi));
 }
+// a + (+-b) and 2a through the Jacobian 28-bit-limb formulas (b must be finite)
+void hs_g1_jac28_add(G1Jac *r, const G1Jac *a, const G1Jac *b, int negate_b) {
+    bool ai, bi;
+    XYZZ28 xa = xyzz28_from_xyzz(xyzz_from_jac(*a), ai), xb = xyzz28_from_xyzz(xyzz_from_jac(*b), bi);
+    JAC28 ja;
+    if (!ai) ja = jac28_from_xyzz(xa);
+    JACT28 tb = jac28_table_entry(jac28_from_xyzz(xb));
+    if (negate_b) tb = jact28_neg(tb);
+    jac28_add(ja, ai, tb);
+    XYZZ28 o;
+    if (!ai) o = jac28_to_xyzz(ja);
+    *r = jac_from_affine(xyzz28_to_affine(o, ai));
+}
+void hs_g1_jac28_dbl_chain(G1Jac *r, const G1Jac *a, int n) {
+    bool ai;
+    XYZZ28 xa = xyzz28_from_xyzz(xyzz_from_jac(*a), ai);
+    JAC28 ja = jac28_from_xyzz(xa);
+    for (int i = 0; i < n; i++) jac28_dbl(ja);
+    *r = jac_from_affine(xyzz28_to_affine(jac28_to_xyzz(ja), false));
+}
 void hs_g1_neg28(G1Jac *r, const G1Jac *a) {
     bool ai;
     XYZZ28 x = xyzz28_from_xyzz(xyzz_from_jac(*a), ai);

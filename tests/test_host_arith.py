@@ -395,6 +395,33 @@ def test_xyzz28_full_add_mul_neg(libs):
         assert o.og1_equal(r, _omul(o, pt, k))
 
 
+def test_jacobian_28bit_formulas(libs):
+    """jac28_dbl / jac28_add (the coordinates of the scalar ladders) against the oracle, including
+    the complete-addition special cases and long doubling chains (value-bound bookkeeping)."""
+    o, h = libs
+    rnd = random.Random(37)
+    g = _buf(144)
+    h.hs_g1_generator(g)
+    inf = _buf(144)
+    for t in range(10):
+        p1, p2 = _omul(o, g, rnd.randrange(1, R)), _omul(o, g, rnd.randrange(1, R))
+        for a, b, neg in ((p1, p2, 0), (p1, p2, 1), (p1, p1, 0), (p1, p1, 1), (inf, p2, 0), (inf, p2, 1)):
+            ref, r, bb = _buf(144), _buf(144), _buf(144)
+            bb.raw = b.raw
+            if neg:
+                o.og1_neg(bb, bb)
+            o.og1_add(ref, a, bb)
+            h.hs_g1_jac28_add(r, a, b, neg)
+            assert o.og1_equal(r, ref), (t, neg)
+        n = [1, 2, 5, 64, 131, 300][t % 6]
+        ref, r = _buf(144), _buf(144)
+        ref.raw = p1.raw
+        for _ in range(n):
+            o.og1_dbl(ref, ref)
+        h.hs_g1_jac28_dbl_chain(r, p1, n)
+        assert o.og1_equal(r, ref), n
+
+
 def test_glv_split_and_glv_scalar_mul(libs):
     """k = k1 + k2*lambda with both halves < 2^128 (lambda = x^2 - 1), and the two-dimensional
     ladder [k1]P + [k2]phi(P) of the G1 FFT equals [k]P for subgroup points."""
