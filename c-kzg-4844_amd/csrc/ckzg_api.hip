@@ -35,6 +35,9 @@ extern "C" C_KZG_RET ckzg_hip_set_option(const char *key, int64_t value) {
     } else if (!strcmp(key, "proof_wbits")) {
         if (value != 0 && (value < 4 || value > 16)) return C_KZG_BADARGS;
         g_opts.proof_wbits = (int)value;
+    } else if (!strcmp(key, "gpu_sha_min")) {
+        if (value < 0 || value > (1 << 30)) return C_KZG_BADARGS;
+        g_opts.gpu_sha_min = (int)value;  // read at call time, unlike the table options
     } else if (!strcmp(key, "direct_max")) {
         if (value < 0 || value > 4096) return C_KZG_BADARGS;
         g_opts.direct_max = (int)value;

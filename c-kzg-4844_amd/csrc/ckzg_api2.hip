@@ -64,9 +64,21 @@ struct ArenaTrim {
         if (!(expr)) return C_KZG_MALLOC; \
     } while (0)
 
-// batches at least this large hash their Fiat-Shamir challenges on the GPU (k_sha256_challenges):
-// the GPU takes ~6 ms whatever the batch, 32 host threads ~10 us per blob
-constexpr size_t GPU_SHA_MIN_N = 512;
+// Batches at least this large hash their Fiat-Shamir challenges on the GPU (k_sha256_challenges): the
+// GPU takes ~6 ms whatever the batch; 32 host threads take ~2 us per blob with the x86 SHA extensions
+// (measured crossover ~2,500 blobs) and ~10 us per blob without them (~600 blobs).
+static size_t gpu_sha_min_n() {
+    if (g_opts.gpu_sha_min > 0) return (size_t)g_opts.gpu_sha_min;  // ckzg_hip_set_option("gpu_sha_min", n)
+    static const size_t dflt = []() {
+        const char *v = getenv("CKZG_HIP_GPU_SHA_MIN");
+        if (v && *v) return (size_t)atol(v);
+#ifdef CKZG_HAVE_SHANI
+        if (host::cpu_has_sha_ni()) return (size_t)3072;
+#endif
+        return (size_t)512;
+    }();
+    return dflt;
+}
 
 struct RawScalar {
     uint32_t l[8];
@@ -331,7 +343,7 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     // Challenges: a lane per blob on the GPU for large batches (the blobs are in HBM anyway; ~2050
     // sequential compressions take a few ms whatever the batch size), on host threads while the GPU
     // validates and converts for small ones.
-    const bool gpu_sha = n >= GPU_SHA_MIN_N;
+    const bool gpu_sha = n >= gpu_sha_min_n();
     std::vector<Fr> z(n), y(n);
     if (gpu_sha) RC(dev::sha256_challenges_device(ctx, d_z.p, d_blobs.p, d_ptb.p, n));
     tr.mark("enqueue H2D + bytes_to_fr (+ GPU validation)");

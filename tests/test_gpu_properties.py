@@ -51,7 +51,8 @@ def test_blob_proof_roundtrip_and_tamper(hip, oracle):
 @pytest.mark.parametrize("n", [2, 3, 8, 9, 70, 513])
 def test_verify_blob_batch_sizes_cover_host_and_gpu_paths(hip, n):
     # n <= 8 keeps the scalar multiplications on the host, larger n uses k_validate_g1 / k_lincomb;
-    # n >= 512 also hashes the Fiat-Shamir challenges on the GPU (k_sha256_challenges)
+    # large batches also hash the Fiat-Shamir challenges on the GPU (k_sha256_challenges); the
+    # threshold depends on the host CPU, so n = 513 is run both ways
     base = [rand_blob(43, i) for i in range(5)]
     cs = [hip.blob_to_kzg_commitment(b) for b in base]
     ps = [hip.compute_blob_kzg_proof(b, c) for b, c in zip(base, cs)]
@@ -59,6 +60,14 @@ def test_verify_blob_batch_sizes_cover_host_and_gpu_paths(hip, n):
     C_ = [cs[i % 5] for i in range(n)]
     P = [ps[i % 5] for i in range(n)]
     assert hip.verify_blob_kzg_proof_batch(blobs, C_, P) is True
+    if n > 500:
+        hip.lib.ckzg_hip_set_option(b"gpu_sha_min", 1)      # force the GPU hash ...
+        try:
+            assert hip.verify_blob_kzg_proof_batch(blobs, C_, P) is True
+            hip.lib.ckzg_hip_set_option(b"gpu_sha_min", 1 << 20)  # ... and the host hash
+            assert hip.verify_blob_kzg_proof_batch(blobs, C_, P) is True
+        finally:
+            hip.lib.ckzg_hip_set_option(b"gpu_sha_min", 0)
     P[n - 1] = ps[n % 5]  # the proof of a different blob
     assert hip.verify_blob_kzg_proof_batch(blobs, C_, P) is False
     # a commitment that is on the curve but outside the subgroup must be rejected as BADARGS;

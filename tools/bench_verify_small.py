@@ -26,7 +26,7 @@ for n in [int(x) for x in sys.argv[1:]] or [1, 2, 3, 4, 6, 8, 9, 12, 16, 32]:
     ok = C.c_bool(False)
     fv(C.byref(ok), bb, cc, pp, n, C.addressof(hip.s))
     best = 1e9
-    for _ in range(5):
+    for _ in range(3 if n > 256 else 5):
         t = time.perf_counter()
         rc = fv(C.byref(ok), bb, cc, pp, n, C.addressof(hip.s))
         best = min(best, time.perf_counter() - t)
