@@ -141,9 +141,11 @@ class Kzg:
         cells = C.create_string_buffer(CELLS_PER_EXT_BLOB * BYTES_PER_CELL) if want_cells else None
         proofs = C.create_string_buffer(CELLS_PER_EXT_BLOB * 48) if want_proofs else None
         self._call("compute_cells_and_kzg_proofs", cells, proofs, bytes(blob), self.sp)
-        cl = [cells.raw[i * BYTES_PER_CELL:(i + 1) * BYTES_PER_CELL]
+        craw = cells.raw if want_cells else b""   # .raw copies the whole buffer: take it once
+        praw = proofs.raw if want_proofs else b""
+        cl = [craw[i * BYTES_PER_CELL:(i + 1) * BYTES_PER_CELL]
               for i in range(CELLS_PER_EXT_BLOB)] if want_cells else None
-        pl = [proofs.raw[i * 48:(i + 1) * 48] for i in range(CELLS_PER_EXT_BLOB)] if want_proofs else None
+        pl = [praw[i * 48:(i + 1) * 48] for i in range(CELLS_PER_EXT_BLOB)] if want_proofs else None
         return cl, pl
 
     def compute_cells(self, blob):
@@ -160,8 +162,9 @@ class Kzg:
         rc = C.create_string_buffer(CELLS_PER_EXT_BLOB * BYTES_PER_CELL)
         rp = C.create_string_buffer(CELLS_PER_EXT_BLOB * 48)
         self._call("recover_cells_and_kzg_proofs", rc, rp, idx, b"".join(cells), C.c_uint64(n), self.sp)
-        return ([rc.raw[i * BYTES_PER_CELL:(i + 1) * BYTES_PER_CELL] for i in range(CELLS_PER_EXT_BLOB)],
-                [rp.raw[i * 48:(i + 1) * 48] for i in range(CELLS_PER_EXT_BLOB)])
+        craw, praw = rc.raw, rp.raw
+        return ([craw[i * BYTES_PER_CELL:(i + 1) * BYTES_PER_CELL] for i in range(CELLS_PER_EXT_BLOB)],
+                [praw[i * 48:(i + 1) * 48] for i in range(CELLS_PER_EXT_BLOB)])
 
     def recover_cells_and_kzg_proofs_batch(self, cell_indices, rows, want_cells=True, want_proofs=True):
         """rows: one list of cells per blob, every row holding the columns `cell_indices` (additive
@@ -177,9 +180,11 @@ class Kzg:
         self._call("ckzg_hip_recover_cells_and_kzg_proofs_batch", rc, rp, None, idx,
                    b"".join(b"".join(r) for r in rows), C.c_uint64(nc), C.c_uint64(nb), self.sp)
         cs = BYTES_PER_CELL * CELLS_PER_EXT_BLOB
-        out_c = [[rc.raw[b * cs + i * BYTES_PER_CELL: b * cs + (i + 1) * BYTES_PER_CELL]
+        craw = rc.raw if want_cells else b""      # .raw copies the whole buffer: take it once
+        praw = rp.raw if want_proofs else b""
+        out_c = [[craw[b * cs + i * BYTES_PER_CELL: b * cs + (i + 1) * BYTES_PER_CELL]
                   for i in range(CELLS_PER_EXT_BLOB)] for b in range(nb)] if want_cells else None
-        out_p = [[rp.raw[(b * CELLS_PER_EXT_BLOB + i) * 48:(b * CELLS_PER_EXT_BLOB + i + 1) * 48]
+        out_p = [[praw[(b * CELLS_PER_EXT_BLOB + i) * 48:(b * CELLS_PER_EXT_BLOB + i + 1) * 48]
                   for i in range(CELLS_PER_EXT_BLOB)] for b in range(nb)] if want_proofs else None
         return out_c, out_p
 
