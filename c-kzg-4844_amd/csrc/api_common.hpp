@@ -101,6 +101,26 @@ struct DeviceBuffer {
     }
 };
 
+// the same interface over a slice of a persistent arena (device.hpp: Arena): no hipMalloc/hipFree
+template <class T>
+struct ABuf {
+    T *p;
+    ABuf(dev::Arena &a, size_t count) : p(a.get<T>(count)) {}
+    bool up(const T *h, size_t count) { return hipMemcpy(p, h, count * sizeof(T), hipMemcpyHostToDevice) == hipSuccess; }
+    bool down(T *h, size_t count) const { return hipMemcpy(h, p, count * sizeof(T), hipMemcpyDeviceToHost) == hipSuccess; }
+};
+using dev::Arena;
+
+// a very large batch must not pin its temporaries in HBM for ever: blocks above 256 MiB are returned
+// when the call ends (one hipFree per such call), smaller ones stay for the next call
+struct ArenaTrim {
+    Arena &a;
+    explicit ArenaTrim(Arena &ar) : a(ar) {}
+    ~ArenaTrim() {
+        if (a.cap > ((size_t)256 << 20)) a.release();
+    }
+};
+
 // src/common/utils.c:103-140 (n must be a power of two)
 inline void bit_reversal_permutation(void *values, size_t size, size_t n) {
     if (n < 2) return;

@@ -289,15 +289,18 @@ extern "C" C_KZG_RET ckzg_hip_blob_to_kzg_commitment_batch(KZGCommitment *out, u
     const uint64_t FIRST = CH < 64 ? CH : 64;
     const uint64_t m = n < CH ? n : CH;
     Trace tr("commit_batch");
-    DeviceBuffer d_blobs[2], d_out, d_status;
-    hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
+    // device temporaries from the context's arena, events kept in the context: a single-blob call
+    // must not pay for hipMalloc/hipFree/hipEventCreate
+    Arena &ar = ctx->api_arena;
+    if (!ar.begin(2 * m * BYTES_PER_BLOB + n * 49)) return C_KZG_MALLOC;
+    ArenaTrim trim(ar);
+    ABuf<uint8_t> d_blobs[2] = {ABuf<uint8_t>(ar, m * BYTES_PER_BLOB), ABuf<uint8_t>(ar, n > FIRST ? m * BYTES_PER_BLOB : 1)};
+    ABuf<uint8_t> d_out(ar, n * 48), d_status(ar, n);
+    if (!d_blobs[0].p || !d_blobs[1].p || !d_out.p || !d_status.p) return C_KZG_MALLOC;
+    hipEvent_t *copied = ctx->stage_ev, *consumed = ctx->stage_ev + 2;
     C_KZG_RET ret = C_KZG_OK;
     std::vector<uint8_t> st(n);
     bool pending[2] = {false, false};
-    if (!d_blobs[0].alloc(m * BYTES_PER_BLOB) || (n > FIRST && !d_blobs[1].alloc(m * BYTES_PER_BLOB)) ||
-        !d_out.alloc(n * 48) || !d_status.alloc(n)) {
-        return C_KZG_MALLOC;
-    }
     if (dev::scratch_reserve(ctx, dev::commit_scratch_bytes(ctx, m)) != 0) return C_KZG_MALLOC;
     for (int i = 0; i < 2; i++) {
         if (!ctx->h_stage[i] && hipHostMalloc(&ctx->h_stage[i], CH * BYTES_PER_BLOB, hipHostMallocDefault) != hipSuccess) {
@@ -305,9 +308,9 @@ extern "C" C_KZG_RET ckzg_hip_blob_to_kzg_commitment_batch(KZGCommitment *out, u
             return C_KZG_MALLOC;
         }
     }
-    for (int i = 0; i < 2; i++) {
-        if (hipEventCreateWithFlags(&copied[i], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&consumed[i], hipEventDisableTiming) != hipSuccess) {
+    for (int i = 0; i < 4; i++) {
+        if (!ctx->stage_ev[i] && hipEventCreateWithFlags(&ctx->stage_ev[i], hipEventDisableTiming) != hipSuccess) {
+            ctx->stage_ev[i] = nullptr;
             ret = C_KZG_ERROR;
         }
     }
@@ -345,10 +348,6 @@ extern "C" C_KZG_RET ckzg_hip_blob_to_kzg_commitment_batch(KZGCommitment *out, u
     if (hipStreamSynchronize(ctx->copy_stream) != hipSuccess) ret = ret == C_KZG_OK ? C_KZG_ERROR : ret;
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) ret = ret == C_KZG_OK ? C_KZG_ERROR : ret;
     tr.mark("wait for the GPU");
-    for (int i = 0; i < 2; i++) {
-        if (copied[i]) (void)hipEventDestroy(copied[i]);
-        if (consumed[i]) (void)hipEventDestroy(consumed[i]);
-    }
     if (ret != C_KZG_OK) return ret;
     if (hipMemcpy(out, d_out.p, n * 48, hipMemcpyDeviceToHost) != hipSuccess) return C_KZG_ERROR;
     if (hipMemcpy(st.data(), d_status.p, n, hipMemcpyDeviceToHost) != hipSuccess) return C_KZG_ERROR;
@@ -393,10 +392,14 @@ extern "C" C_KZG_RET ckzg_hip_compute_cells_and_kzg_proofs_batch(Cell *cells, KZ
     const uint64_t CH = 2048;  // >= 2 waves of G1-FFT butterflies per SIMD per stage launch
     uint64_t m = n < CH ? n : CH;
     const size_t cells_per = (size_t)CELLS_PER_EXT_BLOB * BYTES_PER_CELL, proofs_per = (size_t)CELLS_PER_EXT_BLOB * 48;
-    DeviceBuffer d_blobs, d_cells, d_proofs, d_status;
-    if (!d_blobs.alloc(m * BYTES_PER_BLOB) || !d_status.alloc(m)) return C_KZG_MALLOC;
-    if (cells && !d_cells.alloc(m * cells_per)) return C_KZG_MALLOC;
-    if (proofs && !d_proofs.alloc(m * proofs_per)) return C_KZG_MALLOC;
+    Arena &ar = ctx->api_arena;
+    if (!ar.begin(m * (BYTES_PER_BLOB + 1 + (cells ? cells_per : 0) + (proofs ? proofs_per : 0)))) return C_KZG_MALLOC;
+    ArenaTrim trim(ar);
+    ABuf<uint8_t> d_blobs(ar, m * BYTES_PER_BLOB), d_status(ar, m);
+    ABuf<uint8_t> d_cells(ar, cells ? m * cells_per : 1), d_proofs(ar, proofs ? m * proofs_per : 1);
+    if (!d_blobs.p || !d_status.p || !d_cells.p || !d_proofs.p) return C_KZG_MALLOC;
+    if (!cells) d_cells.p = nullptr;
+    if (!proofs) d_proofs.p = nullptr;
     std::vector<uint8_t> st(m);
     C_KZG_RET ret = C_KZG_OK;
     for (uint64_t off = 0; off < n; off += CH) {

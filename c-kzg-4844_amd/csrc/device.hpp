@@ -77,7 +77,8 @@ struct DeviceCtx {
     FixedBaseTable mono;          // over g1_values_monomial (4096 points): low-latency cell proofs
     int direct_max = 24;          // batches up to this many blobs use the direct proof path
     Scratch scratch;              // reused by every call under `mu`
-    Arena api_arena, lc_arena;    // temporaries of the verification entry points / of gpu_lincomb_multi
+    Arena api_arena, lc_arena;    // temporaries of the host-pointer entry points / of gpu_lincomb_multi
+    hipEvent_t stage_ev[4] = {};  // copied[2], consumed[2] of the staging pipeline (created on first use)
     hipEvent_t ev[8] = {};        // timing events
     float last_ms[4] = {-1, -1, -1, -1};
     // Fr tables for NTTs and evaluation (Montgomery form, 8 x u32)

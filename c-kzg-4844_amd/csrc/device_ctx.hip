@@ -55,6 +55,9 @@ void destroy_device_ctx(dev::DeviceCtx *ctx) {
     for (auto &e : ctx->ev) {
         if (e) (void)hipEventDestroy(e);
     }
+    for (auto &e : ctx->stage_ev) {
+        if (e) (void)hipEventDestroy(e);
+    }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     for (auto &h : ctx->h_stage) {
