@@ -435,8 +435,11 @@ extern "C" C_KZG_RET compute_kzg_proof(KZGProof *proof_out, Bytes32 *y_out, cons
     return C_KZG_OK;
 }
 
-extern "C" C_KZG_RET compute_blob_kzg_proof(KZGProof *out, const Blob *blob, const Bytes48 *commitment_bytes,
-                                            const KZGSettings *s) {
+// compute_blob_kzg_proof with the evaluation and the quotient polynomial on the host (only the MSM on
+// the GPU): the general form, which also covers a challenge that falls inside the evaluation domain
+// (eip4844.c:458-481).  The batch entry point sends such blobs here.
+static C_KZG_RET blob_proof_host_quotient(KZGProof *out, const Blob *blob, const Bytes48 *commitment_bytes,
+                                          const KZGSettings *s) {
     dev::DeviceCtx *ctx = ctx_of(s);
     if (!ctx) return C_KZG_ERROR;
     std::vector<Fr> poly(FIELD_ELEMENTS_PER_BLOB);
@@ -466,14 +469,17 @@ extern "C" C_KZG_RET ckzg_hip_compute_blob_kzg_proof_batch(KZGProof *proofs, uin
         OKB(hipSetDevice(ctx->device) == hipSuccess);
         const uint64_t CH = 256;
         const uint64_t m = n < CH ? n : CH;
-        DBuf<uint8_t> d_blobs, d_ptb, d_pst, d_out;
-        DBuf<G1Affine> d_pts;
-        DBuf<Fr> d_poly, d_z, d_y;
-        DBuf<uint32_t> d_bad, d_q;
-        DBuf<int> d_hit;
-        OKM(d_blobs.alloc(m * BYTES_PER_BLOB) && d_ptb.alloc(m * 48) && d_pst.alloc(m) && d_pts.alloc(m) &&
-            d_out.alloc(m * 48) && d_poly.alloc(m * FIELD_ELEMENTS_PER_BLOB) && d_z.alloc(m) && d_y.alloc(m) &&
-            d_bad.alloc(m) && d_q.alloc(m * FIELD_ELEMENTS_PER_BLOB * 8) && d_hit.alloc(m));
+        Arena &ar = ctx->api_arena;
+        OKM(ar.begin(m * (BYTES_PER_BLOB + 48 + 1 + sizeof(G1Affine) + 48 + 2 * FIELD_ELEMENTS_PER_BLOB * sizeof(Fr) +
+                          2 * sizeof(Fr) + 8)));
+        ArenaTrim trim(ar);
+        ABuf<uint8_t> d_blobs(ar, m * BYTES_PER_BLOB), d_ptb(ar, m * 48), d_pst(ar, m), d_out(ar, m * 48);
+        ABuf<G1Affine> d_pts(ar, m);
+        ABuf<Fr> d_poly(ar, m * FIELD_ELEMENTS_PER_BLOB), d_z(ar, m), d_y(ar, m);
+        ABuf<uint32_t> d_bad(ar, m), d_q(ar, m * FIELD_ELEMENTS_PER_BLOB * 8);
+        ABuf<int> d_hit(ar, m);
+        OKM(d_blobs.p && d_ptb.p && d_pst.p && d_out.p && d_pts.p && d_poly.p && d_z.p && d_y.p && d_bad.p && d_q.p &&
+            d_hit.p);
         std::vector<Fr> z(m);
         std::vector<uint8_t> pst(m);
         std::vector<uint32_t> bad(m);
@@ -511,7 +517,7 @@ extern "C" C_KZG_RET ckzg_hip_compute_blob_kzg_proof_batch(KZGProof *proofs, uin
         }
     }
     for (int i : redo) {
-        C_KZG_RET r = compute_blob_kzg_proof(&proofs[i], &blobs[i], &commitments_bytes[i], s);
+        C_KZG_RET r = blob_proof_host_quotient(&proofs[i], &blobs[i], &commitments_bytes[i], s);
         if (r != C_KZG_OK) {
             st[i] = (uint8_t)r;
             ret = r;
@@ -519,6 +525,13 @@ extern "C" C_KZG_RET ckzg_hip_compute_blob_kzg_proof_batch(KZGProof *proofs, uin
     }
     if (status) memcpy(status, st.data(), n);
     return ret;
+}
+
+extern "C" C_KZG_RET compute_blob_kzg_proof(KZGProof *out, const Blob *blob, const Bytes48 *commitment_bytes,
+                                            const KZGSettings *s) {
+    // eip4844.c:496-535; evaluation, quotient and MSM on the GPU (a batch of one)
+    uint8_t st = 0;
+    return ckzg_hip_compute_blob_kzg_proof_batch(out, &st, blob, commitment_bytes, 1, s);
 }
 
 extern "C" C_KZG_RET verify_kzg_proof(bool *ok, const Bytes48 *commitment_bytes, const Bytes32 *z_bytes,
