@@ -422,13 +422,41 @@ extern "C" void compute_challenge(fr_t *eval_challenge_out, const Blob *blob, co
 
 extern "C" C_KZG_RET compute_kzg_proof(KZGProof *proof_out, Bytes32 *y_out, const Blob *blob,
                                        const Bytes32 *z_bytes, const KZGSettings *s) {
+    // eip4844.c:386-415.  Evaluation, quotient polynomial and MSM on the GPU; a z inside the evaluation
+    // domain (eip4844.c:458-481) takes the host form of the quotient instead.
     dev::DeviceCtx *ctx = ctx_of(s);
     if (!ctx) return C_KZG_ERROR;
-    std::vector<Fr> poly(FIELD_ELEMENTS_PER_BLOB);
     Fr z, y;
+    if (!fr_from_bytes_canonical(z, z_bytes->bytes)) return C_KZG_BADARGS;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        OKB(hipSetDevice(ctx->device) == hipSuccess);
+        Arena &ar = ctx->api_arena;
+        OKM(ar.begin(BYTES_PER_BLOB + 2 * FIELD_ELEMENTS_PER_BLOB * sizeof(Fr) + 2 * sizeof(Fr) + 64));
+        ABuf<uint8_t> d_blob(ar, BYTES_PER_BLOB), d_out(ar, 48);
+        ABuf<Fr> d_poly(ar, FIELD_ELEMENTS_PER_BLOB), d_z(ar, 1), d_y(ar, 1);
+        ABuf<uint32_t> d_bad(ar, 1), d_q(ar, FIELD_ELEMENTS_PER_BLOB * 8);
+        ABuf<int> d_hit(ar, 1);
+        OKM(d_blob.p && d_out.p && d_poly.p && d_z.p && d_y.p && d_bad.p && d_q.p && d_hit.p);
+        OKB(hipMemcpyAsync(d_blob.p, blob->bytes, BYTES_PER_BLOB, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
+        OKB(hipMemcpyAsync(d_z.p, &z, sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
+        OKB(hipMemsetAsync(d_bad.p, 0, 4, ctx->stream) == hipSuccess);
+        RC(dev::bytes_to_fr_batch(ctx, d_poly.p, d_bad.p, d_blob.p, FIELD_ELEMENTS_PER_BLOB, FIELD_ELEMENTS_PER_BLOB));
+        RC(dev::eval_quotient_batch_device(ctx, d_y.p, d_q.p, d_hit.p, d_poly.p, d_z.p, 1));
+        RC(dev::msm_commit_table_raw_device(ctx, d_out.p, d_q.p, 1));
+        uint32_t bad = 0;
+        int hit = -1;
+        OKB(d_bad.down(&bad, 1) && d_hit.down(&hit, 1));
+        if (bad) return C_KZG_BADARGS;  // a non-canonical field element in the blob (blob.c:31-38)
+        if (hit < 0) {
+            OKB(d_y.down(&y, 1) && d_out.down(proof_out->bytes, 48));
+            fr_to_bytes(y_out->bytes, y);
+            return C_KZG_OK;
+        }
+    }
+    std::vector<Fr> poly(FIELD_ELEMENTS_PER_BLOB);
     C_KZG_RET ret = blob_to_polynomial(poly.data(), blob);
     if (ret != C_KZG_OK) return ret;
-    if (!fr_from_bytes_canonical(z, z_bytes->bytes)) return C_KZG_BADARGS;
     ret = compute_kzg_proof_impl(proof_out, y, poly.data(), z, s, ctx);
     if (ret != C_KZG_OK) return ret;
     fr_to_bytes(y_out->bytes, y);
