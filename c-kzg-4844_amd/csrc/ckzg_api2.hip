@@ -637,8 +637,9 @@ static C_KZG_RET recover_cells_gpu(dev::DeviceCtx *ctx, Fr *d_e, size_t count, c
     std::vector<Fr> shortp, zc(n, Fr::zero()), ones(n, Fr::one());
     vanishing_poly_from_roots(shortp, roots);
     for (size_t i = 0; i < shortp.size(); i++) zc[i * FIELD_ELEMENTS_PER_CELL] = shortp[i];
-    DBuf<Fr> d_zc, d_zev, d_zinv;
-    OKM(d_zc.alloc(n) && d_zev.alloc(n) && d_zinv.alloc(n));
+    // (the caller's arena scope is open: these three vectors come out of it too)
+    ABuf<Fr> d_zc(ctx->api_arena, n), d_zev(ctx->api_arena, n), d_zinv(ctx->api_arena, n);
+    OKM(d_zc.p && d_zev.p && d_zinv.p);
     OKB(d_zc.up(zc.data(), n));
     OKB(d_zinv.up(ones.data(), n));
     OKB(hipMemcpyAsync(d_zev.p, d_zc.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess);
@@ -684,12 +685,17 @@ extern "C" C_KZG_RET ckzg_hip_recover_cells_and_kzg_proofs_batch(Cell *recovered
     C_KZG_RET result = C_KZG_OK;
     std::lock_guard<std::mutex> lock(ctx->mu);
     OKB(hipSetDevice(ctx->device) == hipSuccess);
-    DBuf<uint8_t> d_img, d_in, d_proofs;
-    DBuf<Fr> d_e, d_poly;
-    DBuf<uint32_t> d_bad, d_idx;
-    OKM(d_img.alloc(m * n * 32) && d_in.alloc(m * num_cells * BYTES_PER_CELL) && d_e.alloc(m * n) &&
-        d_bad.alloc(m) && d_idx.alloc(num_cells));
-    if (recovered_proofs) OKM(d_proofs.alloc(m * CELLS_PER_EXT_BLOB * 48) && d_poly.alloc(m * FIELD_ELEMENTS_PER_BLOB));
+    Arena &ar = ctx->api_arena;
+    const size_t nchunks = (size_t)((num_blobs + CH - 1) / CH);  // recover_cells_gpu takes 3 vectors per chunk
+    OKM(ar.begin(m * (n * 32 + num_cells * BYTES_PER_CELL + n * sizeof(Fr) + 4) + num_cells * 4 +
+                 nchunks * 3 * (n * sizeof(Fr) + 256) +
+                 (recovered_proofs ? m * (CELLS_PER_EXT_BLOB * 48 + FIELD_ELEMENTS_PER_BLOB * sizeof(Fr)) : 0)));
+    ArenaTrim trim(ar);
+    ABuf<uint8_t> d_img(ar, m * n * 32), d_in(ar, m * num_cells * BYTES_PER_CELL);
+    ABuf<uint8_t> d_proofs(ar, recovered_proofs ? m * CELLS_PER_EXT_BLOB * 48 : 1);
+    ABuf<Fr> d_e(ar, m * n), d_poly(ar, recovered_proofs ? m * FIELD_ELEMENTS_PER_BLOB : 1);
+    ABuf<uint32_t> d_bad(ar, m), d_idx(ar, num_cells);
+    OKM(d_img.p && d_in.p && d_proofs.p && d_e.p && d_poly.p && d_bad.p && d_idx.p);
     OKB(d_idx.up(idx32.data(), num_cells));
     for (size_t off = 0; off < num_blobs; off += CH) {
         const size_t k = num_blobs - off < CH ? (size_t)(num_blobs - off) : CH;
