@@ -154,8 +154,9 @@ int fk20_proofs_device(DeviceCtx *ctx, uint8_t *d_proofs, const Fr *d_poly_monom
 int eval_poly_batch_device(DeviceCtx *ctx, Fr *d_y, const Fr *d_poly, const Fr *d_z, size_t n);
 int eval_quotient_batch_device(DeviceCtx *ctx, Fr *d_y, uint32_t *d_q_raw, int *d_hit, const Fr *d_poly,
                                const Fr *d_z, size_t n);
+// stream: nullptr = the context's compute stream
 int validate_g1_batch_device(DeviceCtx *ctx, G1Affine *d_out, uint8_t *d_status, const uint8_t *d_in48,
-                             size_t n);
+                             size_t n, hipStream_t stream = nullptr);
 // d_off: njobs + 1 words of device scratch
 int lincomb_multi_device(DeviceCtx *ctx, G1Affine *d_out, G1XYZZ *d_partials, uint32_t *d_off, const G1Affine *d_pts,
                          const uint32_t *d_scalars, size_t total, const uint32_t *h_part_off, int njobs);

@@ -233,9 +233,9 @@ __global__ void k_validate_g1(G1Affine *out, uint8_t *status, const uint8_t *in4
 }
 
 int validate_g1_batch_device(DeviceCtx *ctx, G1Affine *d_out, uint8_t *d_status, const uint8_t *d_in48,
-                             size_t n) {
+                             size_t n, hipStream_t stream) {
     if (!n) return 0;
-    hipLaunchKernelGGL(k_validate_g1, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, d_out,
+    hipLaunchKernelGGL(k_validate_g1, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream ? stream : ctx->stream, d_out,
                        d_status, d_in48, n);
     HIP_TRY(hipGetLastError());
     return 0;
