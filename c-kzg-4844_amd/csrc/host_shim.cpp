@@ -76,6 +76,7 @@ void hs_sha256(uint8_t *out, const uint8_t *msg, size_t len) {
 
 // ---- 28-bit-limb device arithmetic (fp28.hpp / g1_28.hpp), exercised on the host ----
 #include "g1_28.hpp"
+#include "fr_inv.hpp"
 extern "C" {
 // r = a*b in the 2^384 domain, computed through the 2^392-domain multiplier
 void hs_fp28_mul(Fp *r, const Fp *a, const Fp *b) { *r = f28_to_fp(mul(f28_from_fp(*a), f28_from_fp(*b))); }
@@ -211,6 +212,9 @@ void hs_g1_madd28_chain(G1Jac *r, const G1Affine *pts, int n) {
 // (guards against a test that cannot fail).  Returns 0 when everything agrees.
 extern "C" int hs_g1_in_subgroup_host(const G1Affine *a) { return g1_in_subgroup_host(*a) ? 1 : 0; }
 extern "C" void hs_g1_mul_glv_host(G1Jac *r, const G1Jac *p, const uint32_t *k) { *r = g1_mul_glv_host(*p, k); }
+
+extern "C" void hs_fr_inv_safegcd(Fr *r, const Fr *a) { *r = fr_inv_safegcd(*a); }
+extern "C" void hs_fr_inv_fermat(Fr *r, const Fr *a) { *r = fr_inv(*a); }
 
 extern "C" int hs_fp12_selftest(uint32_t seed) {
     auto rnd_fp = [&](uint32_t i) {

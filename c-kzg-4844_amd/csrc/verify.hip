@@ -10,6 +10,7 @@
 #include "device.hpp"
 #include "dev_inline.hpp"
 #include "g1_28.hpp"
+#include "fr_inv.hpp"
 
 namespace ckzg {
 namespace dev {
@@ -29,7 +30,8 @@ __device__ __forceinline__ void vst_fr(Fr *p, const Fr &v) {
     q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
 }
 
-__device__ __noinline__ Fr fr_inv_dev(const Fr &a) { return fr_inv(a); }
+// safegcd (fr_inv.hpp): ~10x fewer instructions than the 255-squaring Fermat ladder
+__device__ __noinline__ Fr fr_inv_dev(const Fr &a) { return fr_inv_safegcd(a); }
 
 // ------------------------------------------------------------------------------------------
 // barycentric evaluation: one 256-thread workgroup per polynomial

@@ -461,6 +461,24 @@ def test_glv_split_and_glv_scalar_mul(libs):
     assert o.og1_is_inf(r)
 
 
+def test_fr_safegcd_inverse(libs):
+    """fr_inv.hpp (the inversion of the barycentric evaluation kernel) against Python and the Fermat ladder"""
+    o, h = libs
+    rnd = random.Random(41)
+    r256 = pow(2, 256, R)
+    vals = [0, 1, 2, R - 1, R - 2, (R - 1) // 2, 3, 7, 2 ** 254, 2 ** 255 - 19 - R, R - 3, 2 ** 32, 2 ** 32 - 1]
+    vals += [rnd.randrange(R) for _ in range(3000)]
+    for a in vals:
+        ab = (a * r256 % R).to_bytes(32, "little")
+        r1, r2 = _buf(32), _buf(32)
+        h.hs_fr_inv_safegcd(r1, ab)
+        got = int.from_bytes(r1.raw, "little") * pow(r256, -1, R) % R
+        assert got == (pow(a, -1, R) if a else 0), a
+        if a < 2 ** 33 or a > R - 4:
+            h.hs_fr_inv_fermat(r2, ab)
+            assert r1.raw == r2.raw
+
+
 def test_endomorphism_subgroup_test_is_exact(libs):
     """g1_28_in_subgroup ([x^2]P == (beta^2 X, -Y)) against the oracle's [r]P == inf on points of
     G1, of the cofactor subgroup, mixed points, the order-3 point and random curve points."""
