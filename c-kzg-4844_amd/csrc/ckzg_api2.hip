@@ -240,11 +240,11 @@ C_KZG_RET gpu_lincomb_multi(dev::DeviceCtx *ctx, G1Jac *outs, const LincombJob *
         total += nb[j] * 64;
     }
     Arena &ar = ctx->lc_arena;
-    OKM(ar.begin(total * (sizeof(RawScalar) + sizeof(G1Affine)) + (total / 64) * sizeof(G1XYZZ) +
+    OKM(ar.begin(total * (sizeof(RawScalar) + sizeof(G1Affine)) + (total / 32) * sizeof(G1XYZZ) +
                  njobs * sizeof(G1Affine) + (njobs + 1) * 4));
     struct { RawScalar *p; } d_k = {ar.get<RawScalar>(total)};
     struct { G1Affine *p; } d_p = {ar.get<G1Affine>(total)}, d_out = {ar.get<G1Affine>(njobs)};
-    struct { G1XYZZ *p; } d_part = {ar.get<G1XYZZ>(total / 64)};
+    struct { G1XYZZ *p; } d_part = {ar.get<G1XYZZ>(total / 32)};  // one partial per 64 lanes = 32 terms
     uint32_t *d_off = ar.get<uint32_t>(njobs + 1);
     OKM(d_k.p && d_p.p && d_out.p && d_part.p && d_off);
     OKB(hipMemsetAsync(d_p.p, 0, total * sizeof(G1Affine), ctx->stream) == hipSuccess);  // (0,0) = infinity
@@ -259,8 +259,8 @@ C_KZG_RET gpu_lincomb_multi(dev::DeviceCtx *ctx, G1Jac *outs, const LincombJob *
         }
     }
     std::vector<uint32_t> part_off(njobs + 1);
-    for (int j = 0; j < njobs; j++) part_off[j] = (uint32_t)(off[j] / 64);
-    part_off[njobs] = (uint32_t)(total / 64);
+    for (int j = 0; j < njobs; j++) part_off[j] = (uint32_t)(off[j] / 32);
+    part_off[njobs] = (uint32_t)(total / 32);
     RC(dev::lincomb_multi_device(ctx, d_out.p, d_part.p, d_off, d_p.p, (const uint32_t *)d_k.p, total, part_off.data(), njobs));
     std::vector<G1Affine> res(njobs);
     OKB(hipMemcpy(res.data(), d_out.p, njobs * sizeof(G1Affine), hipMemcpyDeviceToHost) == hipSuccess);
@@ -279,7 +279,7 @@ G1Jac host_lincomb(const std::vector<G1Jac> &pts, const std::vector<Fr> &k) {
 // random-linear-combination sums) stay on the host next to the pairing: a single 255-bit scalar
 // multiplication is ~0.25 ms on a CPU core but ~5 ms of dependent latency on one GPU lane.  The
 // data-parallel part (bytes -> Fr, 4096-term evaluation) runs on the GPU for every n.
-constexpr uint64_t SMALL_VERIFY_N = 8;
+constexpr uint64_t SMALL_VERIFY_N = 6;
 
 // Shared core of verify_blob_kzg_proof and verify_blob_kzg_proof_batch (eip4844.c:537-595,
 // 697-844).  Per blob, on the GPU: point validation, bytes -> Fr, evaluation at the challenge;

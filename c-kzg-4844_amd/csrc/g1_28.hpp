@@ -502,6 +502,36 @@ HDNI inline void xyzz28_mul_glv_w4(XYZZ28 &out, bool &out_inf, const XYZZ28 &p, 
     out_inf = inf;
 }
 
+// [k]P for a 128-bit k (one GLV half), uniform 4-bit windows, Jacobian inside: 128 doublings, 32 table
+// additions.  The variable-base sums give each GLV half its own lane (the second one on phi(P)) instead
+// of interleaving both in one ladder: the lanes are idle anyway and the dependent chain is what costs.
+HDNI inline void xyzz28_mul_w4_128(XYZZ28 &out, bool &out_inf, const XYZZ28 &p, bool p_inf, const uint32_t *k) {
+    JACT28 tbl[15];
+    JAC28 acc;
+    bool inf = true;
+    if (!p_inf) {
+        JAC28 cur = jac28_from_xyzz(p);
+        tbl[0] = jac28_table_entry(cur);
+        for (int i = 1; i < 15; i++) {
+            bool ci = false;
+            jac28_add(cur, ci, tbl[0]);
+            tbl[i] = jac28_table_entry(cur);
+        }
+        for (int w = 31; w >= 0; w--) {
+            if (!inf) {
+                jac28_dbl(acc);
+                jac28_dbl(acc);
+                jac28_dbl(acc);
+                jac28_dbl(acc);
+            }
+            uint32_t d = (k[w >> 3] >> ((w & 7) * 4)) & 15u;
+            if (d) jac28_add(acc, inf, tbl[d - 1]);
+        }
+    }
+    if (!inf) out = jac28_to_xyzz(acc);
+    out_inf = inf;
+}
+
 // a^e for a public exponent e (little-endian limbs, nbits bits) by a 4-bit sliding window: nbits
 // squarings and ~nbits/5 multiplications (odd powers a, a^3, ..., a^15 precomputed).
 HDNI inline F28<1, 2> f28_pow_public(const F28<1, 2> &a, const uint32_t *e, int nbits) {

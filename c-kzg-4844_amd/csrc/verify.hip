@@ -249,27 +249,31 @@ int validate_g1_batch_device(DeviceCtx *ctx, G1Affine *d_out, uint8_t *d_status,
 
 constexpr int LC_THREADS = 64;
 
-// One lane per term: split the scalar (GLV, the points were subgroup-checked), run the
-// two-dimensional ladder, then fold the workgroup's 64 products in LDS (28-bit-limb domain).
+// Two lanes per term: the scalar is split (GLV, the points were subgroup-checked) and lane 2i takes
+// [k1]P_i, lane 2i+1 takes [k2]phi(P_i) -- 128 doublings + 32 additions each instead of one lane doing
+// 128 + 64 -- then the workgroup's 64 products (32 terms) are folded in LDS (28-bit-limb domain).
 __global__ __launch_bounds__(LC_THREADS) void k_lincomb_partial(G1XYZZ *partials, const G1Affine *pts,
                                                                 const uint32_t *scalars, size_t n) {
     __shared__ uint32_t sh[57][LC_THREADS / 2];
-    size_t g = blockIdx.x * (size_t)LC_THREADS + threadIdx.x;
+    const size_t g = blockIdx.x * (size_t)LC_THREADS + threadIdx.x;
+    const size_t term = g >> 1;
+    const bool second = (g & 1) != 0;
     XYZZ28 acc;
     bool inf = true;
-    if (g < n) {
-        G1Affine a = pts[g];
+    if (term < n) {
+        G1Affine a = pts[term];
         if (!a.is_inf()) {
             uint32_t k[8], glv[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) k[i] = scalars[g * 8 + i];
+            for (int i = 0; i < 8; i++) k[i] = scalars[term * 8 + i];
             glv_split(k, glv, glv + 4);
             XYZZ28 p;
             p.x = widen<1, 10>(f28_from_fp(a.x));
+            if (second) p.x = widen<1, 10>(mul(p.x, f28_const<1, 1>(FP28_BETA_LAMBDA)));
             p.y = widen<1, 6>(f28_from_fp(a.y));
             p.zz = widen<1, 2>(f28_one());
             p.zzz = p.zz;
-            xyzz28_mul_glv_w4(acc, inf, p, false, glv);
+            xyzz28_mul_w4_128(acc, inf, p, false, second ? glv + 4 : glv);
         }
     }
     block_reduce_xyzz28<LC_THREADS>(acc, inf, sh);
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(64) void k_lincomb_final(G1Affine *out, const G1XYZ
 int lincomb_multi_device(DeviceCtx *ctx, G1Affine *d_out, G1XYZZ *d_partials, uint32_t *d_off, const G1Affine *d_pts,
                          const uint32_t *d_scalars, size_t total, const uint32_t *h_part_off, int njobs) {
     HIP_TRY(hipMemcpyAsync(d_off, h_part_off, (njobs + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_lincomb_partial, dim3((unsigned)(total / LC_THREADS)), dim3(LC_THREADS), 0, ctx->stream,
+    hipLaunchKernelGGL(k_lincomb_partial, dim3((unsigned)(2 * total / LC_THREADS)), dim3(LC_THREADS), 0, ctx->stream,
                        d_partials, d_pts, d_scalars, total);
     hipLaunchKernelGGL(k_lincomb_final, dim3(njobs), dim3(64), 0, ctx->stream, d_out, d_partials, d_off, njobs);
     HIP_TRY(hipGetLastError());
