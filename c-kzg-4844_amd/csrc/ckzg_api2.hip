@@ -279,7 +279,7 @@ G1Jac host_lincomb(const std::vector<G1Jac> &pts, const std::vector<Fr> &k) {
 // random-linear-combination sums) stay on the host next to the pairing: a single 255-bit scalar
 // multiplication is ~0.25 ms on a CPU core but ~5 ms of dependent latency on one GPU lane.  The
 // data-parallel part (bytes -> Fr, 4096-term evaluation) runs on the GPU for every n.
-constexpr uint64_t SMALL_VERIFY_N = 6;
+constexpr uint64_t SMALL_VERIFY_N = 8;
 
 // Shared core of verify_blob_kzg_proof and verify_blob_kzg_proof_batch (eip4844.c:537-595,
 // 697-844).  Per blob, on the GPU: point validation, bytes -> Fr, evaluation at the challenge;

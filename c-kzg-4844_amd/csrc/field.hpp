@@ -113,8 +113,61 @@ HD void mod_limbs(uint32_t *m) {
 }
 
 // Both moduli leave the top limb with spare bits (381 < 384, 255 < 256): a + b never carries out.
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__SIZEOF_INT128__)
+// host forms of add / sub on 64-bit limbs (same bytes, half the carry chain)
+template <class P>
+inline Mont<P> host_addsub(const Mont<P> &a, const Mont<P> &b, bool subtract) {
+    constexpr int H = P::N / 2;
+    typedef unsigned __int128 u128;
+    uint64_t x[H], y[H], m[H], t[H], u[H];
+    __builtin_memcpy(x, a.l, sizeof x);
+    __builtin_memcpy(y, b.l, sizeof y);
+#pragma unroll
+    for (int i = 0; i < H; i++) m[i] = (uint64_t)P::mod(2 * i) | ((uint64_t)P::mod(2 * i + 1) << 32);
+    uint64_t c = 0, c2 = 0;
+    if (!subtract) {
+#pragma unroll
+        for (int i = 0; i < H; i++) {
+            u128 s = (u128)x[i] + y[i] + c;
+            t[i] = (uint64_t)s;
+            c = (uint64_t)(s >> 64);
+        }
+#pragma unroll
+        for (int i = 0; i < H; i++) {
+            u128 d = (u128)t[i] - m[i] - c2;
+            u[i] = (uint64_t)d;
+            c2 = (uint64_t)(d >> 64) & 1;
+        }
+        // a + b never carries out of the top limb (both moduli leave spare bits): keep t if t < m
+#pragma unroll
+        for (int i = 0; i < H; i++) t[i] = c2 ? t[i] : u[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < H; i++) {
+            u128 d = (u128)x[i] - y[i] - c;
+            t[i] = (uint64_t)d;
+            c = (uint64_t)(d >> 64) & 1;
+        }
+#pragma unroll
+        for (int i = 0; i < H; i++) {
+            u128 s = (u128)t[i] + m[i] + c2;
+            u[i] = (uint64_t)s;
+            c2 = (uint64_t)(s >> 64);
+        }
+#pragma unroll
+        for (int i = 0; i < H; i++) t[i] = c ? u[i] : t[i];
+    }
+    Mont<P> r;
+    __builtin_memcpy(r.l, t, sizeof t);
+    return r;
+}
+#endif
+
 template <class P>
 HD Mont<P> add(const Mont<P> &a, const Mont<P> &b) {
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__SIZEOF_INT128__)
+    return host_addsub<P>(a, b, false);
+#else
     constexpr int N = P::N;
     uint32_t m[N], t[N], s[N];
     mod_limbs<P>(m);
@@ -124,10 +177,14 @@ HD Mont<P> add(const Mont<P> &a, const Mont<P> &b) {
 #pragma unroll
     for (int i = 0; i < N; i++) r.l[i] = br ? t[i] : s[i];
     return r;
+#endif
 }
 
 template <class P>
 HD Mont<P> sub(const Mont<P> &a, const Mont<P> &b) {
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__SIZEOF_INT128__)
+    return host_addsub<P>(a, b, true);
+#else
     constexpr int N = P::N;
     uint32_t m[N], t[N], s[N];
     mod_limbs<P>(m);
@@ -137,6 +194,7 @@ HD Mont<P> sub(const Mont<P> &a, const Mont<P> &b) {
 #pragma unroll
     for (int i = 0; i < N; i++) r.l[i] = br ? s[i] : t[i];
     return r;
+#endif
 }
 
 template <class P>
@@ -155,26 +213,27 @@ template <class P>
 HD Mont<P> mul(const Mont<P> &a, const Mont<P> &b) {
     constexpr int N = P::N;
 #if !defined(__HIP_DEVICE_COMPILE__) && defined(__SIZEOF_INT128__)
-    // Host code path (setup, pairing): same CIOS on 64-bit limbs -- the bytes are identical,
-    // only the word size differs.
+    // Host code path (setup, pairing, small-batch verification): the same CIOS on 64-bit limbs -- on a
+    // little-endian host the 32-bit limb array IS the 64-bit limb array -- with the modulus words and
+    // -m^-1 mod 2^64 folded at compile time.
     constexpr int H = N / 2;
     typedef unsigned __int128 u128;
-    uint64_t x[H], y[H], m[H], t[H + 2];
-    for (int i = 0; i < H; i++) {
-        x[i] = (uint64_t)a.l[2 * i] | ((uint64_t)a.l[2 * i + 1] << 32);
-        y[i] = (uint64_t)b.l[2 * i] | ((uint64_t)b.l[2 * i + 1] << 32);
-        m[i] = (uint64_t)P::mod(2 * i) | ((uint64_t)P::mod(2 * i + 1) << 32);
-    }
-    // -m^-1 mod 2^64 from the 32-bit constant by one Newton step
-    uint64_t ninv = (uint64_t)P::NINV;  // -m^-1 mod 2^32
-    {
-        uint64_t inv = (uint64_t)0 - ninv;        // m^-1 mod 2^32
-        inv *= 2 - m[0] * inv;                    // m^-1 mod 2^64
-        ninv = (uint64_t)0 - inv;
-    }
+    uint64_t x[H], y[H], t[H + 2];
+    __builtin_memcpy(x, a.l, sizeof x);
+    __builtin_memcpy(y, b.l, sizeof y);
+    constexpr uint64_t m0 = (uint64_t)P::mod(0) | ((uint64_t)P::mod(1) << 32);
+    // m^-1 mod 2^64 from the 32-bit constant by one Newton step
+    constexpr uint64_t inv32 = (uint64_t)0 - (uint64_t)P::NINV;
+    constexpr uint64_t ninv = (uint64_t)0 - inv32 * (2 - m0 * inv32);
+    uint64_t m[H];
+#pragma unroll
+    for (int i = 0; i < H; i++) m[i] = (uint64_t)P::mod(2 * i) | ((uint64_t)P::mod(2 * i + 1) << 32);
+#pragma unroll
     for (int i = 0; i < H + 2; i++) t[i] = 0;
+#pragma unroll
     for (int i = 0; i < H; i++) {
         u128 c = 0;
+#pragma unroll
         for (int j = 0; j < H; j++) {
             c += (u128)x[j] * y[i] + t[j];
             t[j] = (uint64_t)c;
@@ -183,8 +242,9 @@ HD Mont<P> mul(const Mont<P> &a, const Mont<P> &b) {
         c += t[H];
         t[H] = (uint64_t)c;
         t[H + 1] = (uint64_t)(c >> 64);
-        uint64_t q = t[0] * ninv;
+        const uint64_t q = t[0] * ninv;
         c = ((u128)q * m[0] + t[0]) >> 64;
+#pragma unroll
         for (int j = 1; j < H; j++) {
             c += (u128)q * m[j] + t[j];
             t[j - 1] = (uint64_t)c;
@@ -196,17 +256,16 @@ HD Mont<P> mul(const Mont<P> &a, const Mont<P> &b) {
     }
     uint64_t s64[H];
     uint64_t br = 0;
+#pragma unroll
     for (int i = 0; i < H; i++) {
         u128 d = (u128)t[i] - m[i] - br;
         s64[i] = (uint64_t)d;
         br = (uint64_t)(d >> 64) & 1;
     }
     Mont<P> r;
-    for (int i = 0; i < H; i++) {
-        uint64_t v = br ? t[i] : s64[i];
-        r.l[2 * i] = (uint32_t)v;
-        r.l[2 * i + 1] = (uint32_t)(v >> 32);
-    }
+#pragma unroll
+    for (int i = 0; i < H; i++) s64[i] = br ? t[i] : s64[i];
+    __builtin_memcpy(r.l, s64, sizeof s64);
     return r;
 #else
     uint32_t t[N + 2];

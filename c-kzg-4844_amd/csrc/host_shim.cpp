@@ -216,6 +216,22 @@ extern "C" void hs_g1_mul_glv_host(G1Jac *r, const G1Jac *p, const uint32_t *k) 
 extern "C" void hs_fr_inv_safegcd(Fr *r, const Fr *a) { *r = fr_inv_safegcd(*a); }
 extern "C" void hs_fr_inv_fermat(Fr *r, const Fr *a) { *r = fr_inv(*a); }
 
+// timing helpers (tools only): n pairing-product checks with prepared G2 arguments / n Fp products
+extern "C" int hs_bench_pairing(const G1Jac *a1, const G2Jac *q1, const G1Jac *a2, const G2Jac *q2, int n) {
+    G2Prepared p1, p2;
+    g2_prepare(p1, g2_to_affine(*q1));
+    g2_prepare(p2, g2_to_affine(*q2));
+    G1Affine x1 = jac_to_affine(*a1), x2 = jac_to_affine(*a2);
+    int ok = 0;
+    for (int i = 0; i < n; i++) ok += pairing_product_is_one(x1, p1, x2, p2) ? 1 : 0;
+    return ok;
+}
+extern "C" void hs_bench_fp_mul(Fp *r, const Fp *a, const Fp *b, int n) {
+    Fp x = *a;
+    for (int i = 0; i < n; i++) x = mul(x, *b);
+    *r = x;
+}
+
 extern "C" int hs_fp12_selftest(uint32_t seed) {
     auto rnd_fp = [&](uint32_t i) {
         uint8_t in[8], d[64];
