@@ -45,15 +45,16 @@ struct DBuf {
     } while (0)
 
 // Batches at least this large hash their Fiat-Shamir challenges on the GPU (k_sha256_challenges): the
-// GPU takes ~6 ms whatever the batch; 32 host threads take ~2 us per blob with the x86 SHA extensions
-// (measured crossover ~2,500 blobs) and ~10 us per blob without them (~600 blobs).
+// GPU takes ~6 ms whatever the batch.  32 host threads take ~2 us per blob with the x86 SHA extensions,
+// less than the blob copy they run under, so such hosts never switch; without the extensions the host
+// needs ~10 us per blob and the GPU takes over at 512 blobs.
 static size_t gpu_sha_min_n() {
     if (g_opts.gpu_sha_min > 0) return (size_t)g_opts.gpu_sha_min;  // ckzg_hip_set_option("gpu_sha_min", n)
     static const size_t dflt = []() {
         const char *v = getenv("CKZG_HIP_GPU_SHA_MIN");
         if (v && *v) return (size_t)atol(v);
 #ifdef CKZG_HAVE_SHANI
-        if (host::cpu_has_sha_ni()) return (size_t)3072;
+        if (host::cpu_has_sha_ni()) return (size_t)1 << 30;  // the host hash hides under the blob copy
 #endif
         return (size_t)512;
     }();
@@ -323,18 +324,30 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
         RC(dev::validate_g1_batch_device(ctx, d_pts.p, d_st.p, d_ptb.p, 2 * n, vs));
         OKB(hipEventRecord(ctx->stage_ev[0], vs) == hipSuccess);
     }
+    // Challenges: on host threads, started BEFORE the blob copy -- a copy from pageable memory blocks
+    // this thread for its whole duration (3.5 us per blob), and with the x86 SHA extensions the hashing
+    // (2 us per blob on 32 threads) finishes underneath it.  Hosts without the extensions hash large
+    // batches on the GPU instead (a lane per blob; ~6 ms whatever the batch size).
+    const bool gpu_sha = n >= gpu_sha_min_n();
+    std::vector<Fr> z(n), y(n);
+    struct Joiner {
+        std::thread t;
+        ~Joiner() {
+            if (t.joinable()) t.join();
+        }
+    } hasher;
+    if (!gpu_sha) {
+        hasher.t = std::thread([&]() {
+            parallel_for(n, [&](size_t i) { z[i] = challenge_from_bytes(blobs[i].bytes, cb[i].bytes); });
+        });
+    }
     OKB(hipMemcpyAsync(d_blobs.p, blobs, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
     OKB(hipMemsetAsync(d_bad.p, 0, n * 4, ctx->stream) == hipSuccess);
     RC(dev::bytes_to_fr_batch(ctx, d_poly.p, d_bad.p, d_blobs.p, n * FIELD_ELEMENTS_PER_BLOB, FIELD_ELEMENTS_PER_BLOB));
-    // Challenges: a lane per blob on the GPU for large batches (the blobs are in HBM anyway; ~2050
-    // sequential compressions take a few ms whatever the batch size), on host threads while the GPU
-    // validates and converts for small ones.
-    const bool gpu_sha = n >= gpu_sha_min_n();
-    std::vector<Fr> z(n), y(n);
     if (!small) OKB(hipStreamWaitEvent(ctx->stream, ctx->stage_ev[0], 0) == hipSuccess);  // d_ptb, d_pts, d_st ready
     if (gpu_sha) RC(dev::sha256_challenges_device(ctx, d_z.p, d_blobs.p, d_ptb.p, n));
     tr.mark("enqueue H2D + bytes_to_fr (+ GPU validation)");
-    if (!gpu_sha) parallel_for(n, [&](size_t i) { z[i] = challenge_from_bytes(blobs[i].bytes, cb[i].bytes); });
+    if (hasher.t.joinable()) hasher.t.join();
     tr.mark("host SHA-256 challenges");
     OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
     tr.mark("wait for GPU");

@@ -30,7 +30,8 @@ extern "C" {
  *   "direct_max"    largest batch that takes the low-latency proof path (default 24; larger batches
  *                   use FK20, which does ~10x fewer point additions but has a long dependency chain)
  *   "gpu_sha_min"   smallest verify_blob_kzg_proof_batch size whose Fiat-Shamir challenges are hashed on
- *                   the GPU; 0 (default) picks 3072 on hosts with the x86 SHA extensions, 512 otherwise.
+ *                   the GPU; 0 (default): never on hosts with the x86 SHA extensions (the host hash runs under the
+ *                   blob copy), from 512 blobs otherwise.
  *                   Takes effect immediately (the table options are read by load_trusted_setup).
  * Returns C_KZG_BADARGS for an unknown key or out-of-range value. */
 C_KZG_RET ckzg_hip_set_option(const char *key, int64_t value);
