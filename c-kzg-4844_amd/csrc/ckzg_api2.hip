@@ -336,11 +336,11 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
             if (t.joinable()) t.join();
         }
     } hasher;
-    if (!gpu_sha) {
-        hasher.t = std::thread([&]() {
-            parallel_for(n, [&](size_t i) { z[i] = challenge_from_bytes(blobs[i].bytes, cb[i].bytes); });
-        });
-    }
+    auto hash_all = [&]() {
+        parallel_for(n, [&](size_t i) { z[i] = challenge_from_bytes(blobs[i].bytes, cb[i].bytes); });
+    };
+    const bool threaded = !gpu_sha && n >= 16;  // a thread costs ~0.2 ms: not for the single-blob call
+    if (threaded) hasher.t = std::thread(hash_all);
     OKB(hipMemcpyAsync(d_blobs.p, blobs, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
     OKB(hipMemsetAsync(d_bad.p, 0, n * 4, ctx->stream) == hipSuccess);
     RC(dev::bytes_to_fr_batch(ctx, d_poly.p, d_bad.p, d_blobs.p, n * FIELD_ELEMENTS_PER_BLOB, FIELD_ELEMENTS_PER_BLOB));
@@ -348,6 +348,7 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     if (gpu_sha) RC(dev::sha256_challenges_device(ctx, d_z.p, d_blobs.p, d_ptb.p, n));
     tr.mark("enqueue H2D + bytes_to_fr (+ GPU validation)");
     if (hasher.t.joinable()) hasher.t.join();
+    if (!gpu_sha && !threaded) hash_all();
     tr.mark("host SHA-256 challenges");
     OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
     tr.mark("wait for GPU");
@@ -544,10 +545,26 @@ extern "C" C_KZG_RET ckzg_hip_compute_blob_kzg_proof_batch(KZGProof *proofs, uin
                     pst[i] = validate_kzg_g1(c, commitments_bytes[off + i].bytes) == C_KZG_OK ? 0 : 1;
                 }
             }
-            OKB(hipMemcpyAsync(d_blobs.p, blobs + off, k * BYTES_PER_BLOB, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
-            OKB(hipMemsetAsync(d_bad.p, 0, k * 4, ctx->stream) == hipSuccess);
-            RC(dev::bytes_to_fr_batch(ctx, d_poly.p, d_bad.p, d_blobs.p, k * FIELD_ELEMENTS_PER_BLOB, FIELD_ELEMENTS_PER_BLOB));
-            parallel_for(k, [&](size_t i) { z[i] = challenge_from_bytes(blobs[off + i].bytes, commitments_bytes[off + i].bytes); });
+            {
+                // the challenges are hashed by host threads underneath the (thread-blocking) blob copy
+                struct Joiner {
+                    std::thread t;
+                    ~Joiner() {
+                        if (t.joinable()) t.join();
+                    }
+                } hasher;
+                auto hash_all = [&]() {
+                    parallel_for(k, [&](size_t i) {
+                        z[i] = challenge_from_bytes(blobs[off + i].bytes, commitments_bytes[off + i].bytes);
+                    });
+                };
+                const bool threaded = k >= 16;  // a thread costs ~0.2 ms: not for the single-blob call
+                if (threaded) hasher.t = std::thread(hash_all);
+                OKB(hipMemcpyAsync(d_blobs.p, blobs + off, k * BYTES_PER_BLOB, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
+                OKB(hipMemsetAsync(d_bad.p, 0, k * 4, ctx->stream) == hipSuccess);
+                RC(dev::bytes_to_fr_batch(ctx, d_poly.p, d_bad.p, d_blobs.p, k * FIELD_ELEMENTS_PER_BLOB, FIELD_ELEMENTS_PER_BLOB));
+                if (!threaded) hash_all();
+            }
             OKB(hipMemcpyAsync(d_z.p, z.data(), k * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
             RC(dev::eval_quotient_batch_device(ctx, d_y.p, d_q.p, d_hit.p, d_poly.p, d_z.p, k));
             RC(dev::msm_commit_table_raw_device(ctx, d_out.p, d_q.p, k));
