@@ -111,13 +111,13 @@ struct ABuf {
 };
 using dev::Arena;
 
-// a very large batch must not pin its temporaries in HBM for ever: blocks above 1 GiB are returned
+// a very large batch must not pin its temporaries in HBM for ever: blocks above 2 GiB are returned
 // when the call ends (one hipFree per such call), smaller ones stay for the next call
 struct ArenaTrim {
     Arena &a;
     explicit ArenaTrim(Arena &ar) : a(ar) {}
     ~ArenaTrim() {
-        if (a.cap > ((size_t)1 << 30)) a.release();
+        if (a.cap > ((size_t)2 << 30)) a.release();
     }
 };
 
