@@ -177,8 +177,16 @@ def main():
     mod = ge.load_package()
     # headline leg: the widest commitment table that fits (16-bit windows = 206 GB of the 288 GB);
     # the cell-proof tables stay at their small defaults here and are widened for the secondary leg
-    hip = mod.Kzg(mod.HIP_SO, options={"device": local_rank, "commit_wbits": args.wbits, "proof_wbits": 8,
-                                       "fk20_wbits": 8})
+    hip = None
+    for w in range(args.wbits, 9, -1):
+        try:
+            hip = mod.Kzg(mod.HIP_SO, options={"device": local_rank, "commit_wbits": w, "proof_wbits": 8,
+                                               "fk20_wbits": 8})
+            break
+        except Exception as e:  # the library already narrows to the free HBM; this is the belt to its braces
+            sys.stderr.write("bench: load with commit_wbits=%d failed (%s), trying %d\n" % (w, e, w - 1))
+    if hip is None:
+        raise SystemExit("bench: load_trusted_setup failed for every table width")
     lib = hip.lib
     lib.ckzg_hip_table_wbits.restype = C.c_int
     lib.ckzg_hip_table_wbits.argtypes = [C.c_void_p, C.c_int]
