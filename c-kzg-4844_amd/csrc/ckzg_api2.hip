@@ -280,7 +280,7 @@ G1Jac host_lincomb(const std::vector<G1Jac> &pts, const std::vector<Fr> &k) {
 // random-linear-combination sums) stay on the host next to the pairing: a single 255-bit scalar
 // multiplication is ~0.25 ms on a CPU core but ~5 ms of dependent latency on one GPU lane.  The
 // data-parallel part (bytes -> Fr, 4096-term evaluation) runs on the GPU for every n.
-constexpr uint64_t SMALL_VERIFY_N = 8;
+constexpr uint64_t SMALL_VERIFY_N = 5;
 
 // Shared core of verify_blob_kzg_proof and verify_blob_kzg_proof_batch (eip4844.c:537-595,
 // 697-844).  Per blob, on the GPU: point validation, bytes -> Fr, evaluation at the challenge;
@@ -304,26 +304,42 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     OKB(hipSetDevice(ctx->device) == hipSuccess);
     Arena &ar = ctx->api_arena;
     OKM(ar.begin(n * BYTES_PER_BLOB + (n * FIELD_ELEMENTS_PER_BLOB + 2 * n) * sizeof(Fr) + n * 4 +
-                 2 * n * (48 + 1 + sizeof(G1Affine))));
-    ABuf<uint8_t> d_ptb(ar, 2 * n * 48), d_st(ar, 2 * n), d_blobs(ar, n * BYTES_PER_BLOB);
+                 2 * n * (48 + 2 + sizeof(G1Affine))));
+    ABuf<uint8_t> d_ptb(ar, 2 * n * 48), d_st(ar, 2 * n), d_st2(ar, 2 * n), d_blobs(ar, n * BYTES_PER_BLOB);
     ABuf<G1Affine> d_pts(ar, 2 * n);
     ABuf<Fr> d_poly(ar, n * FIELD_ELEMENTS_PER_BLOB), d_z(ar, n), d_y(ar, n);
     ABuf<uint32_t> d_bad(ar, n);
-    OKM(d_ptb.p && d_st.p && d_blobs.p && d_pts.p && d_poly.p && d_z.p && d_y.p && d_bad.p);
+    OKM(d_ptb.p && d_st.p && d_st2.p && d_blobs.p && d_pts.p && d_poly.p && d_z.p && d_y.p && d_bad.p);
     ArenaTrim trim(ar);
     tr.mark("arena");
+    const bool split_validation = !small && n < 1024;
     if (!small) {
         // commitments [0,n), proofs [n,2n): decompress + subgroup-check on the GPU, on the second stream
         // so that the ladder kernel runs under the (host-blocking, pageable) copy of the blobs
         // (only for batches whose blob copy is short: measured, a concurrent kernel slows a long pageable
         // copy by more than the ~1.3 ms it hides -- n = 4096: 30 -> 37 ms; n = 64: 8.0 -> 5.6 ms)
-        hipStream_t vs = n < 1024 ? ctx->copy_stream : ctx->stream;
+        // Below 1024 blobs the validation is also split: event 0 marks the decompressed points, the
+        // subgroup test (event 1) keeps running on the second stream underneath evaluation and sums.
+        hipStream_t vs = split_validation ? ctx->copy_stream : ctx->stream;
         if (!ctx->stage_ev[0]) OKB(hipEventCreateWithFlags(&ctx->stage_ev[0], hipEventDisableTiming) == hipSuccess);
+        if (!ctx->stage_ev[1]) OKB(hipEventCreateWithFlags(&ctx->stage_ev[1], hipEventDisableTiming) == hipSuccess);
         OKB(hipMemcpyAsync(d_ptb.p, cb, n * 48, hipMemcpyHostToDevice, vs) == hipSuccess);
         OKB(hipMemcpyAsync(d_ptb.p + n * 48, pb, n * 48, hipMemcpyHostToDevice, vs) == hipSuccess);
-        RC(dev::validate_g1_batch_device(ctx, d_pts.p, d_st.p, d_ptb.p, 2 * n, vs));
-        OKB(hipEventRecord(ctx->stage_ev[0], vs) == hipSuccess);
+        if (split_validation) {
+            RC(dev::decompress_g1_batch_device(ctx, d_pts.p, d_st.p, d_ptb.p, 2 * n, vs));
+            OKB(hipEventRecord(ctx->stage_ev[0], vs) == hipSuccess);
+            RC(dev::subgroup_g1_batch_device(ctx, d_st2.p, d_pts.p, 2 * n, vs));
+            OKB(hipEventRecord(ctx->stage_ev[1], vs) == hipSuccess);
+        } else {
+            RC(dev::validate_g1_batch_device(ctx, d_pts.p, d_st.p, d_ptb.p, 2 * n, vs));
+            OKB(hipEventRecord(ctx->stage_ev[0], vs) == hipSuccess);
+        }
     }
+    // whatever path leaves this function, the second stream must be idle before the arena is reused
+    struct StreamDrain {
+        hipStream_t s;
+        ~StreamDrain() { (void)hipStreamSynchronize(s); }
+    } drain{ctx->copy_stream};
     // Challenges: on host threads, started BEFORE the blob copy -- a copy from pageable memory blocks
     // this thread for its whole duration (3.5 us per blob), and with the x86 SHA extensions the hashing
     // (2 us per blob on 32 threads) finishes underneath it.  Hosts without the extensions hash large
@@ -418,6 +434,14 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
         LincombJob jobs[3] = {{d_pts.p + n, &rp}, {d_pts.p + n, &rz}, {d_pts.p, &rp}};
         C_KZG_RET ret = gpu_lincomb_multi(ctx, lc, jobs, 3);
         if (ret != C_KZG_OK) return ret;
+    }
+    if (split_validation) {
+        OKB(hipEventSynchronize(ctx->stage_ev[1]) == hipSuccess);
+        std::vector<uint8_t> st2(2 * n);
+        OKB(d_st2.down(st2.data(), 2 * n));
+        for (size_t i = 0; i < 2 * n; i++) {
+            if (st2[i]) return C_KZG_BADARGS;  // a point outside G1: the sums above are discarded
+        }
     }
     tr.mark("transcript + lincombs");
     // sum r^i (C_i - [y_i]G) = sum r^i C_i - [sum r^i y_i]G
@@ -844,13 +868,14 @@ extern "C" C_KZG_RET verify_cell_kzg_proof_batch(bool *ok, const Bytes48 *commit
     std::lock_guard<std::mutex> lock(ctx->mu);
     OKB(hipSetDevice(ctx->device) == hipSuccess);
     Arena &ar = ctx->api_arena;
-    OKM(ar.begin((n + nc) * (48 + 1 + sizeof(G1Affine)) + ((size_t)CELLS_PER_EXT_BLOB * l + l + n * l + n) * sizeof(Fr) +
+    OKM(ar.begin((n + nc) * (48 + 2 + sizeof(G1Affine)) + ((size_t)CELLS_PER_EXT_BLOB * l + l + n * l + n) * sizeof(Fr) +
                  n * BYTES_PER_CELL + (n + CELLS_PER_EXT_BLOB + 1 + n) * 4));
-    ABuf<uint8_t> d_ptb(ar, (n + nc) * 48), d_st(ar, n + nc), d_cells(ar, n * BYTES_PER_CELL);
+    ABuf<uint8_t> d_ptb(ar, (n + nc) * 48), d_st(ar, n + nc), d_st2(ar, n + nc), d_cells(ar, n * BYTES_PER_CELL);
     ABuf<G1Affine> d_pts(ar, n + nc);
     ABuf<Fr> d_agg(ar, (size_t)CELLS_PER_EXT_BLOB * l), d_interp(ar, l), d_cellfr(ar, n * l), d_rp(ar, n);
     ABuf<uint32_t> d_bad(ar, n), d_csr(ar, CELLS_PER_EXT_BLOB + 1 + n);
-    OKM(d_ptb.p && d_st.p && d_cells.p && d_pts.p && d_agg.p && d_interp.p && d_cellfr.p && d_rp.p && d_bad.p && d_csr.p);
+    OKM(d_ptb.p && d_st.p && d_st2.p && d_cells.p && d_pts.p && d_agg.p && d_interp.p && d_cellfr.p && d_rp.p &&
+        d_bad.p && d_csr.p);
     ArenaTrim trim(ar);
     // proofs [0,n), unique commitments [n, n+nc): decompression and subgroup checks start on the GPU,
     // followed by the cells' bytes -> Fr conversion, while the host hashes the transcript
@@ -861,7 +886,21 @@ extern "C" C_KZG_RET verify_cell_kzg_proof_batch(bool *ok, const Bytes48 *commit
     OKB(hipMemcpyAsync(d_cells.p, cells, n * BYTES_PER_CELL, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
     OKB(hipMemsetAsync(d_bad.p, 0, n * 4, ctx->stream) == hipSuccess);
     RC(dev::bytes_to_fr_batch(ctx, d_cellfr.p, d_bad.p, d_cells.p, n * l, (uint32_t)l));
-    RC(dev::validate_g1_batch_device(ctx, d_pts.p, d_st.p, d_ptb.p, n + nc));
+    // Validation in two launches: decompression (a square root, ~0.35 ms) here, the subgroup test
+    // (~1 ms of dependent doublings) on the second stream, next to the sums that already use the points.
+    // A point outside the subgroup makes those sums meaningless, not unsafe; they are discarded below.
+    RC(dev::decompress_g1_batch_device(ctx, d_pts.p, d_st.p, d_ptb.p, n + nc));
+    if (!ctx->stage_ev[0]) OKB(hipEventCreateWithFlags(&ctx->stage_ev[0], hipEventDisableTiming) == hipSuccess);
+    if (!ctx->stage_ev[1]) OKB(hipEventCreateWithFlags(&ctx->stage_ev[1], hipEventDisableTiming) == hipSuccess);
+    OKB(hipEventRecord(ctx->stage_ev[0], ctx->stream) == hipSuccess);
+    OKB(hipStreamWaitEvent(ctx->copy_stream, ctx->stage_ev[0], 0) == hipSuccess);
+    RC(dev::subgroup_g1_batch_device(ctx, d_st2.p, d_pts.p, n + nc, ctx->copy_stream));
+    OKB(hipEventRecord(ctx->stage_ev[1], ctx->copy_stream) == hipSuccess);
+    // whatever path leaves this function, the second stream must be idle before the arena is reused
+    struct StreamDrain {
+        hipStream_t s;
+        ~StreamDrain() { (void)hipStreamSynchronize(s); }
+    } drain{ctx->copy_stream};
     tr.mark("dedup + enqueue validation");
     Fr r;
     compute_verify_cell_kzg_proof_batch_challenge((fr_t *)&r, uniq.data(), nc, cidx.data(), cell_indices, cells,
@@ -912,10 +951,11 @@ extern "C" C_KZG_RET verify_cell_kzg_proof_batch(bool *ok, const Bytes48 *commit
         C_KZG_RET ret = gpu_lincomb_multi(ctx, lc, jobs, 4);
         if (ret != C_KZG_OK) return ret;
     }
-    std::vector<uint8_t> st(n + nc);
-    OKB(d_st.down(st.data(), n + nc));
-    for (auto b : st) {
-        if (b) return C_KZG_BADARGS;  // rejected points were replaced by infinity: the sums above are discarded
+    OKB(hipEventSynchronize(ctx->stage_ev[1]) == hipSuccess);  // the subgroup test on the second stream
+    std::vector<uint8_t> st(n + nc), st2(n + nc);
+    OKB(d_st.down(st.data(), n + nc) && d_st2.down(st2.data(), n + nc));
+    for (size_t i = 0; i < n + nc; i++) {
+        if (st[i] || st2[i]) return C_KZG_BADARGS;  // bad encoding / off the curve / outside G1: sums discarded
     }
     {
         std::vector<uint32_t> bad(n);

@@ -157,6 +157,13 @@ int eval_quotient_batch_device(DeviceCtx *ctx, Fr *d_y, uint32_t *d_q_raw, int *
 // stream: nullptr = the context's compute stream
 int validate_g1_batch_device(DeviceCtx *ctx, G1Affine *d_out, uint8_t *d_status, const uint8_t *d_in48,
                              size_t n, hipStream_t stream = nullptr);
+// the two halves of the validation as separate launches: curve membership + decompression, then the
+// subgroup test on the decompressed points (status 1 = finite point outside G1), so that the test can
+// run on a second stream next to the kernels that already consume the points
+int decompress_g1_batch_device(DeviceCtx *ctx, G1Affine *d_out, uint8_t *d_status, const uint8_t *d_in48, size_t n,
+                               hipStream_t stream = nullptr);
+int subgroup_g1_batch_device(DeviceCtx *ctx, uint8_t *d_status, const G1Affine *d_pts, size_t n,
+                             hipStream_t stream = nullptr);
 // d_off: njobs + 1 words of device scratch
 int lincomb_multi_device(DeviceCtx *ctx, G1Affine *d_out, G1XYZZ *d_partials, uint32_t *d_off, const G1Affine *d_pts,
                          const uint32_t *d_scalars, size_t total, const uint32_t *h_part_off, int njobs);

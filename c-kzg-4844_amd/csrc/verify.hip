@@ -188,6 +188,9 @@ __device__ __noinline__ G1XYZZ affine_mul_w4(const G1Affine &a, const uint32_t *
 // the square root is a sliding-window power (381 squarings + ~80 products) and the subgroup test
 // the endomorphism identity [x^2]P = (beta^2 X, -Y) (g1_28.hpp: 126 doublings + 10 additions)
 // instead of a 255-bit ladder by r -- about 3x fewer instructions per point.
+// MODE 0: decompress and subgroup-check; MODE 1: decompress only (curve membership), the caller runs
+// k_subgroup_g1 on the result -- on another stream, next to the work that consumes the points.
+template <int MODE>
 __global__ void k_validate_g1(G1Affine *out, uint8_t *status, const uint8_t *in48, size_t n) {
     size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (g >= n) return;
@@ -222,7 +225,7 @@ __global__ void k_validate_g1(G1Affine *out, uint8_t *status, const uint8_t *in4
                     y = neg(y);
                     y28 = f28_from_fp(y);
                 }
-                if (!g1_28_in_subgroup(x28, y28)) {
+                if (MODE == 0 && !g1_28_in_subgroup(x28, y28)) {
                     st = 1;
                 } else {
                     a = {x, y};
@@ -234,11 +237,38 @@ __global__ void k_validate_g1(G1Affine *out, uint8_t *status, const uint8_t *in4
     status[g] = st;
 }
 
+// status[i] = 1 for a finite point outside the prime-order subgroup (points are left untouched)
+__global__ void k_subgroup_g1(uint8_t *status, const G1Affine *pts, size_t n) {
+    size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    G1Affine a = pts[g];
+    uint8_t st = 0;
+    if (!a.is_inf() && !g1_28_in_subgroup(f28_from_fp(a.x), f28_from_fp(a.y))) st = 1;
+    status[g] = st;
+}
+
 int validate_g1_batch_device(DeviceCtx *ctx, G1Affine *d_out, uint8_t *d_status, const uint8_t *d_in48,
                              size_t n, hipStream_t stream) {
     if (!n) return 0;
-    hipLaunchKernelGGL(k_validate_g1, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream ? stream : ctx->stream, d_out,
-                       d_status, d_in48, n);
+    hipLaunchKernelGGL(k_validate_g1<0>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream ? stream : ctx->stream,
+                       d_out, d_status, d_in48, n);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int decompress_g1_batch_device(DeviceCtx *ctx, G1Affine *d_out, uint8_t *d_status, const uint8_t *d_in48, size_t n,
+                               hipStream_t stream) {
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_validate_g1<1>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream ? stream : ctx->stream,
+                       d_out, d_status, d_in48, n);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int subgroup_g1_batch_device(DeviceCtx *ctx, uint8_t *d_status, const G1Affine *d_pts, size_t n, hipStream_t stream) {
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_subgroup_g1, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream ? stream : ctx->stream,
+                       d_status, d_pts, n);
     HIP_TRY(hipGetLastError());
     return 0;
 }
