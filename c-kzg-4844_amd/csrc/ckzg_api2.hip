@@ -553,6 +553,10 @@ extern "C" C_KZG_RET ckzg_hip_compute_blob_kzg_proof_batch(KZGProof *proofs, uin
         ABuf<int> d_hit(ar, m);
         OKM(d_blobs.p && d_ptb.p && d_pst.p && d_out.p && d_pts.p && d_poly.p && d_z.p && d_y.p && d_bad.p && d_q.p &&
             d_hit.p);
+        struct StreamDrain {  // the second stream must be idle before the arena is reused, on every exit path
+            hipStream_t s;
+            ~StreamDrain() { (void)hipStreamSynchronize(s); }
+        } drain{ctx->copy_stream};
         std::vector<Fr> z(m);
         std::vector<uint8_t> pst(m);
         std::vector<uint32_t> bad(m);
@@ -561,8 +565,10 @@ extern "C" C_KZG_RET ckzg_hip_compute_blob_kzg_proof_batch(KZGProof *proofs, uin
             const uint64_t k = n - off < CH ? n - off : CH;
             // commitments must be valid G1 points (bytes_to_kzg_commitment, eip4844.c:513)
             if (k > SMALL_VERIFY_N) {
-                OKB(hipMemcpyAsync(d_ptb.p, commitments_bytes + off, k * 48, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
-                RC(dev::validate_g1_batch_device(ctx, d_pts.p, d_pst.p, d_ptb.p, k));
+                // only a verdict is needed: the whole validation runs on the second stream, underneath
+                // the copy, evaluation and MSM of this chunk
+                OKB(hipMemcpyAsync(d_ptb.p, commitments_bytes + off, k * 48, hipMemcpyHostToDevice, ctx->copy_stream) == hipSuccess);
+                RC(dev::validate_g1_batch_device(ctx, d_pts.p, d_pst.p, d_ptb.p, k, ctx->copy_stream));
             } else {
                 for (uint64_t i = 0; i < k; i++) {
                     G1Jac c;
@@ -592,7 +598,10 @@ extern "C" C_KZG_RET ckzg_hip_compute_blob_kzg_proof_batch(KZGProof *proofs, uin
             OKB(hipMemcpyAsync(d_z.p, z.data(), k * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
             RC(dev::eval_quotient_batch_device(ctx, d_y.p, d_q.p, d_hit.p, d_poly.p, d_z.p, k));
             RC(dev::msm_commit_table_raw_device(ctx, d_out.p, d_q.p, k));
-            if (k > SMALL_VERIFY_N) OKB(d_pst.down(pst.data(), k));
+            if (k > SMALL_VERIFY_N) {
+                OKB(hipStreamSynchronize(ctx->copy_stream) == hipSuccess);
+                OKB(d_pst.down(pst.data(), k));
+            }
             OKB(d_bad.down(bad.data(), k) && d_hit.down(hit.data(), k));
             OKB(hipMemcpy(proofs + off, d_out.p, k * 48, hipMemcpyDeviceToHost) == hipSuccess);
             for (uint64_t i = 0; i < k; i++) {
