@@ -51,7 +51,7 @@ struct Options {
     int commit_wbits = 10;  // env CKZG_HIP_COMMIT_WBITS overrides the default
     int fk20_wbits = 0;     // 0: max(8, precompute); env CKZG_HIP_FK20_WBITS
     int proof_wbits = 8;    // monomial-point table for the direct proof path; 0 disables it
-    int direct_max = 24;    // largest batch that takes the direct path (0 disables it)
+    int direct_max = -1;    // largest batch that takes the direct path (0 disables it; -1: by table width)
     int gpu_sha_min = 0;    // smallest verify batch that hashes its challenges on the GPU; 0 = by host CPU
 };
 extern Options g_opts;

@@ -39,7 +39,7 @@ extern "C" C_KZG_RET ckzg_hip_set_option(const char *key, int64_t value) {
         if (value < 0 || value > (1 << 30)) return C_KZG_BADARGS;
         g_opts.gpu_sha_min = (int)value;  // read at call time, unlike the table options
     } else if (!strcmp(key, "direct_max")) {
-        if (value < 0 || value > 4096) return C_KZG_BADARGS;
+        if (value < -1 || value > 4096) return C_KZG_BADARGS;
         g_opts.direct_max = (int)value;
     } else {
         return C_KZG_BADARGS;

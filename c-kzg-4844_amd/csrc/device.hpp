@@ -75,7 +75,7 @@ struct DeviceCtx {
     std::mutex mu;
     FixedBaseTable commit;        // over g1_values_lagrange_brp (4096 points)
     FixedBaseTable mono;          // over g1_values_monomial (4096 points): low-latency cell proofs
-    int direct_max = 24;          // batches up to this many blobs use the direct proof path
+    int direct_max = 10;          // batches up to this many blobs use the direct proof path (set at load)
     Scratch scratch;              // reused by every call under `mu`
     Arena api_arena, lc_arena;    // temporaries of the host-pointer entry points / of gpu_lincomb_multi
     hipEvent_t stage_ev[4] = {};  // copied[2], consumed[2] of the staging pipeline (created on first use)

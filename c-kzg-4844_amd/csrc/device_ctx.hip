@@ -181,7 +181,7 @@ C_KZG_RET create_device_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affine,
     {
         int wbits = env_int("CKZG_HIP_PROOF_WBITS", g_opts.proof_wbits);
         ctx->direct_max = env_int("CKZG_HIP_DIRECT_MAX", g_opts.direct_max);
-        if (wbits != 0 && ctx->direct_max > 0) {
+        if (wbits != 0 && ctx->direct_max != 0) {
             if (wbits < 4 || wbits > 16) wbits = 8;
             wbits = fit_wbits("proof", wbits, 8, (int)NUM_G1_POINTS);
             int rc = dev::build_fixed_base_table(ctx, &ctx->mono, ctx->d_mono, (int)NUM_G1_POINTS, wbits);
@@ -189,7 +189,12 @@ C_KZG_RET create_device_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affine,
                 destroy_device_ctx(ctx);
                 return (C_KZG_RET)rc;
             }
+            // Automatic hand-over point (measured, tools/bench_direct_vs_fk20.py): FK20 costs ~28 ms for any
+            // batch of up to ~48 blobs (13 dependent ladder launches), the direct path 3.5 ms for one blob
+            // plus 2.5 / 1.9 / 1.5 ms per further blob with an 8 / 13 / 16-bit table.
+            if (ctx->direct_max < 0) ctx->direct_max = wbits >= 15 ? 18 : (wbits >= 11 ? 14 : 10);
         }
+        if (ctx->direct_max < 0) ctx->direct_max = 0;
     }
     {
         PreparedG2 *pg = new PreparedG2();

@@ -27,8 +27,10 @@ extern "C" {
  *   "fk20_wbits"    window width of the FK20 fixed-base tables (8192 points); default: max(8, precompute)
  *   "proof_wbits"   window width of the table over the 4096 monomial points used by the low-latency
  *                   (no G1 FFT) cell-proof path; default 8 (1.6 GB), 0 disables the path
- *   "direct_max"    largest batch that takes the low-latency proof path (default 24; larger batches
- *                   use FK20, which does ~10x fewer point additions but has a long dependency chain)
+ *   "direct_max"    largest batch that takes the low-latency proof path; larger batches use FK20, which
+ *                   does ~10x fewer point additions but costs ~28 ms for any small batch (13 dependent
+ *                   ladder launches).  -1 (default): 10 / 14 / 18 blobs for a proof table of <= 10 / <= 14 /
+ *                   >= 15 bits, the measured hand-over points; 0 disables the path
  *   "gpu_sha_min"   smallest verify_blob_kzg_proof_batch size whose Fiat-Shamir challenges are hashed on
  *                   the GPU; 0 (default): never on hosts with the x86 SHA extensions (the host hash runs under the
  *                   blob copy), from 512 blobs otherwise.

@@ -52,7 +52,7 @@ def hip_fk20():
         pytest.fail("libckzg_hip.so is not built")
     api = Kzg(HIP_SO, "", precompute=0, options={"direct_max": 0, "commit_wbits": 8})
     # restore the defaults for settings loaded later in the session
-    api.lib.ckzg_hip_set_option(b"direct_max", 24)
+    api.lib.ckzg_hip_set_option(b"direct_max", -1)
     api.lib.ckzg_hip_set_option(b"commit_wbits", 10)
     yield api
     api.close()

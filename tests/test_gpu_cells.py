@@ -79,7 +79,8 @@ def test_direct_and_fk20_paths_agree(hip, hip_fk20):
 
 
 def test_large_batch_takes_fk20_and_16_lane_msm_path(hip):
-    # 40 blobs > direct_max (24): FK20 path with 5120 small MSMs -> the 16-lanes-per-vector kernel
+    # 40 blobs > direct_max (10 with the default 8-bit proof table): FK20 path with 5120 small MSMs ->
+    # the 16-lanes-per-vector kernel
     n = 40
     base = [rand_blob(32, i) for i in range(4)]
     blobs = [base[i % 4] for i in range(n)]

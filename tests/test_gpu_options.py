@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _restore(api):
-    for k, v in (("commit_wbits", 10), ("fk20_wbits", 0), ("proof_wbits", 8), ("direct_max", 24)):
+    for k, v in (("commit_wbits", 10), ("fk20_wbits", 0), ("proof_wbits", 8), ("direct_max", -1)):
         api.lib.ckzg_hip_set_option(k.encode(), v)
 
 
