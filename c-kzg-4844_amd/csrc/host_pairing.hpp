@@ -26,16 +26,178 @@ inline Fp2 add(const Fp2 &a, const Fp2 &b) { return {add(a.c0, b.c0), add(a.c1, 
 inline Fp2 sub(const Fp2 &a, const Fp2 &b) { return {sub(a.c0, b.c0), sub(a.c1, b.c1)}; }
 inline Fp2 neg(const Fp2 &a) { return {neg(a.c0), neg(a.c1)}; }
 inline Fp2 dbl(const Fp2 &a) { return add(a, a); }
+#if defined(__SIZEOF_INT128__)
+// ---- double-width helpers for lazily reduced Fp2 products (host only, 64-bit limbs) ----
+struct FpWide {
+    uint64_t w[12];
+};
+inline void fp_load64(uint64_t x[6], const Fp &a) { __builtin_memcpy(x, a.l, 48); }
+// 6 x 6 -> 12 limbs, no reduction
+inline void fp_mul_wide(FpWide &r, const uint64_t a[6], const uint64_t b[6]) {
+    typedef unsigned __int128 u128;
+    uint64_t t[12] = {0};
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        u128 c = 0;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            c += (u128)a[j] * b[i] + t[i + j];
+            t[i + j] = (uint64_t)c;
+            c >>= 64;
+        }
+        t[i + 6] = (uint64_t)c;
+    }
+    __builtin_memcpy(r.w, t, sizeof t);
+}
+inline void wide_add(FpWide &r, const FpWide &a, const FpWide &b) {
+    typedef unsigned __int128 u128;
+    u128 c = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        c += (u128)a.w[i] + b.w[i];
+        r.w[i] = (uint64_t)c;
+        c >>= 64;
+    }
+}
+inline void wide_sub(FpWide &r, const FpWide &a, const FpWide &b) {  // a >= b required
+    typedef unsigned __int128 u128;
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        u128 d = (u128)a.w[i] - b.w[i] - br;
+        r.w[i] = (uint64_t)d;
+        br = (uint64_t)(d >> 64) & 1;
+    }
+}
+inline const FpWide &fp_p_squared() {
+    static const FpWide p2 = []() {
+        uint64_t m[6];
+        for (int i = 0; i < 6; i++) m[i] = (uint64_t)FP_P[2 * i] | ((uint64_t)FP_P[2 * i + 1] << 32);
+        FpWide r;
+        fp_mul_wide(r, m, m);
+        return r;
+    }();
+    return p2;
+}
+// Montgomery reduction of t < p * 2^384: t / 2^384 mod p, fully reduced
+inline Fp fp_redc(const FpWide &tin) {
+    typedef unsigned __int128 u128;
+    uint64_t t[13], m[6];
+    __builtin_memcpy(t, tin.w, sizeof tin.w);
+    t[12] = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) m[i] = (uint64_t)FP_P[2 * i] | ((uint64_t)FP_P[2 * i + 1] << 32);
+    constexpr uint64_t m0 = (uint64_t)FP_P[0] | ((uint64_t)FP_P[1] << 32);
+    constexpr uint64_t inv32 = (uint64_t)0 - (uint64_t)FP_NINV32;
+    constexpr uint64_t ninv = (uint64_t)0 - inv32 * (2 - m0 * inv32);
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const uint64_t q = t[i] * ninv;
+        u128 c = 0;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            c += (u128)q * m[j] + t[i + j];
+            t[i + j] = (uint64_t)c;
+            c >>= 64;
+        }
+#pragma unroll
+        for (int k = i + 6; k < 13; k++) {
+            c += t[k];
+            t[k] = (uint64_t)c;
+            c >>= 64;
+        }
+    }
+    uint64_t s[6], br = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        u128 d = (u128)t[6 + i] - m[i] - br;
+        s[i] = (uint64_t)d;
+        br = (uint64_t)(d >> 64) & 1;
+    }
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 6; i++) s[i] = br ? t[6 + i] : s[i];
+    __builtin_memcpy(r.l, s, 48);
+    return r;
+}
+inline Fp2 mul(const Fp2 &a, const Fp2 &b) {
+    // Karatsuba with lazy reduction: three double-width products, two Montgomery reductions.
+    // a0 + a1 < 2p needs no reduction (2p < 2^382), its product with b0 + b1 is < 4p^2 < p 2^384.
+    typedef unsigned __int128 u128;
+    uint64_t a0[6], a1[6], b0[6], b1[6], sa[6], sb[6];
+    fp_load64(a0, a.c0);
+    fp_load64(a1, a.c1);
+    fp_load64(b0, b.c0);
+    fp_load64(b1, b.c1);
+    u128 ca = 0, cb = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        ca += (u128)a0[i] + a1[i];
+        sa[i] = (uint64_t)ca;
+        ca >>= 64;
+        cb += (u128)b0[i] + b1[i];
+        sb[i] = (uint64_t)cb;
+        cb >>= 64;
+    }
+    FpWide t0, t1, t2, u;
+    fp_mul_wide(t0, a0, b0);
+    fp_mul_wide(t1, a1, b1);
+    fp_mul_wide(t2, sa, sb);
+    wide_sub(t2, t2, t0);             // a0 b1 + a1 b0 + a1 b1
+    wide_sub(t2, t2, t1);             // a0 b1 + a1 b0            (< 2p^2)
+    wide_add(u, t0, fp_p_squared());  // a0 b0 + p^2
+    wide_sub(u, u, t1);               // a0 b0 - a1 b1 + p^2      (in (0, 2p^2))
+    return {fp_redc(u), fp_redc(t2)};
+}
+#else
 inline Fp2 mul(const Fp2 &a, const Fp2 &b) {
     // Karatsuba: 3 base-field products
     Fp t0 = mul(a.c0, b.c0), t1 = mul(a.c1, b.c1);
     Fp t2 = mul(add(a.c0, a.c1), add(b.c0, b.c1));
     return {sub(t0, t1), sub(sub(t2, t0), t1)};
 }
+#endif
+#if defined(__SIZEOF_INT128__)
+inline Fp2 sqr(const Fp2 &a) {
+    // (a0 + a1)(a0 - a1 + p) and 2 a0 a1 as double-width products: both < 4p^2 < p 2^384
+    typedef unsigned __int128 u128;
+    uint64_t a0[6], a1[6], s[6], d[6], m[6];
+    fp_load64(a0, a.c0);
+    fp_load64(a1, a.c1);
+#pragma unroll
+    for (int i = 0; i < 6; i++) m[i] = (uint64_t)FP_P[2 * i] | ((uint64_t)FP_P[2 * i + 1] << 32);
+    u128 c = 0;
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        c += (u128)a0[i] + a1[i];
+        s[i] = (uint64_t)c;
+        c >>= 64;
+    }
+    c = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {  // a0 + p - a1 > 0
+        c += (u128)a0[i] + m[i];
+        uint64_t lo = (uint64_t)c;
+        c >>= 64;
+        u128 t = (u128)lo - a1[i] - br;
+        d[i] = (uint64_t)t;
+        br = (uint64_t)(t >> 64) & 1;
+        // a borrow out of limb i is repaid from the carry chain's next limb via br
+    }
+    // the final carry and borrow cancel: a0 + p - a1 < 2p < 2^384
+    FpWide t0, t1;
+    fp_mul_wide(t0, s, d);
+    fp_mul_wide(t1, a0, a1);
+    wide_add(t1, t1, t1);
+    return {fp_redc(t0), fp_redc(t1)};
+}
+#else
 inline Fp2 sqr(const Fp2 &a) {
     Fp m = mul(a.c0, a.c1);
     return {mul(add(a.c0, a.c1), sub(a.c0, a.c1)), dbl(m)};
 }
+#endif
 inline Fp2 mul_fp(const Fp2 &a, const Fp &k) { return {mul(a.c0, k), mul(a.c1, k)}; }
 inline Fp2 mul_xi(const Fp2 &a) { return {sub(a.c0, a.c1), add(a.c0, a.c1)}; }  // * (1+u)
 inline Fp2 inv(const Fp2 &a) {

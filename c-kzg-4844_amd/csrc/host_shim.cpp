@@ -275,6 +275,18 @@ extern "C" int hs_fp12_selftest(uint32_t seed) {
     a = mul(frobenius(a, 2), a);  // in the cyclotomic subgroup
     if (!same(cyclotomic_sqr(a), mul(a, a))) bad |= 4;
     if (same(cyclotomic_sqr(f), mul(f, f))) bad |= 8;
+    // bit 4: the lazily reduced Fp2 product and square against the schoolbook formulas on Fp
+    for (int rep = 0; rep < 8; rep++) {
+        Fp2 x = rnd_fp2(), y = rnd_fp2();
+        if (rep == 0) y = x;
+        if (rep == 1) { x.c0 = Fp::zero(); y.c1 = Fp::zero(); }
+        if (rep == 2) { x.c0 = neg(Fp::one()); x.c1 = neg(Fp::one()); y = x; }  // p - 1 in both slots
+        Fp2 want = {sub(mul(x.c0, y.c0), mul(x.c1, y.c1)), add(mul(x.c0, y.c1), mul(x.c1, y.c0))};
+        Fp2 got = mul(x, y);
+        if (!(got == want)) bad |= 16;
+        Fp2 sq = sqr(x), sqw = {sub(mul(x.c0, x.c0), mul(x.c1, x.c1)), dbl(mul(x.c0, x.c1))};
+        if (!(sq == sqw)) bad |= 16;
+    }
     return bad;
 }
 
