@@ -226,6 +226,13 @@ extern "C" int hs_bench_pairing(const G1Jac *a1, const G2Jac *q1, const G1Jac *a
     for (int i = 0; i < n; i++) ok += pairing_product_is_one(x1, p1, x2, p2) ? 1 : 0;
     return ok;
 }
+// n final exponentiations of a fixed Miller-loop value (timing only)
+extern "C" int hs_bench_final_exp(const G1Jac *a1, const G2Jac *q1, int n) {
+    Fp12 f = miller_loop(g2_to_affine(*q1), jac_to_affine(*a1));
+    int ones = 0;
+    for (int i = 0; i < n; i++) ones += final_exp(f).is_one() ? 1 : 0;
+    return ones;
+}
 extern "C" void hs_bench_fp_mul(Fp *r, const Fp *a, const Fp *b, int n) {
     Fp x = *a;
     for (int i = 0; i < n; i++) x = mul(x, *b);
