@@ -32,22 +32,27 @@ struct FpWide {
     uint64_t w[12];
 };
 inline void fp_load64(uint64_t x[6], const Fp &a) { __builtin_memcpy(x, a.l, 48); }
-// 6 x 6 -> 12 limbs, no reduction
+// 6 x 6 -> 12 limbs, no reduction: product scanning (Comba) with a three-word column accumulator
 inline void fp_mul_wide(FpWide &r, const uint64_t a[6], const uint64_t b[6]) {
     typedef unsigned __int128 u128;
-    uint64_t t[12] = {0};
+    uint64_t acc0 = 0, acc1 = 0, acc2 = 0;
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-        u128 c = 0;
+    for (int k = 0; k < 11; k++) {
 #pragma unroll
-        for (int j = 0; j < 6; j++) {
-            c += (u128)a[j] * b[i] + t[i + j];
-            t[i + j] = (uint64_t)c;
-            c >>= 64;
+        for (int i = (k < 6 ? 0 : k - 5); i <= (k < 6 ? k : 5); i++) {
+            u128 p = (u128)a[i] * b[k - i];
+            u128 s = (u128)acc0 + (uint64_t)p;
+            acc0 = (uint64_t)s;
+            s = (u128)acc1 + (uint64_t)(p >> 64) + (uint64_t)(s >> 64);
+            acc1 = (uint64_t)s;
+            acc2 += (uint64_t)(s >> 64);
         }
-        t[i + 6] = (uint64_t)c;
+        r.w[k] = acc0;
+        acc0 = acc1;
+        acc1 = acc2;
+        acc2 = 0;
     }
-    __builtin_memcpy(r.w, t, sizeof t);
+    r.w[11] = acc0;
 }
 inline void wide_add(FpWide &r, const FpWide &a, const FpWide &b) {
     typedef unsigned __int128 u128;
