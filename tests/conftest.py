@@ -17,6 +17,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A checkout without build products (they are git-ignored) still gets a usable suite: build what is
+    missing once, the way __graft_entry__.build() does.  hipcc cross-compiles gfx950 without a GPU."""
+    if os.environ.get("CKZG_TESTS_NO_AUTOBUILD"):
+        return
+    try:
+        if not os.path.exists(HIP_SO) or not os.path.exists(SHIM_SO):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "c-kzg-4844_amd"), "-j", "8", "all"],
+                                  stdout=subprocess.DEVNULL)
+        if not os.path.exists(ORACLE_SO):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    except (OSError, subprocess.CalledProcessError) as e:  # the tests that need the artefact fail loudly themselves
+        sys.stderr.write("conftest: automatic build failed: %s\n" % e)
+
+
 def _ensure_oracle():
     if not os.path.exists(ORACLE_SO):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
