@@ -19,26 +19,15 @@ __device__ __forceinline__ void load_be256(uint32_t s[8], const uint8_t *p) {
     s[0] = __builtin_bswap32(b.w);
 }
 
-// signed base-2^wbits digits of a 256-bit integer, digit w written at dst[w * stride].
-// Digits lie in [-2^(wbits-1), 2^(wbits-1) - 1], so they fit int16_t up to wbits = 16.  With
-// wbits in {4, 8, 16} the nwin windows cover exactly 256 bits: the top digit of a canonical scalar
-// (< r < 0.46 * 2^255) stays below 2^(wbits-1) and never carries out.
-__device__ __forceinline__ void recode_signed(int16_t *dst, size_t stride, uint32_t s[8], int wbits,
-                                              int nwin) {
-    const uint32_t mask = (1u << wbits) - 1u, half = 1u << (wbits - 1);
-    uint32_t carry = 0;
-    for (int w = 0; w < nwin; w++) {
-        int d = (int)((s[0] & mask) + carry);
-#pragma unroll
-        for (int k = 0; k < 7; k++) s[k] = (s[k] >> wbits) | (s[k + 1] << (32 - wbits));
-        s[7] >>= wbits;
-        carry = 0;
-        if ((uint32_t)d >= half) {
-            d -= (int)(mask + 1u);
-            carry = 1;
-        }
-        dst[(size_t)w * stride] = (int16_t)d;
-    }
+// Digits of one canonical scalar for the fixed-base MSM kernels (device.hpp: FixedBaseTable): balanced
+// GLV split, then twin signed windows per half -- windows 0..twin-1 from k2 (the phi half),
+// twin..2*twin-1 from k1; digit w lands at dst[w * stride].
+__device__ __forceinline__ void glv_digits(int16_t *dst, size_t stride, const uint32_t *s, int wbits, int twin) {
+    uint32_t m1[4], m2[4];
+    bool n1, n2;
+    glv_split_signed(s, m1, n1, m2, n2);
+    recode_signed_128(dst, stride, m2, n2, wbits, twin);
+    recode_signed_128(dst + (size_t)twin * stride, stride, m1, n1, wbits, twin);
 }
 
 // Fold the per-thread accumulators (28-bit domain) of a workgroup into thread 0.  LDS is

@@ -18,16 +18,23 @@ constexpr int N_CELL = 64;         // FIELD_ELEMENTS_PER_CELL
 constexpr int N_CELLS_EXT = 128;   // CELLS_PER_EXT_BLOB
 
 // Fixed-base table over `npoints` bases: entry (w, i, e) = (e+1) * 2^(wbits*w) * P_i, affine,
-// Montgomery form, laid out [w][i][e] with e < half = 2^(wbits-1).  A scalar is recoded into
-// nwin = floor(255/wbits)+1 signed digits in [-half, half]; the MSM is then a plain sum of
-// npoints*nwin table entries -- no buckets, no doublings, no data-dependent scatter.
+// Montgomery form, laid out [w][i][e] with e < half = 2^(wbits-1), w < twin.  The table covers only
+// 128-bit half-scalars: a scalar k is split as k = k1 + lambda*k2 (balanced GLV, g1_28.hpp:
+// glv_split_signed, |k1|, |k2| < 0.68 * 2^127) and phi(P) = (beta*x, y) = [lambda]P turns the k2 half
+// into the same table entries with x multiplied by beta -- applied ONCE to the partial sum of all k2
+// terms (phi is a homomorphism), never per addition.  So twin = floor(127/wbits)+1 windows are stored
+// and each scalar yields nwin = 2*twin signed digits in [-half, half]: windows 0..twin-1 are the k2
+// (phi) half, twin..nwin-1 the k1 half.  The MSM is a plain sum of npoints*nwin table entries -- no
+// buckets, no doublings, no data-dependent scatter -- at half the memory of a 255-bit table.
 struct FixedBaseTable {
     G1Affine *d_table = nullptr;
     int npoints = 0;
     int wbits = 0;
-    int nwin = 0;
+    int nwin = 0;   // digit windows per scalar (both GLV halves)
+    int twin = 0;   // table windows = nwin / 2
     size_t half = 0;
-    size_t bytes() const { return (size_t)nwin * npoints * half * sizeof(G1Affine); }
+    size_t bytes() const { return (size_t)twin * npoints * half * sizeof(G1Affine); }
+    static int twin_for(int wbits) { return 127 / wbits + 1; }
 };
 
 struct Scratch {

@@ -23,9 +23,9 @@ static int fit_wbits(const char *what, int wbits, int floor_bits, int npoints) {
     const size_t margin = (size_t)6 << 30;
     const int asked = wbits;
     while (wbits > floor_bits) {
-        size_t nwin = 255 / wbits + 1, half = (size_t)1 << (wbits - 1), slab = (size_t)npoints * half;
-        size_t need = nwin * slab * sizeof(G1Affine) + nwin * npoints * sizeof(G1XYZZ) +
-                      slab * (sizeof(G1XYZZ) + sizeof(Fp)) + margin;
+        size_t twin = dev::FixedBaseTable::twin_for(wbits), half = (size_t)1 << (wbits - 1);
+        // table + window bases + construction scratch (bounded at ~2 GiB, msm.hip) + per-call scratch
+        size_t need = twin * npoints * half * sizeof(G1Affine) + twin * npoints * sizeof(G1XYZZ) + ((size_t)3 << 30) + margin;
         if (need <= free_b) break;
         wbits--;
     }

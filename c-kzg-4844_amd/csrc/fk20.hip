@@ -62,7 +62,7 @@ __global__ void k_fk20_circulant(Fr *circ, const Fr *poly, size_t total) {
 
 // cfft[v][i][p] holds (after the DIF NTT, already scaled by 1/128) the value for MSM column
 // j = brp7(p).  Recode it into digits[(v*128 + j)][w][i].
-__global__ void k_fk20_digits(int16_t *digits, const Fr *cfft, size_t total, int wbits, int nwin) {
+__global__ void k_fk20_digits(int16_t *digits, const Fr *cfft, size_t total, int wbits, int twin) {
     size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (g >= total) return;
     size_t v = g >> 13;
@@ -70,7 +70,7 @@ __global__ void k_fk20_digits(int16_t *digits, const Fr *cfft, size_t total, int
     uint32_t j = brp7(p);
     uint32_t s[8];
     to_raw<FrParams>(s, ld_fr(cfft + g));
-    recode_signed(digits + ((v * 128 + j) * (size_t)nwin * 64) + i, 64, s, wbits, nwin);
+    glv_digits(digits + ((v * 128 + j) * (size_t)(2 * twin) * 64) + i, 64, s, wbits, twin);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -313,7 +313,7 @@ static int fk20_run(DeviceCtx *ctx, uint8_t *d_proofs, const Fr *d_poly, size_t 
     rc = fr_ntt_batch(ctx, s.circ, n * 64, 7, /*dif=*/true, /*inverse=*/false, /*scale=*/true);
     if (rc) return rc;
     hipLaunchKernelGGL(k_fk20_digits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
-                       s.digits, s.circ, total, t.wbits, t.nwin);
+                       s.digits, s.circ, total, t.wbits, t.twin);
     HIP_TRY(hipGetLastError());
     rc = msm_small_vectors_device(ctx, t, s.u, s.digits, n * 128, 64, 128);
     if (rc) return rc;
@@ -360,14 +360,14 @@ __global__ void k_direct_fill(Fr *a, const Fr *poly, size_t total) {
 }
 
 // a[v][u][k'] -> digits[(v*128 + k')][w][u]
-__global__ void k_direct_digits(int16_t *digits, const Fr *a, size_t total, int wbits, int nwin) {
+__global__ void k_direct_digits(int16_t *digits, const Fr *a, size_t total, int wbits, int twin) {
     size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (g >= total) return;
     uint32_t u = (uint32_t)g & 4095u, kp = (uint32_t)(g >> 12) & 127u;
     size_t v = g >> 19;
     uint32_t s[8];
     to_raw<FrParams>(s, ld_fr(a + (((v << 12) + u) << 7) + kp));
-    recode_signed(digits + ((v * 128 + kp) * (size_t)nwin * N_BLOB) + u, N_BLOB, s, wbits, nwin);
+    glv_digits(digits + ((v * 128 + kp) * (size_t)(2 * twin) * N_BLOB) + u, N_BLOB, s, wbits, twin);
 }
 
 struct DirectScratch {
@@ -400,7 +400,7 @@ static int direct_run(DeviceCtx *ctx, uint8_t *d_proofs, const Fr *d_poly, size_
     int rc = fr_ntt_batch(ctx, s.a, n * 4096, 7, /*dif=*/true, /*inverse=*/false, /*scale=*/false);
     if (rc) return rc;
     hipLaunchKernelGGL(k_direct_digits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
-                       s.digits, s.a, total, t.wbits, t.nwin);
+                       s.digits, s.a, total, t.wbits, t.twin);
     HIP_TRY(hipGetLastError());
     return msm_from_digits_device(ctx, t, d_proofs, s.digits, s.partials, n * 128);
 }

@@ -274,6 +274,210 @@ HDNI inline void glv_split(const uint32_t *k, uint32_t *k1, uint32_t *k2) {
     }
 }
 
+// Balanced GLV split for the fixed-base tables: k = s1*m1 + lambda * s2*m2 (mod r) with signs s1, s2 and
+// magnitudes m1, m2 <= (lambda + 3)/2 < 0.68 * 2^127, so that a signed c-bit recoding of either half fits
+// floor(127/c) + 1 windows without a carry out of the top one (msm.hip).  Straight-line code, one per
+// blob field element: k2 = floor(k / lambda) by a Barrett product with G = floor(2^383 / lambda)
+// (estimate is k2 or k2 - 1, fixed by one conditional subtraction), then the two centring steps
+//   k1 > lambda/2      ->  (k1 - lambda, k2 + 1)              [same value]
+//   k2 > (lambda+1)/2  ->  (k1 - 1, k2 - (lambda + 1))        [value - r, since lambda^2 + lambda + 1 = r]
+// k: canonical (< r) little-endian u32 limbs.
+HD void glv_split_signed(const uint32_t *k, uint32_t *m1, bool &neg1, uint32_t *m2, bool &neg2) {
+    // high part of k * G: only limbs 11..15 of the 512-bit product are needed, but the carries into them
+    // come from every column, so all 64 partial products are accumulated (column sums in 64 + 32 bits)
+    uint32_t prod[16];
+    {
+        uint64_t lo = 0;
+        uint32_t hi = 0;  // column accumulator: hi:lo
+#pragma unroll
+        for (int c = 0; c < 15; c++) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int j = c - i;
+                if (j < 0 || j > 7) continue;
+                const uint64_t t = (uint64_t)k[i] * FR_LAMBDA_RECIP383[j];
+                lo += t;
+                hi += lo < t ? 1u : 0u;
+            }
+            prod[c] = (uint32_t)lo;
+            lo = (lo >> 32) | ((uint64_t)hi << 32);
+            hi = 0;
+        }
+        prod[15] = (uint32_t)lo;
+    }
+    uint32_t q[5];
+#pragma unroll
+    for (int i = 0; i < 4; i++) q[i] = (prod[11 + i] >> 31) | (prod[12 + i] << 1);
+    q[4] = prod[15] >> 31;  // 0: k < 2^255 and G < 2^256
+    // rem = k - q * lambda, low 160 bits (the true value is in [0, 2 lambda))
+    uint32_t ql[5];
+    {
+        uint64_t lo = 0;
+        uint32_t hi = 0;
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int j = c - i;
+                if (j < 0 || j > 3) continue;
+                const uint64_t t = (uint64_t)q[i] * FR_LAMBDA[j];
+                lo += t;
+                hi += lo < t ? 1u : 0u;
+            }
+            ql[c] = (uint32_t)lo;
+            lo = (lo >> 32) | ((uint64_t)hi << 32);
+            hi = 0;
+        }
+    }
+    uint32_t rem[5];
+    {
+        uint32_t br = 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const uint64_t d = (uint64_t)k[i] - ql[i] - br;
+            rem[i] = (uint32_t)d;
+            br = (uint32_t)(d >> 32) & 1u;
+        }
+    }
+    auto geq_lambda = [](const uint32_t *v) {  // v (5 limbs) >= lambda
+        if (v[4]) return true;
+        for (int i = 3; i >= 0; i--) {
+            if (v[i] != FR_LAMBDA[i]) return v[i] > FR_LAMBDA[i];
+        }
+        return true;
+    };
+    if (geq_lambda(rem)) {
+        uint32_t br = 0, c = 1;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const uint64_t d = (uint64_t)rem[i] - (i < 4 ? FR_LAMBDA[i] : 0u) - br;
+            rem[i] = (uint32_t)d;
+            br = (uint32_t)(d >> 32) & 1u;
+            const uint64_t a = (uint64_t)q[i] + c;
+            q[i] = (uint32_t)a;
+            c = (uint32_t)(a >> 32);
+        }
+    }
+    // now k = rem + lambda * q with 0 <= rem < lambda, 0 <= q <= lambda + 1
+    // centre k1: 2*rem > lambda ?
+    uint32_t dbl[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) dbl[i] = (rem[i] << 1) | (i ? rem[i - 1] >> 31 : 0u);
+    bool n1 = false;
+    {
+        bool gt = dbl[4] != 0;
+        if (!gt) {
+            gt = false;
+            for (int i = 3; i >= 0; i--) {
+                if (dbl[i] != FR_LAMBDA[i]) {
+                    gt = dbl[i] > FR_LAMBDA[i];
+                    break;
+                }
+            }
+        }
+        if (gt) {
+            // rem <- lambda - rem (magnitude of the negative value), q <- q + 1
+            uint32_t br = 0, c = 1;
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                const uint64_t d = (uint64_t)(i < 4 ? FR_LAMBDA[i] : 0u) - rem[i] - br;
+                rem[i] = (uint32_t)d;
+                br = (uint32_t)(d >> 32) & 1u;
+                const uint64_t a = (uint64_t)q[i] + c;
+                q[i] = (uint32_t)a;
+                c = (uint32_t)(a >> 32);
+            }
+            n1 = true;
+        }
+    }
+    // centre k2: 2*q > lambda + 1 ?   (lambda + 1 = x^2: limb 0 of lambda is 0xffffffff, so add with carry)
+    uint32_t lp1[5];
+    {
+        uint32_t c = 1;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const uint64_t a = (uint64_t)(i < 4 ? FR_LAMBDA[i] : 0u) + c;
+            lp1[i] = (uint32_t)a;
+            c = (uint32_t)(a >> 32);
+        }
+    }
+    bool n2 = false;
+    {
+        uint32_t d2[6];
+#pragma unroll
+        for (int i = 0; i < 5; i++) d2[i] = (q[i] << 1) | (i ? q[i - 1] >> 31 : 0u);
+        d2[5] = q[4] >> 31;
+        bool gt = d2[5] != 0;
+        if (!gt) {
+            for (int i = 4; i >= 0; i--) {
+                if (d2[i] != lp1[i]) {
+                    gt = d2[i] > lp1[i];
+                    break;
+                }
+            }
+        }
+        if (gt) {
+            // q <- (lambda + 1) - q (magnitude), k1 <- k1 - 1
+            uint32_t br = 0;
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                const uint64_t d = (uint64_t)lp1[i] - q[i] - br;
+                q[i] = (uint32_t)d;
+                br = (uint32_t)(d >> 32) & 1u;
+            }
+            n2 = true;
+            const bool zero = (rem[0] | rem[1] | rem[2] | rem[3] | rem[4]) == 0;
+            if (n1 || zero) {  // magnitude grows: -(m) - 1 = -(m + 1);  0 - 1 = -(1)
+                uint32_t c = 1;
+#pragma unroll
+                for (int i = 0; i < 5; i++) {
+                    const uint64_t a = (uint64_t)rem[i] + c;
+                    rem[i] = (uint32_t)a;
+                    c = (uint32_t)(a >> 32);
+                }
+                n1 = true;
+            } else {
+                uint32_t br2 = 1;
+#pragma unroll
+                for (int i = 0; i < 5; i++) {
+                    const uint64_t d = (uint64_t)rem[i] - br2;
+                    rem[i] = (uint32_t)d;
+                    br2 = (uint32_t)(d >> 32) & 1u;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        m1[i] = rem[i];
+        m2[i] = q[i];
+    }
+    neg1 = n1;
+    neg2 = n2;
+}
+
+// Signed base-2^wbits digits of the signed half-scalar (neg ? -m : m), m < 2^(wbits*nwh - 1), digit w
+// written at dst[w * stride].  Stored digits lie in [-2^(wbits-1), 2^(wbits-1) - 1] (int16_t up to
+// wbits = 16): a non-negative value rounds a window of exactly 2^(wbits-1) down to -2^(wbits-1) with a
+// carry, a negative one keeps +2^(wbits-1) and stores its negation.
+HD void recode_signed_128(int16_t *dst, size_t stride, const uint32_t *m, bool neg, int wbits, int nwh) {
+    uint32_t s[5] = {m[0], m[1], m[2], m[3], 0u};
+    const uint32_t mask = (1u << wbits) - 1u, half = 1u << (wbits - 1);
+    uint32_t carry = 0;
+    for (int w = 0; w < nwh; w++) {
+        int d = (int)((s[0] & mask) + carry);
+#pragma unroll
+        for (int k = 0; k < 4; k++) s[k] = (s[k] >> wbits) | (s[k + 1] << (32 - wbits));
+        s[4] >>= wbits;
+        carry = 0;
+        if (neg ? (uint32_t)d > half : (uint32_t)d >= half) {
+            d -= (int)(mask + 1u);
+            carry = 1;
+        }
+        dst[(size_t)w * stride] = (int16_t)(neg ? -d : d);
+    }
+}
+
 // Width-4 non-adjacent form of a 128-bit k: digits in {0, +-1, +-3, +-5, +-7}, digit i has weight 2^i,
 // at most one non-zero digit in any 4 consecutive positions (density 1/5).  out has GLV_NAF_LEN entries.
 constexpr int GLV_NAF_LEN = 132;

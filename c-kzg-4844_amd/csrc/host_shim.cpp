@@ -2,6 +2,7 @@
 // test-suite (tests/test_host_arith.py) can compare it limb for limb with the oracle.  Built with
 // plain g++ (no GPU needed); it is a test aid for the product's own headers, not part of
 // libckzg_hip.so.
+#include <vector>
 #include "host_pairing.hpp"
 using namespace ckzg;
 using namespace ckzg::host;
@@ -315,3 +316,62 @@ void hs_fp28_inv(Fp *r, const Fp *a) { *r = f28_to_fp(f28_inv_fermat(f28_from_fp
 }
 
 extern "C" void hs_fp28_inv_safegcd(Fp *r, const Fp *a) { *r = f28_to_fp(f28_inv_safegcd(f28_from_fp(*a))); }
+
+// balanced GLV split + signed window recoding of the fixed-base MSM kernels (g1_28.hpp)
+extern "C" void hs_glv_split_signed(const uint32_t *k, uint32_t *m1, int *neg1, uint32_t *m2, int *neg2) {
+    bool n1, n2;
+    glv_split_signed(k, m1, n1, m2, n2);
+    *neg1 = n1;
+    *neg2 = n2;
+}
+extern "C" void hs_recode_signed_128(int16_t *dst, const uint32_t *m, int neg, int wbits, int nwh) {
+    recode_signed_128(dst, 1, m, neg != 0, wbits, nwh);
+}
+
+// The fixed-base MSM kernels' algorithm (msm.hip: k_msm_accumulate / k_msm_small) replayed on the host
+// with the very same inline functions: GLV digits, table entries (mag * 2^(wbits*tw) * P_i, computed here
+// on demand instead of read from HBM), sign-alternating mixed additions, phi applied once per lane when it
+// crosses from the k2 half into the k1 half, lane partials folded with xyzz28_add.
+extern "C" void hs_msm_glv_emulate(G1Jac *r, const G1Affine *pts, const uint32_t *scalars, int n, int wbits,
+                                   int lanes) {
+    const int twin = 127 / wbits + 1, nwin = 2 * twin;
+    std::vector<int16_t> dg((size_t)nwin * n);
+    for (int i = 0; i < n; i++) {
+        uint32_t m1[4], m2[4];
+        bool n1, n2;
+        glv_split_signed(scalars + 8 * i, m1, n1, m2, n2);
+        recode_signed_128(dg.data() + i, n, m2, n2, wbits, twin);
+        recode_signed_128(dg.data() + (size_t)twin * n + i, n, m1, n1, wbits, twin);
+    }
+    const uint32_t pairs = (uint32_t)nwin * n, phi_pairs = pairs / 2;
+    XYZZ28 total;
+    bool tinf = true;
+    for (int l = 0; l < lanes; l++) {
+        XYZZ28 acc;
+        bool inf = true, yneg = false, phi_pending = (uint32_t)l < phi_pairs;
+        for (uint32_t q = l; q < pairs; q += lanes) {
+            if (phi_pending && q >= phi_pairs) {
+                if (!inf) acc.x = widen<1, 10>(mul(acc.x, f28_const<1, 1>(FP28_BETA_LAMBDA)));
+                phi_pending = false;
+            }
+            int d = dg[q];
+            if (d == 0) continue;
+            uint32_t w = q / n, i = q - w * n, tw = w >= (uint32_t)twin ? w - twin : w;
+            uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+            G1Jac e = jac_from_affine(pts[i]);
+            for (uint32_t k = 0; k < tw * (uint32_t)wbits; k++) e = jac_dbl(e);
+            G1Jac m = G1Jac::inf();
+            for (int b = 31; b >= 0; b--) {
+                m = jac_dbl(m);
+                if ((mag >> b) & 1u) m = jac_add(m, e);
+            }
+            if (m.is_inf()) continue;  // a table entry at infinity is skipped by the kernels too
+            G1Affine a = jac_to_affine(m);
+            xyzz28_madd_alt(acc, inf, yneg, table_coord(a.x), table_coord(a.y), d < 0);
+        }
+        if (phi_pending && !inf) acc.x = widen<1, 10>(mul(acc.x, f28_const<1, 1>(FP28_BETA_LAMBDA)));
+        xyzz28_fix_sign(acc, inf, yneg);
+        xyzz28_add(total, tinf, acc, inf);
+    }
+    *r = jac_from_affine(xyzz28_to_affine(total, tinf));
+}

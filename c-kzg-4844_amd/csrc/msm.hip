@@ -33,6 +33,7 @@ int scratch_reserve(DeviceCtx *ctx, size_t bytes) {
     size_t want = bytes + (bytes >> 2);
     hipError_t e = hipMalloc(&ctx->scratch.ptr, want);
     if (e != hipSuccess) {
+        (void)hipGetLastError();  // the failed attempt must not surface at the next hipGetLastError()
         want = bytes;
         HIP_TRY(hipMalloc(&ctx->scratch.ptr, want));
     }
@@ -126,37 +127,55 @@ int batch_to_affine_device(DeviceCtx *ctx, G1Affine *d_out, const G1XYZZ *d_in, 
     return 0;
 }
 
+namespace {
+struct DevTmp {  // freed on every exit path of build_fixed_base_table
+    void *p = nullptr;
+    ~DevTmp() {
+        if (p) (void)hipFree(p);
+    }
+};
+}  // namespace
+
 int build_fixed_base_table(DeviceCtx *ctx, FixedBaseTable *t, const G1Affine *d_bases, int npoints,
                            int wbits) {
     if (wbits < 2 || wbits > 16) return 1;
     t->npoints = npoints;
     t->wbits = wbits;
-    t->nwin = 255 / wbits + 1;
+    t->twin = FixedBaseTable::twin_for(wbits);
+    t->nwin = 2 * t->twin;
     t->half = (size_t)1 << (wbits - 1);
-    size_t slab = (size_t)npoints * t->half;
-    G1XYZZ *d_wb = nullptr, *d_tmp = nullptr;
-    Fp *d_prefix = nullptr;
+    // one window of a chunk of points at a time, so that the construction scratch (240 B per entry) stays
+    // below ~2 GiB whatever the table width
+    size_t per_point = t->half * (sizeof(G1XYZZ) + sizeof(Fp));
+    int chunk = (int)(((size_t)2 << 30) / per_point);
+    if (chunk < 1) chunk = 1;
+    if (chunk > npoints) chunk = npoints;
+    const size_t slab = (size_t)chunk * t->half;
+    DevTmp wb, tmp, prefix;
     HIP_TRY(hipMalloc(&t->d_table, t->bytes()));
-    HIP_TRY(hipMalloc(&d_wb, (size_t)t->nwin * npoints * sizeof(G1XYZZ)));
-    HIP_TRY(hipMalloc(&d_tmp, slab * sizeof(G1XYZZ)));
-    HIP_TRY(hipMalloc(&d_prefix, slab * sizeof(Fp)));
+    HIP_TRY(hipMalloc(&wb.p, (size_t)t->twin * npoints * sizeof(G1XYZZ)));
+    HIP_TRY(hipMalloc(&tmp.p, slab * sizeof(G1XYZZ)));
+    HIP_TRY(hipMalloc(&prefix.p, slab * sizeof(Fp)));
+    G1XYZZ *d_wb = static_cast<G1XYZZ *>(wb.p), *d_tmp = static_cast<G1XYZZ *>(tmp.p);
+    Fp *d_prefix = static_cast<Fp *>(prefix.p);
     hipLaunchKernelGGL(k_window_bases, dim3((npoints + 63) / 64), dim3(64), 0, ctx->stream, d_wb,
-                       d_bases, npoints, wbits, t->nwin);
+                       d_bases, npoints, wbits, t->twin);
     const int L = 128;
-    size_t segs = (t->half + CHAIN_SEG - 1) / CHAIN_SEG;
-    size_t chain_threads = (size_t)npoints * segs;
-    size_t aff_threads = (slab + L - 1) / L;
-    for (int w = 0; w < t->nwin; w++) {
-        hipLaunchKernelGGL(k_table_chain, dim3((unsigned)((chain_threads + 63) / 64)), dim3(64), 0,
-                           ctx->stream, d_tmp, d_wb + (size_t)w * npoints, npoints, t->half);
-        hipLaunchKernelGGL(k_batch_to_affine, dim3((unsigned)((aff_threads + 63) / 64)), dim3(64), 0,
-                           ctx->stream, t->d_table + (size_t)w * slab, d_tmp, d_prefix, slab, L, 1);
+    const size_t segs = (t->half + CHAIN_SEG - 1) / CHAIN_SEG;
+    for (int w = 0; w < t->twin; w++) {
+        for (int i0 = 0; i0 < npoints; i0 += chunk) {
+            const int cnt = npoints - i0 < chunk ? npoints - i0 : chunk;
+            const size_t entries = (size_t)cnt * t->half;
+            const size_t chain_threads = (size_t)cnt * segs, aff_threads = (entries + L - 1) / L;
+            hipLaunchKernelGGL(k_table_chain, dim3((unsigned)((chain_threads + 63) / 64)), dim3(64), 0,
+                               ctx->stream, d_tmp, d_wb + (size_t)w * npoints + i0, cnt, t->half);
+            hipLaunchKernelGGL(k_batch_to_affine, dim3((unsigned)((aff_threads + 63) / 64)), dim3(64), 0,
+                               ctx->stream, t->d_table + ((size_t)w * npoints + i0) * t->half, d_tmp, d_prefix,
+                               entries, L, 1);
+        }
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipFree(d_wb));
-    HIP_TRY(hipFree(d_tmp));
-    HIP_TRY(hipFree(d_prefix));
     return 0;
 }
 
@@ -165,9 +184,10 @@ int build_fixed_base_table(DeviceCtx *ctx, FixedBaseTable *t, const G1Affine *d_
 // ------------------------------------------------------------------------------------------
 
 // One thread per field element of the batch: big-endian bytes -> canonical check (blob.c:31-38 /
-// bytes.c:64-70: a value >= r makes the whole blob BADARGS) -> digits[blob][w][i].
+// bytes.c:64-70: a value >= r makes the whole blob BADARGS) -> balanced GLV split -> signed digits
+// digits[blob][w][i]: windows 0..twin-1 from k2 (the phi half), twin..2*twin-1 from k1.
 __global__ void k_blob_digits(int16_t *digits, uint32_t *bad, const uint8_t *blobs, size_t total,
-                              int wbits, int nwin) {
+                              int wbits, int twin) {
     size_t gid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (gid >= total) return;
     size_t blob = gid >> 12;
@@ -176,13 +196,18 @@ __global__ void k_blob_digits(int16_t *digits, uint32_t *bad, const uint8_t *blo
     load_be256(s, blobs + gid * 32);
 #pragma unroll
     for (int k = 0; k < 8; k++) r[k] = FR_R[k];
-    if (limbs_geq<8>(s, r)) atomicOr(&bad[blob], 1u);
-    recode_signed(digits + blob * (size_t)nwin * N_BLOB + i, N_BLOB, s, wbits, nwin);
+    if (limbs_geq<8>(s, r)) {
+        atomicOr(&bad[blob], 1u);
+        // the blob's output is unspecified, but its digits must stay inside the table
+#pragma unroll
+        for (int k = 0; k < 8; k++) s[k] = 0;
+    }
+    glv_digits(digits + blob * (size_t)(2 * twin) * N_BLOB + i, N_BLOB, s, wbits, twin);
 }
 
 // Same for scalars that are already canonical little-endian integers ([n][4096][8] u32)
 __global__ void k_raw_digits(int16_t *digits, const uint32_t *scalars, size_t total, int wbits,
-                             int nwin) {
+                             int twin) {
     size_t gid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (gid >= total) return;
     size_t vec = gid >> 12;
@@ -192,19 +217,45 @@ __global__ void k_raw_digits(int16_t *digits, const uint32_t *scalars, size_t to
     uint4 a = q[0], b = q[1];
     s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
     s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
-    recode_signed(digits + vec * (size_t)nwin * N_BLOB + i, N_BLOB, s, wbits, nwin);
+    glv_digits(digits + vec * (size_t)(2 * twin) * N_BLOB + i, N_BLOB, s, wbits, twin);
 }
 
 // ------------------------------------------------------------------------------------------
 // accumulate: the dominant kernel
 // ------------------------------------------------------------------------------------------
 
+// One term of a fixed-base sum: gather table entry (tw, pt, |d|) and add its +-multiple to the accumulator.
+__device__ __forceinline__ void msm_term(XYZZ28 &acc28, bool &inf, bool &yneg, const G1Affine *table, size_t p,
+                                         int half_shift, int d) {
+    uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+    const uint4 *src = reinterpret_cast<const uint4 *>(table + ((p << half_shift) + (mag - 1)));
+    uint32_t wd[24];
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        uint4 v = src[k];
+        wd[4 * k] = v.x; wd[4 * k + 1] = v.y; wd[4 * k + 2] = v.z; wd[4 * k + 3] = v.w;
+        any |= v.x | v.y | v.z | v.w;
+    }
+    if (any != 0) {  // (0,0) encodes a table entry at infinity
+        xyzz28_madd_alt(acc28, inf, yneg, f28_unpack<1>(wd), f28_unpack<1>(wd + 12), d < 0);
+    }
+}
+
+// phi(X, Y, ZZ, ZZZ) = (beta X, Y, ZZ, ZZZ) = [lambda](X, Y, ZZ, ZZZ) on G1: turns the sum of the k2-half
+// terms, which were gathered from the plain table, into the sum over the phi-mapped bases.
+__device__ __forceinline__ void msm_apply_phi(XYZZ28 &acc28) {
+    acc28.x = widen<1, 10>(mul(acc28.x, f28_const<1, 1>(FP28_BETA_LAMBDA)));
+}
+
 // grid: nvec * blocks_per_vec workgroups.  A "vector" is one MSM: ppv (points per vector) scalars
-// recoded to digits[vec][w][i], i < ppv.  Its bases are points voff..voff+ppv of a table over
-// npoints bases, voff = (vec % vecs_per_group) * ppv  (commitment: ppv = npoints = 4096, one
-// group; FK20: ppv = 64, 128 vectors per blob over the 8192 x_ext_fft points).
+// recoded to digits[vec][w][i], i < ppv, w < nwin = 2*twin.  Its bases are points voff..voff+ppv of a
+// table over npoints bases, voff = (vec % vecs_per_group) * ppv  (commitment: ppv = npoints = 4096,
+// one group; FK20: ppv = 64, 128 vectors per blob over the 8192 x_ext_fft points).
 // Workgroup (v, c) sums the table entries selected by pairs q in [c*ppb, (c+1)*ppb) of vector v,
-// q = w*ppv + i, into partials[v*blocks_per_vec + c].
+// q = w*ppv + i, into partials[v*blocks_per_vec + c].  Pairs below phi_pairs = twin*ppv belong to the
+// k2 half: a thread walks its pairs in ascending order, so it maps its accumulator through phi once,
+// when it crosses that boundary (or at the end, if it never does).
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_msm_accumulate(
     G1XYZZ *partials, const G1Affine *table, const int16_t *digits, uint32_t pairs_per_vec,
@@ -215,34 +266,29 @@ __global__ __launch_bounds__(THREADS) void k_msm_accumulate(
     const uint32_t q0 = chunk * pairs_per_block;
     const uint32_t q1 = q0 + pairs_per_block < pairs_per_vec ? q0 + pairs_per_block : pairs_per_vec;
     const uint32_t voff = (vec % vecs_per_group) * ppv;
+    const uint32_t phi_pairs = pairs_per_vec >> 1, twin = phi_pairs / ppv;
     const int16_t *dg = digits + (size_t)vec * pairs_per_vec;
     // accumulator in the 28-bit-limb / 2^392 domain (fp28.hpp), infinity tracked by a flag
     XYZZ28 acc28;
     bool inf = true, yneg = false;  // yneg: acc28.y currently holds -Y (xyzz28_madd_alt)
+    bool phi_pending = q0 + threadIdx.x < phi_pairs;
     // (Measured alternatives: requesting the next entry before the current addition -- 10.45 ms vs
     // 10.32 ms, the second wave of the SIMD already hides the gather; unrolling by two -- 14.4 ms,
     // two copies of the ~40 KB addition body thrash the instruction cache; capping VGPRs for 3 or
     // 4 waves per SIMD -- 11.4 / 13.2 ms.)
     for (uint32_t q = q0 + threadIdx.x; q < q1; q += THREADS) {
+        if (phi_pending && q >= phi_pairs) {
+            if (!inf) msm_apply_phi(acc28);
+            phi_pending = false;
+        }
         int d = dg[q];
         if (d != 0) {
             uint32_t w = q / ppv, i = q - w * ppv;
-            size_t p = (size_t)w * npoints + voff + i;
-            uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-            const uint4 *src = reinterpret_cast<const uint4 *>(table + ((p << half_shift) + (mag - 1)));
-            uint32_t wd[24];
-            uint32_t any = 0;
-#pragma unroll
-            for (int k = 0; k < 6; k++) {
-                uint4 v = src[k];
-                wd[4 * k] = v.x; wd[4 * k + 1] = v.y; wd[4 * k + 2] = v.z; wd[4 * k + 3] = v.w;
-                any |= v.x | v.y | v.z | v.w;
-            }
-            if (any != 0) {  // (0,0) encodes a table entry at infinity
-                xyzz28_madd_alt(acc28, inf, yneg, f28_unpack<1>(wd), f28_unpack<1>(wd + 12), d < 0);
-            }
+            uint32_t tw = w >= twin ? w - twin : w;
+            msm_term(acc28, inf, yneg, table, (size_t)tw * npoints + voff + i, half_shift, d);
         }
     }
+    if (phi_pending && !inf) msm_apply_phi(acc28);
     xyzz28_fix_sign(acc28, inf, yneg);
     block_reduce_xyzz28<THREADS>(acc28, inf, sh);
     if (threadIdx.x == 0) partials[blockIdx.x] = xyzz28_to_xyzz(acc28, inf);
@@ -260,29 +306,26 @@ __global__ __launch_bounds__(64) void k_msm_small(G1XYZZ *out, const G1Affine *t
     constexpr int GROUPS = 64 / LPV;
     const int tid = threadIdx.x, grp = tid / LPV, l = tid % LPV;
     const uint32_t vec = blockIdx.x * GROUPS + grp;
+    const uint32_t phi_pairs = pairs_per_vec >> 1, twin = phi_pairs / ppv;
     XYZZ28 acc28;
     bool inf = true, yneg = false;
     if (vec < nvec) {
         const uint32_t voff = (vec % vecs_per_group) * ppv;
         const int16_t *dg = digits + (size_t)vec * pairs_per_vec;
+        bool phi_pending = (uint32_t)l < phi_pairs;
         for (uint32_t q = l; q < pairs_per_vec; q += LPV) {
+            if (phi_pending && q >= phi_pairs) {
+                if (!inf) msm_apply_phi(acc28);
+                phi_pending = false;
+            }
             int d = dg[q];
             if (d != 0) {
                 uint32_t w = q / ppv, i = q - w * ppv;
-                size_t p = (size_t)w * npoints + voff + i;
-                uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-                const uint4 *src = reinterpret_cast<const uint4 *>(table + ((p << half_shift) + (mag - 1)));
-                uint32_t wd[24];
-                uint32_t any = 0;
-#pragma unroll
-                for (int k = 0; k < 6; k++) {
-                    uint4 v = src[k];
-                    wd[4 * k] = v.x; wd[4 * k + 1] = v.y; wd[4 * k + 2] = v.z; wd[4 * k + 3] = v.w;
-                    any |= v.x | v.y | v.z | v.w;
-                }
-                if (any != 0) xyzz28_madd_alt(acc28, inf, yneg, f28_unpack<1>(wd), f28_unpack<1>(wd + 12), d < 0);
+                uint32_t tw = w >= twin ? w - twin : w;
+                msm_term(acc28, inf, yneg, table, (size_t)tw * npoints + voff + i, half_shift, d);
             }
         }
+        if (phi_pending && !inf) msm_apply_phi(acc28);
     }
     xyzz28_fix_sign(acc28, inf, yneg);
     for (int s = LPV / 2; s >= 1; s >>= 1) {
@@ -484,7 +527,7 @@ int commit_blobs_enqueue(DeviceCtx *ctx, uint8_t *d_out48, uint8_t *d_status, co
     HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     size_t total = n * N_BLOB;
     hipLaunchKernelGGL(k_blob_digits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
-                       d_digits, d_bad, d_blobs, total, t.wbits, t.nwin);
+                       d_digits, d_bad, d_blobs, total, t.wbits, t.twin);
     return run_msm(ctx, t, d_out48, d_status, d_digits, d_bad, d_partials, n, ppb);
 }
 
@@ -517,7 +560,7 @@ int msm_commit_table_raw_device(DeviceCtx *ctx, uint8_t *d_out48, const uint32_t
     HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     size_t total = n * N_BLOB;
     hipLaunchKernelGGL(k_raw_digits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
-                       d_digits, d_scalars, total, t.wbits, t.nwin);
+                       d_digits, d_scalars, total, t.wbits, t.twin);
     rc = run_msm(ctx, t, d_out48, nullptr, d_digits, nullptr, d_partials, n, ppb);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));

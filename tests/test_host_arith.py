@@ -542,3 +542,74 @@ def test_safegcd_inverse_matches_fermat_and_python(libs):
         if a < 2 ** 20 or a > P - 4:
             h.hs_fp28_inv(r2, ab)  # sliding-window Fermat ladder
             assert r1.raw == r2.raw
+
+
+LAMBDA = 0xd201000000010000 ** 2 - 1
+
+
+def test_glv_split_signed_and_window_recoding(libs):
+    """glv_split_signed / recode_signed_128 (g1_28.hpp) feed every fixed-base MSM kernel: k must equal
+    s1*m1 + lambda*s2*m2 mod r with both magnitudes small enough that no table width carries out of its
+    top window, and the signed digits must rebuild the half-scalar and stay inside the table."""
+    _, h = libs
+    assert (LAMBDA * LAMBDA + LAMBDA + 1) == R
+    rnd = random.Random(99)
+    edge = [0, 1, 2, R - 1, R - 2, LAMBDA, LAMBDA - 1, LAMBDA + 1, LAMBDA // 2, LAMBDA // 2 + 1,
+            (LAMBDA + 1) * (LAMBDA // 2), (LAMBDA + 1) * (LAMBDA // 2) + LAMBDA // 2 + 1, R // 2, R // 3,
+            LAMBDA * LAMBDA, LAMBDA * LAMBDA + LAMBDA, (1 << 254), (1 << 128) - 1, (1 << 128), (1 << 127)]
+    edge += [q * LAMBDA + t for q in (1, 2, LAMBDA // 2, LAMBDA // 2 + 1, LAMBDA - 1, LAMBDA)
+             for t in (0, 1, LAMBDA // 2, LAMBDA // 2 + 1, LAMBDA - 1) if q * LAMBDA + t < R]
+    bound = (LAMBDA + 3) // 2
+    for it in range(20000):
+        k = edge[it] if it < len(edge) else rnd.randrange(R)
+        kk = (C.c_uint32 * 8)(*[(k >> (32 * i)) & 0xffffffff for i in range(8)])
+        m1, m2 = (C.c_uint32 * 4)(), (C.c_uint32 * 4)()
+        n1, n2 = C.c_int(), C.c_int()
+        h.hs_glv_split_signed(kk, m1, C.byref(n1), m2, C.byref(n2))
+        a = sum(v << (32 * i) for i, v in enumerate(m1))
+        b = sum(v << (32 * i) for i, v in enumerate(m2))
+        assert a <= bound and b <= bound, (k, a, b)
+        sa, sb = (-a if n1.value else a), (-b if n2.value else b)
+        assert (sa + LAMBDA * sb - k) % R == 0, k
+        if it % 7 == 0 or it < len(edge):
+            for wbits in (4, 7, 8, 10, 13, 15, 16):
+                nwh = 127 // wbits + 1
+                for m, neg, sv in ((m1, n1.value, sa), (m2, n2.value, sb)):
+                    dg = (C.c_int16 * nwh)()
+                    h.hs_recode_signed_128(dg, m, neg, wbits, nwh)
+                    assert sum(int(d) << (wbits * w) for w, d in enumerate(dg)) == sv, (k, wbits)
+                    assert all(abs(int(d)) <= (1 << (wbits - 1)) for d in dg)
+
+
+def test_fixed_base_glv_msm_algorithm_matches_oracle(libs):
+    """The accumulate kernels' algorithm (GLV digits -> half-width table entries -> sign-alternating mixed
+    additions -> phi once per lane -> fold), replayed on the host with the same inline functions
+    (hs_msm_glv_emulate), equals sum k_i P_i computed by the oracle -- for several table widths, lane
+    counts that do and do not split at the half boundary, and scalars that exercise every centring case."""
+    o, h = libs
+    rnd = random.Random(2027)
+    g = _buf(144)
+    h.hs_g1_generator(g)
+    n = 6
+    pts_j = [_omul(o, g, rnd.randrange(1, R)) for _ in range(n)]
+    aff = _buf(96 * n)
+    for i, p in enumerate(pts_j):
+        a = _buf(96)
+        o.og1_to_affine(a, p)
+        aff[96 * i:96 * (i + 1)] = a.raw
+    special = [0, 1, R - 1, LAMBDA, LAMBDA + 1, LAMBDA // 2 + 1, (LAMBDA + 1) * (LAMBDA // 2 + 1)]
+    for wbits, lanes in ((4, 1), (5, 7), (8, 64), (13, 16), (16, 3)):
+        ks = [special[(i + wbits) % len(special)] if i < 3 else rnd.randrange(R) for i in range(n)]
+        sc = (C.c_uint32 * (8 * n))(*[(k >> (32 * j)) & 0xffffffff for k in ks for j in range(8)])
+        got = _buf(144)
+        h.hs_msm_glv_emulate(got, aff, sc, n, wbits, lanes)
+        acc = None
+        for p, k in zip(pts_j, ks):
+            t = _omul(o, p, k)
+            if acc is None:
+                acc = t
+            else:
+                s = _buf(144)
+                o.og1_add(s, acc, t)
+                acc = s
+        assert o.og1_equal(got, acc), (wbits, lanes)
