@@ -3,11 +3,16 @@
 // KZGSettings to its GPU context, small host helpers.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <chrono>
 #include <cinttypes>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/ckzg_hip.h"
@@ -48,35 +53,20 @@ struct Trace {
 
 struct Options {
     int device = -1;        // -1: env CKZG_HIP_DEVICE, else LOCAL_RANK, else 0
+    int64_t devices = 0;    // bit mask of devices to load on (bit i = device i; -1 = every visible one); 0: `device` only
+    int replicas = 1;       // independent pools (own tables) per selected device: exercises the multi-device
+                            // fan-out on a one-GPU box; 1 in production
+    int streams = 8;        // slots (stream + scratch) per pool = concurrent calls per device
     int commit_wbits = 10;  // env CKZG_HIP_COMMIT_WBITS overrides the default
     int fk20_wbits = 0;     // 0: max(8, precompute); env CKZG_HIP_FK20_WBITS
     int proof_wbits = 8;    // monomial-point table for the direct proof path; 0 disables it
     int direct_max = -1;    // largest batch that takes the direct path (0 disables it; -1: by table width)
-    int gpu_sha_min = 0;    // smallest verify batch that hashes its challenges on the GPU; 0 = by host CPU
 };
-extern Options g_opts;
-
-// Lives immediately in front of KZGSettings::roots_of_unity.
-constexpr uint64_t SETTINGS_MAGIC = 0x434b5a47484950ULL;  // "CKZGHIP"
-struct alignas(64) SettingsHeader {
-    uint64_t magic;
-    dev::DeviceCtx *ctx;
-};
-
-inline SettingsHeader *header_of(const KZGSettings *s) {
-    if (!s || !s->roots_of_unity) return nullptr;
-    SettingsHeader *h = reinterpret_cast<SettingsHeader *>(s->roots_of_unity) - 1;
-    return h->magic == SETTINGS_MAGIC ? h : nullptr;
-}
-
-inline dev::DeviceCtx *ctx_of(const KZGSettings *s) {
-    SettingsHeader *h = header_of(s);
-    if (!h || !h->ctx) {
-        fprintf(stderr, "[ckzg-hip] KZGSettings has no GPU context (not loaded by this library, or freed)\n");
-        return nullptr;
-    }
-    return h->ctx;
-}
+// options of the NEXT load_trusted_setup; snapshotted under a lock when a load starts, so concurrent loads
+// with different options do not see each other's half-written state
+Options options_snapshot();
+// read at call time (ckzg_hip_set_option("gpu_sha_min", n)); 0 = decide by host CPU
+extern std::atomic<int> g_gpu_sha_min;
 
 // line tables of the three G2 constants that appear in verification equations
 struct PreparedG2 {
@@ -88,10 +78,99 @@ inline const PreparedG2 *prepared_of(const dev::DeviceCtx *ctx) {
     return static_cast<const PreparedG2 *>(ctx->host_prepared);
 }
 
+// One device's share of a loaded KZGSettings: the tables (owned by slots[0]) and the slots that alias them.
+struct DevicePool {
+    int device = 0;
+    std::vector<dev::DeviceCtx *> slots;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<int> free_slots;
+    std::atomic<dev::DeviceCtx *> last{nullptr};  // slot of the most recent call (ckzg_hip_last_kernel_ms)
+};
+
+// Everything this library hangs off one KZGSettings.  Found through a registry keyed by the struct's
+// roots_of_unity pointer: that pointer survives the by-value copies/moves bindings make of KZGSettings
+// (Go embeds it, Rust moves it), and a struct that was not loaded by this library is simply not in the
+// registry -- nothing is read through a foreign pointer.
+struct SettingsCtx {
+    std::vector<DevicePool *> pools;
+    PreparedG2 prepared;
+    Options opts;
+    std::atomic<unsigned> next{0};
+};
+SettingsCtx *settings_of(const KZGSettings *s, bool complain = true);
+
+// Exclusive use of one slot for the duration of a call.  Default: the first pool with a free slot (round
+// robin), waiting if every slot is busy.  Sets the calling thread's HIP device.
+struct Lease {
+    DevicePool *pool = nullptr;
+    dev::DeviceCtx *ctx = nullptr;
+    explicit Lease(const KZGSettings *s, int pool_index = -1);
+    explicit Lease(DevicePool *p);
+    ~Lease();
+    Lease(const Lease &) = delete;
+    Lease &operator=(const Lease &) = delete;
+
+   private:
+    void take(DevicePool *p);
+};
+// the pool whose device owns this device pointer (0 if unknown), for the *_device entry points
+int pool_of_pointer(const SettingsCtx *sc, const void *dptr);
+
 // implemented in device_ctx.hip
-C_KZG_RET create_device_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affine,
-                            const G1Affine *monomial_affine);
-void destroy_device_ctx(dev::DeviceCtx *ctx);
+C_KZG_RET create_settings_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affine,
+                              const G1Affine *monomial_affine);
+void destroy_settings_ctx(const KZGSettings *s);
+
+// No C++ exception may cross the C ABI (the reference returns C_KZG_MALLOC where these would throw).
+template <class F>
+C_KZG_RET guarded(F &&f) noexcept {
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        return C_KZG_MALLOC;
+    } catch (...) {
+        return C_KZG_ERROR;
+    }
+}
+
+inline C_KZG_RET worse(C_KZG_RET a, C_KZG_RET b) { return (int)a > (int)b ? a : b; }
+
+// Host-pointer batch entry points: contiguous ranges of the n units over the pools (one host thread and
+// one leased slot per device), results written in place by each shard; the reference's equivalent is the
+// goroutine fan-out of bindings/go/main_test.go:953-971.  body(ctx, lo, hi) -> C_KZG_RET.
+template <class F>
+C_KZG_RET for_each_device_shard(const KZGSettings *s, uint64_t n, uint64_t min_shard, F &&body) {
+    SettingsCtx *sc = settings_of(s);
+    if (!sc) return C_KZG_ERROR;
+    size_t np = sc->pools.size();
+    if (min_shard == 0) min_shard = 1;
+    if (np > 1 && n / min_shard < np) np = (size_t)(n / min_shard);
+    if (np <= 1) {
+        Lease lease(s);
+        if (!lease.ctx) return C_KZG_ERROR;
+        return body(lease.ctx, (uint64_t)0, n);
+    }
+    std::vector<C_KZG_RET> rets(np, C_KZG_OK);
+    std::vector<std::thread> th;
+    const uint64_t base = n / np, extra = n % np;
+    uint64_t lo = 0;
+    for (size_t d = 0; d < np; d++) {
+        const uint64_t hi = lo + base + (d < extra ? 1 : 0);
+        th.emplace_back([&, d, lo, hi]() {
+            rets[d] = guarded([&]() -> C_KZG_RET {
+                Lease lease(sc->pools[d]);
+                if (!lease.ctx) return C_KZG_ERROR;
+                return body(lease.ctx, lo, hi);
+            });
+        });
+        lo = hi;
+    }
+    for (auto &t : th) t.join();
+    C_KZG_RET ret = C_KZG_OK;
+    for (auto r : rets) ret = worse(ret, r);
+    return ret;
+}
 
 struct DeviceBuffer {
     void *p = nullptr;

@@ -17,27 +17,43 @@ using namespace ckzg::api;
 
 namespace ckzg {
 namespace api {
-Options g_opts;
+static std::mutex g_opts_mu;
+static Options g_opts;
+std::atomic<int> g_gpu_sha_min{0};
+Options options_snapshot() {
+    std::lock_guard<std::mutex> lock(g_opts_mu);
+    return g_opts;
 }
+}  // namespace api
 }  // namespace ckzg
 
 extern "C" C_KZG_RET ckzg_hip_set_option(const char *key, int64_t value) {
     if (!key) return C_KZG_BADARGS;
+    std::lock_guard<std::mutex> lock(g_opts_mu);
     if (!strcmp(key, "device")) {
         if (value < -1 || value > 1023) return C_KZG_BADARGS;
         g_opts.device = (int)value;
+    } else if (!strcmp(key, "devices")) {
+        if (value < -1) return C_KZG_BADARGS;
+        g_opts.devices = value;
+    } else if (!strcmp(key, "replicas")) {
+        if (value < 1 || value > 8) return C_KZG_BADARGS;
+        g_opts.replicas = (int)value;
+    } else if (!strcmp(key, "streams")) {
+        if (value < 1 || value > 64) return C_KZG_BADARGS;
+        g_opts.streams = (int)value;
     } else if (!strcmp(key, "commit_wbits")) {
         if (value < 4 || value > 16) return C_KZG_BADARGS;
         g_opts.commit_wbits = (int)value;
     } else if (!strcmp(key, "fk20_wbits")) {
-        if (value != 0 && (value < 4 || value > 15)) return C_KZG_BADARGS;
+        if (value != 0 && (value < 4 || value > 16)) return C_KZG_BADARGS;
         g_opts.fk20_wbits = (int)value;
     } else if (!strcmp(key, "proof_wbits")) {
         if (value != 0 && (value < 4 || value > 16)) return C_KZG_BADARGS;
         g_opts.proof_wbits = (int)value;
     } else if (!strcmp(key, "gpu_sha_min")) {
         if (value < 0 || value > (1 << 30)) return C_KZG_BADARGS;
-        g_opts.gpu_sha_min = (int)value;  // read at call time, unlike the table options
+        g_gpu_sha_min.store((int)value);  // read at call time, unlike the load-time options
     } else if (!strcmp(key, "direct_max")) {
         if (value < -1 || value > 4096) return C_KZG_BADARGS;
         g_opts.direct_max = (int)value;
@@ -83,11 +99,8 @@ static C_KZG_RET compute_roots_of_unity(KZGSettings *s) {  // setup.c:99-153
 
 extern "C" void free_trusted_setup(KZGSettings *s) {  // setup.c:162-190
     if (s == NULL) return;
-    if (s->roots_of_unity) {
-        SettingsHeader *h = header_of(s);
-        if (h && h->ctx) destroy_device_ctx(h->ctx);
-        free(h ? (void *)h : (void *)s->roots_of_unity);
-    }
+    if (s->roots_of_unity) destroy_settings_ctx(s);  // no-op for a struct this library did not finish loading
+    free(s->roots_of_unity);
     free(s->brp_roots_of_unity);
     free(s->reverse_roots_of_unity);
     free(s->g1_values_monomial);
@@ -100,12 +113,12 @@ extern "C" void free_trusted_setup(KZGSettings *s) {  // setup.c:162-190
     memset(s, 0, sizeof *s);
 }
 
-extern "C" C_KZG_RET load_trusted_setup(KZGSettings *out, const uint8_t *g1_monomial_bytes,
-                                        uint64_t num_g1_monomial_bytes,
-                                        const uint8_t *g1_lagrange_bytes,
-                                        uint64_t num_g1_lagrange_bytes,
-                                        const uint8_t *g2_monomial_bytes,
-                                        uint64_t num_g2_monomial_bytes, uint64_t precompute) {
+static C_KZG_RET load_trusted_setup_impl(KZGSettings *out, const uint8_t *g1_monomial_bytes,
+                                         uint64_t num_g1_monomial_bytes,
+                                         const uint8_t *g1_lagrange_bytes,
+                                         uint64_t num_g1_lagrange_bytes,
+                                         const uint8_t *g2_monomial_bytes,
+                                         uint64_t num_g2_monomial_bytes, uint64_t precompute) {
     // setup.c:392-505
     C_KZG_RET ret = C_KZG_OK;
     std::vector<G1Affine> lagr_affine(NUM_G1_POINTS), mono_affine(NUM_G1_POINTS);
@@ -116,15 +129,9 @@ extern "C" C_KZG_RET load_trusted_setup(KZGSettings *out, const uint8_t *g1_mono
         num_g2_monomial_bytes != NUM_G2_POINTS * 96) {
         return C_KZG_BADARGS;
     }
-    // roots_of_unity carries the hidden header that links this struct to its GPU context
-    {
-        size_t bytes = sizeof(SettingsHeader) + (FIELD_ELEMENTS_PER_EXT_BLOB + 1) * sizeof(fr_t);
-        SettingsHeader *h = (SettingsHeader *)calloc(1, bytes);
-        if (!h) return C_KZG_MALLOC;
-        h->magic = SETTINGS_MAGIC;
-        h->ctx = nullptr;
-        out->roots_of_unity = (fr_t *)(h + 1);
-    }
+    // (roots_of_unity doubles as the key under which the GPU state of this struct is registered)
+    out->roots_of_unity = (fr_t *)calloc(FIELD_ELEMENTS_PER_EXT_BLOB + 1, sizeof(fr_t));
+    if (!out->roots_of_unity) return C_KZG_MALLOC;
     out->brp_roots_of_unity = (fr_t *)calloc(FIELD_ELEMENTS_PER_EXT_BLOB, sizeof(fr_t));
     out->reverse_roots_of_unity = (fr_t *)calloc(FIELD_ELEMENTS_PER_EXT_BLOB + 1, sizeof(fr_t));
     out->g1_values_monomial = (g1_t *)calloc(NUM_G1_POINTS, sizeof(g1_t));
@@ -180,8 +187,8 @@ extern "C" C_KZG_RET load_trusted_setup(KZGSettings *out, const uint8_t *g1_mono
     if (ret != C_KZG_OK) goto fail;
     bit_reversal_permutation(out->g1_values_lagrange_brp, sizeof(g1_t), NUM_G1_POINTS);
     bit_reversal_permutation(lagr_affine.data(), sizeof(G1Affine), NUM_G1_POINTS);
-    // GPU context: commitment tables, NTT twiddles, FK20 columns and tables (setup.c:238-330)
-    ret = create_device_ctx(out, lagr_affine.data(), mono_affine.data());
+    // GPU state: commitment tables, NTT twiddles, FK20 columns and tables (setup.c:238-330)
+    ret = create_settings_ctx(out, lagr_affine.data(), mono_affine.data());
     if (ret != C_KZG_OK) goto fail;
     return C_KZG_OK;
 fail:
@@ -189,7 +196,22 @@ fail:
     return ret;
 }
 
-extern "C" C_KZG_RET load_trusted_setup_file(KZGSettings *out, FILE *in, uint64_t precompute) {
+extern "C" C_KZG_RET load_trusted_setup(KZGSettings *out, const uint8_t *g1_monomial_bytes,
+                                        uint64_t num_g1_monomial_bytes,
+                                        const uint8_t *g1_lagrange_bytes,
+                                        uint64_t num_g1_lagrange_bytes,
+                                        const uint8_t *g2_monomial_bytes,
+                                        uint64_t num_g2_monomial_bytes, uint64_t precompute) {
+    if (out) memset(out, 0, sizeof *out);
+    C_KZG_RET ret = guarded([&]() {
+        return load_trusted_setup_impl(out, g1_monomial_bytes, num_g1_monomial_bytes, g1_lagrange_bytes,
+                                       num_g1_lagrange_bytes, g2_monomial_bytes, num_g2_monomial_bytes, precompute);
+    });
+    if (ret != C_KZG_OK && out) free_trusted_setup(out);  // also after an exception half-way through
+    return ret;
+}
+
+static C_KZG_RET load_trusted_setup_file_impl(KZGSettings *out, FILE *in, uint64_t precompute) {
     // setup.c:519-600: "<n_g1> <n_g2>" then hex of: G1 Lagrange, G2 monomial, G1 monomial
     uint64_t n1 = 0, n2 = 0;
     memset(out, 0, sizeof *out);
@@ -207,6 +229,11 @@ extern "C" C_KZG_RET load_trusted_setup_file(KZGSettings *out, FILE *in, uint64_
     }
     return load_trusted_setup(out, mono.data(), mono.size(), lagr.data(), lagr.size(), g2.data(),
                               g2.size(), precompute);
+}
+
+extern "C" C_KZG_RET load_trusted_setup_file(KZGSettings *out, FILE *in, uint64_t precompute) {
+    if (out) memset(out, 0, sizeof *out);
+    return guarded([&]() { return load_trusted_setup_file_impl(out, in, precompute); });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -256,31 +283,36 @@ static void staged_copy(void *dst, const void *src, size_t bytes) {
     for (auto &x : th) x.join();
 }
 
+// the slot a *_device entry point runs on: a slot of the pool whose GPU holds the caller's buffers
+struct DeviceLease {
+    Lease lease;
+    DeviceLease(const KZGSettings *s, SettingsCtx *sc, const void *dptr) : lease(s, sc ? pool_of_pointer(sc, dptr) : 0) {}
+};
+
 extern "C" C_KZG_RET ckzg_hip_blob_to_kzg_commitment_batch_device(void *d_out48, void *d_status,
                                                                   const void *d_blobs, uint64_t n,
                                                                   const KZGSettings *s) {
-    dev::DeviceCtx *ctx = ctx_of(s);
-    if (!ctx) return C_KZG_ERROR;
-    std::lock_guard<std::mutex> lock(ctx->mu);
-    if (hipSetDevice(ctx->device) != hipSuccess) return C_KZG_ERROR;
-    return (C_KZG_RET)dev::commit_blobs_device(ctx, (uint8_t *)d_out48, (uint8_t *)d_status,
-                                               (const uint8_t *)d_blobs, n);
+    return guarded([&]() -> C_KZG_RET {
+        SettingsCtx *sc = settings_of(s);
+        if (!sc) return C_KZG_ERROR;
+        DeviceLease dl(s, sc, d_blobs);
+        dev::DeviceCtx *ctx = dl.lease.ctx;
+        if (!ctx) return C_KZG_ERROR;
+        return (C_KZG_RET)dev::commit_blobs_device(ctx, (uint8_t *)d_out48, (uint8_t *)d_status,
+                                                   (const uint8_t *)d_blobs, n);
+    });
 }
 
-extern "C" C_KZG_RET ckzg_hip_blob_to_kzg_commitment_batch(KZGCommitment *out, uint8_t *status,
-                                                           const Blob *blobs, uint64_t n,
-                                                           const KZGSettings *s) {
-    dev::DeviceCtx *ctx = ctx_of(s);
-    if (!ctx) return C_KZG_ERROR;
+// One device's share of a host-pointer commitment batch.
+// Host buffers are pageable, and a pageable hipMemcpyAsync serialises with everything.  So chunk
+// i+1 is memcpy'd by this thread into a pinned staging buffer and DMA'd on the copy stream while
+// the kernels of chunk i execute on the compute stream.  Two staging/device buffers, events
+// both ways.  Chunks grow geometrically (64, 192, 512, 512, ...): the first one is small so that
+// the GPU starts after ~0.5 ms, and since a chunk computes ~3x longer than the next one takes to
+// stage, the following ones can be large enough to run the kernels at full-batch efficiency.
+static C_KZG_RET commit_batch_on(dev::DeviceCtx *ctx, KZGCommitment *out, uint8_t *status, const Blob *blobs,
+                                 uint64_t n) {
     if (n == 0) return C_KZG_OK;
-    std::lock_guard<std::mutex> lock(ctx->mu);
-    if (hipSetDevice(ctx->device) != hipSuccess) return C_KZG_ERROR;
-    // Host buffers are pageable, and a pageable hipMemcpyAsync serialises with everything.  So chunk
-    // i+1 is memcpy'd by this thread into a pinned staging buffer and DMA'd on the copy stream while
-    // the kernels of chunk i execute on the compute stream.  Two staging/device buffers, events
-    // both ways.  Chunks grow geometrically (64, 192, 512, 512, ...): the first one is small so that
-    // the GPU starts after ~0.5 ms, and since a chunk computes ~3x longer than the next one takes to
-    // stage, the following ones can be large enough to run the kernels at full-batch efficiency.
     static const uint64_t CH = []() {
         const char *v = getenv("CKZG_HIP_COMMIT_CHUNK");
         long c = v && *v ? atol(v) : 512;
@@ -289,24 +321,36 @@ extern "C" C_KZG_RET ckzg_hip_blob_to_kzg_commitment_batch(KZGCommitment *out, u
     const uint64_t FIRST = CH < 64 ? CH : 64;
     const uint64_t m = n < CH ? n : CH;
     Trace tr("commit_batch");
-    // device temporaries from the context's arena, events kept in the context: a single-blob call
+    // device temporaries from the slot's arena, events kept in the slot: a single-blob call
     // must not pay for hipMalloc/hipFree/hipEventCreate
     Arena &ar = ctx->api_arena;
     if (!ar.begin(2 * m * BYTES_PER_BLOB + n * 49)) return C_KZG_MALLOC;
     ArenaTrim trim(ar);
     ABuf<uint8_t> d_blobs[2] = {ABuf<uint8_t>(ar, m * BYTES_PER_BLOB), ABuf<uint8_t>(ar, n > FIRST ? m * BYTES_PER_BLOB : 1)};
-    ABuf<uint8_t> d_out(ar, n * 48), d_status(ar, n);
-    if (!d_blobs[0].p || !d_blobs[1].p || !d_out.p || !d_status.p) return C_KZG_MALLOC;
+    ABuf<uint8_t> d_out(ar, n * 49);  // commitments, then the status bytes
+    if (!d_blobs[0].p || !d_blobs[1].p || !d_out.p) return C_KZG_MALLOC;
+    uint8_t *d_status = d_out.p + n * 48;
     hipEvent_t *copied = ctx->stage_ev, *consumed = ctx->stage_ev + 2;
     C_KZG_RET ret = C_KZG_OK;
-    std::vector<uint8_t> st(n);
     bool pending[2] = {false, false};
     if (dev::scratch_reserve(ctx, dev::commit_scratch_bytes(ctx, m)) != 0) return C_KZG_MALLOC;
-    for (int i = 0; i < 2; i++) {
-        if (!ctx->h_stage[i] && hipHostMalloc(&ctx->h_stage[i], CH * BYTES_PER_BLOB, hipHostMallocDefault) != hipSuccess) {
+    // pinned staging: two input buffers of up to CH blobs; the results come back through the first 49 n
+    // bytes of a third one (a pageable destination would make the final copy a blocking staged copy)
+    const size_t stage_bytes = m * BYTES_PER_BLOB;
+    if (ctx->h_stage_bytes < stage_bytes) {
+        for (int i = 0; i < 2; i++) {
+            if (ctx->h_stage[i]) (void)hipHostFree(ctx->h_stage[i]);
             ctx->h_stage[i] = nullptr;
-            return C_KZG_MALLOC;
         }
+        ctx->h_stage_bytes = 0;
+        const size_t want = n == 1 ? stage_bytes : CH * BYTES_PER_BLOB;
+        for (int i = 0; i < 2; i++) {
+            if (hipHostMalloc(&ctx->h_stage[i], want, hipHostMallocDefault) != hipSuccess) {
+                ctx->h_stage[i] = nullptr;
+                return C_KZG_MALLOC;
+            }
+        }
+        ctx->h_stage_bytes = want;
     }
     for (int i = 0; i < 4; i++) {
         if (!ctx->stage_ev[i] && hipEventCreateWithFlags(&ctx->stage_ev[i], hipEventDisableTiming) != hipSuccess) {
@@ -335,8 +379,7 @@ extern "C" C_KZG_RET ckzg_hip_blob_to_kzg_commitment_batch(KZGCommitment *out, u
             ret = C_KZG_ERROR;
             break;
         }
-        int rc = dev::commit_blobs_enqueue(ctx, (uint8_t *)d_out.p + off * 48, (uint8_t *)d_status.p + off,
-                                           (const uint8_t *)d_blobs[b].p, k);
+        int rc = dev::commit_blobs_enqueue(ctx, d_out.p + off * 48, d_status + off, (const uint8_t *)d_blobs[b].p, k);
         if (rc) {
             ret = (C_KZG_RET)rc;
             break;
@@ -346,16 +389,39 @@ extern "C" C_KZG_RET ckzg_hip_blob_to_kzg_commitment_batch(KZGCommitment *out, u
     }
     tr.mark("staging loop (copies + enqueues)");
     if (hipStreamSynchronize(ctx->copy_stream) != hipSuccess) ret = ret == C_KZG_OK ? C_KZG_ERROR : ret;
+    // results: one async copy on the compute stream into pinned memory (free again: every input DMA is done)
+    uint8_t *h_res = static_cast<uint8_t *>(ctx->h_stage[0]);
+    const bool pinned_res = n * 49 <= ctx->h_stage_bytes;
+    std::vector<uint8_t> pageable_res;
+    if (!pinned_res) {
+        pageable_res.resize(n * 49);
+        h_res = pageable_res.data();
+    }
+    if (ret == C_KZG_OK && hipMemcpyAsync(h_res, d_out.p, n * 49, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        ret = C_KZG_ERROR;
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) ret = ret == C_KZG_OK ? C_KZG_ERROR : ret;
     tr.mark("wait for the GPU");
     if (ret != C_KZG_OK) return ret;
-    if (hipMemcpy(out, d_out.p, n * 48, hipMemcpyDeviceToHost) != hipSuccess) return C_KZG_ERROR;
-    if (hipMemcpy(st.data(), d_status.p, n, hipMemcpyDeviceToHost) != hipSuccess) return C_KZG_ERROR;
+    memcpy(out, h_res, n * 48);
+    const uint8_t *st = h_res + n * 48;
     for (uint64_t i = 0; i < n; i++) {
         if (status) status[i] = st[i];
         if (st[i]) ret = C_KZG_BADARGS;
     }
     return ret;
+}
+
+extern "C" C_KZG_RET ckzg_hip_blob_to_kzg_commitment_batch(KZGCommitment *out, uint8_t *status,
+                                                           const Blob *blobs, uint64_t n,
+                                                           const KZGSettings *s) {
+    return guarded([&]() -> C_KZG_RET {
+        if (!settings_of(s)) return C_KZG_ERROR;
+        if (n == 0) return C_KZG_OK;
+        // below 64 blobs per device the launch overheads outweigh a second GPU
+        return for_each_device_shard(s, n, 64, [&](dev::DeviceCtx *ctx, uint64_t lo, uint64_t hi) {
+            return commit_batch_on(ctx, out + lo, status ? status + lo : nullptr, blobs + lo, hi - lo);
+        });
+    });
 }
 
 extern "C" C_KZG_RET blob_to_kzg_commitment(KZGCommitment *out, const Blob *blob, const KZGSettings *s) {
@@ -371,24 +437,21 @@ extern "C" C_KZG_RET ckzg_hip_compute_cells_and_kzg_proofs_batch_device(void *d_
                                                                         void *d_status,
                                                                         const void *d_blobs, uint64_t n,
                                                                         const KZGSettings *s) {
-    if (d_cells == NULL && d_proofs == NULL) return C_KZG_BADARGS;
-    dev::DeviceCtx *ctx = ctx_of(s);
-    if (!ctx) return C_KZG_ERROR;
-    std::lock_guard<std::mutex> lock(ctx->mu);
-    if (hipSetDevice(ctx->device) != hipSuccess) return C_KZG_ERROR;
-    return (C_KZG_RET)dev::cells_and_proofs_device(ctx, (uint8_t *)d_cells, (uint8_t *)d_proofs,
-                                                   (uint8_t *)d_status, (const uint8_t *)d_blobs, n);
+    return guarded([&]() -> C_KZG_RET {
+        if (d_cells == NULL && d_proofs == NULL) return C_KZG_BADARGS;
+        SettingsCtx *sc = settings_of(s);
+        if (!sc) return C_KZG_ERROR;
+        DeviceLease dl(s, sc, d_blobs);
+        dev::DeviceCtx *ctx = dl.lease.ctx;
+        if (!ctx) return C_KZG_ERROR;
+        return (C_KZG_RET)dev::cells_and_proofs_device(ctx, (uint8_t *)d_cells, (uint8_t *)d_proofs,
+                                                       (uint8_t *)d_status, (const uint8_t *)d_blobs, n);
+    });
 }
 
-extern "C" C_KZG_RET ckzg_hip_compute_cells_and_kzg_proofs_batch(Cell *cells, KZGProof *proofs,
-                                                                 uint8_t *status, const Blob *blobs,
-                                                                 uint64_t n, const KZGSettings *s) {
-    if (cells == NULL && proofs == NULL) return C_KZG_BADARGS;  // eip7594.c:72-74
-    dev::DeviceCtx *ctx = ctx_of(s);
-    if (!ctx) return C_KZG_ERROR;
+static C_KZG_RET cells_and_proofs_batch_on(dev::DeviceCtx *ctx, Cell *cells, KZGProof *proofs, uint8_t *status,
+                                           const Blob *blobs, uint64_t n) {
     if (n == 0) return C_KZG_OK;
-    std::lock_guard<std::mutex> lock(ctx->mu);
-    if (hipSetDevice(ctx->device) != hipSuccess) return C_KZG_ERROR;
     const uint64_t CH = 2048;  // >= 2 waves of G1-FFT butterflies per SIMD per stage launch
     uint64_t m = n < CH ? n : CH;
     const size_t cells_per = (size_t)CELLS_PER_EXT_BLOB * BYTES_PER_CELL, proofs_per = (size_t)CELLS_PER_EXT_BLOB * 48;
@@ -422,31 +485,65 @@ extern "C" C_KZG_RET ckzg_hip_compute_cells_and_kzg_proofs_batch(Cell *cells, KZ
     return ret;
 }
 
+extern "C" C_KZG_RET ckzg_hip_compute_cells_and_kzg_proofs_batch(Cell *cells, KZGProof *proofs,
+                                                                 uint8_t *status, const Blob *blobs,
+                                                                 uint64_t n, const KZGSettings *s) {
+    return guarded([&]() -> C_KZG_RET {
+        if (cells == NULL && proofs == NULL) return C_KZG_BADARGS;  // eip7594.c:72-74
+        if (!settings_of(s)) return C_KZG_ERROR;
+        if (n == 0) return C_KZG_OK;
+        return for_each_device_shard(s, n, 32, [&](dev::DeviceCtx *ctx, uint64_t lo, uint64_t hi) {
+            return cells_and_proofs_batch_on(ctx, cells ? cells + lo * CELLS_PER_EXT_BLOB : nullptr,
+                                             proofs ? proofs + lo * CELLS_PER_EXT_BLOB : nullptr,
+                                             status ? status + lo : nullptr, blobs + lo, hi - lo);
+        });
+    });
+}
+
 extern "C" C_KZG_RET compute_cells_and_kzg_proofs(Cell *cells, KZGProof *proofs, const Blob *blob,
                                                   const KZGSettings *s) {
     uint8_t st = 0;
     return ckzg_hip_compute_cells_and_kzg_proofs_batch(cells, proofs, &st, blob, 1, s);
 }
 
+// the slot that served the most recent call on pool 0 (bench.py is single-threaded)
+static dev::DeviceCtx *last_slot(const KZGSettings *s) {
+    SettingsCtx *sc = settings_of(s);
+    if (!sc || sc->pools.empty()) return nullptr;
+    dev::DeviceCtx *c = sc->pools[0]->last.load();
+    return c ? c : sc->pools[0]->slots[0];
+}
+
 extern "C" double ckzg_hip_last_kernel_ms(const KZGSettings *s, int which) {
-    dev::DeviceCtx *ctx = ctx_of(s);
-    if (!ctx || which < 0 || which > 3) return -1.0;
+    dev::DeviceCtx *ctx = last_slot(s);
+    if (!ctx || which < 0 || which > 5) return -1.0;
     return ctx->last_ms[which];
 }
 
 extern "C" uint64_t ckzg_hip_table_bytes(const KZGSettings *s) {
-    dev::DeviceCtx *ctx = ctx_of(s);
-    if (!ctx) return 0;
-    return ctx->commit.bytes() + ctx->fk20.bytes() + ctx->mono.bytes();
+    SettingsCtx *sc = settings_of(s);
+    if (!sc) return 0;
+    uint64_t total = 0;
+    for (auto *p : sc->pools) {
+        const dev::DeviceCtx *ctx = p->slots[0];
+        total += ctx->commit.bytes() + ctx->fk20.bytes() + ctx->mono.bytes();
+    }
+    return total;
 }
 
 extern "C" int ckzg_hip_table_wbits(const KZGSettings *s, int which) {
-    dev::DeviceCtx *ctx = ctx_of(s);
-    if (!ctx) return -1;
+    SettingsCtx *sc = settings_of(s);
+    if (!sc) return -1;
+    const dev::DeviceCtx *ctx = sc->pools[0]->slots[0];
     switch (which) {
         case 0: return ctx->commit.wbits;
         case 1: return ctx->fk20.wbits;
         case 2: return ctx->mono.d_table ? ctx->mono.wbits : 0;
         default: return -1;
     }
+}
+
+extern "C" int ckzg_hip_num_devices(const KZGSettings *s) {
+    SettingsCtx *sc = settings_of(s, false);
+    return sc ? (int)sc->pools.size() : 0;
 }

@@ -49,10 +49,11 @@ struct DBuf {
 // less than the blob copy they run under, so such hosts never switch; without the extensions the host
 // needs ~10 us per blob and the GPU takes over at 512 blobs.
 static size_t gpu_sha_min_n() {
-    if (g_opts.gpu_sha_min > 0) return (size_t)g_opts.gpu_sha_min;  // ckzg_hip_set_option("gpu_sha_min", n)
+    const int opt = g_gpu_sha_min.load();
+    if (opt > 0) return (size_t)opt;  // ckzg_hip_set_option("gpu_sha_min", n)
     static const size_t dflt = []() {
         const char *v = getenv("CKZG_HIP_GPU_SHA_MIN");
-        if (v && *v) return (size_t)atol(v);
+        if (v && *v && atol(v) > 0) return (size_t)atol(v);  // 0 = automatic, like the option
 #ifdef CKZG_HAVE_SHANI
         if (host::cpu_has_sha_ni()) return (size_t)1 << 30;  // the host hash hides under the blob copy
 #endif
@@ -191,8 +192,6 @@ C_KZG_RET compute_kzg_proof_impl(KZGProof *proof_out, Fr &y_out, const Fr *poly,
     }
     std::vector<RawScalar> raw(n);
     for (size_t i = 0; i < n; i++) raw[i] = raw_of(q[i]);
-    std::lock_guard<std::mutex> lock(ctx->mu);
-    OKB(hipSetDevice(ctx->device) == hipSuccess);
     DBuf<RawScalar> d_sc;
     DBuf<uint8_t> d_out;
     OKM(d_sc.alloc(n) && d_out.alloc(48));
@@ -300,8 +299,6 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
         }
     }
     tr.mark("host point validation");
-    std::lock_guard<std::mutex> lock(ctx->mu);
-    OKB(hipSetDevice(ctx->device) == hipSuccess);
     Arena &ar = ctx->api_arena;
     OKM(ar.begin(n * BYTES_PER_BLOB + (n * FIELD_ELEMENTS_PER_BLOB + 2 * n) * sizeof(Fr) + n * 4 +
                  2 * n * (48 + 2 + sizeof(G1Affine))));
@@ -344,7 +341,8 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     // this thread for its whole duration (3.5 us per blob), and with the x86 SHA extensions the hashing
     // (2 us per blob on 32 threads) finishes underneath it.  Hosts without the extensions hash large
     // batches on the GPU instead (a lane per blob; ~6 ms whatever the batch size).
-    const bool gpu_sha = n >= gpu_sha_min_n();
+    // (never for the small path: its commitments are validated on the host and are not in d_ptb)
+    const bool gpu_sha = !small && n >= gpu_sha_min_n();
     std::vector<Fr> z(n), y(n);
     struct Joiner {
         std::thread t;
@@ -465,17 +463,13 @@ extern "C" void compute_challenge(fr_t *eval_challenge_out, const Blob *blob, co
     *as_fr(eval_challenge_out) = challenge_from_bytes(blob->bytes, c48);
 }
 
-extern "C" C_KZG_RET compute_kzg_proof(KZGProof *proof_out, Bytes32 *y_out, const Blob *blob,
-                                       const Bytes32 *z_bytes, const KZGSettings *s) {
+static C_KZG_RET compute_kzg_proof_on(dev::DeviceCtx *ctx, KZGProof *proof_out, Bytes32 *y_out, const Blob *blob,
+                                      const Bytes32 *z_bytes, const KZGSettings *s) {
     // eip4844.c:386-415.  Evaluation, quotient polynomial and MSM on the GPU; a z inside the evaluation
     // domain (eip4844.c:458-481) takes the host form of the quotient instead.
-    dev::DeviceCtx *ctx = ctx_of(s);
-    if (!ctx) return C_KZG_ERROR;
     Fr z, y;
     if (!fr_from_bytes_canonical(z, z_bytes->bytes)) return C_KZG_BADARGS;
     {
-        std::lock_guard<std::mutex> lock(ctx->mu);
-        OKB(hipSetDevice(ctx->device) == hipSuccess);
         Arena &ar = ctx->api_arena;
         OKM(ar.begin(BYTES_PER_BLOB + 2 * FIELD_ELEMENTS_PER_BLOB * sizeof(Fr) + 2 * sizeof(Fr) + 64));
         ABuf<uint8_t> d_blob(ar, BYTES_PER_BLOB), d_out(ar, 48);
@@ -508,13 +502,20 @@ extern "C" C_KZG_RET compute_kzg_proof(KZGProof *proof_out, Bytes32 *y_out, cons
     return C_KZG_OK;
 }
 
+extern "C" C_KZG_RET compute_kzg_proof(KZGProof *proof_out, Bytes32 *y_out, const Blob *blob,
+                                       const Bytes32 *z_bytes, const KZGSettings *s) {
+    return guarded([&]() -> C_KZG_RET {
+        Lease lease(s);
+        if (!lease.ctx) return C_KZG_ERROR;
+        return compute_kzg_proof_on(lease.ctx, proof_out, y_out, blob, z_bytes, s);
+    });
+}
+
 // compute_blob_kzg_proof with the evaluation and the quotient polynomial on the host (only the MSM on
 // the GPU): the general form, which also covers a challenge that falls inside the evaluation domain
 // (eip4844.c:458-481).  The batch entry point sends such blobs here.
-static C_KZG_RET blob_proof_host_quotient(KZGProof *out, const Blob *blob, const Bytes48 *commitment_bytes,
-                                          const KZGSettings *s) {
-    dev::DeviceCtx *ctx = ctx_of(s);
-    if (!ctx) return C_KZG_ERROR;
+static C_KZG_RET blob_proof_host_quotient(dev::DeviceCtx *ctx, KZGProof *out, const Blob *blob,
+                                          const Bytes48 *commitment_bytes, const KZGSettings *s) {
     std::vector<Fr> poly(FIELD_ELEMENTS_PER_BLOB);
     G1Jac c;
     Fr y;
@@ -528,18 +529,13 @@ static C_KZG_RET blob_proof_host_quotient(KZGProof *out, const Blob *blob, const
 
 // compute_blob_kzg_proof for a batch: challenges on the host (SHA-256), evaluation + quotient
 // polynomial and the 4096-term MSMs on the GPU.
-extern "C" C_KZG_RET ckzg_hip_compute_blob_kzg_proof_batch(KZGProof *proofs, uint8_t *status, const Blob *blobs,
-                                                           const Bytes48 *commitments_bytes, uint64_t n,
-                                                           const KZGSettings *s) {
-    dev::DeviceCtx *ctx = ctx_of(s);
-    if (!ctx) return C_KZG_ERROR;
+static C_KZG_RET blob_proof_batch_on(dev::DeviceCtx *ctx, KZGProof *proofs, uint8_t *status, const Blob *blobs,
+                                     const Bytes48 *commitments_bytes, uint64_t n, const KZGSettings *s) {
     if (n == 0) return C_KZG_OK;
     C_KZG_RET ret = C_KZG_OK;
     std::vector<uint8_t> st(n, 0);
     std::vector<int> redo;
     {
-        std::lock_guard<std::mutex> lock(ctx->mu);
-        OKB(hipSetDevice(ctx->device) == hipSuccess);
         const uint64_t CH = 256;
         const uint64_t m = n < CH ? n : CH;
         Arena &ar = ctx->api_arena;
@@ -615,7 +611,7 @@ extern "C" C_KZG_RET ckzg_hip_compute_blob_kzg_proof_batch(KZGProof *proofs, uin
         }
     }
     for (int i : redo) {
-        C_KZG_RET r = blob_proof_host_quotient(&proofs[i], &blobs[i], &commitments_bytes[i], s);
+        C_KZG_RET r = blob_proof_host_quotient(ctx, &proofs[i], &blobs[i], &commitments_bytes[i], s);
         if (r != C_KZG_OK) {
             st[i] = (uint8_t)r;
             ret = r;
@@ -623,6 +619,19 @@ extern "C" C_KZG_RET ckzg_hip_compute_blob_kzg_proof_batch(KZGProof *proofs, uin
     }
     if (status) memcpy(status, st.data(), n);
     return ret;
+}
+
+extern "C" C_KZG_RET ckzg_hip_compute_blob_kzg_proof_batch(KZGProof *proofs, uint8_t *status, const Blob *blobs,
+                                                           const Bytes48 *commitments_bytes, uint64_t n,
+                                                           const KZGSettings *s) {
+    return guarded([&]() -> C_KZG_RET {
+        if (!settings_of(s)) return C_KZG_ERROR;
+        if (n == 0) return C_KZG_OK;
+        return for_each_device_shard(s, n, 64, [&](dev::DeviceCtx *ctx, uint64_t lo, uint64_t hi) {
+            return blob_proof_batch_on(ctx, proofs + lo, status ? status + lo : nullptr, blobs + lo,
+                                       commitments_bytes + lo, hi - lo, s);
+        });
+    });
 }
 
 extern "C" C_KZG_RET compute_blob_kzg_proof(KZGProof *out, const Blob *blob, const Bytes48 *commitment_bytes,
@@ -635,25 +644,29 @@ extern "C" C_KZG_RET compute_blob_kzg_proof(KZGProof *out, const Blob *blob, con
 extern "C" C_KZG_RET verify_kzg_proof(bool *ok, const Bytes48 *commitment_bytes, const Bytes32 *z_bytes,
                                       const Bytes32 *y_bytes, const Bytes48 *proof_bytes,
                                       const KZGSettings *s) {
-    G1Jac c, p;
-    Fr z, y;
-    *ok = false;
-    dev::DeviceCtx *ctx = ctx_of(s);
-    if (!ctx) return C_KZG_ERROR;
-    if (validate_kzg_g1(c, commitment_bytes->bytes) != C_KZG_OK) return C_KZG_BADARGS;
-    if (!fr_from_bytes_canonical(z, z_bytes->bytes)) return C_KZG_BADARGS;
-    if (!fr_from_bytes_canonical(y, y_bytes->bytes)) return C_KZG_BADARGS;
-    if (validate_kzg_g1(p, proof_bytes->bytes) != C_KZG_OK) return C_KZG_BADARGS;
-    *ok = verify_kzg_proof_impl(c, z, y, p, prepared_of(ctx));
-    return C_KZG_OK;
+    return guarded([&]() -> C_KZG_RET {
+        G1Jac c, p;
+        Fr z, y;
+        *ok = false;
+        SettingsCtx *sc = settings_of(s);
+        if (!sc) return C_KZG_ERROR;
+        if (validate_kzg_g1(c, commitment_bytes->bytes) != C_KZG_OK) return C_KZG_BADARGS;
+        if (!fr_from_bytes_canonical(z, z_bytes->bytes)) return C_KZG_BADARGS;
+        if (!fr_from_bytes_canonical(y, y_bytes->bytes)) return C_KZG_BADARGS;
+        if (validate_kzg_g1(p, proof_bytes->bytes) != C_KZG_OK) return C_KZG_BADARGS;
+        *ok = verify_kzg_proof_impl(c, z, y, p, &sc->prepared);
+        return C_KZG_OK;
+    });
 }
 
 extern "C" C_KZG_RET verify_blob_kzg_proof(bool *ok, const Blob *blob, const Bytes48 *commitment_bytes,
                                            const Bytes48 *proof_bytes, const KZGSettings *s) {
-    *ok = false;
-    dev::DeviceCtx *ctx = ctx_of(s);
-    if (!ctx) return C_KZG_ERROR;
-    return verify_blobs_core(ok, blob, commitment_bytes, proof_bytes, 1, s, ctx);
+    return guarded([&]() -> C_KZG_RET {
+        *ok = false;
+        Lease lease(s);
+        if (!lease.ctx) return C_KZG_ERROR;
+        return verify_blobs_core(ok, blob, commitment_bytes, proof_bytes, 1, s, lease.ctx);
+    });
 }
 
 extern "C" C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48 *commitments_bytes,
@@ -664,12 +677,23 @@ extern "C" C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, co
         return C_KZG_OK;
     }
     if (n == 1) return verify_blob_kzg_proof(ok, blobs, commitments_bytes, proofs_bytes, s);
-    dev::DeviceCtx *ctx = ctx_of(s);
-    if (!ctx) return C_KZG_ERROR;
-    bool res = false;
-    C_KZG_RET ret = verify_blobs_core(&res, blobs, commitments_bytes, proofs_bytes, n, s, ctx);
-    if (ret == C_KZG_OK) *ok = res;
-    return ret;
+    return guarded([&]() -> C_KZG_RET {
+        SettingsCtx *sc = settings_of(s);
+        if (!sc) return C_KZG_ERROR;
+        // With several devices each one verifies a contiguous shard with its own random linear combination
+        // and pairing check and the verdicts are AND-ed (SURVEY section 8e sketches one global challenge with
+        // gathered partial sums; independent shards give the same verdict -- soundness error 2^-255 per shard --
+        // with no exchange step, at the price of one ~0.8 ms host pairing per device instead of one per call).
+        std::atomic<int> all_ok(1);
+        C_KZG_RET ret = for_each_device_shard(s, n, 256, [&](dev::DeviceCtx *ctx, uint64_t lo, uint64_t hi) {
+            bool res = false;
+            C_KZG_RET r = verify_blobs_core(&res, blobs + lo, commitments_bytes + lo, proofs_bytes + lo, hi - lo, s, ctx);
+            if (r == C_KZG_OK && !res) all_ok.store(0);
+            return r;
+        });
+        if (ret == C_KZG_OK) *ok = all_ok.load() != 0;
+        return ret;
+    });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -732,19 +756,9 @@ static C_KZG_RET recover_cells_gpu(dev::DeviceCtx *ctx, Fr *d_e, size_t count, c
     return C_KZG_OK;
 }
 
-extern "C" C_KZG_RET ckzg_hip_recover_cells_and_kzg_proofs_batch(Cell *recovered_cells, KZGProof *recovered_proofs,
-                                                                 uint8_t *status, const uint64_t *cell_indices,
-                                                                 const Cell *cells, uint64_t num_cells,
-                                                                 uint64_t num_blobs, const KZGSettings *s) {
-    // eip7594.c:177-304, for num_blobs rows that all hold the same num_cells columns
-    if (recovered_cells == NULL && recovered_proofs == NULL) return C_KZG_BADARGS;
-    if (num_cells > CELLS_PER_EXT_BLOB || num_cells < CELLS_PER_BLOB) return C_KZG_BADARGS;
-    for (size_t i = 0; i < num_cells; i++) {
-        if (cell_indices[i] >= CELLS_PER_EXT_BLOB) return C_KZG_BADARGS;
-        if (i > 0 && cell_indices[i] <= cell_indices[i - 1]) return C_KZG_BADARGS;
-    }
-    dev::DeviceCtx *ctx = ctx_of(s);
-    if (!ctx) return C_KZG_ERROR;
+static C_KZG_RET recover_batch_on(dev::DeviceCtx *ctx, Cell *recovered_cells, KZGProof *recovered_proofs,
+                                  uint8_t *status, const uint64_t *cell_indices, const Cell *cells,
+                                  uint64_t num_cells, uint64_t num_blobs, const KZGSettings *s) {
     if (num_blobs == 0) return C_KZG_OK;
     const size_t n = FIELD_ELEMENTS_PER_EXT_BLOB;
     const size_t CH = 512;  // 512 rows: 128 MiB of byte image + 128 MiB of Fr + 64 MiB of coefficients
@@ -753,8 +767,6 @@ extern "C" C_KZG_RET ckzg_hip_recover_cells_and_kzg_proofs_batch(Cell *recovered
     for (size_t i = 0; i < num_cells; i++) idx32[i] = (uint32_t)cell_indices[i];
     std::vector<uint32_t> bad(m);
     C_KZG_RET result = C_KZG_OK;
-    std::lock_guard<std::mutex> lock(ctx->mu);
-    OKB(hipSetDevice(ctx->device) == hipSuccess);
     Arena &ar = ctx->api_arena;
     const size_t nchunks = (size_t)((num_blobs + CH - 1) / CH);  // recover_cells_gpu takes 3 vectors per chunk
     OKM(ar.begin(m * (n * 32 + num_cells * BYTES_PER_CELL + n * sizeof(Fr) + 4) + num_cells * 4 +
@@ -807,6 +819,29 @@ extern "C" C_KZG_RET ckzg_hip_recover_cells_and_kzg_proofs_batch(Cell *recovered
     return result;
 }
 
+extern "C" C_KZG_RET ckzg_hip_recover_cells_and_kzg_proofs_batch(Cell *recovered_cells, KZGProof *recovered_proofs,
+                                                                 uint8_t *status, const uint64_t *cell_indices,
+                                                                 const Cell *cells, uint64_t num_cells,
+                                                                 uint64_t num_blobs, const KZGSettings *s) {
+    // eip7594.c:177-304, for num_blobs rows that all hold the same num_cells columns
+    return guarded([&]() -> C_KZG_RET {
+        if (recovered_cells == NULL && recovered_proofs == NULL) return C_KZG_BADARGS;
+        if (num_cells > CELLS_PER_EXT_BLOB || num_cells < CELLS_PER_BLOB) return C_KZG_BADARGS;
+        for (size_t i = 0; i < num_cells; i++) {
+            if (cell_indices[i] >= CELLS_PER_EXT_BLOB) return C_KZG_BADARGS;
+            if (i > 0 && cell_indices[i] <= cell_indices[i - 1]) return C_KZG_BADARGS;
+        }
+        if (!settings_of(s)) return C_KZG_ERROR;
+        if (num_blobs == 0) return C_KZG_OK;
+        return for_each_device_shard(s, num_blobs, 16, [&](dev::DeviceCtx *ctx, uint64_t lo, uint64_t hi) {
+            return recover_batch_on(ctx, recovered_cells ? recovered_cells + lo * CELLS_PER_EXT_BLOB : nullptr,
+                                    recovered_proofs ? recovered_proofs + lo * CELLS_PER_EXT_BLOB : nullptr,
+                                    status ? status + lo : nullptr, cell_indices, cells + lo * num_cells, num_cells,
+                                    hi - lo, s);
+        });
+    });
+}
+
 extern "C" C_KZG_RET recover_cells_and_kzg_proofs(Cell *recovered_cells, KZGProof *recovered_proofs,
                                                   const uint64_t *cell_indices, const Cell *cells,
                                                   uint64_t num_cells, const KZGSettings *s) {
@@ -844,21 +879,10 @@ extern "C" C_KZG_RET compute_verify_cell_kzg_proof_batch_challenge(
     return C_KZG_OK;
 }
 
-extern "C" C_KZG_RET verify_cell_kzg_proof_batch(bool *ok, const Bytes48 *commitments_bytes,
-                                                 const uint64_t *cell_indices, const Cell *cells,
-                                                 const Bytes48 *proofs_bytes, uint64_t num_cells,
-                                                 const KZGSettings *s) {
-    // eip7594.c:825-974
+static C_KZG_RET verify_cells_on(dev::DeviceCtx *ctx, bool *ok, const Bytes48 *commitments_bytes,
+                                 const uint64_t *cell_indices, const Cell *cells, const Bytes48 *proofs_bytes,
+                                 uint64_t num_cells, const KZGSettings *s) {
     *ok = false;
-    if (num_cells == 0) {
-        *ok = true;
-        return C_KZG_OK;
-    }
-    for (size_t i = 0; i < num_cells; i++) {
-        if (cell_indices[i] >= CELLS_PER_EXT_BLOB) return C_KZG_BADARGS;
-    }
-    dev::DeviceCtx *ctx = ctx_of(s);
-    if (!ctx) return C_KZG_ERROR;
     const size_t n = num_cells, l = FIELD_ELEMENTS_PER_CELL;
     Trace tr("verify_cells");
     const Fr *rou = as_fr(s->roots_of_unity);
@@ -874,8 +898,6 @@ extern "C" C_KZG_RET verify_cell_kzg_proof_batch(bool *ok, const Bytes48 *commit
         cidx[i] = j;
     }
     const size_t nc = uniq.size();
-    std::lock_guard<std::mutex> lock(ctx->mu);
-    OKB(hipSetDevice(ctx->device) == hipSuccess);
     Arena &ar = ctx->api_arena;
     OKM(ar.begin((n + nc) * (48 + 2 + sizeof(G1Affine)) + ((size_t)CELLS_PER_EXT_BLOB * l + l + n * l + n) * sizeof(Fr) +
                  n * BYTES_PER_CELL + (n + CELLS_PER_EXT_BLOB + 1 + n) * 4));
@@ -981,4 +1003,33 @@ extern "C" C_KZG_RET verify_cell_kzg_proof_batch(bool *ok, const Bytes48 *commit
                                  prepared_of(ctx)->s64);
     tr.mark("pairing check");
     return C_KZG_OK;
+}
+
+extern "C" C_KZG_RET verify_cell_kzg_proof_batch(bool *ok, const Bytes48 *commitments_bytes,
+                                                 const uint64_t *cell_indices, const Cell *cells,
+                                                 const Bytes48 *proofs_bytes, uint64_t num_cells,
+                                                 const KZGSettings *s) {
+    // eip7594.c:825-974
+    return guarded([&]() -> C_KZG_RET {
+        *ok = false;
+        if (num_cells == 0) {
+            *ok = true;
+            return C_KZG_OK;
+        }
+        for (size_t i = 0; i < num_cells; i++) {
+            if (cell_indices[i] >= CELLS_PER_EXT_BLOB) return C_KZG_BADARGS;
+        }
+        if (!settings_of(s)) return C_KZG_ERROR;
+        // several devices: contiguous shards of cells, each with its own challenge and pairing check, AND-ed
+        std::atomic<int> all_ok(1);
+        C_KZG_RET ret = for_each_device_shard(s, num_cells, 2048, [&](dev::DeviceCtx *ctx, uint64_t lo, uint64_t hi) {
+            bool res = false;
+            C_KZG_RET r = verify_cells_on(ctx, &res, commitments_bytes + lo, cell_indices + lo, cells + lo,
+                                          proofs_bytes + lo, hi - lo, s);
+            if (r == C_KZG_OK && !res) all_ok.store(0);
+            return r;
+        });
+        if (ret == C_KZG_OK) *ok = all_ok.load() != 0;
+        return ret;
+    });
 }

@@ -1,12 +1,13 @@
-// device.hpp -- the GPU context that hangs off a loaded KZGSettings, and the launchers the C-ABI
-// layer (ckzg_api.hip) calls.  One context per load_trusted_setup; immutable tables in HBM, one
-// stream, one growable scratch arena guarded by a mutex (the reference allows concurrent readers
-// of one KZGSettings, bindings/rust/src/bindings/mod.rs:910-913; here they serialise on the GPU).
+// device.hpp -- the GPU state that hangs off a loaded KZGSettings, and the launchers the C-ABI layer
+// (ckzg_api.hip) calls.  Per load_trusted_setup and per selected device there is one set of immutable
+// tables in HBM and a small pool of DeviceCtx "slots": each slot has its own streams, events, scratch
+// and arenas and only aliases the tables, so concurrent callers of one KZGSettings (legal in the
+// reference: bindings/rust/src/bindings/mod.rs:910-913, bindings/go/main_test.go:953-971) each lease a
+// slot and overlap on the GPU instead of serialising (api_common.hpp: DevicePool, Lease).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
-#include <mutex>
 #include "g1.hpp"
 
 namespace ckzg {
@@ -76,18 +77,22 @@ struct Arena {
 
 struct DeviceCtx {
     int device = 0;
+    int slot = 0;                 // index in its pool; slot 0 owns the tables, the others alias them
+    bool owns_tables = true;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;  // host-to-device staging, overlapped with `stream`
     void *h_stage[2] = {nullptr, nullptr};  // pinned host staging buffers (allocated on first use)
-    std::mutex mu;
+    size_t h_stage_bytes = 0;
+    void *h_out[2] = {nullptr, nullptr};    // pinned device-to-host staging (cells+proofs / recover pipelines)
+    size_t h_out_bytes = 0;
     FixedBaseTable commit;        // over g1_values_lagrange_brp (4096 points)
     FixedBaseTable mono;          // over g1_values_monomial (4096 points): low-latency cell proofs
     int direct_max = 10;          // batches up to this many blobs use the direct proof path (set at load)
-    Scratch scratch;              // reused by every call under `mu`
+    Scratch scratch;              // per slot: reused by every call that leases the slot
     Arena api_arena, lc_arena;    // temporaries of the host-pointer entry points / of gpu_lincomb_multi
     hipEvent_t stage_ev[4] = {};  // copied[2], consumed[2] of the staging pipeline (created on first use)
-    hipEvent_t ev[8] = {};        // timing events
-    float last_ms[4] = {-1, -1, -1, -1};
+    hipEvent_t ev[12] = {};       // timing events
+    float last_ms[6] = {-1, -1, -1, -1, -1, -1};  // see ckzg_hip_last_kernel_ms
     // Fr tables for NTTs and evaluation (Montgomery form, 8 x u32)
     Fr *d_roots = nullptr;        // w^i, 8193 entries
     Fr *d_brp_roots = nullptr;    // 8192
@@ -98,7 +103,7 @@ struct DeviceCtx {
     G1Affine *d_mono = nullptr;   // g1_values_monomial, affine, 4096
     Fr *d_shift = nullptr;        // 7^i, i < 8192   (coset_fft, fft.c:257-279)
     Fr *d_unshift = nullptr;      // 7^-i, i < 8192  (coset_ifft, fft.c:290-301)
-    void *host_prepared = nullptr; // api::PreparedG2 (host-side line tables for the pairing checks)
+    void *host_prepared = nullptr; // api::PreparedG2 (host-side line tables for the pairing checks; owned by SettingsCtx)
 };
 
 #define HIP_TRY(expr)                                                                          \

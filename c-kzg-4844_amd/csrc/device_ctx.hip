@@ -1,12 +1,116 @@
-// device_ctx.hip -- creation / destruction of the per-KZGSettings GPU context: device selection,
-// stream + timing events, upload of setup points and twiddles, fixed-base table construction.
+// device_ctx.hip -- creation / destruction of the GPU state of a loaded KZGSettings: device selection,
+// per-device table construction, the slot pools (stream + scratch per concurrent call), the registry
+// that maps a KZGSettings to its state, and slot leasing.
 // This is the GPU half of load_trusted_setup (src/setup/setup.c:392-505): the reference builds
 // x_ext_fft_columns and (optionally) blst fixed-base tables on the CPU (setup.c:238-330); here the
 // 64 G1 FFTs and all tables are produced by kernels and stay resident in HBM.
+#include <shared_mutex>
+#include <unordered_map>
+
 #include "api_common.hpp"
 
 namespace ckzg {
 namespace api {
+
+// ------------------------------------------------------------------------------------------
+// registry: KZGSettings::roots_of_unity -> SettingsCtx
+// ------------------------------------------------------------------------------------------
+
+namespace {
+std::shared_mutex g_reg_mu;
+std::unordered_map<const void *, SettingsCtx *> &registry() {
+    static std::unordered_map<const void *, SettingsCtx *> r;
+    return r;
+}
+}  // namespace
+
+SettingsCtx *settings_of(const KZGSettings *s, bool complain) {
+    SettingsCtx *sc = nullptr;
+    if (s && s->roots_of_unity) {
+        std::shared_lock<std::shared_mutex> lock(g_reg_mu);
+        auto it = registry().find(s->roots_of_unity);
+        if (it != registry().end()) sc = it->second;
+    }
+    if (!sc && complain)
+        fprintf(stderr, "[ckzg-hip] KZGSettings has no GPU context (not loaded by this library, or freed)\n");
+    return sc;
+}
+
+// ------------------------------------------------------------------------------------------
+// leases
+// ------------------------------------------------------------------------------------------
+
+void Lease::take(DevicePool *p) {
+    std::unique_lock<std::mutex> lock(p->mu);
+    p->cv.wait(lock, [p]() { return !p->free_slots.empty(); });
+    int idx = p->free_slots.back();
+    p->free_slots.pop_back();
+    lock.unlock();
+    pool = p;
+    ctx = p->slots[idx];
+    p->last.store(ctx, std::memory_order_relaxed);
+    if (hipSetDevice(ctx->device) != hipSuccess) {
+        fprintf(stderr, "[ckzg-hip] hipSetDevice(%d) failed\n", ctx->device);
+        std::lock_guard<std::mutex> relock(p->mu);
+        p->free_slots.push_back(idx);
+        p->cv.notify_one();
+        pool = nullptr;
+        ctx = nullptr;
+    }
+}
+
+Lease::Lease(DevicePool *p) { take(p); }
+
+Lease::Lease(const KZGSettings *s, int pool_index) {
+    SettingsCtx *sc = settings_of(s);
+    if (!sc || sc->pools.empty()) return;
+    const size_t np = sc->pools.size();
+    if (pool_index >= 0) {
+        take(sc->pools[(size_t)pool_index % np]);
+        return;
+    }
+    // round robin over the pools, preferring one that has a free slot right now
+    const unsigned start = sc->next.fetch_add(1, std::memory_order_relaxed);
+    for (size_t k = 0; k < np; k++) {
+        DevicePool *p = sc->pools[(start + k) % np];
+        bool has_free;
+        {
+            std::lock_guard<std::mutex> lock(p->mu);
+            has_free = !p->free_slots.empty();
+        }
+        if (has_free) {
+            take(p);
+            return;
+        }
+    }
+    take(sc->pools[start % np]);
+}
+
+Lease::~Lease() {
+    if (!pool || !ctx) return;
+    {
+        std::lock_guard<std::mutex> lock(pool->mu);
+        pool->free_slots.push_back(ctx->slot);
+    }
+    pool->cv.notify_one();
+}
+
+int pool_of_pointer(const SettingsCtx *sc, const void *dptr) {
+    if (sc->pools.size() <= 1 || !dptr) return 0;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, dptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    for (size_t i = 0; i < sc->pools.size(); i++) {
+        if (sc->pools[i]->device == at.device) return (int)i;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// construction
+// ------------------------------------------------------------------------------------------
 
 static int env_int(const char *name, int dflt) {
     const char *v = getenv(name);
@@ -35,20 +139,23 @@ static int fit_wbits(const char *what, int wbits, int floor_bits, int npoints) {
     return wbits;
 }
 
-void destroy_device_ctx(dev::DeviceCtx *ctx) {
+static void destroy_slot(dev::DeviceCtx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->commit.d_table) (void)hipFree(ctx->commit.d_table);
-    if (ctx->fk20.d_table) (void)hipFree(ctx->fk20.d_table);
-    if (ctx->mono.d_table) (void)hipFree(ctx->mono.d_table);
-    if (ctx->d_xext) (void)hipFree(ctx->d_xext);
-    if (ctx->d_roots) (void)hipFree(ctx->d_roots);
-    if (ctx->d_brp_roots) (void)hipFree(ctx->d_brp_roots);
-    if (ctx->d_roots_raw) (void)hipFree(ctx->d_roots_raw);
-    if (ctx->d_mono) (void)hipFree(ctx->d_mono);
-    if (ctx->d_shift) (void)hipFree(ctx->d_shift);
-    if (ctx->d_unshift) (void)hipFree(ctx->d_unshift);
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    if (ctx->owns_tables) {
+        if (ctx->commit.d_table) (void)hipFree(ctx->commit.d_table);
+        if (ctx->fk20.d_table) (void)hipFree(ctx->fk20.d_table);
+        if (ctx->mono.d_table) (void)hipFree(ctx->mono.d_table);
+        if (ctx->d_xext) (void)hipFree(ctx->d_xext);
+        if (ctx->d_roots) (void)hipFree(ctx->d_roots);
+        if (ctx->d_brp_roots) (void)hipFree(ctx->d_brp_roots);
+        if (ctx->d_roots_raw) (void)hipFree(ctx->d_roots_raw);
+        if (ctx->d_mono) (void)hipFree(ctx->d_mono);
+        if (ctx->d_shift) (void)hipFree(ctx->d_shift);
+        if (ctx->d_unshift) (void)hipFree(ctx->d_unshift);
+    }
     if (ctx->scratch.ptr) (void)hipFree(ctx->scratch.ptr);
     ctx->api_arena.release();
     ctx->lc_arena.release();
@@ -63,8 +170,23 @@ void destroy_device_ctx(dev::DeviceCtx *ctx) {
     for (auto &h : ctx->h_stage) {
         if (h) (void)hipHostFree(h);
     }
-    delete static_cast<PreparedG2 *>(ctx->host_prepared);
+    for (auto &h : ctx->h_out) {
+        if (h) (void)hipHostFree(h);
+    }
     delete ctx;
+}
+
+static void destroy_pool(DevicePool *p) {
+    if (!p) return;
+    // aliases first, the owner of the tables last
+    for (size_t i = p->slots.size(); i-- > 0;) destroy_slot(p->slots[i]);
+    delete p;
+}
+
+static void destroy_settings(SettingsCtx *sc) {
+    if (!sc) return;
+    for (auto *p : sc->pools) destroy_pool(p);
+    delete sc;
 }
 
 #define CTX_TRY(expr)                                                                            \
@@ -73,31 +195,25 @@ void destroy_device_ctx(dev::DeviceCtx *ctx) {
         if (_e != hipSuccess) {                                                                  \
             fprintf(stderr, "[ckzg-hip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(_e),   \
                     __FILE__, __LINE__);                                                         \
-            destroy_device_ctx(ctx);                                                             \
             return _e == hipErrorOutOfMemory ? C_KZG_MALLOC : C_KZG_ERROR;                       \
         }                                                                                        \
     } while (0)
 
-C_KZG_RET create_device_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affine,
-                            const G1Affine *monomial_affine) {
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
-        fprintf(stderr, "[ckzg-hip] no HIP device available: this build has no CPU fallback for the MSM/FFT hot path\n");
-        return C_KZG_ERROR;
-    }
-    int device = g_opts.device;
-    if (device < 0) device = env_int("CKZG_HIP_DEVICE", -1);
-    if (device < 0) device = env_int("LOCAL_RANK", 0) % ndev;
-    if (device >= ndev) {
-        fprintf(stderr, "[ckzg-hip] device %d out of range (%d visible)\n", device, ndev);
-        return C_KZG_ERROR;
-    }
-    dev::DeviceCtx *ctx = new dev::DeviceCtx();
-    ctx->device = device;
-    CTX_TRY(hipSetDevice(device));
+static C_KZG_RET init_slot_runtime(dev::DeviceCtx *ctx) {
     CTX_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     CTX_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     for (auto &e : ctx->ev) CTX_TRY(hipEventCreate(&e));
+    return C_KZG_OK;
+}
+
+// Tables of one pool, built on the calling thread's device into `ctx` (slot 0).  h_xext (optional):
+// host copy of the x_ext_fft columns for the KZGSettings mirror.
+static C_KZG_RET build_owner(dev::DeviceCtx *ctx, const KZGSettings *s, const Options &opts,
+                             const G1Affine *lagrange_brp_affine, const G1Affine *monomial_affine,
+                             G1Affine *h_xext) {
+    CTX_TRY(hipSetDevice(ctx->device));
+    C_KZG_RET r = init_slot_runtime(ctx);
+    if (r != C_KZG_OK) return r;
 
     // Fr twiddles
     CTX_TRY(hipMalloc(&ctx->d_roots, (dev::N_EXT + 1) * sizeof(Fr)));
@@ -124,71 +240,61 @@ C_KZG_RET create_device_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affine,
         CTX_TRY(hipMemcpy(ctx->d_unshift, ush.data(), dev::N_EXT * sizeof(Fr), hipMemcpyHostToDevice));
     }
 
-    // commitment table over the bit-reversed Lagrange points
+    DeviceBuffer d_bases;
+    if (!d_bases.alloc(NUM_G1_POINTS * sizeof(G1Affine))) return C_KZG_MALLOC;
+    CTX_TRY(hipMemcpy(d_bases.p, lagrange_brp_affine, NUM_G1_POINTS * sizeof(G1Affine), hipMemcpyHostToDevice));
+    CTX_TRY(hipMalloc(&ctx->d_mono, NUM_G1_POINTS * sizeof(G1Affine)));
+    CTX_TRY(hipMemcpy(ctx->d_mono, monomial_affine, NUM_G1_POINTS * sizeof(G1Affine), hipMemcpyHostToDevice));
+
+    // The fixed-base tables and the G1 FFT twiddles use the endomorphism phi = [lambda], which holds only
+    // on the prime-order subgroup.  The reference checks setup points for curve membership only
+    // (setup.c:447-477); a file with a point outside G1 is not a trusted setup, and is rejected here
+    // rather than silently giving sums that differ from the reference's.
     {
-        int wbits = env_int("CKZG_HIP_COMMIT_WBITS", g_opts.commit_wbits);
-        if (wbits < 4 || wbits > 16) wbits = 10;
-        wbits = fit_wbits("commit", wbits, 10, (int)NUM_G1_POINTS);
-        DeviceBuffer d_bases;
-        if (!d_bases.alloc(NUM_G1_POINTS * sizeof(G1Affine))) {
-            destroy_device_ctx(ctx);
-            return C_KZG_MALLOC;
-        }
-        CTX_TRY(hipMemcpy(d_bases.p, lagrange_brp_affine, NUM_G1_POINTS * sizeof(G1Affine), hipMemcpyHostToDevice));
-        int rc = dev::build_fixed_base_table(ctx, &ctx->commit, (const G1Affine *)d_bases.p, (int)NUM_G1_POINTS, wbits);
-        if (rc) {
-            destroy_device_ctx(ctx);
-            return (C_KZG_RET)rc;
+        DeviceBuffer d_st;
+        if (!d_st.alloc(2 * NUM_G1_POINTS)) return C_KZG_MALLOC;
+        int rc = dev::subgroup_g1_batch_device(ctx, (uint8_t *)d_st.p, (const G1Affine *)d_bases.p, NUM_G1_POINTS);
+        if (!rc) rc = dev::subgroup_g1_batch_device(ctx, (uint8_t *)d_st.p + NUM_G1_POINTS, ctx->d_mono, NUM_G1_POINTS);
+        if (rc) return (C_KZG_RET)rc;
+        std::vector<uint8_t> st(2 * NUM_G1_POINTS);
+        CTX_TRY(hipStreamSynchronize(ctx->stream));
+        CTX_TRY(hipMemcpy(st.data(), d_st.p, st.size(), hipMemcpyDeviceToHost));
+        for (uint8_t b : st) {
+            if (b) {
+                fprintf(stderr, "[ckzg-hip] trusted setup holds a G1 point outside the prime-order subgroup\n");
+                return C_KZG_BADARGS;
+            }
         }
     }
-    // FK20: x_ext_fft columns by 64 G1 FFTs on the GPU, mirrored into the host struct, then the
-    // fixed-base table over those 8192 points
+
+    // commitment table over the bit-reversed Lagrange points
     {
-        CTX_TRY(hipMalloc(&ctx->d_mono, NUM_G1_POINTS * sizeof(G1Affine)));
-        CTX_TRY(hipMemcpy(ctx->d_mono, monomial_affine, NUM_G1_POINTS * sizeof(G1Affine), hipMemcpyHostToDevice));
-        std::vector<G1Affine> h_xext((size_t)dev::N_CELLS_EXT * dev::N_CELL);
-        int rc = dev::fk20_setup_device(ctx, ctx->d_mono, h_xext.data());
-        if (rc) {
-            destroy_device_ctx(ctx);
-            return (C_KZG_RET)rc;
-        }
-        s->x_ext_fft_columns = (g1_t **)calloc(dev::N_CELLS_EXT, sizeof(g1_t *));
-        if (!s->x_ext_fft_columns) {
-            destroy_device_ctx(ctx);
-            return C_KZG_MALLOC;
-        }
-        for (int j = 0; j < dev::N_CELLS_EXT; j++) {
-            s->x_ext_fft_columns[j] = (g1_t *)calloc(dev::N_CELL, sizeof(g1_t));
-            if (!s->x_ext_fft_columns[j]) {
-                destroy_device_ctx(ctx);
-                return C_KZG_MALLOC;
-            }
-            for (int i = 0; i < dev::N_CELL; i++) {
-                *as_g1(&s->x_ext_fft_columns[j][i]) = jac_from_affine(h_xext[(size_t)j * dev::N_CELL + i]);
-            }
-        }
-        int wbits = env_int("CKZG_HIP_FK20_WBITS", g_opts.fk20_wbits);
+        int wbits = env_int("CKZG_HIP_COMMIT_WBITS", opts.commit_wbits);
+        if (wbits < 4 || wbits > 16) wbits = 10;
+        wbits = fit_wbits("commit", wbits, 8, (int)NUM_G1_POINTS);
+        int rc = dev::build_fixed_base_table(ctx, &ctx->commit, (const G1Affine *)d_bases.p, (int)NUM_G1_POINTS, wbits);
+        if (rc) return (C_KZG_RET)rc;
+    }
+    // FK20: x_ext_fft columns by 64 G1 FFTs on the GPU, then the fixed-base table over those 8192 points
+    {
+        int rc = dev::fk20_setup_device(ctx, ctx->d_mono, h_xext);
+        if (rc) return (C_KZG_RET)rc;
+        int wbits = env_int("CKZG_HIP_FK20_WBITS", opts.fk20_wbits);
         if (wbits == 0) wbits = s->wbits > 8 ? (s->wbits > 13 ? 13 : (int)s->wbits) : 8;
-        if (wbits < 4 || wbits > 15) wbits = 8;
+        if (wbits < 4 || wbits > 16) wbits = 8;
         wbits = fit_wbits("fk20", wbits, 8, dev::N_CELLS_EXT * dev::N_CELL);
         rc = dev::build_fixed_base_table(ctx, &ctx->fk20, ctx->d_xext, dev::N_CELLS_EXT * dev::N_CELL, wbits);
-        if (rc) {
-            destroy_device_ctx(ctx);
-            return (C_KZG_RET)rc;
-        }
+        if (rc) return (C_KZG_RET)rc;
     }
     // table over the monomial points for the low-latency (direct) cell-proof path
     {
-        int wbits = env_int("CKZG_HIP_PROOF_WBITS", g_opts.proof_wbits);
-        ctx->direct_max = env_int("CKZG_HIP_DIRECT_MAX", g_opts.direct_max);
+        int wbits = env_int("CKZG_HIP_PROOF_WBITS", opts.proof_wbits);
+        ctx->direct_max = env_int("CKZG_HIP_DIRECT_MAX", opts.direct_max);
         if (wbits != 0 && ctx->direct_max != 0) {
             if (wbits < 4 || wbits > 16) wbits = 8;
             wbits = fit_wbits("proof", wbits, 8, (int)NUM_G1_POINTS);
             int rc = dev::build_fixed_base_table(ctx, &ctx->mono, ctx->d_mono, (int)NUM_G1_POINTS, wbits);
-            if (rc) {
-                destroy_device_ctx(ctx);
-                return (C_KZG_RET)rc;
-            }
+            if (rc) return (C_KZG_RET)rc;
             // Automatic hand-over point (measured, tools/bench_direct_vs_fk20.py): FK20 costs ~28 ms for any
             // batch of up to ~48 blobs (13 dependent ladder launches), the direct path 3.5 ms for one blob
             // plus 2.5 / 1.9 / 1.5 ms per further blob with an 8 / 13 / 16-bit table.
@@ -196,15 +302,153 @@ C_KZG_RET create_device_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affine,
         }
         if (ctx->direct_max < 0) ctx->direct_max = 0;
     }
-    {
-        PreparedG2 *pg = new PreparedG2();
-        host::g2_prepare(pg->gen, host::g2_to_affine(host::g2_generator()));
-        host::g2_prepare(pg->s1, host::g2_to_affine(*as_g2(&s->g2_values_monomial[1])));
-        host::g2_prepare(pg->s64, host::g2_to_affine(*as_g2(&s->g2_values_monomial[dev::N_CELL])));
-        ctx->host_prepared = pg;
-    }
-    header_of(s)->ctx = ctx;
     return C_KZG_OK;
+}
+
+// a further slot of the same pool: own streams, events, scratch; the owner's tables
+static C_KZG_RET clone_slot(dev::DeviceCtx **out, const dev::DeviceCtx *owner, int slot) {
+    dev::DeviceCtx *c = new dev::DeviceCtx();
+    *out = c;
+    c->device = owner->device;
+    c->slot = slot;
+    c->owns_tables = false;
+    c->commit = owner->commit;
+    c->mono = owner->mono;
+    c->fk20 = owner->fk20;
+    c->direct_max = owner->direct_max;
+    c->d_roots = owner->d_roots;
+    c->d_brp_roots = owner->d_brp_roots;
+    c->d_roots_raw = owner->d_roots_raw;
+    c->d_xext = owner->d_xext;
+    c->d_mono = owner->d_mono;
+    c->d_shift = owner->d_shift;
+    c->d_unshift = owner->d_unshift;
+    c->host_prepared = owner->host_prepared;
+    return init_slot_runtime(c);
+}
+
+C_KZG_RET create_settings_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affine, const G1Affine *monomial_affine) {
+    const Options opts = options_snapshot();
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        fprintf(stderr, "[ckzg-hip] no HIP device available: this build has no CPU fallback for the MSM/FFT hot path\n");
+        return C_KZG_ERROR;
+    }
+    // device list: the "devices" mask if given, else the single `device`
+    std::vector<int> devs;
+    int64_t mask = opts.devices;
+    if (const char *v = getenv("CKZG_HIP_DEVICES")) {
+        if (*v) mask = !strcmp(v, "all") ? -1 : (int64_t)strtoll(v, nullptr, 0);
+    }
+    if (mask != 0) {
+        for (int d = 0; d < ndev && d < 63; d++) {
+            if (mask < 0 || ((mask >> d) & 1)) devs.push_back(d);
+        }
+        if (mask > 0 && (mask >> (ndev < 63 ? ndev : 63)) != 0) {
+            fprintf(stderr, "[ckzg-hip] devices mask 0x%llx names a device that is not visible (%d visible)\n",
+                    (unsigned long long)mask, ndev);
+            return C_KZG_ERROR;
+        }
+    } else {
+        int device = opts.device;
+        if (device < 0) device = env_int("CKZG_HIP_DEVICE", -1);
+        if (device < 0) device = env_int("LOCAL_RANK", 0) % ndev;
+        if (device >= ndev) {
+            fprintf(stderr, "[ckzg-hip] device %d out of range (%d visible)\n", device, ndev);
+            return C_KZG_ERROR;
+        }
+        devs.push_back(device);
+    }
+    if (devs.empty()) return C_KZG_ERROR;
+    int replicas = env_int("CKZG_HIP_REPLICAS", opts.replicas);
+    if (replicas < 1) replicas = 1;
+    if (replicas > 8) replicas = 8;
+    int nslots = env_int("CKZG_HIP_STREAMS", opts.streams);
+    if (nslots < 1) nslots = 1;
+    if (nslots > 64) nslots = 64;
+
+    SettingsCtx *sc = new SettingsCtx();
+    sc->opts = opts;
+    host::g2_prepare(sc->prepared.gen, host::g2_to_affine(host::g2_generator()));
+    host::g2_prepare(sc->prepared.s1, host::g2_to_affine(*as_g2(&s->g2_values_monomial[1])));
+    host::g2_prepare(sc->prepared.s64, host::g2_to_affine(*as_g2(&s->g2_values_monomial[dev::N_CELL])));
+    for (int d : devs) {
+        for (int r = 0; r < replicas; r++) {
+            DevicePool *p = new DevicePool();
+            p->device = d;
+            dev::DeviceCtx *owner = new dev::DeviceCtx();
+            owner->device = d;
+            owner->host_prepared = &sc->prepared;
+            p->slots.push_back(owner);
+            sc->pools.push_back(p);
+        }
+    }
+    // the pools are independent: build them concurrently, one host thread per device (pools that share a
+    // device -- replicas -- build one after the other so that fit_wbits sees what is really free)
+    std::vector<G1Affine> h_xext((size_t)dev::N_CELLS_EXT * dev::N_CELL);
+    std::vector<C_KZG_RET> rets(sc->pools.size(), C_KZG_OK);
+    {
+        std::vector<std::thread> th;
+        for (size_t di = 0; di < devs.size(); di++) {
+            th.emplace_back([&, di]() {
+                for (int r = 0; r < replicas; r++) {
+                    const size_t pi = di * replicas + r;
+                    rets[pi] = guarded([&]() {
+                        return build_owner(sc->pools[pi]->slots[0], s, opts, lagrange_brp_affine, monomial_affine,
+                                           pi == 0 ? h_xext.data() : nullptr);
+                    });
+                    if (rets[pi] != C_KZG_OK) break;
+                }
+            });
+        }
+        for (auto &t : th) t.join();
+    }
+    C_KZG_RET ret = C_KZG_OK;
+    for (auto r : rets) ret = worse(ret, r);
+    for (size_t pi = 0; pi < sc->pools.size() && ret == C_KZG_OK; pi++) {
+        DevicePool *p = sc->pools[pi];
+        if (hipSetDevice(p->device) != hipSuccess) ret = C_KZG_ERROR;
+        for (int k = 1; k < nslots && ret == C_KZG_OK; k++) {
+            dev::DeviceCtx *c = nullptr;
+            ret = clone_slot(&c, p->slots[0], k);
+            p->slots.push_back(c);
+        }
+        for (int k = (int)p->slots.size(); k-- > 0;) p->free_slots.push_back(k);  // slot 0 is handed out first
+    }
+    if (ret == C_KZG_OK) {
+        // mirror of x_ext_fft_columns in the host struct (setup.c:238-330), Jacobian as in the reference
+        s->x_ext_fft_columns = (g1_t **)calloc(dev::N_CELLS_EXT, sizeof(g1_t *));
+        if (!s->x_ext_fft_columns) ret = C_KZG_MALLOC;
+        for (int j = 0; j < dev::N_CELLS_EXT && ret == C_KZG_OK; j++) {
+            s->x_ext_fft_columns[j] = (g1_t *)calloc(dev::N_CELL, sizeof(g1_t));
+            if (!s->x_ext_fft_columns[j]) {
+                ret = C_KZG_MALLOC;
+                break;
+            }
+            for (int i = 0; i < dev::N_CELL; i++) {
+                *as_g1(&s->x_ext_fft_columns[j][i]) = jac_from_affine(h_xext[(size_t)j * dev::N_CELL + i]);
+            }
+        }
+    }
+    if (ret != C_KZG_OK) {
+        destroy_settings(sc);
+        return ret;
+    }
+    std::unique_lock<std::shared_mutex> lock(g_reg_mu);
+    registry()[s->roots_of_unity] = sc;
+    return C_KZG_OK;
+}
+
+void destroy_settings_ctx(const KZGSettings *s) {
+    SettingsCtx *sc = nullptr;
+    {
+        std::unique_lock<std::shared_mutex> lock(g_reg_mu);
+        auto it = registry().find(s->roots_of_unity);
+        if (it == registry().end()) return;
+        sc = it->second;
+        registry().erase(it);
+    }
+    destroy_settings(sc);
 }
 
 }  // namespace api

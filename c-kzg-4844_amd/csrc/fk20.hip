@@ -319,11 +319,13 @@ static int fk20_run(DeviceCtx *ctx, uint8_t *d_proofs, const Fr *d_poly, size_t 
     if (rc) return rc;
     // h = IFFT(u) truncated to its first 64 entries, proofs = FFT(h) (fk20.c:257-269): inverse DIF
     // stages 7..2, the fused stage pair around the truncation, forward DIT stages 2..7
+    HIP_TRY(hipEventRecord(ctx->ev[7], ctx->stream));
     rc = g1_fft_stages(ctx, s.u, d_rr, n, /*dif=*/true, 7, 2, /*inverse=*/1);
     if (rc) return rc;
     hipLaunchKernelGGL(k_g1_fft_fold, dim3((unsigned)((n * 64 + 63) / 64)), dim3(64), 0, ctx->stream, s.u, n * 64);
     rc = g1_fft_stages(ctx, s.u, d_rr, n, /*dif=*/false, 2, 7, /*inverse=*/0);
     if (rc) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev[8], ctx->stream));
     rc = batch_to_affine_device(ctx, s.aff, s.u, s.prefix, n * 128);
     if (rc) return rc;
     hipLaunchKernelGGL(k_compress, dim3((unsigned)((n * 128 + 63) / 64)), dim3(64), 0, ctx->stream,
@@ -486,6 +488,8 @@ int cells_and_proofs_device(DeviceCtx *ctx, uint8_t *d_cells, uint8_t *d_proofs,
     if (hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[4]) == hipSuccess) ctx->last_ms[3] = ms;
     if (d_proofs && !direct && hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6]) == hipSuccess) ctx->last_ms[1] = ms;
     if (d_proofs && direct && hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_ms[1] = ms;
+    ctx->last_ms[4] = -1;
+    if (d_proofs && !direct && hipEventElapsedTime(&ms, ctx->ev[7], ctx->ev[8]) == hipSuccess) ctx->last_ms[4] = ms;
     (void)hipGetLastError();
     return 0;
 }

@@ -19,27 +19,45 @@
 extern "C" {
 #endif
 
-/* Global options read by load_trusted_setup*.  Keys:
+/* Options of the NEXT load_trusted_setup* (snapshotted when the load starts).  Keys:
  *   "device"        HIP device ordinal (default: env CKZG_HIP_DEVICE, else LOCAL_RANK, else 0)
+ *   "devices"       bit mask of devices to load on (bit i = device i, -1 = every visible device; env
+ *                   CKZG_HIP_DEVICES = mask or "all").  0 (default): the single "device".  With several
+ *                   devices every one holds its own tables; the host-pointer *_batch entry points and the
+ *                   two verify_*_batch functions split their batch into contiguous ranges, one host thread
+ *                   and one GPU per range, results written in place (the shape of the reference's goroutine
+ *                   fan-out, bindings/go/main_test.go:953-971); single-unit calls go to whichever device
+ *                   has a free stream.
+ *   "streams"       concurrent calls per device (default 8): every call leases one slot = its own HIP
+ *                   streams + scratch, the tables are shared and immutable, so threads that share a
+ *                   KZGSettings (legal in the reference, bindings/rust/src/bindings/mod.rs:910-913) overlap
+ *                   on the GPU; further callers wait for a free slot.
+ *   "replicas"      independent table sets per selected device (default 1).  Test aid: 2 exercises the
+ *                   multi-device fan-out on a one-GPU box.
  *   "commit_wbits"  window width c (4..16) of the fixed-base table over the 4096 Lagrange points
- *                   used by blob_to_kzg_commitment / compute_*_proof (table bytes =
- *                   (floor(255/c)+1) * 4096 * 2^(c-1) * 96; default 10 -> 5.2 GB)
+ *                   used by blob_to_kzg_commitment / compute_*_proof.  Tables cover 128-bit GLV
+ *                   half-scalars: bytes = (floor(127/c)+1) * 4096 * 2^(c-1) * 96; default 10 -> 2.6 GB,
+ *                   16 -> 103 GB
  *   "fk20_wbits"    window width of the FK20 fixed-base tables (8192 points); default: max(8, precompute)
  *   "proof_wbits"   window width of the table over the 4096 monomial points used by the low-latency
- *                   (no G1 FFT) cell-proof path; default 8 (1.6 GB), 0 disables the path
+ *                   (no G1 FFT) cell-proof path; default 8 (0.8 GB), 0 disables the path
  *   "direct_max"    largest batch that takes the low-latency proof path; larger batches use FK20, which
  *                   does ~10x fewer point additions but costs ~28 ms for any small batch (13 dependent
  *                   ladder launches).  -1 (default): 10 / 14 / 18 blobs for a proof table of <= 10 / <= 14 /
  *                   >= 15 bits, the measured hand-over points; 0 disables the path
  *   "gpu_sha_min"   smallest verify_blob_kzg_proof_batch size whose Fiat-Shamir challenges are hashed on
  *                   the GPU; 0 (default): never on hosts with the x86 SHA extensions (the host hash runs under the
- *                   blob copy), from 512 blobs otherwise.
- *                   Takes effect immediately (the table options are read by load_trusted_setup).
+ *                   blob copy), from 512 blobs otherwise.  Batches of at most 5 blobs always hash on the host.
+ *                   Takes effect immediately (every other option is read by load_trusted_setup).
+ * A width that does not fit the free HBM is narrowed at load time (ckzg_hip_table_wbits reports the result).
  * Returns C_KZG_BADARGS for an unknown key or out-of-range value. */
 C_KZG_RET ckzg_hip_set_option(const char *key, int64_t value);
 
 /* Number of visible HIP devices (0 if none / runtime missing). */
 int ckzg_hip_device_count(void);
+
+/* Number of table sets (devices x replicas) this KZGSettings was loaded on; 0 if it has no GPU state. */
+int ckzg_hip_num_devices(const KZGSettings *s);
 
 /* blob_to_kzg_commitment (src/eip4844/eip4844.c:264-280) over n blobs.  Host pointers.
  * out[i] is written for every blob whose field elements are all canonical; the call returns
@@ -49,7 +67,7 @@ C_KZG_RET ckzg_hip_blob_to_kzg_commitment_batch(KZGCommitment *out, uint8_t *sta
                                                 const Blob *blobs, uint64_t n,
                                                 const KZGSettings *s);
 
-/* Same with blobs/out/status resident in HBM (device pointers). */
+/* Same with blobs/out/status resident in HBM (device pointers); runs on the device that holds them. */
 C_KZG_RET ckzg_hip_blob_to_kzg_commitment_batch_device(void *d_out48, void *d_status,
                                                        const void *d_blobs, uint64_t n,
                                                        const KZGSettings *s);
@@ -81,9 +99,11 @@ C_KZG_RET ckzg_hip_recover_cells_and_kzg_proofs_batch(Cell *recovered_cells, KZG
                                                       uint64_t num_blobs, const KZGSettings *s);
 
 /* Timing hook for bench.py: elapsed milliseconds of the named kernel family inside the last
- * batch call, measured with hipEvents on the stream the kernels were launched on.
- * which: 0 = scalar recoding, 1 = MSM bucket-free accumulate (dominant), 2 = reduce+compress,
- *        3 = whole device section.  Returns a negative value if unavailable. */
+ * batch call, measured with hipEvents on the stream the kernels were launched on (for a call that was
+ * processed in several chunks: the last chunk).
+ * which: 0 = scalar recoding, 1 = fixed-base MSM accumulate (k_msm_accumulate; k_msm_small on the FK20 path),
+ *        2 = reduce+compress, 3 = whole device section, 4 = the two G1 FFTs of the FK20 path.
+ * Returns a negative value if unavailable. */
 double ckzg_hip_last_kernel_ms(const KZGSettings *s, int which);
 
 /* Bytes of HBM held by the context's tables. */

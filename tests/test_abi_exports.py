@@ -59,7 +59,10 @@ def test_options_are_validated(lib):
     f.restype = C.c_int
     f.argtypes = [C.c_char_p, C.c_int64]
     assert f(b"commit_wbits", 17) == 1
-    assert f(b"fk20_wbits", 16) == 1
+    assert f(b"fk20_wbits", 17) == 1
+    assert f(b"streams", 0) == 1 and f(b"streams", 65) == 1 and f(b"streams", 8) == 0
+    assert f(b"replicas", 0) == 1 and f(b"replicas", 1) == 0
+    assert f(b"devices", -2) == 1 and f(b"devices", 0) == 0
     assert f(b"commit_wbits", 3) == 1
     assert f(b"nonsense", 1) == 1
     assert f(b"commit_wbits", 10) == 0

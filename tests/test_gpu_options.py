@@ -28,9 +28,9 @@ def test_commitment_for_every_table_width(hip, wbits):
         v = sum(1 << (wbits * w + wbits - 1) for w in range(0, 250 // wbits, 2))
         edge = (v.to_bytes(32, "big") + (v >> 1).to_bytes(32, "big")) * 2048
         assert api.blob_to_kzg_commitment(edge) == hip.blob_to_kzg_commitment(edge)
-        if wbits == 16:  # 206 GB: really built at 16 bits, not silently narrowed
+        if wbits == 16:  # 103 GB (8 windows of GLV half-scalars): really built at 16 bits, not silently narrowed
             api.lib.ckzg_hip_table_bytes.restype = __import__("ctypes").c_uint64
-            assert api.lib.ckzg_hip_table_bytes(api.sp) >= 4096 * 16 * 32768 * 96
+            assert api.lib.ckzg_hip_table_bytes(api.sp) >= 4096 * 8 * 32768 * 96
     finally:
         api.close()
 
@@ -55,7 +55,7 @@ def test_cells_and_proofs_for_precompute_values(hip, precompute, direct):
 
 
 def test_low_latency_proofs_with_the_widest_monomial_table(hip):
-    # proof_wbits = 16: 206 GB table over the monomial points, 16 windows, int16 digits at their limit
+    # proof_wbits = 16: 103 GB table over the monomial points, 2 x 8 windows, int16 digits at their limit
     api = Kzg(HIP_SO, "", precompute=0, options={"commit_wbits": 8, "direct_max": 24, "proof_wbits": 16})
     _restore(api)
     try:

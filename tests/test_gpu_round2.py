@@ -1,0 +1,303 @@
+"""GPU tests for the round-2 work: slot pools (concurrent callers overlap), the C-ABI multi-device
+fan-out (exercised on one GPU through two table replicas), the GPU-hash/small-batch interaction, the
+mirrored x_ext_fft_columns against the oracle's init_fk20_multi_settings, and scalars that sit on the
+edges of the GLV split / signed-window recoding of the fixed-base tables."""
+import ctypes as C
+import threading
+import time
+
+import pytest
+
+from conftest import ORACLE_SO
+from kzg_ctypes import HIP_SO, Kzg
+from test_gpu_commitment import R, _batch, rand_blob
+
+pytestmark = pytest.mark.gpu
+
+LAMBDA = 0xd201000000010000 ** 2 - 1
+
+
+def _restore(api):
+    for k, v in (("commit_wbits", 10), ("fk20_wbits", 0), ("proof_wbits", 8), ("direct_max", -1),
+                 ("replicas", 1), ("streams", 8), ("devices", 0), ("gpu_sha_min", 0)):
+        api.lib.ckzg_hip_set_option(k.encode(), v)
+
+
+# ---------------------------------------------------------------------------------------------
+# GPU challenge hashing must never see the small-batch path's unset buffers
+# ---------------------------------------------------------------------------------------------
+
+def test_small_verify_batches_with_gpu_sha_forced(hip, oracle):
+    blobs = [rand_blob(71, i) for i in range(6)]
+    cm = [hip.blob_to_kzg_commitment(b) for b in blobs]
+    pr = [hip.compute_blob_kzg_proof(b, c) for b, c in zip(blobs, cm)]
+    assert pr[0] == oracle.compute_blob_kzg_proof(blobs[0], cm[0])
+    hip.lib.ckzg_hip_set_option(b"gpu_sha_min", 1)
+    try:
+        # an earlier call leaves other commitments in the slot's arena: a stale read would bind z to them
+        assert hip.verify_blob_kzg_proof_batch(blobs[::-1], cm[::-1], pr[::-1])
+        for n in range(1, 7):
+            assert hip.verify_blob_kzg_proof_batch(blobs[:n], cm[:n], pr[:n]), n
+            if n >= 2:
+                wrong = cm[:n]
+                wrong[n - 1] = cm[0]  # a valid point, but not this blob's commitment
+                assert not hip.verify_blob_kzg_proof_batch(blobs[:n], wrong, pr[:n]), n
+        assert hip.verify_blob_kzg_proof(blobs[3], cm[3], pr[3])
+        assert not hip.verify_blob_kzg_proof(blobs[3], cm[2], pr[3])
+    finally:
+        hip.lib.ckzg_hip_set_option(b"gpu_sha_min", 0)
+
+
+# ---------------------------------------------------------------------------------------------
+# f4: the host mirror of x_ext_fft_columns equals the oracle's (setup.c:238-330)
+# ---------------------------------------------------------------------------------------------
+
+def test_x_ext_fft_columns_match_oracle(hip, oracle):
+    o = C.CDLL(ORACLE_SO)
+    o.og1_equal.restype = C.c_bool
+    o.og1_equal.argtypes = [C.c_void_p, C.c_void_p]
+    cols_h = C.cast(hip.s.x_ext_fft_columns, C.POINTER(C.c_void_p))
+    cols_o = C.cast(oracle.s.x_ext_fft_columns, C.POINTER(C.c_void_p))
+    bad = []
+    for j in range(128):
+        for i in range(64):
+            if not o.og1_equal(cols_h[j] + 144 * i, cols_o[j] + 144 * i):
+                bad.append((j, i))
+    assert not bad, bad[:8]
+    # and the other arrays a binding may read: setup points and roots, byte for byte where the
+    # representation is canonical (Fr Montgomery limbs), projectively for G1
+    assert C.string_at(hip.s.roots_of_unity, 8193 * 32) == C.string_at(oracle.s.roots_of_unity, 8193 * 32)
+    assert C.string_at(hip.s.brp_roots_of_unity, 8192 * 32) == C.string_at(oracle.s.brp_roots_of_unity, 8192 * 32)
+    assert C.string_at(hip.s.reverse_roots_of_unity, 8193 * 32) == C.string_at(oracle.s.reverse_roots_of_unity, 8193 * 32)
+    for i in (0, 1, 2047, 4095):
+        assert o.og1_equal(hip.s.g1_values_monomial + 144 * i, oracle.s.g1_values_monomial + 144 * i)
+        assert o.og1_equal(hip.s.g1_values_lagrange_brp + 144 * i, oracle.s.g1_values_lagrange_brp + 144 * i)
+
+
+# ---------------------------------------------------------------------------------------------
+# GLV tables: scalars on the edges of the split and of the signed windows
+# ---------------------------------------------------------------------------------------------
+
+def _edge_scalars(wbits):
+    half = 1 << (wbits - 1)
+    twin = 127 // wbits + 1
+    vals = [0, 1, R - 1, LAMBDA, LAMBDA + 1, LAMBDA - 1, LAMBDA // 2, LAMBDA // 2 + 1, R - LAMBDA,
+            (LAMBDA + 1) * (LAMBDA // 2), (LAMBDA + 1) * (LAMBDA // 2 + 1) % R, LAMBDA * LAMBDA % R]
+    # half-scalars whose windows are all exactly +-half (the recoding's carry rule), in both halves and signs
+    m = sum(half << (wbits * w) for w in range(0, twin - 1, 2))
+    m2 = sum((half - 1) << (wbits * w) for w in range(twin - 1))
+    for a in (m, m2, m >> 1):
+        for b in (m, m2, 1, 0):
+            for sa in (1, -1):
+                for sb in (1, -1):
+                    vals.append((sa * a + LAMBDA * sb * b) % R)
+    return vals
+
+
+@pytest.mark.parametrize("wbits", [4, 8, 13, 16])
+def test_glv_edge_scalars_vs_oracle(oracle, wbits):
+    api = Kzg(HIP_SO, "", precompute=0, options={"commit_wbits": wbits, "proof_wbits": 0})
+    _restore(api)
+    try:
+        vals = _edge_scalars(wbits)
+        blob = b"".join(vals[j % len(vals)].to_bytes(32, "big") for j in range(4096))
+        assert api.blob_to_kzg_commitment(blob) == oracle.blob_to_kzg_commitment(blob)
+        # a non-canonical element must be flagged, and must not read outside the table while doing so
+        bad = bytearray(blob)
+        bad[32 * 77:32 * 78] = (R + 5).to_bytes(32, "big")
+        bad[32 * 78:32 * 79] = b"\xff" * 32
+        ret, _, st = _batch(api, [blob, bytes(bad), blob])
+        assert ret == 1 and st == [0, 1, 0]
+    finally:
+        api.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# N1: concurrent callers of one KZGSettings overlap on the GPU
+# ---------------------------------------------------------------------------------------------
+
+def test_eight_threads_of_single_blob_commitments_overlap(hip):
+    blobs = [rand_blob(81, i) for i in range(8)]
+    expect = [hip.blob_to_kzg_commitment(b) for b in blobs]
+    per_thread = 60
+
+    def run(nthreads):
+        errs = []
+
+        def work(t):
+            for k in range(per_thread):
+                i = (t + k) % 8
+                if hip.blob_to_kzg_commitment(blobs[i]) != expect[i]:
+                    errs.append((t, k))
+
+        th = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
+        t0 = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        dt = time.perf_counter() - t0
+        assert not errs, errs[:4]
+        return nthreads * per_thread / dt
+
+    run(8)  # every slot allocates its scratch once
+    r1, r8 = run(1), run(8)
+    print("single-blob commitments/s: 1 thread %.0f, 8 threads %.0f (x%.2f)" % (r1, r8, r8 / r1))
+    assert r8 > 2.0 * r1, (r1, r8)
+
+
+def test_mixed_concurrent_calls_are_correct(hip, oracle):
+    blobs = [rand_blob(82, i) for i in range(4)]
+    cm = [hip.blob_to_kzg_commitment(b) for b in blobs]
+    pr = [hip.compute_blob_kzg_proof(b, c) for b, c in zip(blobs, cm)]
+    cp = [hip.compute_cells_and_kzg_proofs(b) for b in blobs]
+    assert cp[1] == oracle.compute_cells_and_kzg_proofs(blobs[1])
+    errs = []
+
+    def work(t):
+        try:
+            for k in range(3):
+                i = (t + k) % 4
+                kind = (t + k) % 5
+                if kind == 0:
+                    ok = hip.blob_to_kzg_commitment(blobs[i]) == cm[i]
+                elif kind == 1:
+                    ok = hip.compute_cells_and_kzg_proofs(blobs[i]) == cp[i]
+                elif kind == 2:
+                    ok = hip.verify_blob_kzg_proof_batch(blobs, cm, pr)
+                elif kind == 3:
+                    keep = list(range(0, 128, 2))
+                    ok = hip.recover_cells_and_kzg_proofs(keep, [cp[i][0][c] for c in keep]) == cp[i]
+                else:
+                    cols = list(range(16 * t % 128, 16 * t % 128 + 16))
+                    ok = hip.verify_cell_kzg_proof_batch([cm[i]] * 16, cols, [cp[i][0][c] for c in cols],
+                                                         [cp[i][1][c] for c in cols])
+                if not ok:
+                    errs.append((t, k, kind))
+        except Exception as e:  # noqa: BLE001
+            errs.append((t, repr(e)))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(12)]  # more threads than slots: some wait
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs
+
+
+# ---------------------------------------------------------------------------------------------
+# C-ABI multi-device fan-out, on one GPU through two replicas of the tables
+# ---------------------------------------------------------------------------------------------
+
+@pytest.fixture(scope="module")
+def hip2():
+    api = Kzg(HIP_SO, "", precompute=0, options={"replicas": 2, "commit_wbits": 8, "proof_wbits": 6})
+    _restore(api)
+    api.lib.ckzg_hip_num_devices.restype = C.c_int
+    assert api.lib.ckzg_hip_num_devices(api.sp) == 2
+    yield api
+    api.close()
+
+
+def test_fan_out_commitments_and_status(hip, hip2):
+    base = [rand_blob(91, i) for i in range(5)]
+    single = [hip.blob_to_kzg_commitment(b) for b in base]
+    n = 203  # ragged halves: 102 + 101
+    blobs = [base[i % 5] for i in range(n)]
+    bad = bytearray(base[0])
+    bad[32 * 9:32 * 10] = R.to_bytes(32, "big")
+    blobs[150] = bytes(bad)  # lands in the second shard
+    ret, outs, st = _batch(hip2, blobs)
+    assert ret == 1
+    assert [i for i, v in enumerate(st) if v] == [150]
+    for i in range(n):
+        if i != 150:
+            assert outs[i] == single[i % 5], i
+    # below the per-device minimum the batch stays on one device
+    ret, outs, st = _batch(hip2, blobs[:7])
+    assert ret == 0 and outs == [single[i % 5] for i in range(7)]
+
+
+def test_fan_out_verify_blob_batch(hip, hip2):
+    base = [rand_blob(92, i) for i in range(4)]
+    cm = [hip.blob_to_kzg_commitment(b) for b in base]
+    pr = [hip.compute_blob_kzg_proof(b, c) for b, c in zip(base, cm)]
+    n = 600
+    bl, cc, pp = [base[i % 4] for i in range(n)], [cm[i % 4] for i in range(n)], [pr[i % 4] for i in range(n)]
+    assert hip2.verify_blob_kzg_proof_batch(bl, cc, pp)
+    for pos in (7, 433):  # a wrong proof in either shard sinks the batch
+        p2 = list(pp)
+        p2[pos] = pr[(pos + 1) % 4]
+        assert not hip2.verify_blob_kzg_proof_batch(bl, cc, p2), pos
+    c2 = list(cc)
+    c2[555] = b"\x00" * 48  # not a valid encoding: BADARGS from the shard that holds it
+    with pytest.raises(Exception):
+        hip2.verify_blob_kzg_proof_batch(bl, c2, pp)
+
+
+def test_fan_out_cells_proofs_recover_and_blob_proofs(hip, hip2):
+    base = [rand_blob(93, i) for i in range(3)]
+    cp = [hip.compute_cells_and_kzg_proofs(b) for b in base]
+    n = 70
+    f = hip2.lib.ckzg_hip_compute_cells_and_kzg_proofs_batch
+    f.restype = C.c_int
+    cells = C.create_string_buffer(n * 128 * 2048)
+    proofs = C.create_string_buffer(n * 128 * 48)
+    st = C.create_string_buffer(n)
+    assert f(cells, proofs, st, b"".join(base[i % 3] for i in range(n)), C.c_uint64(n), hip2.sp) == 0
+    craw, praw = cells.raw, proofs.raw
+    for i in (0, 1, 34, 35, 36, 69):
+        assert craw[i * 262144:(i + 1) * 262144] == b"".join(cp[i % 3][0]), i
+        assert praw[i * 6144:(i + 1) * 6144] == b"".join(cp[i % 3][1]), i
+    keep = list(range(64, 128))
+    nb = 40
+    rc, rp = hip2.recover_cells_and_kzg_proofs_batch(keep, [[cp[b % 3][0][c] for c in keep] for b in range(nb)])
+    for b in (0, 19, 20, 39):
+        assert rc[b] == cp[b % 3][0] and rp[b] == cp[b % 3][1], b
+    cm = [hip.blob_to_kzg_commitment(b) for b in base]
+    pr = [hip.compute_blob_kzg_proof(b, c) for b, c in zip(base, cm)]
+    g = hip2.lib.ckzg_hip_compute_blob_kzg_proof_batch
+    g.restype = C.c_int
+    m = 130
+    out = C.create_string_buffer(48 * m)
+    assert g(out, None, b"".join(base[i % 3] for i in range(m)), b"".join(cm[i % 3] for i in range(m)),
+             C.c_uint64(m), hip2.sp) == 0
+    assert all(out.raw[48 * i:48 * i + 48] == pr[i % 3] for i in range(m))
+
+
+def test_fan_out_verify_cell_batch(hip, hip2):
+    base = [rand_blob(94, i) for i in range(2)]
+    cm = [hip.blob_to_kzg_commitment(b) for b in base]
+    cp = [hip.compute_cells_and_kzg_proofs(b) for b in base]
+    n = 4300  # two shards of 2150 cells
+    rows = [(i // 128) % 2 for i in range(n)]
+    cols = [i % 128 for i in range(n)]
+    args = ([cm[r] for r in rows], cols, [cp[r][0][c] for r, c in zip(rows, cols)],
+            [cp[r][1][c] for r, c in zip(rows, cols)])
+    assert hip2.verify_cell_kzg_proof_batch(*args)
+    pr2 = list(args[3])
+    pr2[4000] = cp[0][1][(cols[4000] + 1) % 128]
+    assert not hip2.verify_cell_kzg_proof_batch(args[0], args[1], args[2], pr2)
+
+
+def test_single_calls_spread_over_the_pools(hip, hip2):
+    b = rand_blob(95, 0)
+    exp = hip.blob_to_kzg_commitment(b)
+    for _ in range(5):  # round robin: both table replicas serve single calls
+        assert hip2.blob_to_kzg_commitment(b) == exp
+    assert hip2.compute_cells_and_kzg_proofs(b) == hip.compute_cells_and_kzg_proofs(b)
+
+
+@pytest.mark.skipif("__import__('torch').cuda.device_count() < 2", reason="needs two visible GPUs")
+def test_two_real_devices(hip):
+    api = Kzg(HIP_SO, "", precompute=0, options={"devices": 3, "commit_wbits": 8})
+    _restore(api)
+    try:
+        api.lib.ckzg_hip_num_devices.restype = C.c_int
+        assert api.lib.ckzg_hip_num_devices(api.sp) == 2
+        base = [rand_blob(96, i) for i in range(4)]
+        single = [hip.blob_to_kzg_commitment(b) for b in base]
+        ret, outs, st = _batch(api, [base[i % 4] for i in range(256)])
+        assert ret == 0 and outs == [single[i % 4] for i in range(256)]
+    finally:
+        api.close()
