@@ -3,22 +3,35 @@
 (BASELINE.json configs[1]); weak scaling over N GPUs = N independent shards, no data-path collective
 (SURVEY.md section 8e).  One JSON line on rank 0.
 
-A step = one call of ckzg_hip_blob_to_kzg_commitment_batch_device over 1024 synthetic blobs that
-are already resident in HBM (device pointers; the PCIe-inclusive host-pointer rate is reported
-separately as pcie_inclusive_blobs_per_s and is never `value`).
+A step = one call of ckzg_hip_blob_to_kzg_commitment_batch_device over 1024 synthetic blobs that are
+already resident in HBM (the task's measurement contract: `value` is the HBM-resident rate).  The same
+1024 blobs through the reference-shaped host-pointer call (H2D + D2H inside the timed region, pageable
+host memory) are timed over the same number of steps and reported next to it as `host_pointer`.
+
+ONE KZGSettings (commit 16-bit + proof 16-bit + FK20 13-bit GLV tables, ~238 GB) serves every wide-table
+row of the line; a second, co-resident KZGSettings with the library's default tables (~7 GB) gives the
+default-footprint figures.  Nothing is reloaded between rows.
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment re-executes itself through
+torch.distributed.run with N ranks (one per GPU); under the driver's own torchrun launch it reads
+RANK / LOCAL_RANK / WORLD_SIZE as usual.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
 import sys
 import time
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # before HIP initialises: concurrent callers need the queues
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BLOBS_PER_STEP = 1024
-ALGO_BYTES_PER_BLOB = 131072 + 48  # SURVEY.md section 8(d): scalars in + commitment out
+ALGO_BYTES_PER_BLOB = 131072 + 48          # SURVEY.md section 8(d): scalars in + commitment out
+ALGO_BYTES_CELLS_PROOFS = 131072 + 262144 + 6144   # SURVEY.md section 8(d): blob in, cells + proofs out
 HBM_PEAK_GBS = 8000.0
 # HBM bytes per k_msm_accumulate launch (1024 blobs) from rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
 # KB units), see profiles/README.md; keyed by table window width.  The traffic is the table gathers
@@ -27,13 +40,30 @@ PMC_TRAFFIC_BYTES = {13: (7658816 + 960) * 1024, 15: (6796321 + 960) * 1024, 16:
 # v_mad_u64_u32 per mixed addition (g1_28.hpp: xyzz28_madd_alt): 6 products x 392, 2 squares x 301,
 # one fused two-product reduction x 588
 MADS_PER_ADDITION = 6 * 392 + 2 * 301 + 588
-# SQ_INSTS_VALU per 1024-blob launch (profiles/r01_c16_pmc_sq_k_msm_accumulate.json)
+# SQ_INSTS_VALU per 1024-blob launch (profiles/)
 PMC_VALU_INSTS = {16: 4.98e9}
+WIDE = {"commit_wbits": 16, "proof_wbits": 16, "fk20_wbits": 13}
+
+
+def respawn(n):
+    """`python bench.py --gpus N` without a launcher: become N ranks through torch.distributed.run."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit("bench: --gpus %d but only %d HIP device(s) visible" % (n, have))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
 
 
 def cpu_baseline(seconds_budget=12.0):
     """Oracle ('port' of the reference algorithm, oracle/okzg.c) timed on this host's cores."""
     import hashlib
+    import threading
     import __graft_entry__ as ge
     mod = ge.load_package()
     so = os.path.join(ROOT, "oracle", "liboracle.so")
@@ -51,7 +81,6 @@ def cpu_baseline(seconds_budget=12.0):
     # the same port on many cores at once, one blob per thread (the shape of the reference's
     # ComputeCellsAndKZGProofsParallel benchmark, bindings/go/main_test.go:953-971); ctypes
     # releases the GIL during the C call
-    import threading
     nthreads = min(64, os.cpu_count() or 1)
     per_thread = 6
     counts = [0] * nthreads
@@ -68,19 +97,144 @@ def cpu_baseline(seconds_budget=12.0):
     for t in ths:
         t.join()
     dt_mt = time.perf_counter() - t1
+    # the other half of the metric: compute_cells_and_kzg_proofs, one call, single thread
+    t2 = time.perf_counter()
+    orc.compute_cells_and_kzg_proofs(blob)
+    dt_cells = time.perf_counter() - t2
     orc.close()
     return {"value": round(n / dt, 3), "unit": "blobs/s", "cores": 1, "kind": "port",
             "sample": "%d x blob_to_kzg_commitment on one 4096-element blob, oracle/liboracle.so "
                       "(portable C, Pippenger), single thread; host has %d logical CPUs"
                       % (n, os.cpu_count() or 0),
             "all_cores": {"value": round(sum(counts) / dt_mt, 2), "unit": "blobs/s", "cores": nthreads,
-                          "sample": "%d threads x %d commitments" % (nthreads, per_thread)}}
+                          "sample": "%d threads x %d commitments" % (nthreads, per_thread)},
+            "compute_cells_and_kzg_proofs_ms_per_call": round(dt_cells * 1e3, 1)}
 
 
-def verify_and_recover_rows(hip, lib, base):
+class Lib:
+    """ctypes prototypes of the additive entry points the bench uses."""
+
+    def __init__(self, lib):
+        self.lib = lib
+        p, u64 = C.c_void_p, C.c_uint64
+        self.commit_dev = self._fn("ckzg_hip_blob_to_kzg_commitment_batch_device", [p, p, p, u64, p])
+        self.commit_host = self._fn("ckzg_hip_blob_to_kzg_commitment_batch", [p, p, C.c_char_p, u64, p])
+        self.cells_dev = self._fn("ckzg_hip_compute_cells_and_kzg_proofs_batch_device", [p, p, p, p, u64, p])
+        self.cells_host = self._fn("ckzg_hip_compute_cells_and_kzg_proofs_batch", [p, p, p, C.c_char_p, u64, p])
+        self.verify_blobs = self._fn("verify_blob_kzg_proof_batch", [p, C.c_char_p, C.c_char_p, C.c_char_p, u64, p])
+        self.verify_cells = self._fn("verify_cell_kzg_proof_batch", [p, C.c_char_p, p, C.c_char_p, C.c_char_p, u64, p])
+        self.recover = self._fn("ckzg_hip_recover_cells_and_kzg_proofs_batch", None)
+        self.kms = self._fn("ckzg_hip_last_kernel_ms", [p, C.c_int], C.c_double)
+        self.table_bytes = self._fn("ckzg_hip_table_bytes", [p], C.c_uint64)
+        self.table_wbits = self._fn("ckzg_hip_table_wbits", [p, C.c_int])
+        self.num_devices = self._fn("ckzg_hip_num_devices", [p])
+
+    def _fn(self, name, argtypes, restype=C.c_int):
+        f = getattr(self.lib, name)
+        f.restype = restype
+        if argtypes is not None:
+            f.argtypes = argtypes
+        return f
+
+
+def tables_of(L, hip):
+    sp = C.addressof(hip.s)
+    return {"commit_wbits": int(L.table_wbits(sp, 0)), "fk20_wbits": int(L.table_wbits(sp, 1)),
+            "proof_wbits": int(L.table_wbits(sp, 2)), "bytes": int(L.table_bytes(sp))}
+
+
+def median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
+
+
+def cells_rows(L, hip, torch, dev, blobs, label):
+    """compute_cells_and_kzg_proofs on one loaded KZGSettings: 1-blob latency (BASELINE configs[2]) and the
+    2048-blob batch, device pointers and host pointers, each with the dominant kernel's own time."""
+    sp = C.addressof(hip.s)
+    nb = 2048
+    blobs2 = blobs.repeat(2, 1, 1)
+    status = torch.empty((nb,), dtype=torch.uint8, device=dev)
+    cells = torch.empty((nb, 128, 2048), dtype=torch.uint8, device=dev)
+    proofs = torch.empty((nb, 128, 48), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+
+    def run(n):
+        rc = L.cells_dev(cells.data_ptr(), proofs.data_ptr(), status.data_ptr(), blobs2.data_ptr(), n, sp)
+        if rc != 0:
+            raise RuntimeError("cells+proofs failed rc=%d" % rc)
+
+    run(1)
+    ts, ks = [], []
+    for _ in range(20):
+        t1 = time.perf_counter()
+        run(1)
+        ts.append(time.perf_counter() - t1)
+        ks.append(L.kms(sp, 1))
+    one_ms, one_k = median(ts) * 1e3, median(ks)
+    proofs_1 = proofs[0].clone()
+    cells_1 = cells[0].clone()
+    # the reference-shaped one-blob call, host pointers in and out
+    hb1 = blobs2[0].cpu().numpy().tobytes()
+    hc1 = C.create_string_buffer(128 * 2048)
+    hp1 = C.create_string_buffer(128 * 48)
+    fn1 = L._fn("compute_cells_and_kzg_proofs", [C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p])
+    fn1(hc1, hp1, hb1, sp)
+    th = []
+    for _ in range(20):
+        t1 = time.perf_counter()
+        rc = fn1(hc1, hp1, hb1, sp)
+        th.append(time.perf_counter() - t1)
+    if rc != 0 or hp1.raw != proofs_1.cpu().numpy().tobytes() or hc1.raw != cells_1.cpu().numpy().tobytes():
+        raise SystemExit("bench: host-pointer compute_cells_and_kzg_proofs differs from the device-pointer call")
+    out = {"tables": tables_of(L, hip),
+           "one_blob": {"ms_per_call": round(median(th) * 1e3, 3), "calls_per_s": round(1.0 / median(th), 1),
+                        "ms_per_call_device_pointers": round(one_ms, 3),
+                        "path": "low-latency (128 fixed-base MSMs over the monomial table, no G1 FFT)",
+                        "roofline": roofline(ALGO_BYTES_CELLS_PROOFS, one_k, "k_msm_accumulate")}}
+    run(nb)
+    tb, kb, fb = [], [], []
+    for _ in range(3):
+        t1 = time.perf_counter()
+        run(nb)
+        tb.append(time.perf_counter() - t1)
+        kb.append(L.kms(sp, 1))
+        fb.append(L.kms(sp, 4))
+    if not torch.equal(proofs[0], proofs_1):
+        raise SystemExit("bench: low-latency and FK20 proof paths disagree")
+    t_b, k_b, f_b = median(tb), median(kb), median(fb)
+    dom, dom_name = (k_b, "k_msm_small") if k_b >= f_b else (f_b, "k_g1_fft_twiddle+k_g1_fft_addsub (2 G1 FFTs)")
+    out["batch_2048"] = {"blobs_per_s": round(nb / t_b, 1), "ms_per_blob": round(t_b / nb * 1e3, 4),
+                         "path": "FK20", "k_msm_small_ms": round(k_b, 3), "g1_fft_ms": round(f_b, 3),
+                         "roofline": roofline(ALGO_BYTES_CELLS_PROOFS * nb, dom, dom_name)}
+    # host pointers: pageable input, pageable outputs (268 KB per blob back over PCIe)
+    hb = blobs2.cpu().numpy().tobytes()
+    hc = C.create_string_buffer(nb * 128 * 2048)
+    hp = C.create_string_buffer(nb * 128 * 48)
+    hs = C.create_string_buffer(nb)
+    L.cells_host(hc, hp, hs, hb, nb, sp)
+    t1 = time.perf_counter()
+    rc = L.cells_host(hc, hp, hs, hb, nb, sp)
+    t_h = time.perf_counter() - t1
+    if rc != 0 or hp.raw[:128 * 48] != proofs_1.cpu().numpy().tobytes():
+        raise SystemExit("bench: host-pointer cells+proofs batch failed or disagrees")
+    out["batch_2048"]["host_pointer_blobs_per_s"] = round(nb / t_h, 1)
+    out["label"] = label
+    return out
+
+
+def roofline(algo_bytes, kernel_ms, kernel, traffic=None):
+    ach = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms and kernel_ms > 0 else None
+    return {"bound": "hbm", "achieved": None if ach is None else round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": None if ach is None else round(ach / HBM_PEAK_GBS, 6), "traffic": traffic, "kernel": kernel,
+            "kernel_ms": None if kernel_ms is None else round(kernel_ms, 3)}
+
+
+def verify_and_recover_rows(L, hip, base):
     """verify_blob_kzg_proof_batch over 4096 blobs (this GPU's view of configs[3]: the whole batch on one
     GPU), verify_cell_kzg_proof_batch over 8192 cells, and a 256-row recover batch (configs[4]),
-    timed at the C-ABI with host buffers; inputs are 8 distinct valid blobs repeated."""
+    timed at the C-ABI with host buffers; inputs are 8 distinct valid blobs repeated.  Kernel-level
+    breakdowns of these rows: profiles/r02_*_kernel_stats.csv (tools/profile_rows.sh)."""
     ub = [base[i].tobytes() for i in range(8)]
     cm = [hip.blob_to_kzg_commitment(b) for b in ub]
     pr = [hip.compute_blob_kzg_proof(b, c) for b, c in zip(ub, cm)]
@@ -90,20 +244,18 @@ def verify_and_recover_rows(hip, lib, base):
     bb = b"".join(ub[i % 8] for i in range(n))
     cc = b"".join(cm[i % 8] for i in range(n))
     pp = b"".join(pr[i % 8] for i in range(n))
-    fv = lib.verify_blob_kzg_proof_batch
-    fv.restype = C.c_int
-    fv.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64, C.c_void_p]
     ok = C.c_bool(False)
     for k in (512, n):
-        fv(C.byref(ok), bb, cc, pp, k, sp)
-        best = 1e9
-        for _ in range(3):
+        L.verify_blobs(C.byref(ok), bb, cc, pp, k, sp)
+        ts = []
+        for _ in range(5):
             t = time.perf_counter()
-            rc = fv(C.byref(ok), bb, cc, pp, k, sp)
-            best = min(best, time.perf_counter() - t)
+            rc = L.verify_blobs(C.byref(ok), bb, cc, pp, k, sp)
+            ts.append(time.perf_counter() - t)
         if rc != 0 or not ok.value:
             raise RuntimeError("verify_blob_kzg_proof_batch rc=%d ok=%s" % (rc, ok.value))
-        out["verify_blob_kzg_proof_batch_n%d_blobs_per_s" % k] = round(k / best, 1)
+        out["verify_blob_kzg_proof_batch_n%d" % k] = {"blobs_per_s": round(k / median(ts), 1),
+                                                      "ms": round(median(ts) * 1e3, 3), "runs": 5}
     del bb
     cp = [hip.compute_cells_and_kzg_proofs(b) for b in ub]
     n = 8192
@@ -113,37 +265,58 @@ def verify_and_recover_rows(hip, lib, base):
     idx = (C.c_uint64 * n)(*cols)
     cells = b"".join(cp[r][0][c] for r, c in zip(rows, cols))
     cprf = b"".join(cp[r][1][c] for r, c in zip(rows, cols))
-    fc = lib.verify_cell_kzg_proof_batch
-    fc.restype = C.c_int
-    fc.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_char_p, C.c_char_p, C.c_uint64, C.c_void_p]
     for k in (128, n):
-        fc(C.byref(ok), ccm, idx, cells, cprf, k, sp)
-        best = 1e9
-        for _ in range(3):
+        L.verify_cells(C.byref(ok), ccm, idx, cells, cprf, k, sp)
+        ts = []
+        for _ in range(5):
             t = time.perf_counter()
-            rc = fc(C.byref(ok), ccm, idx, cells, cprf, k, sp)
-            best = min(best, time.perf_counter() - t)
+            rc = L.verify_cells(C.byref(ok), ccm, idx, cells, cprf, k, sp)
+            ts.append(time.perf_counter() - t)
         if rc != 0 or not ok.value:
             raise RuntimeError("verify_cell_kzg_proof_batch rc=%d ok=%s" % (rc, ok.value))
-        out["verify_cell_kzg_proof_batch_n%d_ms" % k] = round(best * 1e3, 3)
+        out["verify_cell_kzg_proof_batch_n%d" % k] = {"ms": round(median(ts) * 1e3, 3), "runs": 5}
     nb = 256
     keep = list(range(0, 128, 2))
-    fr = lib.ckzg_hip_recover_cells_and_kzg_proofs_batch
-    fr.restype = C.c_int
     data = b"".join(b"".join(cp[b % 8][0][i] for i in keep) for b in range(nb))
     kidx = (C.c_uint64 * len(keep))(*keep)
     rc_buf = C.create_string_buffer(nb * 128 * 2048)
     rp_buf = C.create_string_buffer(nb * 128 * 48)
     args = (rc_buf, rp_buf, None, kidx, data, C.c_uint64(len(keep)), C.c_uint64(nb), C.c_void_p(sp))
-    fr(*args)
-    t = time.perf_counter()
-    rc = fr(*args)
-    dt = time.perf_counter() - t
+    L.recover(*args)
+    ts = []
+    for _ in range(3):
+        t = time.perf_counter()
+        rc = L.recover(*args)
+        ts.append(time.perf_counter() - t)
     if rc != 0 or rp_buf.raw[:128 * 48] != b"".join(cp[0][1]):
         raise RuntimeError("recover batch rc=%d or wrong proofs" % rc)
-    out["recover_cells_and_kzg_proofs_batch256_rows_per_s"] = round(nb / dt, 1)
-    out["recover_note"] = "64 of 128 cells per row, same columns in every row; cells and proofs out"
+    out["recover_cells_and_kzg_proofs_batch256"] = {
+        "rows_per_s": round(nb / median(ts), 1), "ms": round(median(ts) * 1e3, 3), "runs": 3,
+        "note": "64 of 128 cells per row (every other cell), same columns in every row; cells and proofs out"}
     return out
+
+
+def concurrency_row(hip, ub):
+    """Re-entrancy: single-blob blob_to_kzg_commitment calls from 1 and from 8 threads sharing the settings."""
+    import threading
+    per_thread = 100
+
+    def run(nt):
+        def work():
+            for _ in range(per_thread):
+                hip.blob_to_kzg_commitment(ub)
+        th = [threading.Thread(target=work) for _ in range(nt)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return nt * per_thread / (time.perf_counter() - t0)
+
+    run(8)
+    r1, r8 = run(1), run(8)
+    return {"single_blob_commit_calls_per_s_1_thread": round(r1, 1), "8_threads": round(r8, 1),
+            "speedup": round(r8 / r1, 2)}
 
 
 def main():
@@ -151,23 +324,30 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--wbits", type=int, default=int(os.environ.get("CKZG_BENCH_WBITS", "16")))
+    ap.add_argument("--wbits", type=int, default=int(os.environ.get("CKZG_BENCH_WBITS", str(WIDE["commit_wbits"]))))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
-    ap.add_argument("--no-pcie", action="store_true", help="skip the untimed host-pointer (PCIe-inclusive) leg")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host-pointer (PCIe-inclusive) leg")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        respawn(args.gpus)  # does not return
 
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench: --gpus %d but WORLD_SIZE=%d; reporting n_gpus=%d\n" % (args.gpus, world, world))
+    one_gpu = bool(os.environ.get("CKZG_BENCH_ONE_GPU"))
+    if not one_gpu and torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench: rank %d needs device %d but only %d visible" % (rank, local_rank, torch.cuda.device_count()))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # "nccl" is RCCL on ROCm.  CKZG_BENCH_BACKEND=gloo + CKZG_BENCH_ONE_GPU=1 exist only to exercise
         # this file's multi-rank control flow on a one-GPU box (all ranks share device 0).
         dist.init_process_group(os.environ.get("CKZG_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
-    if os.environ.get("CKZG_BENCH_ONE_GPU"):
+    if one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -175,30 +355,17 @@ def main():
 
     import __graft_entry__ as ge
     mod = ge.load_package()
-    # headline leg: the widest commitment table that fits (16-bit windows = 206 GB of the 288 GB);
-    # the cell-proof tables stay at their small defaults here and are widened for the secondary leg
-    hip = None
-    for w in range(args.wbits, 9, -1):
-        try:
-            hip = mod.Kzg(mod.HIP_SO, options={"device": local_rank, "commit_wbits": w, "proof_wbits": 8,
-                                               "fk20_wbits": 8})
-            break
-        except Exception as e:  # the library already narrows to the free HBM; this is the belt to its braces
-            sys.stderr.write("bench: load with commit_wbits=%d failed (%s), trying %d\n" % (w, e, w - 1))
-    if hip is None:
-        raise SystemExit("bench: load_trusted_setup failed for every table width")
-    lib = hip.lib
-    lib.ckzg_hip_table_wbits.restype = C.c_int
-    lib.ckzg_hip_table_wbits.argtypes = [C.c_void_p, C.c_int]
-    wbits = int(lib.ckzg_hip_table_wbits(C.addressof(hip.s), 0))  # what was actually built
-    fn = lib.ckzg_hip_blob_to_kzg_commitment_batch_device
-    fn.restype = C.c_int
-    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
-    kms = lib.ckzg_hip_last_kernel_ms
-    kms.restype = C.c_double
-    kms.argtypes = [C.c_void_p, C.c_int]
-    lib.ckzg_hip_table_bytes.restype = C.c_uint64
-    lib.ckzg_hip_table_bytes.argtypes = [C.c_void_p]
+    # the ONE wide-table load of the run: commitment, low-latency proof and FK20 tables together (GLV
+    # half-scalar tables: 103 + 103 + 32 GB at 16 / 16 / 13 bits); the library narrows what does not fit
+    opts = dict(WIDE, device=local_rank, commit_wbits=args.wbits)
+    if one_gpu and world > 1:
+        opts.update(commit_wbits=min(args.wbits, 12), proof_wbits=8, fk20_wbits=8)  # ranks share one GPU's HBM
+    t_load = time.perf_counter()
+    hip = mod.Kzg(mod.HIP_SO, options=opts)
+    load_s = time.perf_counter() - t_load
+    L = Lib(hip.lib)
+    sp = C.addressof(hip.s)
+    wbits = int(L.table_wbits(sp, 0))  # what was actually built
 
     # synthetic blobs: 31 random bytes per field element, top byte 0 => canonical
     # (same distribution as bindings/go/main_test.go:31-51), fixed seed per rank
@@ -211,7 +378,7 @@ def main():
     torch.cuda.synchronize()
 
     def step():
-        rc = fn(out.data_ptr(), status.data_ptr(), blobs.data_ptr(), BLOBS_PER_STEP, C.addressof(hip.s))
+        rc = L.commit_dev(out.data_ptr(), status.data_ptr(), blobs.data_ptr(), BLOBS_PER_STEP, sp)
         if rc != 0:
             raise RuntimeError("commit batch failed rc=%d" % rc)
 
@@ -224,7 +391,7 @@ def main():
     kern_ms = []
     for _ in range(args.steps):
         step()
-        kern_ms.append(kms(C.addressof(hip.s), 1))
+        kern_ms.append(L.kms(sp, 1))   # hipEvents around k_msm_accumulate on the library's stream
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -233,27 +400,33 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # PCIe-inclusive rate (host pointers), one untimed-for-`value` call on rank 0
-    pcie_rate = None
-    if rank == 0 and not args.no_pcie:
-        try:
-            hb = blobs.cpu().numpy().tobytes()
-            ho = C.create_string_buffer(48 * BLOBS_PER_STEP)
-            hs = C.create_string_buffer(BLOBS_PER_STEP)
-            f2 = lib.ckzg_hip_blob_to_kzg_commitment_batch
-            f2.restype = C.c_int
-            f2.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p]
-            f2(ho, hs, hb, C.c_uint64(BLOBS_PER_STEP), C.addressof(hip.s))  # warm-up: pinned staging, buffers
-            t1 = time.perf_counter()
-            rc = f2(ho, hs, hb, C.c_uint64(BLOBS_PER_STEP), C.addressof(hip.s))
-            t2 = time.perf_counter()
-            if rc == 0:
-                pcie_rate = BLOBS_PER_STEP / (t2 - t1)
-                assert ho.raw == out.cpu().numpy().tobytes(), "host-pointer and device-pointer paths disagree"
-        except AssertionError:
-            raise
-        except Exception as e:  # reported as null, never fatal for the headline
-            sys.stderr.write("bench: PCIe-inclusive leg failed: %s\n" % e)
+    # the reference-shaped call: pageable host pointers, H2D and D2H inside the timed region, same step count
+    host_ptr = None
+    if not args.no_pcie:
+        hb = blobs.cpu().numpy().tobytes()
+        ho = C.create_string_buffer(48 * BLOBS_PER_STEP)
+        hs = C.create_string_buffer(BLOBS_PER_STEP)
+        for _ in range(max(1, min(args.warmup, 2))):
+            rc = L.commit_host(ho, hs, hb, BLOBS_PER_STEP, sp)  # warm-up: pinned staging, buffers
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            rc = L.commit_host(ho, hs, hb, BLOBS_PER_STEP, sp)
+        dth = time.perf_counter() - t1
+        if rc != 0:
+            raise SystemExit("bench: host-pointer commitment batch failed rc=%d" % rc)
+        if ho.raw != out.cpu().numpy().tobytes():
+            raise SystemExit("bench: host-pointer and device-pointer paths disagree")
+        if world > 1:
+            dist.barrier()
+            t = torch.tensor([dth], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dth = float(t.item())
+        host_ptr = {"value": round(BLOBS_PER_STEP * args.steps * world / dth, 2), "unit": "blobs/s",
+                    "ms_per_step": round(dth / args.steps * 1e3, 3), "steps": args.steps,
+                    "note": "ckzg_hip_blob_to_kzg_commitment_batch on pageable host memory: staging copy, H2D, "
+                            "kernels and D2H inside the timed region (SURVEY 8d form); whole job over all ranks"}
 
     # spot-check the timed kernel's output against the CPU oracle (checker only, untimed)
     parity = None
@@ -271,82 +444,85 @@ def main():
         if parity is False:
             raise SystemExit("bench: GPU commitments differ from the oracle -- number would be invalid")
 
-    table_bytes = int(lib.ckzg_hip_table_bytes(C.addressof(hip.s)))
-    # secondary metric of BASELINE.json: compute_cells_and_kzg_proofs (configs[2]), rank 0 only, on two
-    # further loads: a latency configuration (16-bit table over the monomial points for the
-    # low-latency proof path) and a throughput configuration (15-bit FK20 table)
-    # secondary rows: never allowed to take the headline line down with them
+    # the other rows of the path, all from the settings loaded above plus ONE co-resident default-table load
     secondary = None
 
     def secondary_rows():
-        nonlocal hip
-        secondary = None
-        fc = lib.ckzg_hip_compute_cells_and_kzg_proofs_batch_device
-        fc.restype = C.c_int
-        fc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
-        nb = 2048
-        blobs2 = blobs.repeat(2, 1, 1)
-        status2 = torch.empty((nb,), dtype=torch.uint8, device=dev)
-        cells = torch.empty((nb, 128, 2048), dtype=torch.uint8, device=dev)
-        proofs = torch.empty((nb, 128, 48), dtype=torch.uint8, device=dev)
-        torch.cuda.synchronize()
-
-        def run(n):
-            rc = fc(cells.data_ptr(), proofs.data_ptr(), status2.data_ptr(), blobs2.data_ptr(), n, C.addressof(hip.s))
-            if rc != 0:
-                raise RuntimeError("cells+proofs failed rc=%d" % rc)
-
-        def tables():
-            return {"fk20_wbits": int(lib.ckzg_hip_table_wbits(C.addressof(hip.s), 1)),
-                    "proof_wbits": int(lib.ckzg_hip_table_wbits(C.addressof(hip.s), 2)),
-                    "bytes": int(lib.ckzg_hip_table_bytes(C.addressof(hip.s)))}
-
-        hip.close()
-        hip = mod.Kzg(mod.HIP_SO, options={"device": local_rank, "commit_wbits": 10, "proof_wbits": 16,
-                                           "fk20_wbits": 8})
-        run(1)
-        ts = []
-        for _ in range(20):
-            t1 = time.perf_counter()
-            run(1)
-            ts.append(time.perf_counter() - t1)
-        ts.sort()
-        secondary = {"compute_cells_and_kzg_proofs_ms_per_call_1blob": round(ts[len(ts) // 2] * 1e3, 3),
-                     "tables_1blob": tables()}
-        proofs_1 = proofs[0].clone()
-        hip.close()
-        hip = mod.Kzg(mod.HIP_SO, options={"device": local_rank, "commit_wbits": 10, "proof_wbits": 8,
-                                           "fk20_wbits": 15})
-        run(nb)
-        t1 = time.perf_counter()
-        run(nb)
-        tb = time.perf_counter() - t1
-        if not torch.equal(proofs[0], proofs_1):
-            raise SystemExit("bench: low-latency and FK20 proof paths disagree")
-        secondary.update({"compute_cells_and_kzg_proofs_batch2048_blobs_per_s": round(nb / tb, 1),
-                          "tables_batch": tables(),
-                          "note": "1 blob: low-latency path (128 fixed-base MSMs, no G1 FFT); batch: FK20 path; "
-                                  "inputs/outputs resident in HBM; the two paths' proofs are compared"})
-        # the other two rows of the path (BASELINE configs 4 and 5), host pointers at the C-ABI
+        sec = {"load_trusted_setup_s": {"wide_tables": round(load_s, 2)}}
+        sec["cells_and_proofs"] = cells_rows(L, hip, torch, dev, blobs, "wide tables (same KZGSettings as the headline)")
         try:
-            secondary.update(verify_and_recover_rows(hip, lib, blobs[:8].cpu().numpy()))
+            sec.update(verify_and_recover_rows(L, hip, blobs[:8].cpu().numpy()))
         except Exception as e:  # reported, never fatal for the headline
-            secondary["verify_recover_error"] = str(e)
-        return secondary
+            sec["verify_recover_error"] = str(e)
+        try:
+            sec["concurrent_callers"] = concurrency_row(hip, blobs[0].cpu().numpy().tobytes())
+        except Exception as e:
+            sec["concurrent_callers"] = {"error": str(e)}
+        # default footprint: what a caller gets from load_trusted_setup(precompute=0) without any option
+        t1 = time.perf_counter()
+        small = mod.Kzg(mod.HIP_SO, options={"device": local_rank, "commit_wbits": 10, "proof_wbits": 8, "fk20_wbits": 0})
+        sec["load_trusted_setup_s"]["default_tables"] = round(time.perf_counter() - t1, 2)
+        try:
+            sps = C.addressof(small.s)
+            L.commit_dev(out.data_ptr(), status.data_ptr(), blobs.data_ptr(), BLOBS_PER_STEP, sps)
+            ts, ks = [], []
+            for _ in range(5):
+                t1 = time.perf_counter()
+                rc = L.commit_dev(out.data_ptr(), status.data_ptr(), blobs.data_ptr(), BLOBS_PER_STEP, sps)
+                ts.append(time.perf_counter() - t1)
+                ks.append(L.kms(sps, 1))
+            if rc != 0:
+                raise RuntimeError("default-table commit rc=%d" % rc)
+            d = {"tables": tables_of(L, small),
+                 "commit_blobs_per_s": round(BLOBS_PER_STEP / median(ts), 1),
+                 "commit_roofline": roofline(ALGO_BYTES_PER_BLOB * BLOBS_PER_STEP, median(ks), "k_msm_accumulate")}
+            d["cells_and_proofs"] = cells_rows(L, small, torch, dev, blobs, "default tables")
+            sec["default_footprint"] = d
+        finally:
+            small.close()
+        return sec
 
     if rank == 0 and world == 1 and not args.no_secondary:
         try:
             secondary = secondary_rows()
         except BaseException as e:  # noqa: BLE001 -- report, keep the headline
-            if isinstance(e, SystemExit) and 'disagree' in str(e):
+            if isinstance(e, SystemExit) and ("disagree" in str(e) or "differs" in str(e)):
                 raise
             secondary = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    # C-ABI multi-device form (one process, ckzg_hip_set_option("devices", mask), host threads fan the batch
+    # out): measured by rank 0 after the timed region while the other ranks wait, on small tables that fit
+    # next to every rank's wide ones
+    fan_out = None
+    if world > 1 and not one_gpu and not args.no_secondary:
+        if rank == 0:
+            try:
+                ndev = torch.cuda.device_count()
+                multi = mod.Kzg(mod.HIP_SO, options={"devices": (1 << world) - 1 if world <= ndev else -1,
+                                                     "commit_wbits": 10, "proof_wbits": 0, "fk20_wbits": 0})
+                spm = C.addressof(multi.s)
+                nd = int(L.num_devices(spm))
+                n = BLOBS_PER_STEP * nd
+                hb = blobs.cpu().numpy().tobytes() * nd
+                ho = C.create_string_buffer(48 * n)
+                hs = C.create_string_buffer(n)
+                L.commit_host(ho, hs, hb, n, spm)
+                t1 = time.perf_counter()
+                rc = L.commit_host(ho, hs, hb, n, spm)
+                dtm = time.perf_counter() - t1
+                multi.close()
+                fan_out = {"devices": nd, "blobs": n, "blobs_per_s": round(n / dtm, 1), "rc": rc, "table_wbits": 10,
+                           "note": "one process, ckzg_hip_blob_to_kzg_commitment_batch fanning contiguous ranges over "
+                                   "all devices from host threads (host pointers, PCIe inclusive)"}
+            except BaseException as e:  # noqa: BLE001
+                fan_out = {"error": "%s: %s" % (type(e).__name__, e)}
+        dist.barrier()
 
     if rank == 0:
         total_blobs = BLOBS_PER_STEP * args.steps * world
         value = total_blobs / dt
-        avg_k = sum(kern_ms) / len(kern_ms) * 1e-3
-        achieved = ALGO_BYTES_PER_BLOB * BLOBS_PER_STEP / avg_k / 1e9
+        avg_k = sum(kern_ms) / len(kern_ms)
+        adds_per_blob = (2 * (127 // wbits + 1)) * 4096
         line = {
             "metric": "blob_to_kzg_commitment throughput",
             "value": round(value, 2), "unit": "blobs/s", "n_gpus": world, "steps": args.steps,
@@ -355,26 +531,27 @@ def main():
             "data": "synthetic",
             "config": {"workload": "blob_to_kzg_commitment batch of 1024 blobs per GPU (4096-point G1 MSM per blob), "
                                    "inputs resident in HBM", "blobs_per_step_per_gpu": BLOBS_PER_STEP,
-                       "table_wbits": wbits, "table_bytes": table_bytes,
+                       "table_wbits": wbits, "tables": tables_of(L, hip),
                        "parallelism": "independent blob shards per GPU, no collective"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": PMC_TRAFFIC_BYTES.get(wbits),
-                         "kernel": "k_msm_accumulate", "kernel_ms": round(avg_k * 1e3, 3),
-                         "note": "integer-VALU-bound kernel (v_mad_u64_u32 chains); HBM fraction is small by nature"},
+            "roofline": dict(roofline(ALGO_BYTES_PER_BLOB * BLOBS_PER_STEP, avg_k, "k_msm_accumulate",
+                                      PMC_TRAFFIC_BYTES.get(wbits)),
+                             note="integer-VALU-bound kernel (v_mad_u64_u32 chains); HBM fraction is small by nature"),
             # the physical bound of this kernel: integer multiply-add issue rate.  peak = measured
             # v_mad_u64_u32 rate of the chip (tools/ubench/instr_rates.hip: 32.9e12 lane-ops/s);
             # achieved counts only the multiply-adds of the field products of each table addition
             # (MADS_PER_ADDITION; nwin*4096 additions per blob), not the ~25 % of other instructions.
             "roofline_valu": {"bound": "v_mad_u64_u32 issue", "unit": "T lane-mad/s", "peak": 32.9,
-                              "achieved": round(BLOBS_PER_STEP * (255 // wbits + 1) * 4096 * MADS_PER_ADDITION / avg_k / 1e12, 3),
-                              "frac": round(BLOBS_PER_STEP * (255 // wbits + 1) * 4096 * MADS_PER_ADDITION / avg_k / 32.9e12, 4),
+                              "achieved": round(BLOBS_PER_STEP * adds_per_blob * MADS_PER_ADDITION / (avg_k * 1e-3) / 1e12, 3),
+                              "frac": round(BLOBS_PER_STEP * adds_per_blob * MADS_PER_ADDITION / (avg_k * 1e-3) / 32.9e12, 4),
                               "valu_wave_insts_per_launch": PMC_VALU_INSTS.get(wbits),
-                              "pmc": "profiles/r01_c16_pmc_sq_k_msm_accumulate.json (SQ_INSTS_VALU, GRBM_GUI_ACTIVE): "
-                                     "~95 % of the VALU issue slots at the sustained ~2.1 GHz clock"},
-            "pcie_inclusive_blobs_per_s": None if pcie_rate is None else round(pcie_rate, 2),
+                              "pmc": "profiles/ (SQ_INSTS_VALU, GRBM_GUI_ACTIVE, SQ_WAVES)"},
+            "host_pointer": host_ptr,
+            "pcie_inclusive_blobs_per_s": None if host_ptr is None else host_ptr["value"],
             "parity_spot_check_vs_oracle": parity,
             "secondary": secondary,
         }
+        if fan_out is not None:
+            line["c_abi_fan_out"] = fan_out
         if not args.no_cpu_baseline and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline()

@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cinttypes>
 #include <condition_variable>
+#include <deque>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -171,6 +172,164 @@ C_KZG_RET for_each_device_shard(const KZGSettings *s, uint64_t n, uint64_t min_s
     for (auto r : rets) ret = worse(ret, r);
     return ret;
 }
+
+// pageable <-> pinned staging copy.  One core moves ~10 GB/s, which would make a copy (13 ms per
+// 1024 blobs) longer than the kernels it is supposed to hide behind: large chunks are split over four threads.
+inline void staged_copy(void *dst, const void *src, size_t bytes) {
+    const size_t nt = 4;
+    if (bytes < ((size_t)4 << 20) || std::thread::hardware_concurrency() < 8) {
+        memcpy(dst, src, bytes);
+        return;
+    }
+    const size_t part = (bytes / nt + 4095) & ~(size_t)4095;
+    std::thread th[nt - 1];
+    for (size_t t = 1; t < nt; t++) {
+        size_t o = t * part, len = o >= bytes ? 0 : (bytes - o < part ? bytes - o : part);
+        th[t - 1] = std::thread([=]() {
+            if (len) memcpy((uint8_t *)dst + o, (const uint8_t *)src + o, len);
+        });
+    }
+    memcpy(dst, src, part < bytes ? part : bytes);
+    for (auto &x : th) x.join();
+}
+
+// pinned staging of a slot, grown on demand: h_stage[2] (towards the device), h_out[2] (back)
+inline bool ensure_pinned(void **bufs, size_t &have, size_t want) {
+    if (have >= want) return true;
+    for (int i = 0; i < 2; i++) {
+        if (bufs[i]) (void)hipHostFree(bufs[i]);
+        bufs[i] = nullptr;
+    }
+    have = 0;
+    for (int i = 0; i < 2; i++) {
+        if (hipHostMalloc(&bufs[i], want, hipHostMallocDefault) != hipSuccess) {
+            bufs[i] = nullptr;
+            (void)hipGetLastError();
+            return false;
+        }
+    }
+    have = want;
+    return true;
+}
+
+// Drains results into the caller's (pageable) memory while the compute stream keeps working: the batch
+// entry points push (device source, host destination) pairs as soon as the producing kernels are enqueued;
+// a helper thread waits for each producer, DMAs the bytes into a pinned double buffer on the slot's
+// out_stream and copies them out.  A pageable hipMemcpy would block the enqueueing thread instead, and the
+// 268 KB per blob of compute_cells_and_kzg_proofs would serialise behind -- not under -- the proof kernels.
+class OutPipe {
+   public:
+    static constexpr size_t PIECE = (size_t)32 << 20;
+    explicit OutPipe(dev::DeviceCtx *c) : ctx(c) {}
+    OutPipe(const OutPipe &) = delete;
+    OutPipe &operator=(const OutPipe &) = delete;
+    ~OutPipe() { (void)finish(); }
+    // the bytes at d_src are final once everything enqueued on ctx->stream so far has run
+    bool push(const void *d_src, void *h_dst, size_t bytes) {
+        if (!bytes) return true;
+        if (!started) {
+            if (!ctx->out_stream && hipStreamCreateWithFlags(&ctx->out_stream, hipStreamNonBlocking) != hipSuccess) return false;
+            if (!ensure_pinned(ctx->h_out, ctx->h_out_bytes, PIECE)) return false;
+            for (auto &e : piece_ev) {
+                if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+            }
+            worker = std::thread([this]() { run(); });
+            started = true;
+        }
+        Item it{nullptr, d_src, h_dst, bytes};
+        if (hipEventCreateWithFlags(&it.ready, hipEventDisableTiming) != hipSuccess) return false;
+        if (hipEventRecord(it.ready, ctx->stream) != hipSuccess) {
+            (void)hipEventDestroy(it.ready);
+            return false;
+        }
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            q.push_back(it);
+            pushed++;
+        }
+        cv.notify_all();
+        return true;
+    }
+    size_t pushed_count() const { return pushed; }
+    // blocks until the first `count` pushed items have reached host memory
+    void wait_for(size_t count) {
+        std::unique_lock<std::mutex> lock(mu);
+        cv.wait(lock, [&]() { return drained >= count || failed; });
+    }
+    C_KZG_RET finish() {
+        if (started) {
+            {
+                std::lock_guard<std::mutex> lock(mu);
+                closing = true;
+            }
+            cv.notify_all();
+            worker.join();
+            started = false;
+            for (auto &e : piece_ev) {
+                if (e) (void)hipEventDestroy(e);
+                e = nullptr;
+            }
+        }
+        return failed ? C_KZG_ERROR : C_KZG_OK;
+    }
+
+   private:
+    struct Item {
+        hipEvent_t ready;
+        const void *src;
+        void *dst;
+        size_t bytes;
+    };
+    void run() {
+        bool ok = hipSetDevice(ctx->device) == hipSuccess;
+        for (;;) {
+            Item it;
+            {
+                std::unique_lock<std::mutex> lock(mu);
+                cv.wait(lock, [&]() { return !q.empty() || closing; });
+                if (q.empty()) break;
+                it = q.front();
+                q.pop_front();
+            }
+            ok = ok && hipEventSynchronize(it.ready) == hipSuccess;
+            (void)hipEventDestroy(it.ready);
+            // pieces through the pinned double buffer: the DMA of piece i+1 runs under the host copy of piece i
+            const size_t np = (it.bytes + PIECE - 1) / PIECE;
+            auto issue = [&](size_t i) {
+                const size_t off = i * PIECE, len = it.bytes - off < PIECE ? it.bytes - off : PIECE;
+                ok = ok && hipMemcpyAsync(ctx->h_out[i & 1], (const uint8_t *)it.src + off, len, hipMemcpyDeviceToHost,
+                                          ctx->out_stream) == hipSuccess;
+                ok = ok && hipEventRecord(piece_ev[i & 1], ctx->out_stream) == hipSuccess;
+            };
+            if (ok) issue(0);
+            for (size_t i = 0; i < np && ok; i++) {
+                if (i + 1 < np) issue(i + 1);
+                ok = ok && hipEventSynchronize(piece_ev[i & 1]) == hipSuccess;
+                const size_t off = i * PIECE, len = it.bytes - off < PIECE ? it.bytes - off : PIECE;
+                if (ok) staged_copy((uint8_t *)it.dst + off, ctx->h_out[i & 1], len);
+            }
+            {
+                std::lock_guard<std::mutex> lock(mu);
+                drained++;
+                if (!ok) failed = true;
+            }
+            cv.notify_all();
+        }
+        if (!ok) {
+            std::lock_guard<std::mutex> lock(mu);
+            failed = true;
+            cv.notify_all();
+        }
+    }
+    dev::DeviceCtx *ctx;
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Item> q;
+    hipEvent_t piece_ev[2] = {nullptr, nullptr};
+    size_t pushed = 0, drained = 0;
+    bool started = false, closing = false, failed = false;
+};
 
 struct DeviceBuffer {
     void *p = nullptr;

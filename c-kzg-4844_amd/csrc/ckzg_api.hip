@@ -27,6 +27,13 @@ Options options_snapshot() {
 }  // namespace api
 }  // namespace ckzg
 
+// ROCm multiplexes a process's HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams
+// that share a queue serialise.  Every slot of a pool owns two streams, so the concurrent-caller
+// design needs more queues than the default to overlap: ask for 16 unless the user chose a value.
+// Only effective when this library is loaded before the process's first HIP call; a host that
+// initialises HIP earlier (e.g. imports torch first) sets the variable itself.
+__attribute__((constructor)) static void ckzg_hip_queue_hint() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 extern "C" C_KZG_RET ckzg_hip_set_option(const char *key, int64_t value) {
     if (!key) return C_KZG_BADARGS;
     std::lock_guard<std::mutex> lock(g_opts_mu);
@@ -262,27 +269,6 @@ extern "C" C_KZG_RET bytes_to_kzg_proof(g1_t *out, const Bytes48 *b) {
 // blob_to_kzg_commitment (src/eip4844/eip4844.c:264-280) and its batch forms
 // ------------------------------------------------------------------------------------------
 
-// pageable -> pinned staging copy.  One core moves ~10 GB/s, which would make the copy (13 ms per
-// 1024 blobs) longer than the kernels it is supposed to hide behind (10.4 ms): large chunks are split
-// over four threads.
-static void staged_copy(void *dst, const void *src, size_t bytes) {
-    const size_t nt = 4;
-    if (bytes < ((size_t)4 << 20) || std::thread::hardware_concurrency() < 8) {
-        memcpy(dst, src, bytes);
-        return;
-    }
-    const size_t part = (bytes / nt + 4095) & ~(size_t)4095;
-    std::thread th[nt - 1];
-    for (size_t t = 1; t < nt; t++) {
-        size_t o = t * part, len = o >= bytes ? 0 : (bytes - o < part ? bytes - o : part);
-        th[t - 1] = std::thread([=]() {
-            if (len) memcpy((uint8_t *)dst + o, (const uint8_t *)src + o, len);
-        });
-    }
-    memcpy(dst, src, part < bytes ? part : bytes);
-    for (auto &x : th) x.join();
-}
-
 // the slot a *_device entry point runs on: a slot of the pool whose GPU holds the caller's buffers
 struct DeviceLease {
     Lease lease;
@@ -336,22 +322,7 @@ static C_KZG_RET commit_batch_on(dev::DeviceCtx *ctx, KZGCommitment *out, uint8_
     if (dev::scratch_reserve(ctx, dev::commit_scratch_bytes(ctx, m)) != 0) return C_KZG_MALLOC;
     // pinned staging: two input buffers of up to CH blobs; the results come back through the first 49 n
     // bytes of a third one (a pageable destination would make the final copy a blocking staged copy)
-    const size_t stage_bytes = m * BYTES_PER_BLOB;
-    if (ctx->h_stage_bytes < stage_bytes) {
-        for (int i = 0; i < 2; i++) {
-            if (ctx->h_stage[i]) (void)hipHostFree(ctx->h_stage[i]);
-            ctx->h_stage[i] = nullptr;
-        }
-        ctx->h_stage_bytes = 0;
-        const size_t want = n == 1 ? stage_bytes : CH * BYTES_PER_BLOB;
-        for (int i = 0; i < 2; i++) {
-            if (hipHostMalloc(&ctx->h_stage[i], want, hipHostMallocDefault) != hipSuccess) {
-                ctx->h_stage[i] = nullptr;
-                return C_KZG_MALLOC;
-            }
-        }
-        ctx->h_stage_bytes = want;
-    }
+    if (!ensure_pinned(ctx->h_stage, ctx->h_stage_bytes, n == 1 ? (size_t)BYTES_PER_BLOB : CH * BYTES_PER_BLOB)) return C_KZG_MALLOC;
     for (int i = 0; i < 4; i++) {
         if (!ctx->stage_ev[i] && hipEventCreateWithFlags(&ctx->stage_ev[i], hipEventDisableTiming) != hipSuccess) {
             ctx->stage_ev[i] = nullptr;
@@ -359,6 +330,25 @@ static C_KZG_RET commit_batch_on(dev::DeviceCtx *ctx, KZGCommitment *out, uint8_
         }
     }
     tr.mark("buffers + events");
+    if (n <= FIRST && ret == C_KZG_OK) {
+        // one small chunk (the reference-shaped single-blob call among them): nothing to overlap, so the
+        // copy in, the kernels and the copy out run on the one compute stream with a single wait
+        uint8_t *h_in = static_cast<uint8_t *>(ctx->h_stage[0]), *h_res = static_cast<uint8_t *>(ctx->h_stage[1]);
+        memcpy(h_in, blobs, n * BYTES_PER_BLOB);
+        if (hipMemcpyAsync(d_blobs[0].p, h_in, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+            return C_KZG_ERROR;
+        int rc = dev::commit_blobs_enqueue(ctx, d_out.p, d_status, (const uint8_t *)d_blobs[0].p, n);
+        if (rc) return (C_KZG_RET)rc;
+        if (hipMemcpyAsync(h_res, d_out.p, n * 49, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return C_KZG_ERROR;
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return C_KZG_ERROR;
+        tr.mark("copy in + kernels + copy out");
+        memcpy(out, h_res, n * 48);
+        for (uint64_t i = 0; i < n; i++) {
+            if (status) status[i] = h_res[n * 48 + i];
+            if (h_res[n * 48 + i]) ret = C_KZG_BADARGS;
+        }
+        return ret;
+    }
     uint64_t chunk = 0, k = 0, want = FIRST;
     for (uint64_t off = 0; off < n && ret == C_KZG_OK; off += k, chunk++) {
         const int b = (int)(chunk & 1);
@@ -449,38 +439,139 @@ extern "C" C_KZG_RET ckzg_hip_compute_cells_and_kzg_proofs_batch_device(void *d_
     });
 }
 
+static bool ensure_stage_events(dev::DeviceCtx *ctx) {
+    for (int i = 0; i < 4; i++) {
+        if (!ctx->stage_ev[i] && hipEventCreateWithFlags(&ctx->stage_ev[i], hipEventDisableTiming) != hipSuccess) {
+            ctx->stage_ev[i] = nullptr;
+            return false;
+        }
+    }
+    return true;
+}
+
+static size_t al256(size_t v) { return (v + 255) / 256 * 256; }
+
+// One device's share of a host-pointer compute_cells_and_kzg_proofs batch.
 static C_KZG_RET cells_and_proofs_batch_on(dev::DeviceCtx *ctx, Cell *cells, KZGProof *proofs, uint8_t *status,
                                            const Blob *blobs, uint64_t n) {
     if (n == 0) return C_KZG_OK;
-    const uint64_t CH = 2048;  // >= 2 waves of G1-FFT butterflies per SIMD per stage launch
-    uint64_t m = n < CH ? n : CH;
     const size_t cells_per = (size_t)CELLS_PER_EXT_BLOB * BYTES_PER_CELL, proofs_per = (size_t)CELLS_PER_EXT_BLOB * 48;
     Arena &ar = ctx->api_arena;
-    if (!ar.begin(m * (BYTES_PER_BLOB + 1 + (cells ? cells_per : 0) + (proofs ? proofs_per : 0)))) return C_KZG_MALLOC;
     ArenaTrim trim(ar);
-    ABuf<uint8_t> d_blobs(ar, m * BYTES_PER_BLOB), d_status(ar, m);
-    ABuf<uint8_t> d_cells(ar, cells ? m * cells_per : 1), d_proofs(ar, proofs ? m * proofs_per : 1);
-    if (!d_blobs.p || !d_status.p || !d_cells.p || !d_proofs.p) return C_KZG_MALLOC;
-    if (!cells) d_cells.p = nullptr;
-    if (!proofs) d_proofs.p = nullptr;
-    std::vector<uint8_t> st(m);
     C_KZG_RET ret = C_KZG_OK;
-    for (uint64_t off = 0; off < n; off += CH) {
-        uint64_t k = n - off < CH ? n - off : CH;
-        if (hipMemcpyAsync(d_blobs.p, blobs + off, k * BYTES_PER_BLOB, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+    if (n <= 64) {
+        // latency path (the reference-shaped one-blob call among them): pinned staging both ways, one stream
+        const size_t out_per = (cells ? cells_per : 0) + (proofs ? proofs_per : 0) + 1;
+        if (!ar.begin(n * (BYTES_PER_BLOB + out_per) + 1024)) return C_KZG_MALLOC;
+        ABuf<uint8_t> d_blobs(ar, n * BYTES_PER_BLOB), d_out(ar, n * out_per);
+        if (!d_blobs.p || !d_out.p) return C_KZG_MALLOC;
+        if (!ensure_pinned(ctx->h_stage, ctx->h_stage_bytes, n == 1 ? (size_t)BYTES_PER_BLOB : 64 * (size_t)BYTES_PER_BLOB))
+            return C_KZG_MALLOC;
+        if (!ensure_pinned(ctx->h_out, ctx->h_out_bytes, n == 1 ? cells_per + proofs_per + 64 : OutPipe::PIECE)) return C_KZG_MALLOC;
+        uint8_t *d_cells = cells ? d_out.p : nullptr;
+        uint8_t *d_proofs = proofs ? d_out.p + (cells ? n * cells_per : 0) : nullptr;
+        uint8_t *d_status = d_out.p + n * (out_per - 1);
+        memcpy(ctx->h_stage[0], blobs, n * BYTES_PER_BLOB);
+        if (hipMemcpyAsync(d_blobs.p, ctx->h_stage[0], n * BYTES_PER_BLOB, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
             return C_KZG_ERROR;
-        int rc = dev::cells_and_proofs_device(ctx, (uint8_t *)d_cells.p, (uint8_t *)d_proofs.p,
-                                              (uint8_t *)d_status.p, (const uint8_t *)d_blobs.p, k);
+        int rc = dev::cells_and_proofs_device(ctx, d_cells, d_proofs, d_status, d_blobs.p, n);
         if (rc) return (C_KZG_RET)rc;
-        if (cells && hipMemcpy(cells + off * CELLS_PER_EXT_BLOB, d_cells.p, k * cells_per, hipMemcpyDeviceToHost) != hipSuccess)
-            return C_KZG_ERROR;
-        if (proofs && hipMemcpy(proofs + off * CELLS_PER_EXT_BLOB, d_proofs.p, k * proofs_per, hipMemcpyDeviceToHost) != hipSuccess)
-            return C_KZG_ERROR;
-        if (hipMemcpy(st.data(), d_status.p, k, hipMemcpyDeviceToHost) != hipSuccess) return C_KZG_ERROR;
-        for (uint64_t i = 0; i < k; i++) {
-            if (status) status[off + i] = st[i];
+        uint8_t *h = static_cast<uint8_t *>(ctx->h_out[0]);
+        if (hipMemcpyAsync(h, d_out.p, n * out_per, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return C_KZG_ERROR;
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return C_KZG_ERROR;
+        if (cells) memcpy(cells, h, n * cells_per);
+        if (proofs) memcpy(proofs, h + (cells ? n * cells_per : 0), n * proofs_per);
+        const uint8_t *st = h + n * (out_per - 1);
+        for (uint64_t i = 0; i < n; i++) {
+            if (status) status[i] = st[i];
             if (st[i]) ret = C_KZG_BADARGS;
         }
+        return ret;
+    }
+    // Throughput path.  Per chunk of up to 2048 blobs (>= 2 waves of G1-FFT butterflies per SIMD per stage
+    // launch): sub-chunks of 256 blobs are staged into pinned memory and DMA'd on the copy stream while the
+    // previous sub-chunk's Fr kernels (bytes -> coefficients -> cells) run; the cells of each sub-chunk start
+    // draining to the caller's memory (OutPipe) as soon as they exist, so that the bulk of the output
+    // (256 KB per blob) crosses PCIe underneath the proof kernels that follow; proofs and status bytes last.
+    const bool direct = proofs != nullptr && dev::proofs_use_direct(ctx, n);
+    const uint64_t CH = direct ? 64 : 2048, SC = direct ? 64 : 256;
+    const uint64_t m = n < CH ? n : CH;
+    if (!ar.begin(2 * SC * BYTES_PER_BLOB + 2 * m * ((cells ? cells_per : 0) + (proofs ? proofs_per : 0) + 1) + 4096))
+        return C_KZG_MALLOC;
+    ABuf<uint8_t> d_in[2] = {ABuf<uint8_t>(ar, SC * BYTES_PER_BLOB), ABuf<uint8_t>(ar, SC * BYTES_PER_BLOB)};
+    ABuf<uint8_t> d_cells[2] = {ABuf<uint8_t>(ar, cells ? m * cells_per : 1), ABuf<uint8_t>(ar, cells ? m * cells_per : 1)};
+    ABuf<uint8_t> d_proofs[2] = {ABuf<uint8_t>(ar, proofs ? m * proofs_per : 1), ABuf<uint8_t>(ar, proofs ? m * proofs_per : 1)};
+    ABuf<uint8_t> d_status[2] = {ABuf<uint8_t>(ar, m), ABuf<uint8_t>(ar, m)};
+    for (int i = 0; i < 2; i++) {
+        if (!d_in[i].p || !d_cells[i].p || !d_proofs[i].p || !d_status[i].p) return C_KZG_MALLOC;
+    }
+    const size_t poly_b = al256(m * FIELD_ELEMENTS_PER_BLOB * sizeof(Fr)), ext_b = al256(SC * FIELD_ELEMENTS_PER_EXT_BLOB * sizeof(Fr)),
+                 bad_b = al256(m * 4);
+    const size_t proof_b = proofs ? dev::proofs_scratch_bytes(ctx, m, direct) : 0;
+    int rc = dev::scratch_reserve(ctx, poly_b + ext_b + bad_b + proof_b);
+    if (rc) return (C_KZG_RET)rc;
+    uint8_t *base = static_cast<uint8_t *>(ctx->scratch.ptr);
+    Fr *d_poly = reinterpret_cast<Fr *>(base), *d_ext = reinterpret_cast<Fr *>(base + poly_b);
+    uint32_t *d_bad = reinterpret_cast<uint32_t *>(base + poly_b + ext_b);
+    uint8_t *proof_scratch = base + poly_b + ext_b + bad_b;
+    if (!ensure_pinned(ctx->h_stage, ctx->h_stage_bytes, SC * (size_t)BYTES_PER_BLOB)) return C_KZG_MALLOC;
+    if (!ensure_stage_events(ctx)) return C_KZG_ERROR;
+    hipEvent_t *copied = ctx->stage_ev, *consumed = ctx->stage_ev + 2;
+    std::vector<uint8_t> st(n);
+    std::vector<size_t> mark;
+    OutPipe pipe(ctx);
+    struct StreamDrain {  // nothing may still read the arena or the staging buffers when this function leaves
+        dev::DeviceCtx *c;
+        OutPipe &p;
+        ~StreamDrain() {
+            (void)p.finish();
+            (void)hipStreamSynchronize(c->copy_stream);
+            (void)hipStreamSynchronize(c->stream);
+        }
+    } drain{ctx, pipe};
+    bool pending[2] = {false, false};
+    uint64_t sub_index = 0, chunk = 0;
+    for (uint64_t off = 0; off < n; off += CH, chunk++) {
+        const uint64_t k = n - off < CH ? n - off : CH;
+        const int cb = (int)(chunk & 1);
+        if (chunk >= 2) pipe.wait_for(mark[chunk - 2]);  // this chunk's output buffers have been drained
+        if (hipMemsetAsync(d_bad, 0, k * 4, ctx->stream) != hipSuccess) return C_KZG_ERROR;
+        for (uint64_t so = 0; so < k; so += SC, sub_index++) {
+            const uint64_t ks = k - so < SC ? k - so : SC;
+            const int b = (int)(sub_index & 1);
+            bool ok = true;
+            if (pending[b]) {
+                ok = ok && hipEventSynchronize(copied[b]) == hipSuccess;
+                ok = ok && hipStreamWaitEvent(ctx->copy_stream, consumed[b], 0) == hipSuccess;
+            }
+            staged_copy(ctx->h_stage[b], blobs + off + so, ks * BYTES_PER_BLOB);
+            ok = ok && hipMemcpyAsync(d_in[b].p, ctx->h_stage[b], ks * BYTES_PER_BLOB, hipMemcpyHostToDevice,
+                                      ctx->copy_stream) == hipSuccess;
+            ok = ok && hipEventRecord(copied[b], ctx->copy_stream) == hipSuccess;
+            ok = ok && hipStreamWaitEvent(ctx->stream, copied[b], 0) == hipSuccess;
+            if (!ok) return C_KZG_ERROR;
+            uint8_t *dc = cells ? d_cells[cb].p + so * cells_per : nullptr;
+            rc = dev::cells_stage_enqueue(ctx, dc, d_poly + so * FIELD_ELEMENTS_PER_BLOB, d_ext, d_bad + so, d_in[b].p, ks);
+            if (rc) return (C_KZG_RET)rc;
+            if (hipEventRecord(consumed[b], ctx->stream) != hipSuccess) return C_KZG_ERROR;
+            pending[b] = true;
+            if (cells && !pipe.push(dc, cells + (off + so) * CELLS_PER_EXT_BLOB, ks * cells_per)) return C_KZG_ERROR;
+        }
+        if (proofs) {
+            rc = dev::proofs_stage_enqueue(ctx, d_proofs[cb].p, d_poly, k, proof_scratch, direct);
+            if (rc) return (C_KZG_RET)rc;
+            if (!pipe.push(d_proofs[cb].p, proofs + off * CELLS_PER_EXT_BLOB, k * proofs_per)) return C_KZG_ERROR;
+        }
+        rc = dev::bad_to_status_enqueue(ctx, d_status[cb].p, d_bad, k);
+        if (rc) return (C_KZG_RET)rc;
+        if (!pipe.push(d_status[cb].p, st.data() + off, k)) return C_KZG_ERROR;
+        mark.push_back(pipe.pushed_count());
+    }
+    if (pipe.finish() != C_KZG_OK) return C_KZG_ERROR;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return C_KZG_ERROR;
+    for (uint64_t i = 0; i < n; i++) {
+        if (status) status[i] = st[i];
+        if (st[i]) ret = C_KZG_BADARGS;
     }
     return ret;
 }

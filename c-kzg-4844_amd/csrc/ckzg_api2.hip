@@ -763,30 +763,50 @@ static C_KZG_RET recover_batch_on(dev::DeviceCtx *ctx, Cell *recovered_cells, KZ
     const size_t n = FIELD_ELEMENTS_PER_EXT_BLOB;
     const size_t CH = 512;  // 512 rows: 128 MiB of byte image + 128 MiB of Fr + 64 MiB of coefficients
     const size_t m = num_blobs < CH ? (size_t)num_blobs : CH;
+    // Batches drain their outputs (256 KB of cells + 6 KB of proofs per row) through an OutPipe: the cells
+    // of a chunk cross PCIe while its proofs are computed, the proofs while the next chunk starts.  Output
+    // buffers alternate between chunks.  A call with a few rows copies directly (no helper thread).
+    const bool piped = num_blobs > 8;
+    const int nbuf = piped ? 2 : 1;
     std::vector<uint32_t> idx32(num_cells);
     for (size_t i = 0; i < num_cells; i++) idx32[i] = (uint32_t)cell_indices[i];
     std::vector<uint32_t> bad(m);
     C_KZG_RET result = C_KZG_OK;
     Arena &ar = ctx->api_arena;
     const size_t nchunks = (size_t)((num_blobs + CH - 1) / CH);  // recover_cells_gpu takes 3 vectors per chunk
-    OKM(ar.begin(m * (n * 32 + num_cells * BYTES_PER_CELL + n * sizeof(Fr) + 4) + num_cells * 4 +
+    OKM(ar.begin(m * (nbuf * n * 32 + num_cells * BYTES_PER_CELL + n * sizeof(Fr) + 4) + num_cells * 4 +
                  nchunks * 3 * (n * sizeof(Fr) + 256) +
-                 (recovered_proofs ? m * (CELLS_PER_EXT_BLOB * 48 + FIELD_ELEMENTS_PER_BLOB * sizeof(Fr)) : 0)));
+                 (recovered_proofs ? m * (nbuf * CELLS_PER_EXT_BLOB * 48 + FIELD_ELEMENTS_PER_BLOB * sizeof(Fr)) : 0) + 4096));
     ArenaTrim trim(ar);
-    ABuf<uint8_t> d_img(ar, m * n * 32), d_in(ar, m * num_cells * BYTES_PER_CELL);
-    ABuf<uint8_t> d_proofs(ar, recovered_proofs ? m * CELLS_PER_EXT_BLOB * 48 : 1);
+    ABuf<uint8_t> d_img0(ar, m * n * 32), d_img1(ar, piped ? m * n * 32 : 1), d_in(ar, m * num_cells * BYTES_PER_CELL);
+    ABuf<uint8_t> d_pr0(ar, recovered_proofs ? m * CELLS_PER_EXT_BLOB * 48 : 1);
+    ABuf<uint8_t> d_pr1(ar, recovered_proofs && piped ? m * CELLS_PER_EXT_BLOB * 48 : 1);
     ABuf<Fr> d_e(ar, m * n), d_poly(ar, recovered_proofs ? m * FIELD_ELEMENTS_PER_BLOB : 1);
     ABuf<uint32_t> d_bad(ar, m), d_idx(ar, num_cells);
-    OKM(d_img.p && d_in.p && d_proofs.p && d_e.p && d_poly.p && d_bad.p && d_idx.p);
+    OKM(d_img0.p && d_img1.p && d_in.p && d_pr0.p && d_pr1.p && d_e.p && d_poly.p && d_bad.p && d_idx.p);
+    uint8_t *img_buf[2] = {d_img0.p, piped ? d_img1.p : d_img0.p}, *pr_buf[2] = {d_pr0.p, piped ? d_pr1.p : d_pr0.p};
     OKB(d_idx.up(idx32.data(), num_cells));
-    for (size_t off = 0; off < num_blobs; off += CH) {
+    OutPipe pipe(ctx);
+    struct Drain {  // nothing may still read the arena when this function leaves, on any path
+        dev::DeviceCtx *c;
+        OutPipe &p;
+        ~Drain() {
+            (void)p.finish();
+            (void)hipStreamSynchronize(c->stream);
+        }
+    } drain{ctx, pipe};
+    std::vector<size_t> mark;
+    size_t chunk = 0;
+    for (size_t off = 0; off < num_blobs; off += CH, chunk++) {
         const size_t k = num_blobs - off < CH ? (size_t)(num_blobs - off) : CH;
         const size_t in_bytes = k * num_cells * BYTES_PER_CELL;
+        uint8_t *d_img = img_buf[chunk & 1], *d_proofs = pr_buf[chunk & 1];
+        if (piped && chunk >= 2) pipe.wait_for(mark[chunk - 2]);
         OKB(hipMemcpyAsync(d_in.p, cells + off * num_cells, in_bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
-        OKB(hipMemsetAsync(d_img.p, 0, k * n * 32, ctx->stream) == hipSuccess);
+        OKB(hipMemsetAsync(d_img, 0, k * n * 32, ctx->stream) == hipSuccess);
         OKB(hipMemsetAsync(d_bad.p, 0, k * 4, ctx->stream) == hipSuccess);
-        RC(dev::scatter_cells_device(ctx, d_img.p, d_in.p, d_idx.p, (uint32_t)num_cells, k));
-        RC(dev::bytes_to_fr_batch(ctx, d_e.p, d_bad.p, d_img.p, k * n, (uint32_t)n));
+        RC(dev::scatter_cells_device(ctx, d_img, d_in.p, d_idx.p, (uint32_t)num_cells, k));
+        RC(dev::bytes_to_fr_batch(ctx, d_e.p, d_bad.p, d_img, k * n, (uint32_t)n));
         OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
         OKB(d_bad.down(bad.data(), k));
         bool any_bad = false;
@@ -798,11 +818,15 @@ static C_KZG_RET recover_batch_on(dev::DeviceCtx *ctx, Cell *recovered_cells, KZ
         if (num_cells != CELLS_PER_EXT_BLOB) {
             C_KZG_RET ret = recover_cells_gpu(ctx, d_e.p, k, cell_indices, num_cells, s);
             if (ret != C_KZG_OK) return ret;
-            if (recovered_cells) RC(dev::fr_to_bytes_batch(ctx, d_img.p, d_e.p, k * n));
+            if (recovered_cells) RC(dev::fr_to_bytes_batch(ctx, d_img, d_e.p, k * n));
         }
         if (recovered_cells) {
-            OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
-            OKB(hipMemcpy(recovered_cells + off * CELLS_PER_EXT_BLOB, d_img.p, k * n * 32, hipMemcpyDeviceToHost) == hipSuccess);
+            if (piped) {
+                OKB(pipe.push(d_img, recovered_cells + off * CELLS_PER_EXT_BLOB, k * n * 32));
+            } else {
+                OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
+                OKB(hipMemcpy(recovered_cells + off * CELLS_PER_EXT_BLOB, d_img, k * n * 32, hipMemcpyDeviceToHost) == hipSuccess);
+            }
         }
         if (recovered_proofs) {
             // cell order is bit-reversed evaluation order: DIT inverse gives the coefficients
@@ -811,11 +835,17 @@ static C_KZG_RET recover_batch_on(dev::DeviceCtx *ctx, Cell *recovered_cells, KZ
             OKB(hipMemcpy2DAsync(d_poly.p, FIELD_ELEMENTS_PER_BLOB * sizeof(Fr), d_e.p, n * sizeof(Fr),
                                  FIELD_ELEMENTS_PER_BLOB * sizeof(Fr), k, hipMemcpyDeviceToDevice,
                                  ctx->stream) == hipSuccess);
-            RC(dev::fk20_proofs_device(ctx, d_proofs.p, d_poly.p, k));
-            OKB(hipMemcpy(recovered_proofs + off * CELLS_PER_EXT_BLOB, d_proofs.p, k * CELLS_PER_EXT_BLOB * 48,
-                          hipMemcpyDeviceToHost) == hipSuccess);
+            RC(dev::fk20_proofs_device(ctx, d_proofs, d_poly.p, k));
+            if (piped) {
+                OKB(pipe.push(d_proofs, recovered_proofs + off * CELLS_PER_EXT_BLOB, k * CELLS_PER_EXT_BLOB * 48));
+            } else {
+                OKB(hipMemcpy(recovered_proofs + off * CELLS_PER_EXT_BLOB, d_proofs, k * CELLS_PER_EXT_BLOB * 48,
+                              hipMemcpyDeviceToHost) == hipSuccess);
+            }
         }
+        mark.push_back(pipe.pushed_count());
     }
+    if (pipe.finish() != C_KZG_OK) return C_KZG_ERROR;
     return result;
 }
 

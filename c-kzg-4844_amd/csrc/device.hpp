@@ -81,6 +81,7 @@ struct DeviceCtx {
     bool owns_tables = true;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;  // host-to-device staging, overlapped with `stream`
+    hipStream_t out_stream = nullptr;   // device-to-host draining of results (OutPipe), created on first use
     void *h_stage[2] = {nullptr, nullptr};  // pinned host staging buffers (allocated on first use)
     size_t h_stage_bytes = 0;
     void *h_out[2] = {nullptr, nullptr};    // pinned device-to-host staging (cells+proofs / recover pipelines)
@@ -160,6 +161,13 @@ int fk20_setup_device(DeviceCtx *ctx, const G1Affine *d_monomial, G1Affine *h_xe
 // cells (n*128*2048 B) and/or proofs (n*128*48 B) for n blobs in HBM; either output may be null
 int cells_and_proofs_device(DeviceCtx *ctx, uint8_t *d_cells, uint8_t *d_proofs, uint8_t *d_status,
                             const uint8_t *d_blobs, size_t n);
+// the same in enqueue-only stages, for callers that pipeline host copies against them (fk20.hip)
+int cells_stage_enqueue(DeviceCtx *ctx, uint8_t *d_cells, Fr *d_poly, Fr *d_ext, uint32_t *d_bad,
+                        const uint8_t *d_blobs, size_t k);
+bool proofs_use_direct(const DeviceCtx *ctx, size_t n);
+size_t proofs_scratch_bytes(const DeviceCtx *ctx, size_t k, bool direct);
+int proofs_stage_enqueue(DeviceCtx *ctx, uint8_t *d_proofs, const Fr *d_poly, size_t k, uint8_t *scratch, bool direct);
+int bad_to_status_enqueue(DeviceCtx *ctx, uint8_t *d_status, const uint32_t *d_bad, size_t k);
 // FK20 proofs from monomial coefficients already on the device ([n][4096] Fr, Montgomery)
 int fk20_proofs_device(DeviceCtx *ctx, uint8_t *d_proofs, const Fr *d_poly_monomial, size_t n);
 // verify.hip

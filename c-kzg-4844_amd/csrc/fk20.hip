@@ -435,6 +435,51 @@ __global__ void k_bad_to_status(uint8_t *status, const uint32_t *bad, size_t n) 
     if (g < n) status[g] = bad[g] ? 1 : 0;
 }
 
+// ---- the three enqueue-only stages of compute_cells_and_kzg_proofs (no waits): callers that pipeline
+// ---- copies against them (ckzg_api.hip) order them with events on ctx->stream ----
+
+// blobs -> monomial coefficients d_poly[k][4096] (kept for the proof stage) and, if d_cells != nullptr,
+// the 128 cells per blob; d_ext is k x 8192 Fr of scratch (only touched when cells are wanted);
+// d_bad[k] must have been zeroed on the stream.
+int cells_stage_enqueue(DeviceCtx *ctx, uint8_t *d_cells, Fr *d_poly, Fr *d_ext, uint32_t *d_bad,
+                        const uint8_t *d_blobs, size_t k) {
+    if (k == 0) return 0;
+    int rc = bytes_to_fr_batch(ctx, d_poly, d_bad, d_blobs, k * N_BLOB, N_BLOB);
+    if (rc) return rc;
+    // blob = evaluations in bit-reversed order: DIT inverse transform gives the coefficients
+    // (poly_lagrange_to_monomial, poly.c:58-80, without its permutation pass)
+    rc = fr_ntt_batch(ctx, d_poly, k, 12, /*dif=*/false, /*inverse=*/true, /*scale=*/true);
+    if (rc) return rc;
+    if (d_cells) {
+        rc = zero_extend_batch(ctx, d_ext, d_poly, k, N_BLOB, N_EXT);
+        if (rc) return rc;
+        rc = fr_ntt_batch(ctx, d_ext, k, 13, /*dif=*/true, /*inverse=*/false, /*scale=*/false);
+        if (rc) return rc;
+        rc = fr_to_bytes_batch(ctx, d_cells, d_ext, k * N_EXT);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+bool proofs_use_direct(const DeviceCtx *ctx, size_t n) { return use_direct(ctx, n); }
+
+size_t proofs_scratch_bytes(const DeviceCtx *ctx, size_t k, bool direct) {
+    return direct ? direct_layout(nullptr, k, ctx->mono).bytes : fk20_layout(nullptr, k, ctx->fk20.nwin).bytes;
+}
+
+// d_poly[k][4096] -> 128 proofs per blob; `scratch` holds proofs_scratch_bytes(ctx, k, direct)
+int proofs_stage_enqueue(DeviceCtx *ctx, uint8_t *d_proofs, const Fr *d_poly, size_t k, uint8_t *scratch, bool direct) {
+    if (k == 0) return 0;
+    return direct ? direct_run(ctx, d_proofs, d_poly, k, scratch) : fk20_run(ctx, d_proofs, d_poly, k, scratch);
+}
+
+int bad_to_status_enqueue(DeviceCtx *ctx, uint8_t *d_status, const uint32_t *d_bad, size_t k) {
+    if (k == 0) return 0;
+    hipLaunchKernelGGL(k_bad_to_status, dim3((unsigned)((k + 63) / 64)), dim3(64), 0, ctx->stream, d_status, d_bad, k);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int cells_and_proofs_device(DeviceCtx *ctx, uint8_t *d_cells, uint8_t *d_proofs, uint8_t *d_status,
                             const uint8_t *d_blobs, size_t n) {
     if (n == 0) return 0;
@@ -444,8 +489,7 @@ int cells_and_proofs_device(DeviceCtx *ctx, uint8_t *d_cells, uint8_t *d_proofs,
     size_t m = n < CH ? n : CH;
     size_t poly_b = al(m * N_BLOB * sizeof(Fr)), ext_b = al(m * N_EXT * sizeof(Fr)), bad_b = al(m * 4);
     const bool direct = d_proofs != nullptr && use_direct(ctx, n);
-    size_t proof_scratch = direct ? direct_layout(nullptr, m, ctx->mono).bytes
-                                  : fk20_layout(nullptr, m, ctx->fk20.nwin).bytes;
+    size_t proof_scratch = proofs_scratch_bytes(ctx, m, direct);
     int rc = scratch_reserve(ctx, poly_b + ext_b + bad_b + proof_scratch);
     if (rc) return rc;
     uint8_t *base = static_cast<uint8_t *>(ctx->scratch.ptr);
@@ -457,28 +501,16 @@ int cells_and_proofs_device(DeviceCtx *ctx, uint8_t *d_cells, uint8_t *d_proofs,
     for (size_t off = 0; off < n; off += CH) {
         size_t k = n - off < CH ? n - off : CH;
         HIP_TRY(hipMemsetAsync(d_bad, 0, k * 4, ctx->stream));
-        rc = bytes_to_fr_batch(ctx, d_poly, d_bad, d_blobs + off * (size_t)N_BLOB * 32, k * N_BLOB, N_BLOB);
+        rc = cells_stage_enqueue(ctx, d_cells ? d_cells + off * (size_t)N_EXT * 32 : nullptr, d_poly, d_ext, d_bad,
+                                 d_blobs + off * (size_t)N_BLOB * 32, k);
         if (rc) return rc;
-        // blob = evaluations in bit-reversed order: DIT inverse transform gives the coefficients
-        // (poly_lagrange_to_monomial, poly.c:58-80, without its permutation pass)
-        rc = fr_ntt_batch(ctx, d_poly, k, 12, /*dif=*/false, /*inverse=*/true, /*scale=*/true);
-        if (rc) return rc;
-        if (d_cells) {
-            rc = zero_extend_batch(ctx, d_ext, d_poly, k, N_BLOB, N_EXT);
-            if (rc) return rc;
-            rc = fr_ntt_batch(ctx, d_ext, k, 13, /*dif=*/true, /*inverse=*/false, /*scale=*/false);
-            if (rc) return rc;
-            rc = fr_to_bytes_batch(ctx, d_cells + off * (size_t)N_EXT * 32, d_ext, k * N_EXT);
-            if (rc) return rc;
-        }
         if (d_proofs) {
-            rc = direct ? direct_run(ctx, d_proofs + off * 128 * 48, d_poly, k, fk_base)
-                        : fk20_run(ctx, d_proofs + off * 128 * 48, d_poly, k, fk_base);
+            rc = proofs_stage_enqueue(ctx, d_proofs + off * 128 * 48, d_poly, k, fk_base, direct);
             if (rc) return rc;
         }
         if (d_status) {
-            hipLaunchKernelGGL(k_bad_to_status, dim3((unsigned)((k + 63) / 64)), dim3(64), 0, ctx->stream,
-                               d_status + off, d_bad, k);
+            rc = bad_to_status_enqueue(ctx, d_status + off, d_bad, k);
+            if (rc) return rc;
         }
     }
     HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));

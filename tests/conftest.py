@@ -4,6 +4,10 @@ import sys
 
 import pytest
 
+# more hardware queues than ROCm's default 4, before anything initialises HIP (see ckzg_api.hip:
+# ckzg_hip_queue_hint): concurrent callers of one KZGSettings each run on their own streams
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, HERE)
