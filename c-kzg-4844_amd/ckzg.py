@@ -15,7 +15,8 @@ BYTES_PER_CELL = 2048
 CELLS_PER_EXT_BLOB = 128
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
-HIP_SO = os.path.join(PKG, "libckzg_hip.so")
+# CKZG_HIP_SO: another build of the same library (tools/build_variant.sh), for A/B measurements
+HIP_SO = os.path.abspath(os.environ["CKZG_HIP_SO"]) if os.environ.get("CKZG_HIP_SO") else os.path.join(PKG, "libckzg_hip.so")
 TRUSTED_SETUP = os.path.join(PKG, "data", "trusted_setup.txt")
 
 

@@ -230,23 +230,49 @@ struct LincombJob {
     size_t size() const { return k ? k->size() : n_dev; }
 };
 
-C_KZG_RET gpu_lincomb_multi(dev::DeviceCtx *ctx, G1Jac *outs, const LincombJob *jobs, int njobs) {
-    size_t total = 0;
+// Which kernels compute a call's variable-base sums: 1 = one GLV ladder per term (verify.hip), 2 = bucket
+// accumulation (pippenger.hip).  Both end in ~128 sequential doublings of one lane (~1.4 ms: inherent to a
+// 128-bit scalar), and at the sizes this path sees (n <= ~10^4 cells or blobs per call) the ladders still fit
+// the chip in one or two rounds of waves, so the buckets' smaller operation count does not show: measured
+// A/B inside verify_cell_kzg_proof_batch (tools/bench_lincomb.sh) the ladders win at
+// every n up to 65,536.  The default is therefore the ladders; CKZG_HIP_BUCKET_MIN=n (or algo = 2 at the
+// ckzg_hip_g1_lincomb boundary) routes sums of at least n terms to the buckets.
+static size_t bucket_min_terms() {
+    static const size_t v = []() {
+        const char *e = getenv("CKZG_HIP_BUCKET_MIN");
+        return e && *e ? (size_t)atol(e) : ~(size_t)0;
+    }();
+    return v;
+}
+
+C_KZG_RET gpu_lincomb_multi(dev::DeviceCtx *ctx, G1Jac *outs, const LincombJob *jobs, int njobs, int algo = 0) {
+    size_t total = 0, max_job = 0;
     std::vector<size_t> off(njobs), nb(njobs);
     for (int j = 0; j < njobs; j++) {
         off[j] = total;
         nb[j] = (jobs[j].size() + 63) / 64;
         if (nb[j] == 0) nb[j] = 1;
         total += nb[j] * 64;
+        if (jobs[j].size() > max_job) max_job = jobs[j].size();
     }
+    if (algo == 0) {
+        static const int forced = []() {
+            const char *e = getenv("CKZG_HIP_LINCOMB");
+            return e && *e ? atoi(e) : 0;
+        }();
+        algo = forced ? forced : (max_job >= bucket_min_terms() ? 2 : 1);
+    }
+    const int wbits = dev::bucket_msm_wbits(max_job);
+    const size_t bucket_scratch = algo == 2 ? dev::bucket_msm_scratch_bytes(total, njobs, wbits) : 0;
     Arena &ar = ctx->lc_arena;
     OKM(ar.begin(total * (sizeof(RawScalar) + sizeof(G1Affine)) + (total / 32) * sizeof(G1XYZZ) +
-                 njobs * sizeof(G1Affine) + (njobs + 1) * 4));
+                 njobs * sizeof(G1Affine) + (njobs + 1) * 4 + bucket_scratch + 1024));
     struct { RawScalar *p; } d_k = {ar.get<RawScalar>(total)};
     struct { G1Affine *p; } d_p = {ar.get<G1Affine>(total)}, d_out = {ar.get<G1Affine>(njobs)};
     struct { G1XYZZ *p; } d_part = {ar.get<G1XYZZ>(total / 32)};  // one partial per 64 lanes = 32 terms
     uint32_t *d_off = ar.get<uint32_t>(njobs + 1);
-    OKM(d_k.p && d_p.p && d_out.p && d_part.p && d_off);
+    uint8_t *d_bucket = algo == 2 ? ar.get<uint8_t>(bucket_scratch) : nullptr;
+    OKM(d_k.p && d_p.p && d_out.p && d_part.p && d_off && (algo != 2 || d_bucket));
     OKB(hipMemsetAsync(d_p.p, 0, total * sizeof(G1Affine), ctx->stream) == hipSuccess);  // (0,0) = infinity
     OKB(hipMemsetAsync(d_k.p, 0, total * sizeof(RawScalar), ctx->stream) == hipSuccess);
     for (int j = 0; j < njobs; j++) {
@@ -258,10 +284,18 @@ C_KZG_RET gpu_lincomb_multi(dev::DeviceCtx *ctx, G1Jac *outs, const LincombJob *
             OKB(hipMemcpyAsync(d_k.p + off[j], jobs[j].d_k, n * sizeof(RawScalar), hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess);
         }
     }
-    std::vector<uint32_t> part_off(njobs + 1);
-    for (int j = 0; j < njobs; j++) part_off[j] = (uint32_t)(off[j] / 32);
-    part_off[njobs] = (uint32_t)(total / 32);
-    RC(dev::lincomb_multi_device(ctx, d_out.p, d_part.p, d_off, d_p.p, (const uint32_t *)d_k.p, total, part_off.data(), njobs));
+    if (algo == 2) {
+        std::vector<uint32_t> job_off(njobs + 1);
+        for (int j = 0; j < njobs; j++) job_off[j] = (uint32_t)off[j];
+        job_off[njobs] = (uint32_t)total;
+        RC(dev::bucket_msm_enqueue(ctx, d_out.p, d_p.p, (const uint32_t *)d_k.p, total, job_off.data(), njobs, wbits, d_bucket));
+        OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
+    } else {
+        std::vector<uint32_t> part_off(njobs + 1);
+        for (int j = 0; j < njobs; j++) part_off[j] = (uint32_t)(off[j] / 32);
+        part_off[njobs] = (uint32_t)(total / 32);
+        RC(dev::lincomb_multi_device(ctx, d_out.p, d_part.p, d_off, d_p.p, (const uint32_t *)d_k.p, total, part_off.data(), njobs));
+    }
     std::vector<G1Affine> res(njobs);
     OKB(hipMemcpy(res.data(), d_out.p, njobs * sizeof(G1Affine), hipMemcpyDeviceToHost) == hipSuccess);
     for (int j = 0; j < njobs; j++) outs[j] = jac_from_affine(res[j]);
@@ -1061,5 +1095,50 @@ extern "C" C_KZG_RET verify_cell_kzg_proof_batch(bool *ok, const Bytes48 *commit
         });
         if (ret == C_KZG_OK) *ok = all_ok.load() != 0;
         return ret;
+    });
+}
+
+// ------------------------------------------------------------------------------------------
+// g1_lincomb_fast (src/common/lincomb.c:65-123) at the boundary: the variable-base sum on its own
+// ------------------------------------------------------------------------------------------
+
+extern "C" C_KZG_RET ckzg_hip_g1_lincomb(g1_t *out, const g1_t *p, const fr_t *coeffs, uint64_t len, int algo,
+                                         const KZGSettings *s) {
+    return guarded([&]() -> C_KZG_RET {
+        if (algo < 0 || algo > 2) return C_KZG_BADARGS;
+        Lease lease(s);
+        dev::DeviceCtx *ctx = lease.ctx;
+        if (!ctx) return C_KZG_ERROR;
+        if (len == 0) {  // lincomb.c:76-79: the empty sum is the identity
+            *as_g1(out) = G1Jac::inf();
+            return C_KZG_OK;
+        }
+        std::vector<G1Affine> aff(len);
+        std::vector<RawScalar> k(len);
+        for (uint64_t i = 0; i < len; i++) {
+            aff[i] = jac_to_affine(*as_g1(&p[i]));
+            k[i] = raw_of(*as_fr(&coeffs[i]));
+        }
+        Arena &ar = ctx->api_arena;
+        OKM(ar.begin(len * (sizeof(G1Affine) + 1) + 1024));
+        ABuf<G1Affine> d_pts(ar, len);
+        ABuf<uint8_t> d_st(ar, len);
+        OKM(d_pts.p && d_st.p);
+        OKB(d_pts.up(aff.data(), len));
+        // the kernels use the endomorphism: only valid on the prime-order subgroup (every caller inside the
+        // library passes validated points; an outside caller gets the check here)
+        RC(dev::subgroup_g1_batch_device(ctx, d_st.p, d_pts.p, len));
+        OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
+        std::vector<uint8_t> st(len);
+        OKB(d_st.down(st.data(), len));
+        for (uint8_t b : st) {
+            if (b) return C_KZG_BADARGS;
+        }
+        LincombJob job{d_pts.p, &k};
+        G1Jac r;
+        C_KZG_RET ret = gpu_lincomb_multi(ctx, &r, &job, 1, algo);
+        if (ret != C_KZG_OK) return ret;
+        *as_g1(out) = r;
+        return C_KZG_OK;
     });
 }

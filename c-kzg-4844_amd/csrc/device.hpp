@@ -187,6 +187,11 @@ int subgroup_g1_batch_device(DeviceCtx *ctx, uint8_t *d_status, const G1Affine *
 // d_off: njobs + 1 words of device scratch
 int lincomb_multi_device(DeviceCtx *ctx, G1Affine *d_out, G1XYZZ *d_partials, uint32_t *d_off, const G1Affine *d_pts,
                          const uint32_t *d_scalars, size_t total, const uint32_t *h_part_off, int njobs);
+// pippenger.hip: the same sums by bucket accumulation (enqueue-only; see bucket_msm_enqueue)
+size_t bucket_msm_scratch_bytes(size_t total, int njobs, int wbits);
+int bucket_msm_wbits(size_t max_job_terms);
+int bucket_msm_enqueue(DeviceCtx *ctx, G1Affine *d_out, const G1Affine *d_pts, const uint32_t *d_scalars, size_t total,
+                       const uint32_t *h_job_off, int njobs, int wbits, uint8_t *scratch);
 // z_i = hash_to_bls_field(SHA-256(domain | degree | blob_i | commitment_i)) for n blobs in HBM
 int sha256_challenges_device(DeviceCtx *ctx, Fr *d_z, const uint8_t *d_blobs, const uint8_t *d_commit48, size_t n);
 // cells[b][j] (2048 B each) -> image[b][idx[j]] (128 x 2048 B per row, zero-filled by the caller)

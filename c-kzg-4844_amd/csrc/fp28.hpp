@@ -54,6 +54,133 @@ constexpr int pow2_above(int v) {  // smallest power of two > v
 }  // namespace f28detail
 
 // Montgomery product a*b/2^392 mod p: result limbs normalised (< 2^28), value < 2p.
+//
+// Column-wise (product-scanning) form: ONE 64-bit accumulator walks the 28 columns of a*b + q*p.  Column k
+// receives its a_i*b_(k-i) and q_i*p_(k-i) terms, the first 14 columns each fix their quotient digit
+// q_k = -column/p mod 2^28, and the accumulator is shifted down by 28 bits into the next column -- that shift
+// is the whole carry handling, and the upper 14 columns leave the result limbs already normalised.
+// Measured on gfx950 (tools/ubench/mad_latency.hip): 64-bit shifts and adds cost as much issue time as a
+// v_mad_u64_u32 (4.6 vs 4.85 cycles at two waves per SIMD) and a dependent chain of mads runs at the same
+// rate as 16 independent ones, so the single accumulator costs nothing and needs 28 fewer live registers
+// than the row-wise form's 15 accumulators.  CKZG_F28_ROWWISE selects the row-wise form for A/B runs.
+#ifndef CKZG_F28_ROWWISE
+// acc += a * b: one v_mad_u64_u32.  (LLVM re-associates a column's long sum into two chains -- the a*b terms
+// and the q*p terms -- and joins them with a 64-bit add, so the instruction counts of this form and of the
+// row-wise one come out equal: 3548 mads + 236 v_lshl_add_u64 + 234 v_lshrrev_b64 per mixed addition.  Forcing a
+// single chain with inline assembly removes the 236 adds but makes the compiler pad every asm statement with
+// an s_nop and pessimises the ladder kernels: measured 10.77 ms per 1024-blob launch against 10.42 ms
+// row-wise and 10.22 ms for this plain form, which wins through its smaller register footprint --
+// 191 instead of 209 VGPRs.  tools/ab_fp28.sh, profiles/r02_fp28_ab.txt.)
+HD void mad64(uint64_t &acc, uint32_t a, uint32_t b) { acc += (uint64_t)a * b; }
+HD void mad64c(uint64_t &acc, uint32_t a, uint32_t c) { acc += (uint64_t)a * c; }
+
+template <int LA, int VA, int LB, int VB>
+HD F28<1, 2> mul(const F28<LA, VA> &a, const F28<LB, VB> &b) {
+    // a column holds <= 14 products a_i*b_j (< LA*LB*2^56) + 14 products q*p_j (< 2^56) + the carry-in
+    static_assert(14 * LA * LB + 14 + 1 <= 255, "64-bit column accumulator would overflow");
+    // result < a*b/2^392 + p; 2^392/p > 2520
+    static_assert(VA * VB <= 2500, "Montgomery product would not be < 2p");
+    uint32_t q[14];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) mad64(acc, a.l[i], b.l[k - i]);
+#pragma unroll
+        for (int i = 0; i < k; i++) mad64c(acc, q[i], FP28_P[k - i]);
+        q[k] = ((uint32_t)acc * (uint32_t)FP28_NINV) & M28;
+        mad64c(acc, q[k], FP28_P[0]);
+        acc >>= 28;
+    }
+    F28<1, 2> r;
+#pragma unroll
+    for (int k = 14; k < 27; k++) {
+#pragma unroll
+        for (int i = k - 13; i < 14; i++) mad64(acc, a.l[i], b.l[k - i]);
+#pragma unroll
+        for (int i = k - 13; i < 14; i++) mad64c(acc, q[i], FP28_P[k - i]);
+        r.l[k - 14] = (uint32_t)acc & M28;
+        acc >>= 28;
+    }
+    r.l[13] = (uint32_t)acc;
+    return r;
+}
+
+// (a*b + c*d)/2^392 mod p with ONE Montgomery reduction: 588 multiply-adds instead of 784 for two
+// products; both partial products of a column land in the accumulator before its quotient digit is fixed.
+template <int LA, int VA, int LB, int VB, int LC, int VC, int LD, int VD>
+HD F28<1, 2> mul_add2(const F28<LA, VA> &a, const F28<LB, VB> &b, const F28<LC, VC> &c, const F28<LD, VD> &d) {
+    static_assert(14 * (LA * LB + LC * LD) + 14 + 1 <= 255, "64-bit column accumulator would overflow");
+    static_assert(VA * VB + VC * VD <= 2500, "Montgomery result would not be < 2p");
+    uint32_t q[14];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) mad64(acc, a.l[i], b.l[k - i]);
+#pragma unroll
+        for (int i = 0; i <= k; i++) mad64(acc, c.l[i], d.l[k - i]);
+#pragma unroll
+        for (int i = 0; i < k; i++) mad64c(acc, q[i], FP28_P[k - i]);
+        q[k] = ((uint32_t)acc * (uint32_t)FP28_NINV) & M28;
+        mad64c(acc, q[k], FP28_P[0]);
+        acc >>= 28;
+    }
+    F28<1, 2> r;
+#pragma unroll
+    for (int k = 14; k < 27; k++) {
+#pragma unroll
+        for (int i = k - 13; i < 14; i++) mad64(acc, a.l[i], b.l[k - i]);
+#pragma unroll
+        for (int i = k - 13; i < 14; i++) mad64(acc, c.l[i], d.l[k - i]);
+#pragma unroll
+        for (int i = k - 13; i < 14; i++) mad64c(acc, q[i], FP28_P[k - i]);
+        r.l[k - 14] = (uint32_t)acc & M28;
+        acc >>= 28;
+    }
+    r.l[13] = (uint32_t)acc;
+    return r;
+}
+
+// Montgomery square: the 91 cross products are taken once against a doubled operand (105 multiply-adds
+// for the product instead of 196), same column walk: 301 vs 392 mads.
+template <int LA, int VA>
+HD F28<1, 2> sqr(const F28<LA, VA> &a) {
+    // column k holds <= 7 doubled cross terms (< 2*LA^2*2^56) + one square + 14 q*p terms + the carry-in
+    static_assert(15 * LA * LA + 14 + 1 <= 255, "64-bit column accumulator would overflow");
+    static_assert(2 * LA <= 15, "doubled limb would overflow 32 bits");
+    static_assert(VA * VA <= 2500, "Montgomery product would not be < 2p");
+    uint32_t d[14], q[14];
+#pragma unroll
+    for (int j = 0; j < 14; j++) d[j] = a.l[j] << 1;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+#pragma unroll
+        for (int i = 0; 2 * i < k; i++) mad64(acc, a.l[i], d[k - i]);
+        if ((k & 1) == 0) mad64(acc, a.l[k / 2], a.l[k / 2]);
+#pragma unroll
+        for (int i = 0; i < k; i++) mad64c(acc, q[i], FP28_P[k - i]);
+        q[k] = ((uint32_t)acc * (uint32_t)FP28_NINV) & M28;
+        mad64c(acc, q[k], FP28_P[0]);
+        acc >>= 28;
+    }
+    F28<1, 2> r;
+#pragma unroll
+    for (int k = 14; k < 27; k++) {
+#pragma unroll
+        for (int i = k - 13; 2 * i < k; i++) mad64(acc, a.l[i], d[k - i]);
+        if ((k & 1) == 0) mad64(acc, a.l[k / 2], a.l[k / 2]);
+#pragma unroll
+        for (int i = k - 13; i < 14; i++) mad64c(acc, q[i], FP28_P[k - i]);
+        r.l[k - 14] = (uint32_t)acc & M28;
+        acc >>= 28;
+    }
+    r.l[13] = (uint32_t)acc;
+    return r;
+}
+#else
+// row-wise form (15 column accumulators, one row per limb of b)
 template <int LA, int VA, int LB, int VB>
 HD F28<1, 2> mul(const F28<LA, VA> &a, const F28<LB, VB> &b) {
     // column accumulators: 14 products a_j*b_i (< LA*LB*2^56) + 14 products q*p_j (< 2^56) + carry
@@ -157,6 +284,8 @@ HD F28<1, 2> sqr(const F28<LA, VA> &a) {
     r.l[13] = (uint32_t)t[27];
     return r;
 }
+
+#endif  // CKZG_F28_ROWWISE
 
 template <int LA, int VA, int LB, int VB>
 HD F28<LA + LB, VA + VB> add(const F28<LA, VA> &a, const F28<LB, VB> &b) {

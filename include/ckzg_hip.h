@@ -98,6 +98,15 @@ C_KZG_RET ckzg_hip_recover_cells_and_kzg_proofs_batch(Cell *recovered_cells, KZG
                                                       const Cell *cells, uint64_t num_cells,
                                                       uint64_t num_blobs, const KZGSettings *s);
 
+/* g1_lincomb_fast (src/common/lincomb.c:65-123) on the GPU: out = sum_i coeffs[i] * p[i] over `len` points in
+ * the reference's in-memory forms (g1_t Jacobian, fr_t Montgomery); the empty sum is the identity.  The
+ * library's own verify_*_batch paths call the same kernels on points they have already validated; here every
+ * point must lie in the prime-order subgroup (or be the identity), otherwise C_KZG_BADARGS -- the reference
+ * function accepts any curve point.  algo: 0 = choose by size, 1 = one GLV ladder per term (verify.hip),
+ * 2 = bucket accumulation (pippenger.hip). */
+C_KZG_RET ckzg_hip_g1_lincomb(g1_t *out, const g1_t *p, const fr_t *coeffs, uint64_t len, int algo,
+                              const KZGSettings *s);
+
 /* Timing hook for bench.py: elapsed milliseconds of the named kernel family inside the last
  * batch call, measured with hipEvents on the stream the kernels were launched on (for a call that was
  * processed in several chunks: the last chunk).

@@ -301,3 +301,153 @@ def test_two_real_devices(hip):
         assert ret == 0 and outs == [single[i % 4] for i in range(256)]
     finally:
         api.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# pipelined host-pointer batches (staged input, OutPipe-drained output)
+# ---------------------------------------------------------------------------------------------
+
+def _cells_batch(api, blobs_bytes, n, want_cells=True, want_proofs=True):
+    f = api.lib.ckzg_hip_compute_cells_and_kzg_proofs_batch
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p]
+    cells = C.create_string_buffer(n * 128 * 2048) if want_cells else None
+    proofs = C.create_string_buffer(n * 128 * 48) if want_proofs else None
+    st = C.create_string_buffer(n)
+    rc = f(cells, proofs, st, blobs_bytes, n, C.addressof(api.s))
+    return rc, cells, proofs, st
+
+
+@pytest.mark.parametrize("n", [65, 300, 4200])
+def test_pipelined_cells_and_proofs_batch(hip_fk20, oracle, n):
+    # 65: first size of the throughput path; 300: a ragged second sub-chunk; 4200: three chunks, so the
+    # third reuses the first one's output buffers after they have been drained
+    base = [rand_blob(97, i) for i in range(3)]
+    cp = [hip_fk20.compute_cells_and_kzg_proofs(b) for b in base]
+    assert cp[0] == oracle.compute_cells_and_kzg_proofs(base[0])
+    order = [(7 * i + i // 5) % 3 for i in range(n)]
+    bad_at = n - 3
+    blobs = [base[k] for k in order]
+    bad = bytearray(base[0])
+    bad[32 * 4095:32 * 4096] = (R + 1).to_bytes(32, "big")
+    blobs[bad_at] = bytes(bad)
+    rc, cells, proofs, st = _cells_batch(hip_fk20, b"".join(blobs), n)
+    assert rc == 1
+    assert [i for i, v in enumerate(st.raw) if v] == [bad_at]
+    craw, praw = memoryview(cells).cast("B"), memoryview(proofs).cast("B")
+    exp_c = [b"".join(c[0]) for c in cp]
+    exp_p = [b"".join(c[1]) for c in cp]
+    check = range(n) if n <= 300 else list(range(0, n, 97)) + [255, 256, 2047, 2048, 2049, 4095, 4096, 4097, n - 1]
+    for i in check:
+        if i == bad_at:
+            continue
+        assert craw[i * 262144:(i + 1) * 262144] == exp_c[order[i]], i
+        assert praw[i * 6144:(i + 1) * 6144] == exp_p[order[i]], i
+    if n == 300:
+        rc, cells2, none_p, _ = _cells_batch(hip_fk20, b"".join(blobs[:bad_at]), bad_at, True, False)
+        assert rc == 0 and none_p is None and cells2.raw == cells.raw[:bad_at * 262144]
+        rc, none_c, proofs2, _ = _cells_batch(hip_fk20, b"".join(blobs[:bad_at]), bad_at, False, True)
+        assert rc == 0 and none_c is None and proofs2.raw == proofs.raw[:bad_at * 6144]
+
+
+def test_pipelined_recover_batch_over_several_chunks(hip_fk20):
+    base = [rand_blob(98, i) for i in range(3)]
+    cp = [hip_fk20.compute_cells_and_kzg_proofs(b) for b in base]
+    keep = list(range(0, 128, 2))
+    nb = 1100  # chunks of 512: the third chunk reuses the first one's buffers
+    rows = [[cp[b % 3][0][c] for c in keep] for b in range(nb)]
+    rc, rp = hip_fk20.recover_cells_and_kzg_proofs_batch(keep, rows)
+    for b in list(range(0, nb, 53)) + [511, 512, 1023, 1024, nb - 1]:
+        assert rc[b] == cp[b % 3][0] and rp[b] == cp[b % 3][1], b
+
+
+# ---------------------------------------------------------------------------------------------
+# N2: variable-base sums -- bucket kernels and per-term ladders against the oracle's g1_lincomb_fast
+# (src/common/lincomb.c:65-123; the reference's own check is Pippenger == naive, src/test/tests.c:929-946)
+# ---------------------------------------------------------------------------------------------
+
+def _lincomb(hip, pts, scalars_mont, algo):
+    f = hip.lib.ckzg_hip_g1_lincomb
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_uint64, C.c_int, C.c_void_p]
+    out = C.create_string_buffer(144)
+    rc = f(out, b"".join(pts), b"".join(scalars_mont), len(pts), algo, C.addressof(hip.s))
+    return rc, out
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 700, 5000])
+def test_g1_lincomb_buckets_and_ladders_vs_oracle(hip, n):
+    import random
+    o = C.CDLL(ORACLE_SO)
+    o.og1_equal.restype = C.c_bool
+    o.og1_is_inf.restype = C.c_bool
+    o.okzg_g1_lincomb_fast.restype = C.c_int
+    rnd = random.Random(1000 + n)
+    gen = C.create_string_buffer(144)
+    aff = C.create_string_buffer(96)
+    # the generator through its compressed form (draft-irtf-cfrg-pairing-friendly-curves 4.2.1)
+    g48 = bytes.fromhex("97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb")
+    assert o.og1_uncompress(aff, g48) == 0
+    o.og1_from_affine(gen, aff)
+
+    def mul(p, k):
+        r = C.create_string_buffer(144)
+        kk = (C.c_uint64 * 4)(*[(k >> (64 * i)) & (2 ** 64 - 1) for i in range(4)])
+        o.og1_mul_raw(r, p, kk, 255)
+        return r.raw
+
+    def fr_mont(k):
+        raw = (C.c_uint64 * 4)(*[(k >> (64 * i)) & (2 ** 64 - 1) for i in range(4)])
+        out = C.create_string_buffer(32)
+        o.ofr_from_raw(out, raw)
+        return out.raw
+
+    distinct = [mul(gen, rnd.randrange(1, R)) for _ in range(min(n, 40))]
+    inf = bytes(144)
+    pts, ks = [], []
+    for i in range(n):
+        sel = rnd.random()
+        if sel < 0.05:
+            pts.append(inf)                                  # the identity as an input point
+        elif sel < 0.15 and i >= 2:
+            neg = C.create_string_buffer(144)
+            o.og1_neg(neg, pts[i - 1])
+            pts.append(neg.raw)                               # P, -P next to each other
+        else:
+            pts.append(distinct[rnd.randrange(len(distinct))])   # many duplicates
+        k = rnd.choice([0, 1, R - 1, LAMBDA, LAMBDA + 1]) if rnd.random() < 0.1 else rnd.randrange(R)
+        if sel >= 0.05 and sel < 0.15 and i >= 2 and rnd.random() < 0.5:
+            k = ks[-1]                                        # same scalar on P and -P: the pair cancels
+        ks.append(k)
+    if n >= 2:
+        ks[1] = ks[0]
+        pts[1] = pts[0]                                       # an exact duplicate term: a doubling inside a bucket
+    sm = [fr_mont(k) for k in ks]
+    exp = C.create_string_buffer(144)  # all zero = the identity (Z = 0): the value of the empty sum
+    if n:
+        assert o.okzg_g1_lincomb_fast(exp, b"".join(pts), b"".join(sm), n) == 0
+    for algo in (1, 2, 0):
+        rc, got = _lincomb(hip, pts, sm, algo)
+        assert rc == 0, (n, algo)
+        assert o.og1_equal(got, exp), (n, algo)
+    if n == 700:
+        # a point of the curve outside the prime-order subgroup is refused (the kernels use the endomorphism)
+        bad48 = None
+        x = 5
+        P_MOD = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+        while bad48 is None:
+            y2 = (x ** 3 + 4) % P_MOD
+            y = pow(y2, (P_MOD + 1) // 4, P_MOD)
+            if y * y % P_MOD == y2:
+                enc = bytearray(x.to_bytes(48, "big"))
+                enc[0] |= 0x80 | (0x20 if y > P_MOD - y else 0)
+                a2 = C.create_string_buffer(96)
+                if o.og1_uncompress(a2, bytes(enc)) == 0:
+                    j = C.create_string_buffer(144)
+                    o.og1_from_affine(j, a2)
+                    o.og1_in_subgroup.restype = C.c_bool
+                    if not o.og1_in_subgroup(j):
+                        bad48 = j.raw
+            x += 1
+        rc, _ = _lincomb(hip, [bad48] + pts[1:], sm, 2)
+        assert rc == 1

@@ -69,3 +69,13 @@ def test_shard_bounds():
     assert mg.shard_bounds(4096, 8) == [(512 * i, 512 * (i + 1)) for i in range(8)]
     assert mg.shard_bounds(1, 4) == [(0, 1), (1, 1), (1, 1), (1, 1)]
     assert mg.shard_bounds(0, 2) == [(0, 0), (0, 0)]
+
+
+def test_bench_gpus_flag_is_honoured_or_fails_loudly():
+    """`python bench.py --gpus N` without a launcher must spawn N ranks itself -- and must refuse, not
+    silently run on one device, when fewer than N devices are visible (here: none)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "--gpus 2 but only" in (r.stderr + r.stdout)

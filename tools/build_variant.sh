@@ -1,0 +1,15 @@
+#!/bin/bash
+# Build a second copy of the product with extra compiler flags, for A/B runs inside one gpurun call:
+#   bash tools/build_variant.sh rowwise -DCKZG_F28_ROWWISE   ->  c-kzg-4844_amd/libckzg_hip_rowwise.so
+# then   CKZG_HIP_SO=c-kzg-4844_amd/libckzg_hip_rowwise.so python bench.py ...
+set -e
+name=$1; shift
+cd "$(dirname "$0")/../c-kzg-4844_amd"
+mkdir -p build_$name
+for f in csrc/ckzg_api.hip csrc/device_ctx.hip csrc/msm.hip csrc/ntt.hip csrc/fk20.hip csrc/verify.hip csrc/pippenger.hip csrc/ckzg_api2.hip; do
+  o=build_$name/$(basename $f .hip).o
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-pass-failed "$@" -c $f -o $o &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--version-script=exports.map -o libckzg_hip_$name.so build_$name/*.o
+ls -la libckzg_hip_$name.so
