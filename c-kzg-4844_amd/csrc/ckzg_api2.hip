@@ -262,14 +262,23 @@ C_KZG_RET gpu_lincomb_multi(dev::DeviceCtx *ctx, G1Jac *outs, const LincombJob *
         }();
         algo = forced ? forced : (max_job >= bucket_min_terms() ? 2 : 1);
     }
+    // ladders: four lanes per half-term (k_lincomb_partial_quad) while 8 lanes per term still fit the chip in
+    // about two waves per SIMD; beyond that the one-lane-per-half form does fewer lane-products in total
+    // (algo 3 / 4 force the one-lane / four-lane ladders; CKZG_HIP_QUAD_MAX moves the hand-over)
+    static const size_t quad_max = []() {
+        const char *e = getenv("CKZG_HIP_QUAD_MAX");
+        return e && *e ? (size_t)atol(e) : (size_t)8192;
+    }();
+    const bool quad = algo == 4 || (algo == 1 && total <= quad_max);
+    if (algo == 3 || algo == 4) algo = 1;
     const int wbits = dev::bucket_msm_wbits(max_job);
     const size_t bucket_scratch = algo == 2 ? dev::bucket_msm_scratch_bytes(total, njobs, wbits) : 0;
     Arena &ar = ctx->lc_arena;
-    OKM(ar.begin(total * (sizeof(RawScalar) + sizeof(G1Affine)) + (total / 32) * sizeof(G1XYZZ) +
+    OKM(ar.begin(total * (sizeof(RawScalar) + sizeof(G1Affine)) + (total / 8) * sizeof(G1XYZZ) +
                  njobs * sizeof(G1Affine) + (njobs + 1) * 4 + bucket_scratch + 1024));
     struct { RawScalar *p; } d_k = {ar.get<RawScalar>(total)};
     struct { G1Affine *p; } d_p = {ar.get<G1Affine>(total)}, d_out = {ar.get<G1Affine>(njobs)};
-    struct { G1XYZZ *p; } d_part = {ar.get<G1XYZZ>(total / 32)};  // one partial per 64 lanes = 32 terms
+    struct { G1XYZZ *p; } d_part = {ar.get<G1XYZZ>(total / 8)};  // one partial per 64 lanes = 32 terms (8 in quad form)
     uint32_t *d_off = ar.get<uint32_t>(njobs + 1);
     uint8_t *d_bucket = algo == 2 ? ar.get<uint8_t>(bucket_scratch) : nullptr;
     OKM(d_k.p && d_p.p && d_out.p && d_part.p && d_off && (algo != 2 || d_bucket));
@@ -291,10 +300,11 @@ C_KZG_RET gpu_lincomb_multi(dev::DeviceCtx *ctx, G1Jac *outs, const LincombJob *
         RC(dev::bucket_msm_enqueue(ctx, d_out.p, d_p.p, (const uint32_t *)d_k.p, total, job_off.data(), njobs, wbits, d_bucket));
         OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
     } else {
+        const size_t per = quad ? 8 : 32;
         std::vector<uint32_t> part_off(njobs + 1);
-        for (int j = 0; j < njobs; j++) part_off[j] = (uint32_t)(off[j] / 32);
-        part_off[njobs] = (uint32_t)(total / 32);
-        RC(dev::lincomb_multi_device(ctx, d_out.p, d_part.p, d_off, d_p.p, (const uint32_t *)d_k.p, total, part_off.data(), njobs));
+        for (int j = 0; j < njobs; j++) part_off[j] = (uint32_t)(off[j] / per);
+        part_off[njobs] = (uint32_t)(total / per);
+        RC(dev::lincomb_multi_device(ctx, d_out.p, d_part.p, d_off, d_p.p, (const uint32_t *)d_k.p, total, part_off.data(), njobs, quad));
     }
     std::vector<G1Affine> res(njobs);
     OKB(hipMemcpy(res.data(), d_out.p, njobs * sizeof(G1Affine), hipMemcpyDeviceToHost) == hipSuccess);
@@ -1105,7 +1115,7 @@ extern "C" C_KZG_RET verify_cell_kzg_proof_batch(bool *ok, const Bytes48 *commit
 extern "C" C_KZG_RET ckzg_hip_g1_lincomb(g1_t *out, const g1_t *p, const fr_t *coeffs, uint64_t len, int algo,
                                          const KZGSettings *s) {
     return guarded([&]() -> C_KZG_RET {
-        if (algo < 0 || algo > 2) return C_KZG_BADARGS;
+        if (algo < 0 || algo > 4) return C_KZG_BADARGS;
         Lease lease(s);
         dev::DeviceCtx *ctx = lease.ctx;
         if (!ctx) return C_KZG_ERROR;

@@ -186,7 +186,7 @@ int subgroup_g1_batch_device(DeviceCtx *ctx, uint8_t *d_status, const G1Affine *
                              hipStream_t stream = nullptr);
 // d_off: njobs + 1 words of device scratch
 int lincomb_multi_device(DeviceCtx *ctx, G1Affine *d_out, G1XYZZ *d_partials, uint32_t *d_off, const G1Affine *d_pts,
-                         const uint32_t *d_scalars, size_t total, const uint32_t *h_part_off, int njobs);
+                         const uint32_t *d_scalars, size_t total, const uint32_t *h_part_off, int njobs, bool quad);
 // pippenger.hip: the same sums by bucket accumulation (enqueue-only; see bucket_msm_enqueue)
 size_t bucket_msm_scratch_bytes(size_t total, int njobs, int wbits);
 int bucket_msm_wbits(size_t max_job_terms);

@@ -15,6 +15,7 @@
 #include "device.hpp"
 #include "dev_inline.hpp"
 #include "g1_28.hpp"
+#include "g1_quad.hpp"
 
 namespace ckzg {
 namespace dev {
@@ -132,6 +133,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     *slot = xyzz28_to_xyzz(v, vi);
 }
 
+// The latency form for small batches: four lanes per butterfly (g1_quad.hpp), transforms padded to 16 per wave so
+// that a wave (16 quads) still works on ONE twiddle.  The ladder is ~2.3x shorter; a batch of up to a few
+// hundred blobs leaves most SIMDs idle anyway.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_g1_fft_twiddle_quad(
+    G1XYZZ *data, const uint32_t *roots_glv, uint32_t nfft, int s, int inverse) {
+    const size_t q = (blockIdx.x * (size_t)64 + threadIdx.x) >> 2;
+    const int ql = (int)(threadIdx.x & 3);
+    const uint32_t pad = (nfft + 15u) & ~15u;
+    const uint32_t bf = (uint32_t)(q / pad), f = (uint32_t)(q - (size_t)bf * pad);
+    const int half = 1 << (s - 1);
+    const int j = (int)bf & (half - 1);
+    const int i1 = ((((int)bf >> (s - 1)) << s) + j) + half;
+    if (f >= nfft || j == 0 || bf >= 64u) return;
+    int ridx = j * (N_EXT / (2 << (s - 1)));
+    if (inverse) ridx = N_EXT - ridx;
+    G1XYZZ *slot = data + (size_t)f * 128 + i1;
+    bool vi;
+    XYZZ28 v = xyzz28_from_xyzz(*slot, vi), o;
+    bool oi;
+    const uint32_t *rec = roots_glv + (size_t)(ridx / (N_EXT / 128)) * TW_REC_WORDS;
+    const int8_t *naf = reinterpret_cast<const int8_t *>(rec + 8);
+    quad::xyzz28_mul_glv_naf_quad(o, oi, v, vi, naf, naf + GLV_NAF_LEN, ql);
+    if (ql == 0) *slot = xyzz28_to_xyzz(o, oi);
+}
+
 __global__ __launch_bounds__(64) void k_g1_fft_addsub(G1XYZZ *data, uint32_t nfft, int s) {
     const size_t g = blockIdx.x * (size_t)64 + threadIdx.x;
     uint32_t f;
@@ -166,9 +192,20 @@ static int g1_fft_stages(DeviceCtx *ctx, G1XYZZ *d_data, const uint32_t *d_glv, 
                          int s_from, int s_to, int inverse) {
     // dif: s runs downwards from s_from to s_to; dit: upwards
     const dim3 grid((unsigned)((nfft + 63) / 64 * 64)), block(64);  // 64 butterflies x padded transforms / 64 lanes
+    // four lanes per butterfly while that is at most ~two waves per SIMD (64 butterflies x nfft x 4 lanes): up
+    // to there the one-lane form is latency-bound (a lone wave issues a mad every 9.4 cycles) and the quad
+    // form's 12 lane-products per doubling instead of 7 cost nothing
+    static const size_t quad_max = []() {
+        const char *e = getenv("CKZG_HIP_QUAD_FFT_MAX");
+        return e && *e ? (size_t)atol(e) : (size_t)512;
+    }();
+    const bool use_quad = nfft <= quad_max;
+    const dim3 qgrid((unsigned)((nfft + 15) / 16 * 16 * 4));        // 64 butterflies x padded transforms x 4 / 64 lanes
     for (int s = s_from; dif ? s >= s_to : s <= s_to; s += dif ? -1 : 1) {
         if (dif) hipLaunchKernelGGL(k_g1_fft_addsub, grid, block, 0, ctx->stream, d_data, (uint32_t)nfft, s);
-        if (s > 1)
+        if (s > 1 && use_quad)
+            hipLaunchKernelGGL(k_g1_fft_twiddle_quad, qgrid, block, 0, ctx->stream, d_data, d_glv, (uint32_t)nfft, s, inverse);
+        else if (s > 1)
             hipLaunchKernelGGL(k_g1_fft_twiddle, grid, block, 0, ctx->stream, d_data, d_glv, (uint32_t)nfft, s, inverse);
         if (!dif) hipLaunchKernelGGL(k_g1_fft_addsub, grid, block, 0, ctx->stream, d_data, (uint32_t)nfft, s);
     }

@@ -1,0 +1,222 @@
+// g1_quad.hpp -- Jacobian point arithmetic spread over the four lanes of a DPP quad (device only).
+//
+// Why: the scalar ladders of the verification paths and of the small-batch G1 FFT are *latency* work.  A lone
+// wave issues one v_mad_u64_u32 every 9.4 cycles whatever its instruction-level parallelism
+// (tools/ubench/mad_latency.hip), so 128 doublings + 46 additions of one lane are ~2 ms -- and at the sizes of
+// those calls most SIMDs of the chip have no wave at all.  The remedy is lanes, not instructions: the 7 field
+// products of a doubling have only 3 dependency levels and the 16 of an addition only 5, so four cooperating
+// lanes per point shorten the sequential chain 2.3-3x and spread one point's work over four times as many
+// waves.  All four lanes of a quad hold the SAME point (replicated state); in every step each lane multiplies
+// the operand pair chosen for its position, then the products are handed round with DPP quad permutes
+// (v_mov_b32_dpp quad_perm: register-to-register, no LDS).  A step costs one Montgomery product whatever the
+// lane does, so the spare lane of a step simply repeats a neighbour's product.
+//
+// Formulas and value bounds are those of jac28_dbl / jac28_add (g1_28.hpp); the exceptional cases of the
+// addition (equal or opposite points) fall back to the one-lane complete routine, which every lane of the quad
+// then runs on its copy.
+#pragma once
+#include "g1_28.hpp"
+
+namespace ckzg {
+namespace quad {
+
+// the 32-bit value held by lane SRC (0..3) of the calling lane's quad
+template <int SRC>
+__device__ __forceinline__ uint32_t qread(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, SRC * 0x55, 0xf, 0xf, true);
+}
+template <int SRC, int L, int V>
+__device__ __forceinline__ F28<L, V> qread(const F28<L, V> &a) {
+    F28<L, V> r;
+#pragma unroll
+    for (int j = 0; j < 14; j++) r.l[j] = qread<SRC>(a.l[j]);
+    return r;
+}
+
+// operand of this lane: v0..v3 for quad positions 0..3
+template <int L, int V>
+__device__ __forceinline__ F28<L, V> qsel(int ql, const F28<L, V> &v0, const F28<L, V> &v1, const F28<L, V> &v2,
+                                          const F28<L, V> &v3) {
+    F28<L, V> r;
+#pragma unroll
+    for (int j = 0; j < 14; j++) {
+        const uint32_t lo = (ql & 1) ? v1.l[j] : v0.l[j], hi = (ql & 1) ? v3.l[j] : v2.l[j];
+        r.l[j] = (ql & 2) ? hi : lo;
+    }
+    return r;
+}
+
+// a <- 2a.  Three product steps instead of seven products.
+__device__ __forceinline__ void jac28_dbl_quad(JAC28 &a, int ql) {
+    // step 1: X*X | Y*Y | Y*Z | (X*X)
+    {
+        const auto x = widen<2, 34>(a.x), y = widen<2, 34>(a.y), z = widen<2, 34>(a.z);
+        const auto p1 = mul(qsel(ql, x, y, y, x), qsel(ql, x, y, z, x));   // 14*4+15 ok; 34*34 ok
+        const auto A = qread<0>(p1), B = qread<1>(p1), YZ = qread<2>(p1);
+        // step 2: E*E | B*B | X*B | (B*B),  E = 3A
+        const auto E = add(add(A, A), A);                                   // <3,6>
+        const auto e = widen<3, 34>(E), b = widen<3, 34>(B), xx = widen<3, 34>(a.x);
+        const auto p2 = mul(qsel(ql, e, b, xx, b), qsel(ql, e, b, b, b));   // 14*9+15 ok; 34*34 ok
+        const auto F = qread<0>(p2), C = qread<1>(p2), XB = qread<2>(p2);
+        const auto XB2 = add(XB, XB);
+        const auto D = add(XB2, XB2);                                       // <4,8> = 4 X Y^2
+        const auto X3 = norm(sub(F, add(D, D)));                            // <11,34> -> <1,34>
+        const auto dx = norm(sub(D, X3));                                   // <1,72>
+        const auto C2 = add(C, C);
+        const auto C4 = add(C2, C2);
+        const auto C8 = add(C4, C4);                                        // <8,16>
+        // step 3: the same product in every lane
+        const auto Y3 = norm(sub(mul(E, dx), C8));                          // <1,34>
+        a.x = X3;
+        a.y = Y3;
+        a.z = add(YZ, YZ);                                                  // <2,4>
+    }
+}
+
+// a <- a + b (b finite, with cached Z^2, Z^3).  Five product steps instead of sixteen products.
+__device__ __forceinline__ void jac28_add_quad(JAC28 &a, bool &ainf, const JACT28 &b, int ql) {
+    if (ainf) {
+        a.x = b.x;
+        a.y = widen<1, 34>(mul(b.y, f28_one()));
+        a.z = b.z;
+        ainf = false;
+        return;
+    }
+    // step 1: Z1*Z1 | X1*ZZ2 | Y1*ZZZ2 | Z1*Z2
+    const auto az = widen<2, 34>(a.z);
+    const auto p1 = mul(qsel(ql, az, widen<2, 34>(a.x), widen<2, 34>(a.y), az),
+                        qsel(ql, a.z, widen<2, 4>(b.zz), widen<2, 4>(b.zzz), b.z));   // 14*4+15 ok; 34*4 ok
+    const auto z1z1 = qread<0>(p1), u1 = qread<1>(p1), s1 = qread<2>(p1), z1z2 = qread<3>(p1);
+    // step 2: X2*Z1Z1 | Z1*Z1Z1
+    const auto bx = widen<2, 34>(b.x);
+    const auto p2 = mul(qsel(ql, bx, az, bx, az), z1z1);                              // 14*2+15 ok; 34*2 ok
+    const auto u2 = qread<0>(p2), z1c = qread<1>(p2);
+    const auto h = sub(u2, u1);                                                       // <4,6>
+    // step 3: Y2*Z1^3 | H*H | Z1Z2*H | (H*H)
+    const auto h64 = widen<4, 64>(h);
+    const auto p3 = mul(qsel(ql, widen<4, 64>(b.y), h64, widen<4, 64>(z1z2), h64),
+                        qsel(ql, widen<4, 6>(z1c), h, h, h));                          // 14*16+15 = 239 ok; 64*6 ok
+    const auto s2 = qread<0>(p3), hh = qread<1>(p3), z3 = qread<2>(p3);
+    if (is_zero(hh)) {  // same x: the point itself or its negative -- the complete one-lane routine, on every copy
+        jac28_add(a, ainf, b);
+        return;
+    }
+    const auto r = sub(s2, s1);                                                       // <4,6>
+    // step 4: H*HH | U1*HH | R*R | (R*R)
+    const auto hh46 = widen<4, 6>(hh);
+    const auto p4 = mul(qsel(ql, h, widen<4, 6>(u1), r, r), qsel(ql, hh46, hh46, r, r));   // 239 ok; 36 ok
+    const auto hhh = qread<0>(p4), v = qread<1>(p4), rr = qread<2>(p4);
+    const auto x3 = norm(sub(rr, add(hhh, add(v, v))));                               // <6,10> -> <1,10>
+    const auto dv = sub(v, x3);                                                       // <4,18>
+    F28<1, 0> zero;
+#pragma unroll
+    for (int j = 0; j < 14; j++) zero.l[j] = 0;
+    const auto s1n = sub(zero, s1);                                                   // <4,4> = -S1
+    // step 5: R*(V - X3) | (-S1)*HHH ; Y3 is their sum
+    const auto rn = widen<4, 6>(norm(r)), sn = widen<4, 6>(s1n);
+    const auto p5 = mul(qsel(ql, rn, sn, rn, sn), qsel(ql, dv, widen<4, 18>(hhh), dv, widen<4, 18>(hhh)));   // 239 ok; 108 ok
+    const auto y3 = norm(add(qread<0>(p5), qread<1>(p5)));                            // <2,4> -> <1,4>
+    a.x = widen<1, 34>(x3);
+    a.y = widen<1, 34>(y3);
+    a.z = widen<2, 4>(z3);
+}
+
+// [k]P for a 128-bit k (one GLV half), uniform 4-bit windows: the quad form of xyzz28_mul_w4_128.
+// Only for points of the prime-order subgroup (every multiple 1..15 is finite).  All four lanes of the quad
+// pass the same arguments and receive the same result.
+__device__ __noinline__ void xyzz28_mul_w4_128_quad(XYZZ28 &out, bool &out_inf, const XYZZ28 &p, bool p_inf,
+                                                    const uint32_t *k, int ql) {
+    JACT28 tbl[15];
+    JAC28 acc;
+    bool inf = true;
+    if (!p_inf) {
+        JAC28 cur = jac28_from_xyzz(p);
+        tbl[0] = jac28_table_entry(cur);
+        for (int i = 1; i < 15; i++) {
+            bool ci = false;
+            jac28_add_quad(cur, ci, tbl[0], ql);
+            tbl[i] = jac28_table_entry(cur);
+        }
+        for (int w = 31; w >= 0; w--) {
+            if (!inf) {
+                jac28_dbl_quad(acc, ql);
+                jac28_dbl_quad(acc, ql);
+                jac28_dbl_quad(acc, ql);
+                jac28_dbl_quad(acc, ql);
+            }
+            uint32_t d = (k[w >> 3] >> ((w & 7) * 4)) & 15u;
+            if (d) jac28_add_quad(acc, inf, tbl[d - 1], ql);
+        }
+    }
+    if (!inf) out = jac28_to_xyzz(acc);
+    out_inf = inf;
+}
+
+// [|x|]P for the BLS parameter (63 doublings, 5 additions): quad form of jac28_mul_bls_x
+__device__ __forceinline__ void jac28_mul_bls_x_quad(JAC28 &out, bool &out_inf, const JAC28 &p, bool p_inf, int ql) {
+    JAC28 acc = p;
+    bool inf = p_inf;
+    if (!p_inf) {
+        const JACT28 pt = jac28_table_entry(p);
+        for (int b = 62; b >= 0; b--) {
+            if (!inf) jac28_dbl_quad(acc, ql);
+            if (b == 62 || b == 60 || b == 57 || b == 48 || b == 16) jac28_add_quad(acc, inf, pt, ql);
+        }
+    }
+    out = acc;
+    out_inf = inf;
+}
+
+// quad form of g1_28_in_subgroup: [x^2]P == (beta^2 X, -Y) for a finite curve point (any point of E(Fp):
+// the additions fall back to the complete routine when they meet an exceptional case)
+__device__ __noinline__ bool g1_28_in_subgroup_quad(const F28<1, 2> &x, const F28<1, 2> &y, int ql) {
+    JAC28 p, q1, q;
+    p.x = widen<1, 34>(x);
+    p.y = widen<1, 34>(y);
+    p.z = widen<2, 4>(f28_one());
+    bool i1, i2;
+    jac28_mul_bls_x_quad(q1, i1, p, false, ql);
+    jac28_mul_bls_x_quad(q, i2, q1, i1, ql);
+    if (i2) return false;
+    auto zz = sqr(q.z);
+    auto bx = mul(x, f28_const<1, 1>(FP28_BETA_LAMBDA2));
+    if (!f28_equal(q.x, mul(bx, zz))) return false;
+    return is_zero(mul(add(q.y, mul(y, mul(q.z, zz))), f28_one()));
+}
+
+// [k]P = [k1]P + [k2]phi(P) with both halves in width-4 NAF: quad form of xyzz28_mul_glv_naf (the G1 FFT's
+// twiddle multiplication; the digit strings are shared by the whole wave)
+__device__ __noinline__ void xyzz28_mul_glv_naf_quad(XYZZ28 &out, bool &out_inf, const XYZZ28 &p, bool p_inf,
+                                                     const int8_t *naf1, const int8_t *naf2, int ql) {
+    JACT28 tbl[8];  // [2m] = (2m+1)P, [2m+1] = -(2m+1)P
+    JAC28 acc;
+    bool inf = true;
+    if (!p_inf) {
+        const F28<1, 1> beta = f28_const<1, 1>(FP28_BETA_LAMBDA);
+        JAC28 cur = jac28_from_xyzz(p), p2 = cur;
+        jac28_dbl_quad(p2, ql);
+        const JACT28 p2t = jac28_table_entry(p2);
+        tbl[0] = jac28_table_entry(cur);
+        for (int m = 1; m < 4; m++) {
+            bool ci = false;
+            jac28_add_quad(cur, ci, p2t, ql);
+            tbl[2 * m] = jac28_table_entry(cur);
+        }
+        for (int m = 0; m < 4; m++) tbl[2 * m + 1] = jact28_neg(tbl[2 * m]);
+        for (int i = GLV_NAF_LEN - 1; i >= 0; i--) {
+            if (!inf) jac28_dbl_quad(acc, ql);
+            const int d1 = naf1[i], d2 = naf2[i];
+            if (d1) jac28_add_quad(acc, inf, tbl[(d1 > 0 ? d1 - 1 : -d1)], ql);
+            if (d2) {
+                JACT28 e = tbl[(d2 > 0 ? d2 - 1 : -d2)];
+                e.x = widen<1, 34>(mul(e.x, beta));
+                jac28_add_quad(acc, inf, e, ql);
+            }
+        }
+    }
+    if (!inf) out = jac28_to_xyzz(acc);
+    out_inf = inf;
+}
+
+}  // namespace quad
+}  // namespace ckzg

@@ -10,6 +10,7 @@
 #include "device.hpp"
 #include "dev_inline.hpp"
 #include "g1_28.hpp"
+#include "g1_quad.hpp"
 #include "fr_inv.hpp"
 
 namespace ckzg {
@@ -247,6 +248,16 @@ __global__ void k_subgroup_g1(uint8_t *status, const G1Affine *pts, size_t n) {
     status[g] = st;
 }
 
+// the same with four lanes per point (g1_quad.hpp): the 126 doublings are the critical path of a small batch
+__global__ __launch_bounds__(64) void k_subgroup_g1_quad(uint8_t *status, const G1Affine *pts, size_t n) {
+    size_t g = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 2;
+    if (g >= n) return;
+    G1Affine a = pts[g];
+    uint8_t st = 0;
+    if (!a.is_inf() && !quad::g1_28_in_subgroup_quad(f28_from_fp(a.x), f28_from_fp(a.y), (int)(threadIdx.x & 3))) st = 1;
+    if ((threadIdx.x & 3) == 0) status[g] = st;
+}
+
 int validate_g1_batch_device(DeviceCtx *ctx, G1Affine *d_out, uint8_t *d_status, const uint8_t *d_in48,
                              size_t n, hipStream_t stream) {
     if (!n) return 0;
@@ -267,8 +278,18 @@ int decompress_g1_batch_device(DeviceCtx *ctx, G1Affine *d_out, uint8_t *d_statu
 
 int subgroup_g1_batch_device(DeviceCtx *ctx, uint8_t *d_status, const G1Affine *d_pts, size_t n, hipStream_t stream) {
     if (!n) return 0;
-    hipLaunchKernelGGL(k_subgroup_g1, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream ? stream : ctx->stream,
-                       d_status, d_pts, n);
+    // four lanes per point while that is at most ~2 waves per SIMD (CKZG_HIP_QUAD_MAX moves the hand-over)
+    static const size_t quad_max = []() {
+        const char *e = getenv("CKZG_HIP_QUAD_MAX");
+        return e && *e ? (size_t)atol(e) : (size_t)8192;
+    }();
+    if (n <= 4 * quad_max) {
+        hipLaunchKernelGGL(k_subgroup_g1_quad, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, stream ? stream : ctx->stream,
+                           d_status, d_pts, n);
+    } else {
+        hipLaunchKernelGGL(k_subgroup_g1, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream ? stream : ctx->stream,
+                           d_status, d_pts, n);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -310,6 +331,39 @@ __global__ __launch_bounds__(LC_THREADS) void k_lincomb_partial(G1XYZZ *partials
     if (threadIdx.x == 0) partials[blockIdx.x] = xyzz28_to_xyzz(acc, inf);
 }
 
+// The latency form of the same kernel: FOUR lanes per GLV half-term (g1_quad.hpp), i.e. 8 terms per 64-lane
+// workgroup and one partial per 8 terms.  A ladder is ~2.3x shorter and the call's work spreads over four
+// times as many waves; used while that still fits the chip in about two waves per SIMD.
+__global__ __launch_bounds__(LC_THREADS) void k_lincomb_partial_quad(G1XYZZ *partials, const G1Affine *pts,
+                                                                     const uint32_t *scalars, size_t n) {
+    __shared__ uint32_t sh[57][LC_THREADS / 2];
+    const size_t g = blockIdx.x * (size_t)LC_THREADS + threadIdx.x;
+    const int ql = (int)(threadIdx.x & 3);
+    const size_t half_term = g >> 2, term = half_term >> 1;
+    const bool second = (half_term & 1) != 0;
+    XYZZ28 acc;
+    bool inf = true;
+    if (term < n) {
+        G1Affine a = pts[term];
+        if (!a.is_inf()) {
+            uint32_t k[8], glv[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) k[i] = scalars[term * 8 + i];
+            glv_split(k, glv, glv + 4);
+            XYZZ28 p;
+            p.x = widen<1, 10>(f28_from_fp(a.x));
+            if (second) p.x = widen<1, 10>(mul(p.x, f28_const<1, 1>(FP28_BETA_LAMBDA)));
+            p.y = widen<1, 6>(f28_from_fp(a.y));
+            p.zz = widen<1, 2>(f28_one());
+            p.zzz = p.zz;
+            quad::xyzz28_mul_w4_128_quad(acc, inf, p, false, second ? glv + 4 : glv, ql);
+        }
+    }
+    if (ql != 0) inf = true;  // the four lanes of a quad hold the same product: count it once
+    block_reduce_xyzz28<LC_THREADS>(acc, inf, sh);
+    if (threadIdx.x == 0) partials[blockIdx.x] = xyzz28_to_xyzz(acc, inf);
+}
+
 // job j owns partials[part_off[j] .. part_off[j+1]): one 64-lane workgroup per job folds them
 // (lane-strided partial sums, then the LDS tree) and normalises the result
 __global__ __launch_bounds__(64) void k_lincomb_final(G1Affine *out, const G1XYZZ *partials,
@@ -327,12 +381,18 @@ __global__ __launch_bounds__(64) void k_lincomb_final(G1Affine *out, const G1XYZ
     if (threadIdx.x == 0) out[j] = xyzz28_to_affine(acc, inf);
 }
 
-// `total` (a multiple of 64) points/scalars laid out job after job; h_part_off has njobs+1 entries
+// `total` (a multiple of 64) points/scalars laid out job after job; h_part_off has njobs+1 entries, in units of
+// one partial = 32 terms (quad == false) or 8 terms (quad == true); d_partials holds total/32 resp. total/8 points
 int lincomb_multi_device(DeviceCtx *ctx, G1Affine *d_out, G1XYZZ *d_partials, uint32_t *d_off, const G1Affine *d_pts,
-                         const uint32_t *d_scalars, size_t total, const uint32_t *h_part_off, int njobs) {
+                         const uint32_t *d_scalars, size_t total, const uint32_t *h_part_off, int njobs, bool quad) {
     HIP_TRY(hipMemcpyAsync(d_off, h_part_off, (njobs + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_lincomb_partial, dim3((unsigned)(2 * total / LC_THREADS)), dim3(LC_THREADS), 0, ctx->stream,
-                       d_partials, d_pts, d_scalars, total);
+    if (quad) {
+        hipLaunchKernelGGL(k_lincomb_partial_quad, dim3((unsigned)(8 * total / LC_THREADS)), dim3(LC_THREADS), 0,
+                           ctx->stream, d_partials, d_pts, d_scalars, total);
+    } else {
+        hipLaunchKernelGGL(k_lincomb_partial, dim3((unsigned)(2 * total / LC_THREADS)), dim3(LC_THREADS), 0, ctx->stream,
+                           d_partials, d_pts, d_scalars, total);
+    }
     hipLaunchKernelGGL(k_lincomb_final, dim3(njobs), dim3(64), 0, ctx->stream, d_out, d_partials, d_off, njobs);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -42,8 +42,8 @@ extern "C" {
  *   "proof_wbits"   window width of the table over the 4096 monomial points used by the low-latency
  *                   (no G1 FFT) cell-proof path; default 8 (0.8 GB), 0 disables the path
  *   "direct_max"    largest batch that takes the low-latency proof path; larger batches use FK20, which
- *                   does ~10x fewer point additions but costs ~28 ms for any small batch (13 dependent
- *                   ladder launches).  -1 (default): 10 / 14 / 18 blobs for a proof table of <= 10 / <= 14 /
+ *                   does ~10x fewer point additions but costs ~15 ms for any small batch (12 dependent
+ *                   ladder launches).  -1 (default): 6 / 8 / 10 blobs for a proof table of <= 10 / <= 14 /
  *                   >= 15 bits, the measured hand-over points; 0 disables the path
  *   "gpu_sha_min"   smallest verify_blob_kzg_proof_batch size whose Fiat-Shamir challenges are hashed on
  *                   the GPU; 0 (default): never on hosts with the x86 SHA extensions (the host hash runs under the
@@ -102,8 +102,9 @@ C_KZG_RET ckzg_hip_recover_cells_and_kzg_proofs_batch(Cell *recovered_cells, KZG
  * the reference's in-memory forms (g1_t Jacobian, fr_t Montgomery); the empty sum is the identity.  The
  * library's own verify_*_batch paths call the same kernels on points they have already validated; here every
  * point must lie in the prime-order subgroup (or be the identity), otherwise C_KZG_BADARGS -- the reference
- * function accepts any curve point.  algo: 0 = choose by size, 1 = one GLV ladder per term (verify.hip),
- * 2 = bucket accumulation (pippenger.hip). */
+ * function accepts any curve point.  algo: 0 = what the library's own calls use (ladders, form chosen by size),
+ * 1 = GLV ladders, form by size, 2 = bucket accumulation (pippenger.hip), 3 = ladders with one lane per GLV
+ * half-term, 4 = ladders with four lanes per half-term (g1_quad.hpp). */
 C_KZG_RET ckzg_hip_g1_lincomb(g1_t *out, const g1_t *p, const fr_t *coeffs, uint64_t len, int algo,
                               const KZGSettings *s);
 

@@ -426,7 +426,7 @@ def test_g1_lincomb_buckets_and_ladders_vs_oracle(hip, n):
     exp = C.create_string_buffer(144)  # all zero = the identity (Z = 0): the value of the empty sum
     if n:
         assert o.okzg_g1_lincomb_fast(exp, b"".join(pts), b"".join(sm), n) == 0
-    for algo in (1, 2, 0):
+    for algo in (1, 2, 3, 4, 0):  # ladders by size, buckets, one-lane ladders, four-lane (DPP quad) ladders, default
         rc, got = _lincomb(hip, pts, sm, algo)
         assert rc == 0, (n, algo)
         assert o.og1_equal(got, exp), (n, algo)
