@@ -193,6 +193,17 @@ inline void staged_copy(void *dst, const void *src, size_t bytes) {
     for (auto &x : th) x.join();
 }
 
+// true if the caller's host buffer is page-locked (hipHostMalloc / hipHostRegister): such a buffer is DMA'd
+// from directly, chunk by chunk, without the staging copy a pageable one needs
+inline bool host_pointer_is_pinned(const void *p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();  // an ordinary malloc'd pointer is "invalid value" to the runtime
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
 // pinned staging of a slot, grown on demand: h_stage[2] (towards the device), h_out[2] (back)
 inline bool ensure_pinned(void **bufs, size_t &have, size_t want) {
     if (have >= want) return true;

@@ -349,6 +349,7 @@ static C_KZG_RET commit_batch_on(dev::DeviceCtx *ctx, KZGCommitment *out, uint8_
         }
         return ret;
     }
+    const bool src_pinned = host_pointer_is_pinned(blobs);  // page-locked caller memory: no staging copy
     uint64_t chunk = 0, k = 0, want = FIRST;
     for (uint64_t off = 0; off < n && ret == C_KZG_OK; off += k, chunk++) {
         const int b = (int)(chunk & 1);
@@ -360,8 +361,12 @@ static C_KZG_RET commit_batch_on(dev::DeviceCtx *ctx, KZGCommitment *out, uint8_
             ok = ok && hipEventSynchronize(copied[b]) == hipSuccess;
             ok = ok && hipStreamWaitEvent(ctx->copy_stream, consumed[b], 0) == hipSuccess;
         }
-        staged_copy(ctx->h_stage[b], blobs + off, k * BYTES_PER_BLOB);
-        ok = ok && hipMemcpyAsync(d_blobs[b].p, ctx->h_stage[b], k * BYTES_PER_BLOB, hipMemcpyHostToDevice,
+        const void *h_src = blobs + off;
+        if (!src_pinned) {
+            staged_copy(ctx->h_stage[b], blobs + off, k * BYTES_PER_BLOB);
+            h_src = ctx->h_stage[b];
+        }
+        ok = ok && hipMemcpyAsync(d_blobs[b].p, h_src, k * BYTES_PER_BLOB, hipMemcpyHostToDevice,
                                   ctx->copy_stream) == hipSuccess;
         ok = ok && hipEventRecord(copied[b], ctx->copy_stream) == hipSuccess;
         ok = ok && hipStreamWaitEvent(ctx->stream, copied[b], 0) == hipSuccess;
@@ -530,6 +535,7 @@ static C_KZG_RET cells_and_proofs_batch_on(dev::DeviceCtx *ctx, Cell *cells, KZG
         }
     } drain{ctx, pipe};
     bool pending[2] = {false, false};
+    const bool src_pinned = host_pointer_is_pinned(blobs);
     uint64_t sub_index = 0, chunk = 0;
     for (uint64_t off = 0; off < n; off += CH, chunk++) {
         const uint64_t k = n - off < CH ? n - off : CH;
@@ -544,8 +550,12 @@ static C_KZG_RET cells_and_proofs_batch_on(dev::DeviceCtx *ctx, Cell *cells, KZG
                 ok = ok && hipEventSynchronize(copied[b]) == hipSuccess;
                 ok = ok && hipStreamWaitEvent(ctx->copy_stream, consumed[b], 0) == hipSuccess;
             }
-            staged_copy(ctx->h_stage[b], blobs + off + so, ks * BYTES_PER_BLOB);
-            ok = ok && hipMemcpyAsync(d_in[b].p, ctx->h_stage[b], ks * BYTES_PER_BLOB, hipMemcpyHostToDevice,
+            const void *h_src = blobs + off + so;
+            if (!src_pinned) {
+                staged_copy(ctx->h_stage[b], blobs + off + so, ks * BYTES_PER_BLOB);
+                h_src = ctx->h_stage[b];
+            }
+            ok = ok && hipMemcpyAsync(d_in[b].p, h_src, ks * BYTES_PER_BLOB, hipMemcpyHostToDevice,
                                       ctx->copy_stream) == hipSuccess;
             ok = ok && hipEventRecord(copied[b], ctx->copy_stream) == hipSuccess;
             ok = ok && hipStreamWaitEvent(ctx->stream, copied[b], 0) == hipSuccess;

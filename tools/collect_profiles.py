@@ -20,6 +20,6 @@ last = lambda f: json.loads(open(os.path.join(src, f)).read().strip().splitlines
 json.dump({"default_command_python_bench_py": last("bench_default.json"),
            "profiled_timed_only_run": last("bench_timed.json")},
           open(os.path.join(dst, pre + "_bench_lines.json"), "w"), indent=1)
-shutil.copy(glob.glob(os.path.join(src, "timed", "**", "*kernel_stats.csv"), recursive=True)[0],
+shutil.copy(sorted(glob.glob(os.path.join(src, "timed", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)[-1],
             os.path.join(dst, pre + "_bench_timed_only_kernel_stats.csv"))
 print("ok")
