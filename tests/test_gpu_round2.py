@@ -451,3 +451,76 @@ def test_g1_lincomb_buckets_and_ladders_vs_oracle(hip, n):
             x += 1
         rc, _ = _lincomb(hip, [bad48] + pts[1:], sm, 2)
         assert rc == 1
+
+
+def test_pinned_caller_memory_is_read_in_place(hip):
+    """A page-locked host buffer (here a pinned torch tensor) is DMA'd from directly, chunk by chunk, instead
+    of being staged: same commitments, same per-blob status."""
+    rt = C.CDLL("/opt/rocm/lib/libamdhip64.so")  # the runtime the library itself is linked against
+    base = [rand_blob(99, i) for i in range(3)]
+    single = [hip.blob_to_kzg_commitment(b) for b in base]
+    n = 700   # several geometric chunks (64, 192, 444)
+    blobs = [base[i % 3] for i in range(n)]
+    bad = bytearray(base[1])
+    bad[0:32] = R.to_bytes(32, "big")
+    blobs[650] = bytes(bad)
+    raw = b"".join(blobs)
+    pinned = C.c_void_p()
+    assert rt.hipHostMalloc(C.byref(pinned), C.c_size_t(len(raw)), C.c_uint(0)) == 0
+    C.memmove(pinned, raw, len(raw))
+
+    class _T:  # minimal stand-in for the tensor the calls below address
+        @staticmethod
+        def data_ptr():
+            return pinned.value
+    t = _T()
+    f = hip.lib.ckzg_hip_blob_to_kzg_commitment_batch
+    f.restype = C.c_int
+    out = C.create_string_buffer(48 * n)
+    st = C.create_string_buffer(n)
+    rc = f(out, st, C.c_void_p(t.data_ptr()), C.c_uint64(n), hip.sp)
+    assert rc == 1 and [i for i, v in enumerate(st.raw) if v] == [650]
+    assert all(out.raw[48 * i:48 * i + 48] == single[i % 3] for i in range(n) if i != 650)
+    # cells + proofs from pinned memory
+    g = hip.lib.ckzg_hip_compute_cells_and_kzg_proofs_batch
+    g.restype = C.c_int
+    m = 70
+    cells = C.create_string_buffer(m * 128 * 2048)
+    proofs = C.create_string_buffer(m * 128 * 48)
+    assert g(cells, proofs, None, C.c_void_p(t.data_ptr()), C.c_uint64(m), hip.sp) == 0
+    exp = hip.compute_cells_and_kzg_proofs(base[2])
+    assert cells.raw[2 * 262144:3 * 262144] == b"".join(exp[0]) and proofs.raw[68 * 6144:69 * 6144] == b"".join(exp[1])
+    assert rt.hipHostFree(pinned) == 0
+
+
+def _run_bench(extra_env, args):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(extra_env)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_bench_two_ranks_control_flow_on_one_gpu():
+    """`python bench.py --gpus 2` spawns two ranks itself (torch.distributed.run); here both ranks share the one
+    GPU over gloo, which exercises the barrier / MAX-over-ranks timing, the whole-job host-pointer leg and the
+    C-ABI fan-out leg (two table replicas standing in for two devices)."""
+    line = _run_bench({"CKZG_BENCH_ONE_GPU": "1", "CKZG_BENCH_BACKEND": "gloo"},
+                      ["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    assert line["n_gpus"] == 2 and line["parity_spot_check_vs_oracle"] is True
+    assert line["value"] > 0 and line["host_pointer"]["value"] > 0
+    assert line["c_abi_fan_out"]["devices"] == 2 and line["c_abi_fan_out"]["rc"] == 0
+
+
+@pytest.mark.skipif("__import__('subprocess').run(['bash', '-c', 'rocm-smi --showid | grep -c \"Device ID\"'], capture_output=True, text=True).stdout.strip() in ('', '0', '1')",
+                    reason="needs two visible GPUs")
+def test_bench_two_ranks_on_two_gpus_over_rccl():
+    line = _run_bench({}, ["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
+    assert line["n_gpus"] == 2 and line["parity_spot_check_vs_oracle"] is True
+    assert line["c_abi_fan_out"]["devices"] == 2 and line["c_abi_fan_out"]["rc"] == 0
