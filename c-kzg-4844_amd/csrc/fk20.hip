@@ -188,6 +188,202 @@ __global__ __launch_bounds__(64) void k_g1_fft_fold(G1XYZZ *data, size_t npairs)
     data[2 * g + 1] = r;
 }
 
+// ------------------------------------------------------------------------------------------
+// Radix-4 steps for small batches: two butterfly stages per launch pair, ONE ladder deep.
+//
+// In a radix-2 pass the twiddle multiplications of stage s-1 wait for those of stage s: 12 dependent ladders
+// for the two transforms of FK20.  Written out on the four points of a 4-point group, every product of the
+// second stage is a product of an INPUT combination with a product of two twiddles -- again a 128th root of
+// unity -- so all of them can start at once: five independent ladders per group instead of four dependent
+// ones (25 % more ladder work, half the depth; small batches leave the chip idle anyway).
+//   DIF pair (s, s-1), H = 2^(s-1), Q = H/2, E = 128/2^s, points a0..a3 at t, t+Q, t+H, t+H+Q (t < Q):
+//     L0 = (a0-a2) w^(tE)   L1 = (a1-a3) w^(tE+32)   L2 = (a0-a2) w^(3tE)   L3 = (a1-a3) w^(3tE+32)
+//     L4 = ((a0+a2)-(a1+a3)) w^(2tE)
+//     out: [t] = (a0+a2)+(a1+a3)   [t+Q] = L4   [t+H] = L0+L1   [t+H+Q] = L2-L3
+//   DIT pair (s, s+1), H = 2^(s-1), g = t*(128/2^s)/2, points x0..x3 at t, t+H, t+2H, t+3H (t < H):
+//     L0 = x1 w^(2g)   L1 = x2 w^g   L2 = x3 w^(3g)   L3 = x2 w^(g+32)   L4 = x3 w^(3g+32)
+//     y0 = x0+L0, y1 = x0-L0, u = L1+L2, v = L3-L4
+//     out: [t] = y0+u   [t+2H] = y0-u   [t+H] = y1+v   [t+3H] = y1-v
+// (fft.c:164-185 computes the same butterflies recursively.)  The ladders are the four-lane form
+// (g1_quad.hpp); lanes are ordered transform-fastest and padded to 16 transforms, so a wave (16 quads) works
+// on ONE (group, ladder) pair: one twiddle, uniform NAF digits.
+// ------------------------------------------------------------------------------------------
+
+constexpr int R4_LADDERS = 32 * 5;  // per transform and radix-4 step
+
+__device__ __forceinline__ void r4_group(int grp, int s, int dif, int &t, int &p0, int &p1, int &p2, int &p3) {
+    if (dif) {
+        const int Q = 1 << (s - 2), blk = grp / Q;
+        t = grp - blk * Q;
+        p0 = (blk << s) + t;
+        p1 = p0 + Q;
+        p2 = p0 + 2 * Q;
+        p3 = p2 + Q;
+    } else {
+        const int H = 1 << (s - 1), blk = grp / H;
+        t = grp - blk * H;
+        p0 = (blk << (s + 1)) + t;
+        p1 = p0 + H;
+        p2 = p0 + 2 * H;
+        p3 = p0 + 3 * H;
+    }
+}
+
+__device__ __forceinline__ int r4_exponent(int k, int t, int s, int dif) {
+    const int E = 128 >> s;
+    if (dif) {
+        const int tE = t * E;
+        switch (k) {
+            case 0: return tE;
+            case 1: return tE + 32;
+            case 2: return 3 * tE;
+            case 3: return 3 * tE + 32;
+            default: return 2 * tE;
+        }
+    }
+    const int g = t * E / 2;
+    switch (k) {
+        case 0: return 2 * g;
+        case 1: return g;
+        case 2: return 3 * g;
+        case 3: return g + 32;
+        default: return 3 * g + 32;
+    }
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_g1_fft_r4_ladder(
+    G1XYZZ *lad, const G1XYZZ *data, const uint32_t *roots_glv, uint32_t nfft, int s, int dif, int inverse) {
+    const size_t q = (blockIdx.x * (size_t)64 + threadIdx.x) >> 2;
+    const int ql = (int)(threadIdx.x & 3);
+    const uint32_t pad = (nfft + 15u) & ~15u;
+    const uint32_t ell = (uint32_t)(q / pad), f = (uint32_t)(q - (size_t)ell * pad);
+    if (f >= nfft || ell >= (uint32_t)R4_LADDERS) return;
+    const int grp = (int)ell / 5, k = (int)ell % 5;
+    int t, p0, p1, p2, p3;
+    r4_group(grp, s, dif, t, p0, p1, p2, p3);
+    const G1XYZZ *vec = data + (size_t)f * 128;
+    XYZZ28 v;
+    bool vi;
+    if (dif) {
+        bool i0, i1, i2, i3;
+        if (k == 0 || k == 2) {         // a0 - a2
+            v = xyzz28_from_xyzz(vec[p0], vi);
+            XYZZ28 b = xyzz28_from_xyzz(vec[p2], i2);
+            xyzz28_add(v, vi, xyzz28_neg(b), i2);
+        } else if (k == 1 || k == 3) {  // a1 - a3
+            v = xyzz28_from_xyzz(vec[p1], vi);
+            XYZZ28 b = xyzz28_from_xyzz(vec[p3], i3);
+            xyzz28_add(v, vi, xyzz28_neg(b), i3);
+        } else {                        // (a0 + a2) - (a1 + a3)
+            v = xyzz28_from_xyzz(vec[p0], vi);
+            XYZZ28 b = xyzz28_from_xyzz(vec[p2], i2);
+            xyzz28_add(v, vi, b, i2);
+            XYZZ28 c = xyzz28_from_xyzz(vec[p1], i1), d = xyzz28_from_xyzz(vec[p3], i3);
+            xyzz28_add(c, i1, d, i3);
+            xyzz28_add(v, vi, xyzz28_neg(c), i1);
+        }
+        (void)i0;
+    } else {
+        const int src = k == 0 ? p1 : ((k == 1 || k == 3) ? p2 : p3);
+        v = xyzz28_from_xyzz(vec[src], vi);
+    }
+    int e = r4_exponent(k, t, s, dif) & 127;
+    XYZZ28 o = v;
+    bool oi = vi;
+    if (e != 0) {
+        const int rec_i = inverse ? 128 - e : e;
+        const uint32_t *rec = roots_glv + (size_t)rec_i * TW_REC_WORDS;
+        const int8_t *naf = reinterpret_cast<const int8_t *>(rec + 8);
+        quad::xyzz28_mul_glv_naf_quad(o, oi, v, vi, naf, naf + GLV_NAF_LEN, ql);
+    }
+    if (ql == 0) lad[(size_t)f * R4_LADDERS + ell] = xyzz28_to_xyzz(o, oi);
+}
+
+// one lane per OUTPUT point: lane g -> (transform f, group, which of the four outputs)
+__global__ __launch_bounds__(64) void k_g1_fft_r4_post(G1XYZZ *out, const G1XYZZ *data, const G1XYZZ *lad, uint32_t nfft,
+                                                      int s, int dif) {
+    const size_t g = blockIdx.x * (size_t)64 + threadIdx.x;
+    const uint32_t f = (uint32_t)(g >> 7);
+    if (f >= nfft) return;
+    const int grp = (int)((g >> 2) & 31), w = (int)(g & 3);
+    int t, p0, p1, p2, p3;
+    r4_group(grp, s, dif, t, p0, p1, p2, p3);
+    const G1XYZZ *vec = data + (size_t)f * 128, *L = lad + (size_t)f * R4_LADDERS + grp * 5;
+    XYZZ28 r;
+    bool ri;
+    int dst;
+    if (dif) {
+        if (w == 0) {          // (a0 + a2) + (a1 + a3)
+            bool i1, i2, i3;
+            r = xyzz28_from_xyzz(vec[p0], ri);
+            XYZZ28 b = xyzz28_from_xyzz(vec[p2], i2);
+            xyzz28_add(r, ri, b, i2);
+            XYZZ28 c = xyzz28_from_xyzz(vec[p1], i1), d = xyzz28_from_xyzz(vec[p3], i3);
+            xyzz28_add(c, i1, d, i3);
+            xyzz28_add(r, ri, c, i1);
+            dst = p0;
+        } else if (w == 1) {   // L4
+            r = xyzz28_from_xyzz(L[4], ri);
+            dst = p1;
+        } else if (w == 2) {   // L0 + L1
+            bool bi;
+            r = xyzz28_from_xyzz(L[0], ri);
+            XYZZ28 b = xyzz28_from_xyzz(L[1], bi);
+            xyzz28_add(r, ri, b, bi);
+            dst = p2;
+        } else {               // L2 - L3
+            bool bi;
+            r = xyzz28_from_xyzz(L[2], ri);
+            XYZZ28 b = xyzz28_from_xyzz(L[3], bi);
+            xyzz28_add(r, ri, xyzz28_neg(b), bi);
+            dst = p3;
+        }
+    } else {
+        // w = 0: y0 + u -> [t]; 1: y1 + v -> [t+H]; 2: y0 - u -> [t+2H]; 3: y1 - v -> [t+3H]
+        bool ai, bi, ci;
+        r = xyzz28_from_xyzz(vec[p0], ri);
+        XYZZ28 a = xyzz28_from_xyzz(L[0], ai);
+        xyzz28_add(r, ri, (w & 1) ? xyzz28_neg(a) : a, ai);              // y0 / y1
+        XYZZ28 b = xyzz28_from_xyzz(L[(w & 1) ? 3 : 1], bi), c = xyzz28_from_xyzz(L[(w & 1) ? 4 : 2], ci);
+        xyzz28_add(b, bi, (w & 1) ? xyzz28_neg(c) : c, ci);              // u = L1 + L2 / v = L3 - L4
+        xyzz28_add(r, ri, (w & 2) ? xyzz28_neg(b) : b, bi);
+        dst = w == 0 ? p0 : (w == 1 ? p1 : (w == 2 ? p2 : p3));
+    }
+    out[(size_t)f * 128 + dst] = xyzz28_to_xyzz(r, ri);
+}
+
+// a radix-4 pass over stage pairs: DIF (s_hi, s_hi-1), ..., down to s_lo; DIT (s_lo, s_lo+1), ... up to s_hi.
+// d_tmp: nfft x 128 points (the post kernel cannot write in place: every output reads all four inputs),
+// d_lad: nfft x R4_LADDERS points.  The result ends in d_data.
+static int g1_fft_r4_pairs(DeviceCtx *ctx, G1XYZZ *d_data, G1XYZZ *d_tmp, G1XYZZ *d_lad, const uint32_t *d_glv, size_t nfft,
+                           bool dif, int s_from, int s_to, int inverse) {
+    const size_t pad = (nfft + 15) / 16 * 16;
+    const dim3 lgrid((unsigned)(pad * R4_LADDERS * 4 / 64)), pgrid((unsigned)(nfft * 128 / 64)), block(64);
+    G1XYZZ *cur = d_data, *nxt = d_tmp;
+    for (int s = s_from; dif ? s >= s_to + 1 : s + 1 <= s_to; s += dif ? -2 : 2) {
+        hipLaunchKernelGGL(k_g1_fft_r4_ladder, lgrid, block, 0, ctx->stream, d_lad, cur, d_glv, (uint32_t)nfft, s, dif ? 1 : 0,
+                           inverse);
+        hipLaunchKernelGGL(k_g1_fft_r4_post, pgrid, block, 0, ctx->stream, nxt, cur, d_lad, (uint32_t)nfft, s, dif ? 1 : 0);
+        G1XYZZ *x = cur;
+        cur = nxt;
+        nxt = x;
+    }
+    if (cur != d_data)
+        HIP_TRY(hipMemcpyAsync(d_data, cur, nfft * 128 * sizeof(G1XYZZ), hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static size_t r4_max_transforms() {
+    static const size_t v = []() {
+        // measured hand-over (tools/bench_fk20_sizes.py, profiles/r02_quad_ab.txt): radix-4 pairs win up to ~100
+        // transforms, tie with the radix-2 four-lane form up to ~200, lose beyond
+        const char *e = getenv("CKZG_HIP_R4_FFT_MAX");
+        return e && *e ? (size_t)atol(e) : (size_t)128;
+    }();
+    return v;
+}
+
 static int g1_fft_stages(DeviceCtx *ctx, G1XYZZ *d_data, const uint32_t *d_glv, size_t nfft, bool dif,
                          int s_from, int s_to, int inverse) {
     // dif: s runs downwards from s_from to s_to; dit: upwards
@@ -314,6 +510,8 @@ struct Fk20Scratch {
     G1XYZZ *u;         // [n][128]
     G1Affine *aff;     // [n][128]
     Fp *prefix;        // [n][128]
+    G1XYZZ *r4_tmp;    // [n][128]          (small batches: radix-4 G1 FFT steps)
+    G1XYZZ *r4_lad;    // [n][R4_LADDERS]
     size_t bytes;
 };
 
@@ -330,6 +528,13 @@ static Fk20Scratch fk20_layout(uint8_t *base, size_t n, int nwin) {
     off += al(n * 128 * sizeof(G1Affine));
     s.prefix = reinterpret_cast<Fp *>(base + off);
     off += al(n * 128 * sizeof(Fp));
+    s.r4_tmp = s.r4_lad = nullptr;
+    if (n <= r4_max_transforms()) {
+        s.r4_tmp = reinterpret_cast<G1XYZZ *>(base + off);
+        off += al(n * 128 * sizeof(G1XYZZ));
+        s.r4_lad = reinterpret_cast<G1XYZZ *>(base + off);
+        off += al(n * R4_LADDERS * sizeof(G1XYZZ));
+    }
     s.bytes = off;
     return s;
 }
@@ -357,10 +562,13 @@ static int fk20_run(DeviceCtx *ctx, uint8_t *d_proofs, const Fr *d_poly, size_t 
     // h = IFFT(u) truncated to its first 64 entries, proofs = FFT(h) (fk20.c:257-269): inverse DIF
     // stages 7..2, the fused stage pair around the truncation, forward DIT stages 2..7
     HIP_TRY(hipEventRecord(ctx->ev[7], ctx->stream));
-    rc = g1_fft_stages(ctx, s.u, d_rr, n, /*dif=*/true, 7, 2, /*inverse=*/1);
+    const bool r4 = s.r4_lad != nullptr;   // small batch: stage pairs with independent ladders (6 ladder depths, not 12)
+    rc = r4 ? g1_fft_r4_pairs(ctx, s.u, s.r4_tmp, s.r4_lad, d_rr, n, /*dif=*/true, 7, 2, /*inverse=*/1)
+            : g1_fft_stages(ctx, s.u, d_rr, n, /*dif=*/true, 7, 2, /*inverse=*/1);
     if (rc) return rc;
     hipLaunchKernelGGL(k_g1_fft_fold, dim3((unsigned)((n * 64 + 63) / 64)), dim3(64), 0, ctx->stream, s.u, n * 64);
-    rc = g1_fft_stages(ctx, s.u, d_rr, n, /*dif=*/false, 2, 7, /*inverse=*/0);
+    rc = r4 ? g1_fft_r4_pairs(ctx, s.u, s.r4_tmp, s.r4_lad, d_rr, n, /*dif=*/false, 2, 7, /*inverse=*/0)
+            : g1_fft_stages(ctx, s.u, d_rr, n, /*dif=*/false, 2, 7, /*inverse=*/0);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(ctx->ev[8], ctx->stream));
     rc = batch_to_affine_device(ctx, s.aff, s.u, s.prefix, n * 128);
