@@ -391,6 +391,48 @@ __global__ __launch_bounds__(64) void k_msm_finalize(uint8_t *out48, uint8_t *st
     if (status) status[v] = (bad && bad[v]) ? 1 : 0;
 }
 
+// The same with LPV lanes per vector: each lane takes one of the (2..8) partials, an LDS tree folds them in
+// log2(LPV) additions instead of a chain of bpv - 1, lane 0 of the group normalises.  For the few hundred
+// vectors of a latency-bound call (one blob's 128 cell proofs: 4 partials each) the chain was a third of the
+// kernel's time.
+template <int LPV>
+__global__ __launch_bounds__(64) void k_msm_finalize_tree(uint8_t *out48, uint8_t *status, const G1XYZZ *partials,
+                                                         const uint32_t *bad, uint32_t blocks_per_vec, size_t n) {
+    __shared__ uint32_t sh[57][32];
+    constexpr int GROUPS = 64 / LPV;
+    const int tid = threadIdx.x, grp = tid / LPV, l = tid % LPV;
+    const size_t v = blockIdx.x * (size_t)GROUPS + grp;
+    XYZZ28 acc;
+    bool inf = true;
+    if (v < n && (uint32_t)l < blocks_per_vec) acc = xyzz28_from_xyzz(partials[v * blocks_per_vec + l], inf);
+    for (int s = LPV / 2; s >= 1; s >>= 1) {
+        if (l >= s && l < 2 * s) {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(&acc);
+            const int slot = grp * (LPV / 2) + (l - s);
+#pragma unroll
+            for (int k = 0; k < 56; k++) sh[k][slot] = src[k];
+            sh[56][slot] = inf ? 1u : 0u;
+        }
+        __syncthreads();
+        if (l < s) {
+            XYZZ28 o;
+            uint32_t *dst = reinterpret_cast<uint32_t *>(&o);
+            const int slot = grp * (LPV / 2) + l;
+#pragma unroll
+            for (int k = 0; k < 56; k++) dst[k] = sh[k][slot];
+            xyzz28_add(acc, inf, o, sh[56][slot] != 0);
+        }
+        __syncthreads();
+    }
+    if (l == 0 && v < n) {
+        G1Affine a = xyzz28_to_affine(acc, inf);
+        uint8_t buf[48];
+        g1_compress_affine(buf, a);
+        for (int k = 0; k < 48; k++) out48[v * 48 + k] = buf[k];
+        if (status) status[v] = (bad && bad[v]) ? 1 : 0;
+    }
+}
+
 // How many (window, point) pairs one 256-thread workgroup of k_msm_accumulate sums.  The chip holds
 // 512 such workgroups at once (2 per CU at ~200 VGPRs); a launch is `rounds` waves of resident
 // workgroups, each costing its threads' additions plus the 8-level LDS tree, so the choice trades
@@ -437,6 +479,17 @@ static int run_msm(DeviceCtx *ctx, const FixedBaseTable &t, uint8_t *d_out48, ui
                            d_partials, bpv);
         hipLaunchKernelGGL(k_msm_finalize, dim3((unsigned)((nvec + 63) / 64)), dim3(64), 0, ctx->stream,
                            d_out48, d_status, d_sums, d_bad, 1u, nvec);
+    } else if (bpv >= 2 && nvec <= 4096) {
+        // few vectors: fold the partials in a tree (latency); many: one lane per vector (dense inversions)
+        if (bpv <= 2)
+            hipLaunchKernelGGL(k_msm_finalize_tree<2>, dim3((unsigned)((nvec + 31) / 32)), dim3(64), 0, ctx->stream, d_out48,
+                               d_status, d_partials, d_bad, bpv, nvec);
+        else if (bpv <= 4)
+            hipLaunchKernelGGL(k_msm_finalize_tree<4>, dim3((unsigned)((nvec + 15) / 16)), dim3(64), 0, ctx->stream, d_out48,
+                               d_status, d_partials, d_bad, bpv, nvec);
+        else
+            hipLaunchKernelGGL(k_msm_finalize_tree<8>, dim3((unsigned)((nvec + 7) / 8)), dim3(64), 0, ctx->stream, d_out48,
+                               d_status, d_partials, d_bad, bpv, nvec);
     } else {
         hipLaunchKernelGGL(k_msm_finalize, dim3((unsigned)((nvec + 63) / 64)), dim3(64), 0, ctx->stream,
                            d_out48, d_status, d_partials, d_bad, bpv, nvec);

@@ -478,7 +478,7 @@ def test_pinned_caller_memory_is_read_in_place(hip):
     f.restype = C.c_int
     out = C.create_string_buffer(48 * n)
     st = C.create_string_buffer(n)
-    rc = f(out, st, C.c_void_p(t.data_ptr()), C.c_uint64(n), hip.sp)
+    rc = f(out, st, C.cast(t.data_ptr(), C.c_char_p), C.c_uint64(n), hip.sp)
     assert rc == 1 and [i for i, v in enumerate(st.raw) if v] == [650]
     assert all(out.raw[48 * i:48 * i + 48] == single[i % 3] for i in range(n) if i != 650)
     # cells + proofs from pinned memory
@@ -487,7 +487,7 @@ def test_pinned_caller_memory_is_read_in_place(hip):
     m = 70
     cells = C.create_string_buffer(m * 128 * 2048)
     proofs = C.create_string_buffer(m * 128 * 48)
-    assert g(cells, proofs, None, C.c_void_p(t.data_ptr()), C.c_uint64(m), hip.sp) == 0
+    assert g(cells, proofs, None, C.cast(t.data_ptr(), C.c_char_p), C.c_uint64(m), hip.sp) == 0
     exp = hip.compute_cells_and_kzg_proofs(base[2])
     assert cells.raw[2 * 262144:3 * 262144] == b"".join(exp[0]) and proofs.raw[68 * 6144:69 * 6144] == b"".join(exp[1])
     assert rt.hipHostFree(pinned) == 0
