@@ -743,6 +743,35 @@ int cells_and_proofs_device(DeviceCtx *ctx, uint8_t *d_cells, uint8_t *d_proofs,
     uint32_t *d_bad = reinterpret_cast<uint32_t *>(base + poly_b + ext_b);
     uint8_t *fk_base = base + poly_b + ext_b + bad_b;
     HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+    if (n <= 64 && d_cells && d_proofs) {
+        // Latency path (the one-blob call): cells and proofs both hang off the coefficients and share nothing
+        // else, so the three small kernels of the cells run on the slot's second stream underneath the first
+        // kernels of the proof path instead of in front of them.
+        for (int i = 0; i < 2; i++) {
+            if (!ctx->stage_ev[i]) HIP_TRY(hipEventCreateWithFlags(&ctx->stage_ev[i], hipEventDisableTiming));
+        }
+        HIP_TRY(hipMemsetAsync(d_bad, 0, n * 4, ctx->stream));
+        rc = cells_stage_enqueue(ctx, nullptr, d_poly, d_ext, d_bad, d_blobs, n);  // coefficients only
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(ctx->stage_ev[0], ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ctx->stage_ev[0], 0));
+        hipStream_t main_stream = ctx->stream;
+        ctx->stream = ctx->copy_stream;  // the slot is leased exclusively: the launchers below follow ctx->stream
+        rc = zero_extend_batch(ctx, d_ext, d_poly, n, N_BLOB, N_EXT);
+        if (!rc) rc = fr_ntt_batch(ctx, d_ext, n, 13, /*dif=*/true, /*inverse=*/false, /*scale=*/false);
+        if (!rc) rc = fr_to_bytes_batch(ctx, d_cells, d_ext, n * N_EXT);
+        ctx->stream = main_stream;
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(ctx->stage_ev[1], ctx->copy_stream));
+        rc = proofs_stage_enqueue(ctx, d_proofs, d_poly, n, fk_base, direct);
+        if (rc) return rc;
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->stage_ev[1], 0));
+        if (d_status) {
+            rc = bad_to_status_enqueue(ctx, d_status, d_bad, n);
+            if (rc) return rc;
+        }
+        n = 0;  // done: skip the chunk loop below
+    }
     for (size_t off = 0; off < n; off += CH) {
         size_t k = n - off < CH ? n - off : CH;
         HIP_TRY(hipMemsetAsync(d_bad, 0, k * 4, ctx->stream));

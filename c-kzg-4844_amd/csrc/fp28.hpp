@@ -72,6 +72,16 @@ constexpr int pow2_above(int v) {  // smallest power of two > v
 // row-wise and 10.22 ms for this plain form, which wins through its smaller register footprint --
 // 191 instead of 209 VGPRs.  tools/ab_fp28.sh, profiles/r02_fp28_ab.txt.)
 HD void mad64(uint64_t &acc, uint32_t a, uint32_t b) { acc += (uint64_t)a * b; }
+// A zero-instruction fence on the accumulator (device only, opt-in with CKZG_F28_FENCE): the value must exist in
+// a register pair here, so the a*b terms before it and the q*p terms after it cannot be re-associated into two
+// chains that a 64-bit add then joins.
+HD void acc_fence(uint64_t &acc) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(CKZG_F28_FENCE)
+    asm("" : "+v"(acc));
+#else
+    (void)acc;
+#endif
+}
 HD void mad64c(uint64_t &acc, uint32_t a, uint32_t c) { acc += (uint64_t)a * c; }
 
 template <int LA, int VA, int LB, int VB>
@@ -86,6 +96,7 @@ HD F28<1, 2> mul(const F28<LA, VA> &a, const F28<LB, VB> &b) {
     for (int k = 0; k < 14; k++) {
 #pragma unroll
         for (int i = 0; i <= k; i++) mad64(acc, a.l[i], b.l[k - i]);
+        acc_fence(acc);
 #pragma unroll
         for (int i = 0; i < k; i++) mad64c(acc, q[i], FP28_P[k - i]);
         q[k] = ((uint32_t)acc * (uint32_t)FP28_NINV) & M28;
@@ -97,6 +108,7 @@ HD F28<1, 2> mul(const F28<LA, VA> &a, const F28<LB, VB> &b) {
     for (int k = 14; k < 27; k++) {
 #pragma unroll
         for (int i = k - 13; i < 14; i++) mad64(acc, a.l[i], b.l[k - i]);
+        acc_fence(acc);
 #pragma unroll
         for (int i = k - 13; i < 14; i++) mad64c(acc, q[i], FP28_P[k - i]);
         r.l[k - 14] = (uint32_t)acc & M28;
@@ -120,6 +132,7 @@ HD F28<1, 2> mul_add2(const F28<LA, VA> &a, const F28<LB, VB> &b, const F28<LC, 
         for (int i = 0; i <= k; i++) mad64(acc, a.l[i], b.l[k - i]);
 #pragma unroll
         for (int i = 0; i <= k; i++) mad64(acc, c.l[i], d.l[k - i]);
+        acc_fence(acc);
 #pragma unroll
         for (int i = 0; i < k; i++) mad64c(acc, q[i], FP28_P[k - i]);
         q[k] = ((uint32_t)acc * (uint32_t)FP28_NINV) & M28;
@@ -133,6 +146,7 @@ HD F28<1, 2> mul_add2(const F28<LA, VA> &a, const F28<LB, VB> &b, const F28<LC, 
         for (int i = k - 13; i < 14; i++) mad64(acc, a.l[i], b.l[k - i]);
 #pragma unroll
         for (int i = k - 13; i < 14; i++) mad64(acc, c.l[i], d.l[k - i]);
+        acc_fence(acc);
 #pragma unroll
         for (int i = k - 13; i < 14; i++) mad64c(acc, q[i], FP28_P[k - i]);
         r.l[k - 14] = (uint32_t)acc & M28;
@@ -159,6 +173,7 @@ HD F28<1, 2> sqr(const F28<LA, VA> &a) {
 #pragma unroll
         for (int i = 0; 2 * i < k; i++) mad64(acc, a.l[i], d[k - i]);
         if ((k & 1) == 0) mad64(acc, a.l[k / 2], a.l[k / 2]);
+        acc_fence(acc);
 #pragma unroll
         for (int i = 0; i < k; i++) mad64c(acc, q[i], FP28_P[k - i]);
         q[k] = ((uint32_t)acc * (uint32_t)FP28_NINV) & M28;
@@ -171,6 +186,7 @@ HD F28<1, 2> sqr(const F28<LA, VA> &a) {
 #pragma unroll
         for (int i = k - 13; 2 * i < k; i++) mad64(acc, a.l[i], d[k - i]);
         if ((k & 1) == 0) mad64(acc, a.l[k / 2], a.l[k / 2]);
+        acc_fence(acc);
 #pragma unroll
         for (int i = k - 13; i < 14; i++) mad64c(acc, q[i], FP28_P[k - i]);
         r.l[k - 14] = (uint32_t)acc & M28;
