@@ -84,12 +84,27 @@ HD void acc_fence(uint64_t &acc) {
 }
 HD void mad64c(uint64_t &acc, uint32_t a, uint32_t c) { acc += (uint64_t)a * c; }
 
+// CKZG_F28_ASM_BLOCKS (device code of the translation units that define it -- msm.hip): the same three
+// routines with each column's multiply-adds as one inline-asm block per operand group, which keeps the single
+// accumulator chain LLVM otherwise splits (tools/gen_fp28_asm.py explains; fp28_asm_cols.inc is generated).
+#if defined(__HIP_DEVICE_COMPILE__) && defined(CKZG_F28_ASM_BLOCKS)
+#define CKZG_F28_USE_ASM_BLOCKS 1
+#include "fp28_asm_cols.inc"
+#endif
+
 template <int LA, int VA, int LB, int VB>
 HD F28<1, 2> mul(const F28<LA, VA> &a, const F28<LB, VB> &b) {
     // a column holds <= 14 products a_i*b_j (< LA*LB*2^56) + 14 products q*p_j (< 2^56) + the carry-in
     static_assert(14 * LA * LB + 14 + 1 <= 255, "64-bit column accumulator would overflow");
     // result < a*b/2^392 + p; 2^392/p > 2520
     static_assert(VA * VB <= 2500, "Montgomery product would not be < 2p");
+#ifdef CKZG_F28_USE_ASM_BLOCKS
+    {
+        F28<1, 2> ra;
+        f28asm_mul(ra.l, a.l, b.l);
+        return ra;
+    }
+#endif
     uint32_t q[14];
     uint64_t acc = 0;
 #pragma unroll
@@ -124,6 +139,13 @@ template <int LA, int VA, int LB, int VB, int LC, int VC, int LD, int VD>
 HD F28<1, 2> mul_add2(const F28<LA, VA> &a, const F28<LB, VB> &b, const F28<LC, VC> &c, const F28<LD, VD> &d) {
     static_assert(14 * (LA * LB + LC * LD) + 14 + 1 <= 255, "64-bit column accumulator would overflow");
     static_assert(VA * VB + VC * VD <= 2500, "Montgomery result would not be < 2p");
+#ifdef CKZG_F28_USE_ASM_BLOCKS
+    {
+        F28<1, 2> ra;
+        f28asm_mul_add2(ra.l, a.l, b.l, c.l, d.l);
+        return ra;
+    }
+#endif
     uint32_t q[14];
     uint64_t acc = 0;
 #pragma unroll
@@ -167,6 +189,13 @@ HD F28<1, 2> sqr(const F28<LA, VA> &a) {
     uint32_t d[14], q[14];
 #pragma unroll
     for (int j = 0; j < 14; j++) d[j] = a.l[j] << 1;
+#ifdef CKZG_F28_USE_ASM_BLOCKS
+    {
+        F28<1, 2> ra;
+        f28asm_sqr(ra.l, a.l, d);
+        return ra;
+    }
+#endif
     uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < 14; k++) {

@@ -8,7 +8,11 @@ cd "$(dirname "$0")/../c-kzg-4844_amd"
 mkdir -p build_$name
 for f in csrc/ckzg_api.hip csrc/device_ctx.hip csrc/msm.hip csrc/ntt.hip csrc/fk20.hip csrc/verify.hip csrc/pippenger.hip csrc/ckzg_api2.hip; do
   o=build_$name/$(basename $f .hip).o
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-pass-failed "$@" -c $f -o $o &
+  # ONLY=<file stem> restricts the extra flags to that translation unit (e.g. ONLY=msm)
+  # (a space-separated list is accepted: ONLY="msm fk20")
+  stem=$(basename $f .hip)
+  if [ -z "$ONLY" ] || [[ " $ONLY " == *" $stem "* ]]; then extra=("$@"); else extra=(); fi
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-pass-failed "${extra[@]}" -c $f -o $o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--version-script=exports.map -o libckzg_hip_$name.so build_$name/*.o
