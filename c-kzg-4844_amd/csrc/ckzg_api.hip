@@ -310,12 +310,30 @@ static C_KZG_RET commit_batch_on(dev::DeviceCtx *ctx, KZGCommitment *out, uint8_
     // device temporaries from the slot's arena, events kept in the slot: a single-blob call
     // must not pay for hipMalloc/hipFree/hipEventCreate
     Arena &ar = ctx->api_arena;
-    if (!ar.begin(2 * m * BYTES_PER_BLOB + n * 49)) return C_KZG_MALLOC;
+    // One finalize for the whole batch (partial sums of every chunk parked in d_part8) when every chunk of the
+    // schedule splits a blob into at most 8 partial sums; otherwise each chunk finalizes itself.
+    bool deferred = n > FIRST;
+    {
+        uint64_t want = FIRST;
+        for (uint64_t off = 0, k = 0; off < n && deferred; off += k) {
+            k = n - off < want ? n - off : want;
+            want = 3 * want < CH ? 3 * want : CH;
+            deferred = dev::commit_chunk_fits8(ctx, k);
+        }
+    }
+    if (!ar.begin(2 * m * BYTES_PER_BLOB + n * 49 + (deferred ? n * (8 * sizeof(G1XYZZ) + 4) : 0) + 2048)) return C_KZG_MALLOC;
     ArenaTrim trim(ar);
     ABuf<uint8_t> d_blobs[2] = {ABuf<uint8_t>(ar, m * BYTES_PER_BLOB), ABuf<uint8_t>(ar, n > FIRST ? m * BYTES_PER_BLOB : 1)};
     ABuf<uint8_t> d_out(ar, n * 49);  // commitments, then the status bytes
-    if (!d_blobs[0].p || !d_blobs[1].p || !d_out.p) return C_KZG_MALLOC;
+    ABuf<G1XYZZ> d_part8(ar, deferred ? n * 8 : 1);
+    ABuf<uint32_t> d_bad_all(ar, deferred ? n : 1);
+    if (!d_blobs[0].p || !d_blobs[1].p || !d_out.p || !d_part8.p || !d_bad_all.p) return C_KZG_MALLOC;
     uint8_t *d_status = d_out.p + n * 48;
+    if (deferred) {
+        if (hipMemsetAsync(d_part8.p, 0, n * 8 * sizeof(G1XYZZ), ctx->stream) != hipSuccess ||
+            hipMemsetAsync(d_bad_all.p, 0, n * 4, ctx->stream) != hipSuccess)
+            return C_KZG_ERROR;
+    }
     hipEvent_t *copied = ctx->stage_ev, *consumed = ctx->stage_ev + 2;
     C_KZG_RET ret = C_KZG_OK;
     bool pending[2] = {false, false};
@@ -374,13 +392,18 @@ static C_KZG_RET commit_batch_on(dev::DeviceCtx *ctx, KZGCommitment *out, uint8_
             ret = C_KZG_ERROR;
             break;
         }
-        int rc = dev::commit_blobs_enqueue(ctx, d_out.p + off * 48, d_status + off, (const uint8_t *)d_blobs[b].p, k);
+        int rc = deferred ? dev::commit_accumulate8_enqueue(ctx, d_part8.p + off * 8, d_bad_all.p + off, (const uint8_t *)d_blobs[b].p, k)
+                          : dev::commit_blobs_enqueue(ctx, d_out.p + off * 48, d_status + off, (const uint8_t *)d_blobs[b].p, k);
         if (rc) {
-            ret = (C_KZG_RET)rc;
+            ret = rc == 4 ? C_KZG_ERROR : (C_KZG_RET)rc;
             break;
         }
         if (hipEventRecord(consumed[b], ctx->stream) != hipSuccess) ret = C_KZG_ERROR;
         pending[b] = true;
+    }
+    if (deferred && ret == C_KZG_OK) {
+        int rc = dev::commit_finalize8_enqueue(ctx, d_out.p, d_status, d_part8.p, d_bad_all.p, n);
+        if (rc) ret = (C_KZG_RET)rc;
     }
     tr.mark("staging loop (copies + enqueues)");
     if (hipStreamSynchronize(ctx->copy_stream) != hipSuccess) ret = ret == C_KZG_OK ? C_KZG_ERROR : ret;

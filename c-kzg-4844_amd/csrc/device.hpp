@@ -133,6 +133,12 @@ size_t commit_scratch_bytes(const DeviceCtx *ctx, size_t n);
 int commit_blobs_enqueue(DeviceCtx *ctx, uint8_t *d_out48, uint8_t *d_status, const uint8_t *d_blobs,
                          size_t n);
 
+// the pipelined host-pointer form: accumulate per chunk into d_part8[blob][8], one finalize for the batch
+int commit_accumulate8_enqueue(DeviceCtx *ctx, G1XYZZ *d_part8, uint32_t *d_bad, const uint8_t *d_blobs, size_t k);
+bool commit_chunk_fits8(const DeviceCtx *ctx, size_t k);
+int commit_finalize8_enqueue(DeviceCtx *ctx, uint8_t *d_out48, uint8_t *d_status, const G1XYZZ *d_part8,
+                             const uint32_t *d_bad, size_t n);
+
 // Generic: sum_i scalar_i * P_i over the ctx->commit table for n independent scalar vectors that
 // are already canonical little-endian 8xu32 integers in HBM ([n][4096][8]); writes n compressed
 // points.  Used by compute_kzg_proof (quotient polynomial) and friends.

@@ -260,7 +260,7 @@ template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_msm_accumulate(
     G1XYZZ *partials, const G1Affine *table, const int16_t *digits, uint32_t pairs_per_vec,
     uint32_t pairs_per_block, int half_shift, uint32_t blocks_per_vec, uint32_t ppv,
-    uint32_t npoints, uint32_t vecs_per_group) {
+    uint32_t npoints, uint32_t vecs_per_group, uint32_t part_stride) {
     __shared__ uint32_t sh[57][THREADS / 2];
     const uint32_t vec = blockIdx.x / blocks_per_vec, chunk = blockIdx.x % blocks_per_vec;
     const uint32_t q0 = chunk * pairs_per_block;
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(THREADS) void k_msm_accumulate(
     if (phi_pending && !inf) msm_apply_phi(acc28);
     xyzz28_fix_sign(acc28, inf, yneg);
     block_reduce_xyzz28<THREADS>(acc28, inf, sh);
-    if (threadIdx.x == 0) partials[blockIdx.x] = xyzz28_to_xyzz(acc28, inf);
+    if (threadIdx.x == 0) partials[(size_t)vec * part_stride + chunk] = xyzz28_to_xyzz(acc28, inf);
 }
 
 // Many small MSMs (FK20: 128 vectors of 64 points per blob).  A 64-lane workgroup serves 64/LPV
@@ -470,7 +470,7 @@ static int run_msm(DeviceCtx *ctx, const FixedBaseTable &t, uint8_t *d_out48, ui
     HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
     hipLaunchKernelGGL(k_msm_accumulate<256>, dim3((unsigned)(nvec * bpv)), dim3(256), 0, ctx->stream,
                        d_partials, t.d_table, d_digits, pairs_per_vec, ppb, t.wbits - 1, bpv,
-                       (uint32_t)t.npoints, (uint32_t)t.npoints, 1u);
+                       (uint32_t)t.npoints, (uint32_t)t.npoints, 1u, bpv);
     HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
     if (bpv > 8) {
         // partials[nvec*bpv ..] is free: run_msm callers size d_partials for nvec*bpv + nvec
@@ -582,6 +582,52 @@ int commit_blobs_enqueue(DeviceCtx *ctx, uint8_t *d_out48, uint8_t *d_status, co
     hipLaunchKernelGGL(k_blob_digits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
                        d_digits, d_bad, d_blobs, total, t.wbits, t.twin);
     return run_msm(ctx, t, d_out48, d_status, d_digits, d_bad, d_partials, n, ppb);
+}
+
+// The host-pointer pipeline's form: only recoding + accumulation for a chunk of k blobs, partial sums left in
+// d_part8[blob][8] (unused slots stay all-zero = infinity; the caller zeroed the array) and the per-blob flags in
+// d_bad; ONE commit_finalize8_enqueue over the whole batch follows the last chunk.  A finalize per chunk would put
+// a latency-bound launch (~0.2 ms, one lane per blob) between the accumulations of consecutive chunks.
+// Returns 4 if this chunk size splits a blob into more than 8 partial sums (callers then use the plain form).
+int commit_accumulate8_enqueue(DeviceCtx *ctx, G1XYZZ *d_part8, uint32_t *d_bad, const uint8_t *d_blobs, size_t k) {
+    if (k == 0) return 0;
+    const FixedBaseTable &t = ctx->commit;
+    if (!t.d_table) return 2;
+    uint32_t pairs_per_vec = (uint32_t)t.nwin * t.npoints;
+    uint32_t ppb = pick_pairs_per_block(k, pairs_per_vec);
+    uint32_t bpv = (pairs_per_vec + ppb - 1) / ppb;
+    if (bpv > 8) return 4;
+    size_t dig_bytes = align_up(k * (size_t)pairs_per_vec * sizeof(int16_t), 256);
+    if (ctx->scratch.cap < dig_bytes) return 2;
+    int16_t *d_digits = reinterpret_cast<int16_t *>(ctx->scratch.ptr);
+    size_t total = k * N_BLOB;
+    hipLaunchKernelGGL(k_blob_digits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       d_digits, d_bad, d_blobs, total, t.wbits, t.twin);
+    hipLaunchKernelGGL(k_msm_accumulate<256>, dim3((unsigned)(k * bpv)), dim3(256), 0, ctx->stream,
+                       d_part8, t.d_table, d_digits, pairs_per_vec, ppb, t.wbits - 1, bpv,
+                       (uint32_t)t.npoints, (uint32_t)t.npoints, 1u, 8u);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+bool commit_chunk_fits8(const DeviceCtx *ctx, size_t k) {
+    const FixedBaseTable &t = ctx->commit;
+    uint32_t pairs_per_vec = (uint32_t)t.nwin * t.npoints;
+    uint32_t ppb = pick_pairs_per_block(k, pairs_per_vec);
+    return (pairs_per_vec + ppb - 1) / ppb <= 8;
+}
+
+int commit_finalize8_enqueue(DeviceCtx *ctx, uint8_t *d_out48, uint8_t *d_status, const G1XYZZ *d_part8,
+                             const uint32_t *d_bad, size_t n) {
+    if (n == 0) return 0;
+    if (n <= 4096)
+        hipLaunchKernelGGL(k_msm_finalize_tree<8>, dim3((unsigned)((n + 7) / 8)), dim3(64), 0, ctx->stream, d_out48, d_status,
+                           d_part8, d_bad, 8u, n);
+    else
+        hipLaunchKernelGGL(k_msm_finalize, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, d_out48, d_status,
+                           d_part8, d_bad, 8u, n);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 int commit_blobs_device(DeviceCtx *ctx, uint8_t *d_out48, uint8_t *d_status, const uint8_t *d_blobs,
