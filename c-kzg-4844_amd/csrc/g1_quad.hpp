@@ -152,6 +152,91 @@ __device__ __noinline__ void xyzz28_mul_w4_128_quad(XYZZ28 &out, bool &out_inf, 
     out_inf = inf;
 }
 
+// a <- a + b in XYZZ coordinates (add-2008-s), both operands general: four product steps instead of fourteen
+// products.  Quad form of xyzz28_add; ainf / binf are the (replicated) infinity flags.
+__device__ __forceinline__ void xyzz28_add_quad(XYZZ28 &a, bool &ainf, const XYZZ28 &b, bool binf, int ql) {
+    if (binf) return;
+    if (ainf) {
+        a = b;
+        ainf = false;
+        return;
+    }
+    // step 1: X1*ZZ2 | X2*ZZ1 | Y1*ZZZ2 | Y2*ZZZ1
+    const auto p1 = mul(qsel(ql, a.x, b.x, widen<1, 10>(a.y), widen<1, 10>(b.y)), qsel(ql, b.zz, a.zz, b.zzz, a.zzz));  // 14+15 ok; 20 ok
+    const auto u1 = qread<0>(p1), u2 = qread<1>(p1), s1 = qread<2>(p1), s2 = qread<3>(p1);
+    const auto p = sub(u2, u1);   // <4,6>
+    const auto r = sub(s2, s1);   // <4,6>
+    // step 2: P*P | ZZ1*ZZ2 | ZZZ1*ZZZ2 | R*R
+    const auto zz1 = widen<4, 6>(a.zz), zz2 = widen<4, 6>(b.zz), zzz1 = widen<4, 6>(a.zzz), zzz2 = widen<4, 6>(b.zzz);
+    const auto p2 = mul(qsel(ql, p, zz1, zzz1, r), qsel(ql, p, zz2, zzz2, r));   // 14*16+15 = 239 ok; 36 ok
+    const auto pp = qread<0>(p2), zzab = qread<1>(p2), zzzab = qread<2>(p2), rr = qread<3>(p2);
+    if (is_zero(pp)) {  // same x: the complete one-lane routine, on every copy
+        xyzz28_add(a, ainf, b, binf);
+        return;
+    }
+    // step 3: P*PP | U1*PP | ZZ1ZZ2*PP
+    const auto p3 = mul(qsel(ql, p, widen<4, 6>(u1), widen<4, 6>(zzab), p), pp);   // 14*4+15 ok; 12 ok
+    const auto ppp = qread<0>(p3), q = qread<1>(p3), zz3 = qread<2>(p3);
+    const auto x3 = norm(sub(rr, add(ppp, add(q, q))));   // <6,10> -> <1,10>
+    const auto d = sub(q, x3);                            // <4,18>
+    F28<1, 0> zero;
+#pragma unroll
+    for (int j = 0; j < 14; j++) zero.l[j] = 0;
+    const auto s1n = sub(zero, s1);                       // <4,4> = -S1
+    // step 4: R*(Q - X3) | (-S1)*PPP | ZZZ1ZZZ2*PPP ; Y3 is the sum of the first two
+    const auto rn = widen<4, 6>(norm(r)), sn = widen<4, 6>(s1n), zn = widen<4, 6>(zzzab);
+    const auto ppp18 = widen<4, 18>(ppp);
+    const auto p4 = mul(qsel(ql, rn, sn, zn, rn), qsel(ql, d, ppp18, ppp18, d));   // 239 ok; 108 ok
+    const auto y3 = norm(add(qread<0>(p4), qread<1>(p4)));   // <2,4> -> <1,4>
+    a.x = x3;
+    a.y = widen<1, 6>(y3);
+    a.zz = zz3;
+    a.zzz = qread<2>(p4);
+}
+
+// Fold the THREADS per-thread accumulators of a workgroup into thread 0 with the quad addition: every pair of a
+// level is added by one quad (four product steps instead of a lane's fourteen products), so a level of the
+// 256-thread tree costs ~1/3 of the one-lane fold and the tail of an accumulate workgroup -- when its SIMDs are
+// nearly empty -- shrinks accordingly.  LDS is limb-major ([56 limbs + flag][THREADS] u32).
+template <int THREADS>
+__device__ __forceinline__ void block_reduce_xyzz28_quad(XYZZ28 &acc, bool &inf, uint32_t (*sh)[THREADS]) {
+    const int tid = threadIdx.x, ql = tid & 3, quad_id = tid >> 2;
+    constexpr int QUADS = THREADS / 4;
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(&acc);
+#pragma unroll
+        for (int k = 0; k < 56; k++) sh[k][tid] = src[k];
+        sh[56][tid] = inf ? 1u : 0u;
+    }
+    __syncthreads();
+    for (int s = THREADS / 2; s >= 1; s >>= 1) {
+        for (int pr = quad_id; pr < s; pr += QUADS) {
+            XYZZ28 x, y;
+            uint32_t *dx = reinterpret_cast<uint32_t *>(&x), *dy = reinterpret_cast<uint32_t *>(&y);
+#pragma unroll
+            for (int k = 0; k < 56; k++) {
+                dx[k] = sh[k][pr];
+                dy[k] = sh[k][pr + s];
+            }
+            bool xi = sh[56][pr] != 0;
+            const bool yi = sh[56][pr + s] != 0;
+            xyzz28_add_quad(x, xi, y, yi, ql);
+            if (ql == 0) {
+#pragma unroll
+                for (int k = 0; k < 56; k++) sh[k][pr] = dx[k];
+                sh[56][pr] = xi ? 1u : 0u;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        uint32_t *dst = reinterpret_cast<uint32_t *>(&acc);
+#pragma unroll
+        for (int k = 0; k < 56; k++) dst[k] = sh[k][0];
+        inf = sh[56][0] != 0;
+    }
+}
+
 // [|x|]P for the BLS parameter (63 doublings, 5 additions): quad form of jac28_mul_bls_x
 __device__ __forceinline__ void jac28_mul_bls_x_quad(JAC28 &out, bool &out_inf, const JAC28 &p, bool p_inf, int ql) {
     JAC28 acc = p;
