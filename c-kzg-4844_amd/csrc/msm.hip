@@ -249,6 +249,78 @@ __device__ __forceinline__ void msm_apply_phi(XYZZ28 &acc28) {
     acc28.x = widen<1, 10>(mul(acc28.x, f28_const<1, 1>(FP28_BETA_LAMBDA)));
 }
 
+// One lane's share of a fixed-base sum: pairs q = first, first + STRIDE, ... < q1 of one vector (q = w*ppv + i;
+// pairs below phi_pairs = twin*ppv belong to the k2 half, so the accumulator goes through phi once, when the lane
+// crosses that boundary or at the end if it never does).
+// Software pipeline: in the iteration that adds pair q the table entry of pair q + STRIDE and the digit of pair
+// q + 2 STRIDE are already requested, so a wave never waits for its own gather (first iteration: nothing to add,
+// it only fills the pipeline).  e[] is written only by the copies at the END of an iteration: that is where the
+// compiler's s_waitcnt vmcnt(0) lands (tools/isa_waits.py) -- a first version that loaded e[] in a prologue got the
+// wait in FRONT of the addition, because vmcnt counts in order, and measured slower than no prefetch at all.
+// Same-box A/B on the headline kernel: 9.76 -> 9.50 ms per 1024 blobs (profiles/r02_fp28_ab.txt).
+template <int STRIDE>
+__device__ __forceinline__ void msm_sum_pairs(XYZZ28 &acc28, bool &inf, bool &yneg, const G1Affine *table,
+                                              const int16_t *dg, uint32_t first, uint32_t q1, uint32_t phi_pairs,
+                                              uint32_t twin, uint32_t ppv, uint32_t npoints, uint32_t voff,
+                                              int half_shift) {
+    bool phi_pending = first < phi_pairs;
+#ifndef CKZG_MSM_NO_PREFETCH
+    uint32_t qn = first;
+    int d = 0, d1 = qn < q1 ? dg[qn] : 0;
+    uint4 e[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) e[k] = make_uint4(0, 0, 0, 0);
+    for (; qn < q1 + STRIDE; qn += STRIDE) {
+        uint4 nx[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) nx[k] = make_uint4(0, 0, 0, 0);
+        if (d1 != 0) {
+            uint32_t w = qn / ppv, i = qn - w * ppv;
+            uint32_t tw = w >= twin ? w - twin : w;
+            uint32_t mag = (uint32_t)(d1 < 0 ? -d1 : d1);
+            const uint4 *src = reinterpret_cast<const uint4 *>(
+                table + ((((size_t)tw * npoints + voff + i) << half_shift) + (mag - 1)));
+#pragma unroll
+            for (int k = 0; k < 6; k++) nx[k] = src[k];
+        }
+        int d2 = qn + STRIDE < q1 ? dg[qn + STRIDE] : 0;
+        if (phi_pending && qn >= phi_pairs + STRIDE) {
+            if (!inf) msm_apply_phi(acc28);
+            phi_pending = false;
+        }
+        if (d != 0) {
+            uint32_t wd[24];
+            uint32_t any = 0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                wd[4 * k] = e[k].x; wd[4 * k + 1] = e[k].y; wd[4 * k + 2] = e[k].z; wd[4 * k + 3] = e[k].w;
+                any |= e[k].x | e[k].y | e[k].z | e[k].w;
+            }
+            // (0,0) encodes a table entry at infinity
+            if (any != 0) xyzz28_madd_alt(acc28, inf, yneg, f28_unpack<1>(wd), f28_unpack<1>(wd + 12), d < 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) e[k] = nx[k];
+        d = d1;
+        d1 = d2;
+    }
+#else
+    for (uint32_t q = first; q < q1; q += STRIDE) {
+        if (phi_pending && q >= phi_pairs) {
+            if (!inf) msm_apply_phi(acc28);
+            phi_pending = false;
+        }
+        int d = dg[q];
+        if (d != 0) {
+            uint32_t w = q / ppv, i = q - w * ppv;
+            uint32_t tw = w >= twin ? w - twin : w;
+            msm_term(acc28, inf, yneg, table, (size_t)tw * npoints + voff + i, half_shift, d);
+        }
+    }
+#endif
+    if (phi_pending && !inf) msm_apply_phi(acc28);
+}
+
 // grid: nvec * blocks_per_vec workgroups.  A "vector" is one MSM: ppv (points per vector) scalars
 // recoded to digits[vec][w][i], i < ppv, w < nwin = 2*twin.  Its bases are points voff..voff+ppv of a
 // table over npoints bases, voff = (vec % vecs_per_group) * ppv  (commitment: ppv = npoints = 4096,
@@ -276,24 +348,10 @@ __global__ __launch_bounds__(THREADS) void k_msm_accumulate(
     // accumulator in the 28-bit-limb / 2^392 domain (fp28.hpp), infinity tracked by a flag
     XYZZ28 acc28;
     bool inf = true, yneg = false;  // yneg: acc28.y currently holds -Y (xyzz28_madd_alt)
-    bool phi_pending = q0 + threadIdx.x < phi_pairs;
-    // (Measured alternatives: requesting the next entry before the current addition -- 10.45 ms vs
-    // 10.32 ms, the second wave of the SIMD already hides the gather; unrolling by two -- 14.4 ms,
-    // two copies of the ~40 KB addition body thrash the instruction cache; capping VGPRs for 3 or
-    // 4 waves per SIMD -- 11.4 / 13.2 ms.)
-    for (uint32_t q = q0 + threadIdx.x; q < q1; q += THREADS) {
-        if (phi_pending && q >= phi_pairs) {
-            if (!inf) msm_apply_phi(acc28);
-            phi_pending = false;
-        }
-        int d = dg[q];
-        if (d != 0) {
-            uint32_t w = q / ppv, i = q - w * ppv;
-            uint32_t tw = w >= twin ? w - twin : w;
-            msm_term(acc28, inf, yneg, table, (size_t)tw * npoints + voff + i, half_shift, d);
-        }
-    }
-    if (phi_pending && !inf) msm_apply_phi(acc28);
+    // (Measured alternatives: unrolling by two -- 14.4 ms, two copies of the ~40 KB addition body thrash the
+    // instruction cache; capping VGPRs for 3 or 4 waves per SIMD -- 11.4 / 13.2 ms.)
+    msm_sum_pairs<THREADS>(acc28, inf, yneg, table, dg, q0 + threadIdx.x, q1, phi_pairs, twin, ppv, npoints, voff,
+                           half_shift);
     xyzz28_fix_sign(acc28, inf, yneg);
 #ifndef CKZG_NO_QUAD_TREE
     quad::block_reduce_xyzz28_quad<THREADS>(acc28, inf, sh);   // four lanes per pair: the fold is ~3x shorter
@@ -321,20 +379,8 @@ __global__ __launch_bounds__(64) void k_msm_small(G1XYZZ *out, const G1Affine *t
     if (vec < nvec) {
         const uint32_t voff = (vec % vecs_per_group) * ppv;
         const int16_t *dg = digits + (size_t)vec * pairs_per_vec;
-        bool phi_pending = (uint32_t)l < phi_pairs;
-        for (uint32_t q = l; q < pairs_per_vec; q += LPV) {
-            if (phi_pending && q >= phi_pairs) {
-                if (!inf) msm_apply_phi(acc28);
-                phi_pending = false;
-            }
-            int d = dg[q];
-            if (d != 0) {
-                uint32_t w = q / ppv, i = q - w * ppv;
-                uint32_t tw = w >= twin ? w - twin : w;
-                msm_term(acc28, inf, yneg, table, (size_t)tw * npoints + voff + i, half_shift, d);
-            }
-        }
-        if (phi_pending && !inf) msm_apply_phi(acc28);
+        msm_sum_pairs<LPV>(acc28, inf, yneg, table, dg, (uint32_t)l, pairs_per_vec, phi_pairs, twin, ppv, npoints,
+                           voff, half_shift);
     }
     xyzz28_fix_sign(acc28, inf, yneg);
     for (int s = LPV / 2; s >= 1; s >>= 1) {
@@ -452,7 +498,13 @@ static uint32_t pick_pairs_per_block(size_t nvec, uint32_t pairs_per_vec) {
         return v && *v ? atol(v) : 0L;
     }();
     if (forced >= 256) return (uint32_t)forced;
-    const double ADD = 3542.0, TREE = 8 * 5110.0 * 0.5;  // the tree overlaps with the CU's other workgroup
+    // the fold: 9 passes of a four-step quad addition (g1_quad.hpp), ~400 multiply-adds a step; it overlaps with
+    // the CU's other workgroup.  CKZG_HIP_TREE_COST overrides it for A/B runs (the one-lane tree was 20440).
+    static const double TREE = []() {
+        const char *v = getenv("CKZG_HIP_TREE_COST");
+        return v && *v ? atof(v) : 9 * 4 * 400.0 * 0.5;
+    }();
+    const double ADD = 3542.0;
     const size_t resident = 512;
     uint32_t best_ppb = pairs_per_vec;
     double best = 1e300;
