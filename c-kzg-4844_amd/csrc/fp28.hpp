@@ -357,6 +357,21 @@ HD F28<LA + LB + 2, VA + f28detail::pow2_above(VB)> sub(const F28<LA, VA> &a, co
     return r;
 }
 
+// The same with the multiple K of p chosen by the caller (any K > VB): a tighter value bound than the
+// power of two when the result feeds a squaring.
+template <int K, int LA, int VA, int LB, int VB>
+HD F28<LA + LB + 2, VA + K> sub_k(const F28<LA, VA> &a, const F28<LB, VB> &b) {
+    constexpr int C = LB + 1;
+    static_assert(LA + LB + 2 <= 15, "limb would overflow 32 bits");
+    static_assert(K > VB && K <= 64, "value bound out of range");
+    constexpr f28detail::Limbs14 m = f28detail::spread_multiple(K, C);
+    static_assert((uint64_t)(K - VB) * (FP28_P[13]) > (uint64_t)C + (uint64_t)VB + 2, "top limb could go negative");
+    F28<LA + LB + 2, VA + K> r;
+#pragma unroll
+    for (int j = 0; j < 14; j++) r.l[j] = a.l[j] + m.v[j] - b.l[j];
+    return r;
+}
+
 // carry-propagate: limbs back below 2^28 (the value, hence the top limb, is bounded by VB)
 template <int LA, int VA>
 HD F28<1, VA> norm(const F28<LA, VA> &a) {

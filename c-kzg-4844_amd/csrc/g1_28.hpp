@@ -630,11 +630,207 @@ HD void jac28_add(JAC28 &a, bool &ainf, const JACT28 &b) {
     a.z = widen<2, 4>(z3);
 }
 
+// ---- the NAF ladder's "effectively affine" table (one-lane form of the G1 FFT twiddle multiplication) ----
+// P, 3P, 5P, 7P are built with co-Z arithmetic (Meloni; Longa-Miri): a co-Z addition of two points that share Z
+// returns the sum AND its first operand over the sum's new Z, and any other point over the old Z follows for two
+// multiplications (X * dX^2, Y * dX^3, both factors are by-products of the addition).  With all four multiples
+// over one Zc, the map (X, Y, Z) -> (X, Y, Z/Zc) is an isomorphism onto the curve y^2 = x^3 + 4 Zc^6, on which
+// the table is AFFINE; doubling and addition for a = 0 never use the constant term, so the whole ladder runs
+// there with mixed additions (3S + 6M + one two-product reduction, 10.5 products instead of 14 + 1 for phi)
+// and the result comes home by one multiplication of Z with Zc.  Table: 37 + 6 products instead of 61.
+struct JE28 {        // accumulator on the isomorphic curve (Jacobian)
+    F28<1, 20> x, y;
+    F28<2, 4> z;
+};
+struct EAT28 {       // table entry: x, beta*x (the phi image), y
+    F28<1, 20> x, bx, y;
+};
+
+// dbl-2009-l for a = 0, as jac28_dbl, with the tighter subtraction constants the mixed addition's squarings need
+HD void je28_dbl(JE28 &a) {
+    auto A = sqr(a.x);                          // 20^2 = 400 ok
+    auto B = sqr(a.y);
+    auto C = sqr(B);
+    auto XB = mul(a.x, B);
+    auto XB2 = add(XB, XB);
+    auto D = add(XB2, XB2);                     // <4,8>
+    auto E = add(add(A, A), A);                 // <3,6>
+    auto F = sqr(E);
+    auto X3 = norm(sub_k<17>(F, add(D, D)));    // <1,2> - <8,16> -> <11,19> -> <1,19>
+    auto dx = norm(sub_k<20>(D, X3));           // <7,28> -> <1,28>
+    auto C2 = add(C, C);
+    auto C4 = add(C2, C2);
+    auto C8 = add(C4, C4);                      // <8,16>
+    auto Y3 = norm(sub_k<17>(mul(E, dx), C8));  // mul: 14*3+15, 6*28 ok; -> <1,19>
+    auto YZ = mul(a.y, a.z);                    // 14*2+15 ok, 20*4 ok
+    a.x = widen<1, 20>(X3);
+    a.y = widen<1, 20>(Y3);
+    a.z = add(YZ, YZ);
+}
+
+// a += (x2, neg ? -y2 : y2), the point affine on the curve a lives on; complete
+HD void je28_madd(JE28 &a, bool &ainf, const F28<1, 20> &x2, const F28<1, 20> &y2in, bool neg) {
+    F28<1, 0> zero;
+#pragma unroll
+    for (int j = 0; j < 14; j++) zero.l[j] = 0;
+    F28<1, 41> y2;
+    {
+        auto ny = norm(sub_k<21>(zero, y2in));   // <3,21> -> <1,21>
+#pragma unroll
+        for (int j = 0; j < 14; j++) y2.l[j] = neg ? ny.l[j] : y2in.l[j];
+    }
+    if (ainf) {
+        a.x = x2;
+        a.y = widen<1, 20>(mul(y2, f28_one()));
+        a.z = widen<2, 4>(f28_one());
+        ainf = false;
+        return;
+    }
+    auto z1z1 = sqr(a.z);
+    auto u2 = mul(x2, z1z1);
+    auto s2 = mul(y2, mul(a.z, z1z1));          // 41*2 ok
+    auto h = sub_k<21>(u2, a.x);                // <4,23>
+    auto r = sub_k<21>(s2, a.y);                // <4,23>
+    auto hh = sqr(h);                           // 15*16+15 = 255 ok, 529 ok
+    if (is_zero(hh)) {
+        if (is_zero(mul(r, f28_one()))) {
+            a.x = x2;                           // acc == the table point: double it
+            a.y = widen<1, 20>(mul(y2, f28_one()));
+            a.z = widen<2, 4>(f28_one());
+            je28_dbl(a);
+        } else {
+            ainf = true;
+        }
+        return;
+    }
+    auto hhh = mul(h, hh);
+    auto v = mul(a.x, hh);
+    auto rr = sqr(r);
+    auto x3 = norm(sub(rr, add(hhh, add(v, v))));   // <1,2> - <3,6> -> <6,10> -> <1,10>
+    auto dv = sub(v, x3);                           // <4,18>
+    auto s1n = sub_k<21>(zero, a.y);                // <3,21>
+    // r*dv - Y1*hhh with one reduction: limbs 14*(1*4 + 3*1)+15 ok; values 23*18 + 21*2 ok
+    auto y3 = mul_add2(norm(r), dv, s1n, hhh);
+    auto z3 = mul(a.z, h);                          // 14*8+15 ok, 4*23 ok
+    a.x = widen<1, 20>(x3);
+    a.y = widen<1, 20>(y3);
+    a.z = widen<2, 4>(z3);
+}
+
+// One co-Z addition (X1,Y1) + (X2,Y2), both over the same Z: returns the sum in (x3, y3), replaces (X1,Y1) by
+// the same point over the new Z3 = Z * dX and (X2,Y2) likewise; c = dX^2 and w = dX^3 rescale any further point.
+struct CoZ28 {
+    F28<1, 20> x, y;
+};
+HD void coz28_addu(CoZ28 &sum, CoZ28 &p1, CoZ28 &p2, F28<1, 2> &z, F28<1, 2> &c, F28<4, 6> &w) {
+    auto dX = sub_k<21>(p2.x, p1.x);                // <4,41>
+    auto dY = sub_k<21>(p2.y, p1.y);
+    c = sqr(dX);                                    // 15*16+15 ok, 41^2 = 1681 ok
+    auto W1 = mul(p1.x, c);
+    auto W2 = mul(p2.x, c);
+    auto D = sqr(dY);
+    w = sub(W2, W1);                                // <4,6>  = dX^3
+    auto A1 = mul(p1.y, w);                         // 14*4+15 ok, 120 ok
+    auto A2 = mul(p2.y, w);
+    auto X3 = norm(sub(D, add(W1, W2)));            // <1,2> - <2,4> -> <5,10> -> <1,10>
+    auto Y3 = norm(sub(mul(dY, sub(W1, X3)), A1));  // inner sub <4,18>: 14*16+15 ok, 41*18 ok; -> <4,6> -> <1,6>
+    z = mul(z, dX);                                 // 14*4+15 ok, 82 ok
+    sum.x = widen<1, 20>(X3);
+    sum.y = widen<1, 20>(Y3);
+    p1.x = widen<1, 20>(W1);
+    p1.y = widen<1, 20>(A1);
+    p2.x = widen<1, 20>(W2);
+    p2.y = widen<1, 20>(A2);
+}
+HD void coz28_rescale(CoZ28 &q, const F28<1, 2> &c, const F28<4, 6> &w) {
+    q.x = widen<1, 20>(mul(q.x, c));
+    q.y = widen<1, 20>(mul(q.y, w));
+}
+
+// tbl[m] = (2m+1)P for a finite P of the prime-order subgroup (so no step is exceptional), zc = the common Z
+HDNI inline void eat28_build(EAT28 (&tbl)[4], F28<1, 2> &zc, const XYZZ28 &p) {
+    // P as a Jacobian triple: (X, Y, Z) = (x*zz, y*zzz, zz)
+    auto X1 = mul(p.x, p.zz);
+    auto Y1 = mul(p.y, p.zzz);
+    // doubling that also returns P over 2P's Z2 = 2 Y1 Z1:  P = (4 X1 Y1^2, 8 Y1^4, Z2)
+    auto A = sqr(X1);
+    auto B = sqr(Y1);
+    auto C = sqr(B);
+    auto XB = mul(X1, B);
+    auto XB2 = add(XB, XB);
+    auto D = add(XB2, XB2);                         // <4,8>
+    auto E = add(add(A, A), A);                     // <3,6>
+    auto F = sqr(E);
+    auto X2 = norm(sub_k<17>(F, add(D, D)));        // <1,19>
+    auto dx = norm(sub_k<20>(D, X2));               // <1,28>
+    auto C2 = add(C, C);
+    auto C4 = add(C2, C2);
+    auto C8 = add(C4, C4);                          // <8,16>
+    auto Y2 = norm(sub_k<17>(mul(E, dx), C8));      // <1,19>
+    auto YZ = mul(Y1, p.zz);
+    F28<1, 2> z = mul(add(YZ, YZ), f28_one());      // Z2, back under <1,2>
+    CoZ28 t1, t2, t3, t5, t7;
+    t1.x = widen<1, 20>(norm(D));
+    t1.y = widen<1, 20>(norm(C8));
+    t2.x = widen<1, 20>(X2);
+    t2.y = widen<1, 20>(Y2);
+    F28<1, 2> c;
+    F28<4, 6> w;
+    coz28_addu(t3, t2, t1, z, c, w);                // 3P = 2P + P; 2P and P follow
+    coz28_addu(t5, t2, t3, z, c, w);                // 5P = 2P + 3P
+    coz28_rescale(t1, c, w);
+    coz28_addu(t7, t2, t5, z, c, w);                // 7P = 2P + 5P
+    coz28_rescale(t1, c, w);
+    coz28_rescale(t3, c, w);
+    const F28<1, 1> beta = f28_const<1, 1>(FP28_BETA_LAMBDA);
+    const CoZ28 *src[4] = {&t1, &t3, &t5, &t7};
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        tbl[m].x = src[m]->x;
+        tbl[m].y = src[m]->y;
+        tbl[m].bx = widen<1, 20>(mul(src[m]->x, beta));
+    }
+    zc = z;
+}
+
 // [k]P = [k1]P + [k2]phi(P) with both halves given in width-4 NAF (wnaf4_128): 131 doublings at most
-// and ~52 additions from the table {+-P, +-3P, +-5P, +-7P} (phi applied on the fly), in Jacobian
-// coordinates.  The schedule depends on the digits, so it is meant for callers whose lanes share the
+// and ~52 mixed additions from the effectively affine table {P, 3P, 5P, 7P} (x, beta*x, y; signs on the fly).
+// The schedule depends on the digits, so it is meant for callers whose lanes share the
 // scalar: the G1 FFT stage kernels, where a wave works on one twiddle.  Only for points of the
 // prime-order subgroup.
+#ifndef CKZG_NAF_JACOBIAN_TABLE
+HDNI inline void xyzz28_mul_glv_naf(XYZZ28 &out, bool &out_inf, const XYZZ28 &p, bool p_inf, const int8_t *naf1,
+                                    const int8_t *naf2) {
+    bool inf = true;
+    if (!p_inf) {
+        EAT28 tbl[4];
+        F28<1, 2> zc;
+        eat28_build(tbl, zc, p);
+        JE28 acc;
+        for (int i = GLV_NAF_LEN - 1; i >= 0; i--) {
+            if (!inf) je28_dbl(acc);
+            const int d1 = naf1[i], d2 = naf2[i];
+            if (d1) {
+                const EAT28 &e = tbl[(d1 > 0 ? d1 : -d1) >> 1];
+                je28_madd(acc, inf, e.x, e.y, d1 < 0);
+            }
+            if (d2) {
+                const EAT28 &e = tbl[(d2 > 0 ? d2 : -d2) >> 1];
+                je28_madd(acc, inf, e.bx, e.y, d2 < 0);
+            }
+        }
+        if (!inf) {
+            JAC28 j;                                  // home: Z * Zc
+            j.x = widen<1, 34>(acc.x);
+            j.y = widen<1, 34>(acc.y);
+            j.z = widen<2, 4>(mul(acc.z, zc));
+            out = jac28_to_xyzz(j);
+        }
+    }
+    out_inf = inf;
+}
+#else
+// (A/B builds: the table in Jacobian form, additions with cached Z^2, Z^3, phi applied per addition)
 HDNI inline void xyzz28_mul_glv_naf(XYZZ28 &out, bool &out_inf, const XYZZ28 &p, bool p_inf, const int8_t *naf1,
                                     const int8_t *naf2) {
     JACT28 tbl[8];  // [2m] = (2m+1)P, [2m+1] = -(2m+1)P
@@ -666,6 +862,8 @@ HDNI inline void xyzz28_mul_glv_naf(XYZZ28 &out, bool &out_inf, const XYZZ28 &p,
     if (!inf) out = jac28_to_xyzz(acc);
     out_inf = inf;
 }
+
+#endif
 
 // [k]P = [k1]P + [k2]phi(P), phi(X, Y, Z) = (beta*X, Y, Z) = [lambda]P for P in G1, for lanes with
 // DIFFERENT scalars: a uniform 4-bit window schedule (4 doublings, then one table addition per half) so

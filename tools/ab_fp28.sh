@@ -13,6 +13,6 @@ print('commit', d['value'], d['roofline']['kernel_ms'], d['roofline_valu']['frac
   CKZG_HIP_SO=c-kzg-4844_amd/libckzg_hip$v.so timeout 240 python tools/row_driver.py cells wide 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('cells 1 blob ms', d['one_blob']['ms_per_call'], 'kernel', d['one_blob']['roofline']['kernel_ms'], 'batch2048', d['batch_2048']['blobs_per_s'], 'k_msm_small ms', d['batch_2048']['k_msm_small_ms'])" >> gpurun_out/r2_ab.log 2>&1
+print('cells 1 blob ms', d['one_blob']['ms_per_call'], 'kernel', d['one_blob']['roofline']['kernel_ms'], 'batch2048', d['batch_2048']['blobs_per_s'], 'k_msm_small ms', d['batch_2048']['k_msm_small_ms'], 'g1_fft ms', d['batch_2048'].get('g1_fft_ms'))" >> gpurun_out/r2_ab.log 2>&1
 done
 cat gpurun_out/r2_ab.log
