@@ -36,12 +36,12 @@ HBM_PEAK_GBS = 8000.0
 # HBM bytes per k_msm_accumulate launch (1024 blobs) from rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
 # KB units), see profiles/README.md; keyed by table window width.  The traffic is the table gathers
 # themselves (nwin*4096 x 96 B per blob), not re-reads of the algorithmic bytes.
-PMC_TRAFFIC_BYTES = {13: (7658816 + 960) * 1024, 15: (6796321 + 960) * 1024, 16: (6326260 + 192) * 1024}
+PMC_TRAFFIC_BYTES = {13: (7658816 + 960) * 1024, 15: (6796321 + 960) * 1024, 16: (6324011 + 192) * 1024}
 # v_mad_u64_u32 per mixed addition (g1_28.hpp: xyzz28_madd_alt): 6 products x 392, 2 squares x 301,
 # one fused two-product reduction x 588
 MADS_PER_ADDITION = 6 * 392 + 2 * 301 + 588
 # SQ_INSTS_VALU per 1024-blob launch (profiles/)
-PMC_VALU_INSTS = {16: 4.745e9}
+PMC_VALU_INSTS = {16: 4.795e9}
 WIDE = {"commit_wbits": 16, "proof_wbits": 16, "fk20_wbits": 13}
 
 
