@@ -578,8 +578,22 @@ int msm_small_vectors_device(DeviceCtx *ctx, const FixedBaseTable &t, G1XYZZ *d_
     if (nvec == 0) return 0;
     uint32_t pairs_per_vec = (uint32_t)t.nwin * ppv;
     HIP_TRY(hipEventRecord(ctx->ev[5], ctx->stream));
-    // few vectors: one wave each (latency); many vectors: 16 lanes each (throughput)
-    if (nvec >= 4096) {
+    // few vectors: one wave each (latency); many vectors: 16 lanes each (throughput); a chip full several times
+    // over: 8 lanes each, whose fold is one level shorter (CKZG_HIP_SMALL_LPV = 4 | 8 | 16 forces a form for A/B)
+    static const long forced_lpv = []() {
+        const char *v = getenv("CKZG_HIP_SMALL_LPV");
+        return v && *v ? atol(v) : 0L;
+    }();
+    const long lpv = forced_lpv ? forced_lpv : (nvec >= 65536 ? 8 : 16);
+    if (nvec >= 4096 && lpv == 4) {
+        hipLaunchKernelGGL(k_msm_small<4>, dim3((unsigned)((nvec + 15) / 16)), dim3(64), 0, ctx->stream, d_out,
+                           t.d_table, d_digits, (uint32_t)nvec, pairs_per_vec, t.wbits - 1, ppv,
+                           (uint32_t)t.npoints, vecs_per_group);
+    } else if (nvec >= 4096 && lpv == 8) {
+        hipLaunchKernelGGL(k_msm_small<8>, dim3((unsigned)((nvec + 7) / 8)), dim3(64), 0, ctx->stream, d_out,
+                           t.d_table, d_digits, (uint32_t)nvec, pairs_per_vec, t.wbits - 1, ppv,
+                           (uint32_t)t.npoints, vecs_per_group);
+    } else if (nvec >= 4096) {
         hipLaunchKernelGGL(k_msm_small<16>, dim3((unsigned)((nvec + 3) / 4)), dim3(64), 0, ctx->stream, d_out,
                            t.d_table, d_digits, (uint32_t)nvec, pairs_per_vec, t.wbits - 1, ppv,
                            (uint32_t)t.npoints, vecs_per_group);
