@@ -156,6 +156,45 @@ void hs_g1_mul28_glv_naf(G1Jac *r, const G1Jac *a, const uint32_t *k) {
     xyzz28_mul_glv_naf(o, oi, x, ai, naf, naf + GLV_NAF_LEN);
     *r = jac_from_affine(xyzz28_to_affine(o, oi));
 }
+// The co-Z table of the NAF ladder and its mixed addition, step by step: r[m] = tbl[m] brought home (m = 0..3:
+// P, 3P, 5P, 7P); then with acc on the table's curve: r[4] = inf + P, r[5] = P + P (the equal-points branch),
+// r[6] = 2P + 3P (generic), r[7] = 5P + (-5P) (must be infinity), r[8] = 2P + phi-entry of 7P.
+void hs_je28_cases(G1Jac *r, const G1Jac *a) {
+    bool ai;
+    XYZZ28 x = xyzz28_from_xyzz(xyzz_from_jac(*a), ai);
+    EAT28 tbl[4];
+    F28<1, 2> zc;
+    eat28_build(tbl, zc, x);
+    auto home = [&](const JE28 &acc, bool inf) {
+        if (inf) return jac_from_affine(xyzz28_to_affine(x, true));
+        JAC28 j;
+        j.x = widen<1, 34>(acc.x);
+        j.y = widen<1, 34>(acc.y);
+        j.z = widen<2, 4>(mul(acc.z, zc));
+        return jac_from_affine(xyzz28_to_affine(jac28_to_xyzz(j), false));
+    };
+    for (int m = 0; m < 4; m++) {
+        JE28 acc;
+        bool inf = true;
+        je28_madd(acc, inf, tbl[m].x, tbl[m].y, false);
+        r[m] = home(acc, inf);
+    }
+    JE28 acc;
+    bool inf = true;
+    je28_madd(acc, inf, tbl[0].x, tbl[0].y, false);
+    r[4] = home(acc, inf);
+    je28_madd(acc, inf, tbl[0].x, tbl[0].y, false);
+    r[5] = home(acc, inf);
+    JE28 two = acc;
+    je28_madd(acc, inf, tbl[1].x, tbl[1].y, false);
+    r[6] = home(acc, inf);
+    je28_madd(acc, inf, tbl[2].x, tbl[2].y, true);
+    r[7] = home(acc, inf);
+    acc = two;
+    inf = false;
+    je28_madd(acc, inf, tbl[3].bx, tbl[3].y, false);
+    r[8] = home(acc, inf);
+}
 // a + (+-b) and 2a through the Jacobian 28-bit-limb formulas (b must be finite)
 void hs_g1_jac28_add(G1Jac *r, const G1Jac *a, const G1Jac *b, int negate_b) {
     bool ai, bi;

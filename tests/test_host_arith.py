@@ -461,6 +461,29 @@ def test_glv_split_and_glv_scalar_mul(libs):
     assert o.og1_is_inf(r)
 
 
+def test_coz_table_and_mixed_addition_branches(libs):
+    """g1_28.hpp: the co-Z table {P, 3P, 5P, 7P} of the G1 FFT's NAF ladder brought home from its isomorphic curve,
+    and every branch of the mixed addition on that curve (from infinity, equal points -> doubling, generic,
+    opposite points -> infinity, the phi image of an entry)."""
+    o, h = libs
+    rnd = random.Random(77)
+    lam = (0xd201000000010000 ** 2 - 1)
+    g = _buf(144)
+    h.hs_g1_generator(g)
+    for _ in range(6):
+        p1 = _omul(o, g, rnd.randrange(1, R))
+        out = _buf(9 * 144)
+        h.hs_je28_cases(out, p1)
+        got = [C.create_string_buffer(out.raw[144 * i:144 * (i + 1)], 144) for i in range(9)]
+        for m in range(4):
+            assert o.og1_equal(got[m], _omul(o, p1, 2 * m + 1)), m
+        assert o.og1_equal(got[4], p1)
+        assert o.og1_equal(got[5], _omul(o, p1, 2))
+        assert o.og1_equal(got[6], _omul(o, p1, 5))
+        assert o.og1_is_inf(got[7])
+        assert o.og1_equal(got[8], _omul(o, p1, (2 + 7 * lam) % R))
+
+
 def test_fr_safegcd_inverse(libs):
     """fr_inv.hpp (the inversion of the barycentric evaluation kernel) against Python and the Fermat ladder"""
     o, h = libs
