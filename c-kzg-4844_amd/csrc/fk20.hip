@@ -141,11 +141,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const size_t q = (blockIdx.x * (size_t)64 + threadIdx.x) >> 2;
     const int ql = (int)(threadIdx.x & 3);
     const uint32_t pad = (nfft + 15u) & ~15u;
-    const uint32_t bf = (uint32_t)(q / pad), f = (uint32_t)(q - (size_t)bf * pad);
+    const uint32_t bf = (uint32_t)(q / pad);
+    uint32_t f = (uint32_t)(q - (size_t)bf * pad);
     const int half = 1 << (s - 1);
     const int j = (int)bf & (half - 1);
     const int i1 = ((((int)bf >> (s - 1)) << s) + j) + half;
-    if (f >= nfft || j == 0 || bf >= 64u) return;
+    if (j == 0 || bf >= 64u) return;   // uniform per wave (a wave serves one butterfly index)
+    // Quads of the padding repeat the last transform instead of leaving the wave partly masked: measured on the
+    // radix-4 ladder kernel, a wave with 4 of its 16 quads active runs the same ladder ~20 % SLOWER than a full one
+    // (one-blob FK20 10.0 -> 8.2 ms, profiles/r02_quad_ab.txt).
+    const bool live = f < nfft;
+    if (!live) f = nfft - 1;
     int ridx = j * (N_EXT / (2 << (s - 1)));
     if (inverse) ridx = N_EXT - ridx;
     G1XYZZ *slot = data + (size_t)f * 128 + i1;
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const uint32_t *rec = roots_glv + (size_t)(ridx / (N_EXT / 128)) * TW_REC_WORDS;
     const int8_t *naf = reinterpret_cast<const int8_t *>(rec + 8);
     quad::xyzz28_mul_glv_naf_quad(o, oi, v, vi, naf, naf + GLV_NAF_LEN, ql);
-    if (ql == 0) *slot = xyzz28_to_xyzz(o, oi);
+    if (ql == 0 && live) *slot = xyzz28_to_xyzz(o, oi);
 }
 
 __global__ __launch_bounds__(64) void k_g1_fft_addsub(G1XYZZ *data, uint32_t nfft, int s) {
@@ -229,6 +235,16 @@ __device__ __forceinline__ void r4_group(int grp, int s, int dif, int &t, int &p
     }
 }
 
+// the additions around the radix-4 ladders: latency work, four lanes per addition (A/B: CKZG_R4_ONE_LANE_ADDS)
+__device__ __forceinline__ void r4_add(XYZZ28 &a, bool &ainf, const XYZZ28 &b, bool binf, int ql) {
+#ifndef CKZG_R4_ONE_LANE_ADDS
+    quad::xyzz28_add_quad(a, ainf, b, binf, ql);
+#else
+    (void)ql;
+    xyzz28_add(a, ainf, b, binf);
+#endif
+}
+
 __device__ __forceinline__ int r4_exponent(int k, int t, int s, int dif) {
     const int E = 128 >> s;
     if (dif) {
@@ -256,8 +272,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const size_t q = (blockIdx.x * (size_t)64 + threadIdx.x) >> 2;
     const int ql = (int)(threadIdx.x & 3);
     const uint32_t pad = (nfft + 15u) & ~15u;
-    const uint32_t ell = (uint32_t)(q / pad), f = (uint32_t)(q - (size_t)ell * pad);
-    if (f >= nfft || ell >= (uint32_t)R4_LADDERS) return;
+    const uint32_t ell = (uint32_t)(q / pad);
+    uint32_t f = (uint32_t)(q - (size_t)ell * pad);
+    if (ell >= (uint32_t)R4_LADDERS) return;
+#ifndef CKZG_R4_PARTIAL_WAVES
+    // quads of the padding repeat the last transform instead of leaving the wave partly masked
+    const bool live = f < nfft;
+    if (!live) f = nfft - 1;
+#else
+    const bool live = true;
+    if (f >= nfft) return;
+#endif
     const int grp = (int)ell / 5, k = (int)ell % 5;
     int t, p0, p1, p2, p3;
     r4_group(grp, s, dif, t, p0, p1, p2, p3);
@@ -269,18 +294,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (k == 0 || k == 2) {         // a0 - a2
             v = xyzz28_from_xyzz(vec[p0], vi);
             XYZZ28 b = xyzz28_from_xyzz(vec[p2], i2);
-            xyzz28_add(v, vi, xyzz28_neg(b), i2);
+            r4_add(v, vi, xyzz28_neg(b), i2, ql);
         } else if (k == 1 || k == 3) {  // a1 - a3
             v = xyzz28_from_xyzz(vec[p1], vi);
             XYZZ28 b = xyzz28_from_xyzz(vec[p3], i3);
-            xyzz28_add(v, vi, xyzz28_neg(b), i3);
+            r4_add(v, vi, xyzz28_neg(b), i3, ql);
         } else {                        // (a0 + a2) - (a1 + a3)
             v = xyzz28_from_xyzz(vec[p0], vi);
             XYZZ28 b = xyzz28_from_xyzz(vec[p2], i2);
-            xyzz28_add(v, vi, b, i2);
+            r4_add(v, vi, b, i2, ql);
             XYZZ28 c = xyzz28_from_xyzz(vec[p1], i1), d = xyzz28_from_xyzz(vec[p3], i3);
-            xyzz28_add(c, i1, d, i3);
-            xyzz28_add(v, vi, xyzz28_neg(c), i1);
+            r4_add(c, i1, d, i3, ql);
+            r4_add(v, vi, xyzz28_neg(c), i1, ql);
         }
         (void)i0;
     } else {
@@ -296,13 +321,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const int8_t *naf = reinterpret_cast<const int8_t *>(rec + 8);
         quad::xyzz28_mul_glv_naf_quad(o, oi, v, vi, naf, naf + GLV_NAF_LEN, ql);
     }
-    if (ql == 0) lad[(size_t)f * R4_LADDERS + ell] = xyzz28_to_xyzz(o, oi);
+    if (ql == 0 && live) lad[(size_t)f * R4_LADDERS + ell] = xyzz28_to_xyzz(o, oi);
 }
 
-// one lane per OUTPUT point: lane g -> (transform f, group, which of the four outputs)
+// one DPP quad per OUTPUT point (its two or three additions are latency, g1_quad.hpp): quad g -> (transform f,
+// group, which of the four outputs)
 __global__ __launch_bounds__(64) void k_g1_fft_r4_post(G1XYZZ *out, const G1XYZZ *data, const G1XYZZ *lad, uint32_t nfft,
                                                       int s, int dif) {
-    const size_t g = blockIdx.x * (size_t)64 + threadIdx.x;
+    const size_t g = (blockIdx.x * (size_t)64 + threadIdx.x) >> 2;
+    const int ql = (int)(threadIdx.x & 3);
     const uint32_t f = (uint32_t)(g >> 7);
     if (f >= nfft) return;
     const int grp = (int)((g >> 2) & 31), w = (int)(g & 3);
@@ -317,10 +344,10 @@ __global__ __launch_bounds__(64) void k_g1_fft_r4_post(G1XYZZ *out, const G1XYZZ
             bool i1, i2, i3;
             r = xyzz28_from_xyzz(vec[p0], ri);
             XYZZ28 b = xyzz28_from_xyzz(vec[p2], i2);
-            xyzz28_add(r, ri, b, i2);
+            r4_add(r, ri, b, i2, ql);
             XYZZ28 c = xyzz28_from_xyzz(vec[p1], i1), d = xyzz28_from_xyzz(vec[p3], i3);
-            xyzz28_add(c, i1, d, i3);
-            xyzz28_add(r, ri, c, i1);
+            r4_add(c, i1, d, i3, ql);
+            r4_add(r, ri, c, i1, ql);
             dst = p0;
         } else if (w == 1) {   // L4
             r = xyzz28_from_xyzz(L[4], ri);
@@ -329,13 +356,13 @@ __global__ __launch_bounds__(64) void k_g1_fft_r4_post(G1XYZZ *out, const G1XYZZ
             bool bi;
             r = xyzz28_from_xyzz(L[0], ri);
             XYZZ28 b = xyzz28_from_xyzz(L[1], bi);
-            xyzz28_add(r, ri, b, bi);
+            r4_add(r, ri, b, bi, ql);
             dst = p2;
         } else {               // L2 - L3
             bool bi;
             r = xyzz28_from_xyzz(L[2], ri);
             XYZZ28 b = xyzz28_from_xyzz(L[3], bi);
-            xyzz28_add(r, ri, xyzz28_neg(b), bi);
+            r4_add(r, ri, xyzz28_neg(b), bi, ql);
             dst = p3;
         }
     } else {
@@ -343,13 +370,13 @@ __global__ __launch_bounds__(64) void k_g1_fft_r4_post(G1XYZZ *out, const G1XYZZ
         bool ai, bi, ci;
         r = xyzz28_from_xyzz(vec[p0], ri);
         XYZZ28 a = xyzz28_from_xyzz(L[0], ai);
-        xyzz28_add(r, ri, (w & 1) ? xyzz28_neg(a) : a, ai);              // y0 / y1
+        r4_add(r, ri, (w & 1) ? xyzz28_neg(a) : a, ai, ql);              // y0 / y1
         XYZZ28 b = xyzz28_from_xyzz(L[(w & 1) ? 3 : 1], bi), c = xyzz28_from_xyzz(L[(w & 1) ? 4 : 2], ci);
-        xyzz28_add(b, bi, (w & 1) ? xyzz28_neg(c) : c, ci);              // u = L1 + L2 / v = L3 - L4
-        xyzz28_add(r, ri, (w & 2) ? xyzz28_neg(b) : b, bi);
+        r4_add(b, bi, (w & 1) ? xyzz28_neg(c) : c, ci, ql);              // u = L1 + L2 / v = L3 - L4
+        r4_add(r, ri, (w & 2) ? xyzz28_neg(b) : b, bi, ql);
         dst = w == 0 ? p0 : (w == 1 ? p1 : (w == 2 ? p2 : p3));
     }
-    out[(size_t)f * 128 + dst] = xyzz28_to_xyzz(r, ri);
+    if (ql == 0) out[(size_t)f * 128 + dst] = xyzz28_to_xyzz(r, ri);
 }
 
 // a radix-4 pass over stage pairs: DIF (s_hi, s_hi-1), ..., down to s_lo; DIT (s_lo, s_lo+1), ... up to s_hi.
@@ -358,7 +385,7 @@ __global__ __launch_bounds__(64) void k_g1_fft_r4_post(G1XYZZ *out, const G1XYZZ
 static int g1_fft_r4_pairs(DeviceCtx *ctx, G1XYZZ *d_data, G1XYZZ *d_tmp, G1XYZZ *d_lad, const uint32_t *d_glv, size_t nfft,
                            bool dif, int s_from, int s_to, int inverse) {
     const size_t pad = (nfft + 15) / 16 * 16;
-    const dim3 lgrid((unsigned)(pad * R4_LADDERS * 4 / 64)), pgrid((unsigned)(nfft * 128 / 64)), block(64);
+    const dim3 lgrid((unsigned)(pad * R4_LADDERS * 4 / 64)), pgrid((unsigned)(nfft * 128 * 4 / 64)), block(64);
     G1XYZZ *cur = d_data, *nxt = d_tmp;
     for (int s = s_from; dif ? s >= s_to + 1 : s + 1 <= s_to; s += dif ? -2 : 2) {
         hipLaunchKernelGGL(k_g1_fft_r4_ladder, lgrid, block, 0, ctx->stream, d_lad, cur, d_glv, (uint32_t)nfft, s, dif ? 1 : 0,

@@ -366,10 +366,10 @@ __global__ __launch_bounds__(THREADS) void k_msm_accumulate(
 // of ~22 before a 6-level fold, so the reduction tree shrinks from ~40 % to ~6 % of the work.
 // Results stay in (fully reduced) XYZZ form in out[nvec].
 template <int LPV>
-__global__ __launch_bounds__(64) void k_msm_small(G1XYZZ *out, const G1Affine *table, const int16_t *digits,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_msm_small(G1XYZZ *out, const G1Affine *table, const int16_t *digits,
                                                  uint32_t nvec, uint32_t pairs_per_vec, int half_shift,
                                                  uint32_t ppv, uint32_t npoints, uint32_t vecs_per_group) {
-    __shared__ uint32_t sh[57][32];
+    __shared__ uint32_t sh[57][LPV == 64 ? 64 : 32];
     constexpr int GROUPS = 64 / LPV;
     const int tid = threadIdx.x, grp = tid / LPV, l = tid % LPV;
     const uint32_t vec = blockIdx.x * GROUPS + grp;
@@ -383,6 +383,13 @@ __global__ __launch_bounds__(64) void k_msm_small(G1XYZZ *out, const G1Affine *t
                            voff, half_shift);
     }
     xyzz28_fix_sign(acc28, inf, yneg);
+    if constexpr (LPV == 64) {
+        // one wave per vector is the latency form (few vectors): fold on four lanes per pair.  (In the throughput
+        // forms the quad fold pushes the kernel past 256 VGPRs: measured slower, profiles/r02_fp28_ab.txt.)
+        quad::block_reduce_xyzz28_quad<64>(acc28, inf, sh);
+        if (l == 0 && vec < nvec) out[vec] = xyzz28_to_xyzz(acc28, inf);
+        return;
+    }
     for (int s = LPV / 2; s >= 1; s >>= 1) {
         if (l >= s && l < 2 * s) {
             const uint32_t *src = reinterpret_cast<const uint32_t *>(&acc28);

@@ -194,7 +194,10 @@ __device__ __noinline__ G1XYZZ affine_mul_w4(const G1Affine &a, const uint32_t *
 template <int MODE>
 __global__ void k_validate_g1(G1Affine *out, uint8_t *status, const uint8_t *in48, size_t n) {
     size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (g >= n) return;
+    // lanes past the end repeat the last point instead of exiting: a partly masked wave runs the 381-squaring
+    // square root measurably slower than a full one (fk20.hip, k_g1_fft_twiddle_quad)
+    const bool live = g < n;
+    if (!live) g = n - 1;
     const uint32_t *src = reinterpret_cast<const uint32_t *>(in48 + g * 48);
     uint32_t raw[12];
 #pragma unroll
@@ -234,8 +237,10 @@ __global__ void k_validate_g1(G1Affine *out, uint8_t *status, const uint8_t *in4
             }
         }
     }
-    out[g] = a;
-    status[g] = st;
+    if (live) {
+        out[g] = a;
+        status[g] = st;
+    }
 }
 
 // status[i] = 1 for a finite point outside the prime-order subgroup (points are left untouched)
@@ -251,11 +256,12 @@ __global__ void k_subgroup_g1(uint8_t *status, const G1Affine *pts, size_t n) {
 // the same with four lanes per point (g1_quad.hpp): the 126 doublings are the critical path of a small batch
 __global__ __launch_bounds__(64) void k_subgroup_g1_quad(uint8_t *status, const G1Affine *pts, size_t n) {
     size_t g = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 2;
-    if (g >= n) return;
+    const bool live = g < n;
+    if (!live) g = n - 1;   // no partly masked waves (see k_validate_g1)
     G1Affine a = pts[g];
     uint8_t st = 0;
     if (!a.is_inf() && !quad::g1_28_in_subgroup_quad(f28_from_fp(a.x), f28_from_fp(a.y), (int)(threadIdx.x & 3))) st = 1;
-    if ((threadIdx.x & 3) == 0) status[g] = st;
+    if ((threadIdx.x & 3) == 0 && live) status[g] = st;
 }
 
 int validate_g1_batch_device(DeviceCtx *ctx, G1Affine *d_out, uint8_t *d_status, const uint8_t *d_in48,
@@ -339,16 +345,30 @@ __global__ __launch_bounds__(LC_THREADS) void k_lincomb_partial_quad(G1XYZZ *par
     __shared__ uint32_t sh[57][LC_THREADS / 2];
     const size_t g = blockIdx.x * (size_t)LC_THREADS + threadIdx.x;
     const int ql = (int)(threadIdx.x & 3);
-    const size_t half_term = g >> 2, term = half_term >> 1;
+    const size_t half_term = g >> 2, term_raw = half_term >> 1;
     const bool second = (half_term & 1) != 0;
     XYZZ28 acc;
     bool inf = true;
-    if (term < n) {
+    // quads past the end repeat the last term (their product is dropped below): no partly masked waves
+    const bool live = term_raw < n;
+    const size_t term = live ? term_raw : n - 1;
+    bool fin = false;
+    if (n != 0) {
         G1Affine a = pts[term];
-        if (!a.is_inf()) {
+        // a point at infinity (the padding of a job is made of them) runs the ladder on the generator and its product
+        // is dropped: the wave stays fully active
+        fin = !a.is_inf();
+        if (!fin) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                a.x.l[i] = G1_GEN_X[i];
+                a.y.l[i] = G1_GEN_Y[i];
+            }
+        }
+        {
             uint32_t k[8], glv[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) k[i] = scalars[term * 8 + i];
+            for (int i = 0; i < 8; i++) k[i] = fin ? scalars[term * 8 + i] : (i == 7 ? 0x1e3779b9u : 0x9e3779b9u);
             glv_split(k, glv, glv + 4);
             XYZZ28 p;
             p.x = widen<1, 10>(f28_from_fp(a.x));
@@ -359,7 +379,7 @@ __global__ __launch_bounds__(LC_THREADS) void k_lincomb_partial_quad(G1XYZZ *par
             quad::xyzz28_mul_w4_128_quad(acc, inf, p, false, second ? glv + 4 : glv, ql);
         }
     }
-    if (ql != 0) inf = true;  // the four lanes of a quad hold the same product: count it once
+    if (ql != 0 || !live || !fin) inf = true;  // the four lanes of a quad hold the same product: count it once
     block_reduce_xyzz28<LC_THREADS>(acc, inf, sh);
     if (threadIdx.x == 0) partials[blockIdx.x] = xyzz28_to_xyzz(acc, inf);
 }

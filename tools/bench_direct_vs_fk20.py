@@ -14,7 +14,7 @@ for dm in (0, 4096):
     f = k.lib.ckzg_hip_compute_cells_and_kzg_proofs_batch
     f.restype = C.c_int
     out = []
-    for n in (1, 2, 4, 8, 12, 16, 24, 32, 48):
+    for n in [int(x) for x in sys.argv[3:]] or [1, 2, 4, 8, 12, 16, 24, 32, 48]:
         cells = C.create_string_buffer(n * 128 * 2048); proofs = C.create_string_buffer(n * 128 * 48); st = C.create_string_buffer(n)
         f(cells, proofs, st, blobs, C.c_uint64(n), k.sp)
         best = 1e9
