@@ -254,7 +254,7 @@ extern "C" C_KZG_RET bytes_to_bls_field(fr_t *out, const Bytes32 *b) {
 extern "C" void bytes_from_bls_field(Bytes32 *out, const fr_t *in) { fr_to_bytes(out->bytes, *as_fr(in)); }
 
 extern "C" void bytes_from_g1(Bytes48 *out, const g1_t *in) {
-    g1_compress_affine(out->bytes, jac_to_affine(*as_g1(in)));
+    g1_compress_affine(out->bytes, jac_to_affine_fast(*as_g1(in)));
 }
 
 extern "C" C_KZG_RET bytes_to_kzg_commitment(g1_t *out, const Bytes48 *b) {

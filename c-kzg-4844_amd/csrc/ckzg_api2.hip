@@ -152,7 +152,7 @@ Fr challenge_from_bytes(const uint8_t *blob, const uint8_t *commitment48) {
 bool verify_kzg_proof_impl(const G1Jac &commitment, const Fr &z, const Fr &y, const G1Jac &proof,
                            const PreparedG2 *pg) {
     G1Jac lhs = jac_add(jac_add(commitment, jac_neg(g1_mul_fr(g1_generator(), y))), g1_mul_fr(proof, z));
-    return pairing_product_is_one(jac_to_affine(lhs), pg->gen, jac_to_affine(jac_neg(proof)), pg->s1);
+    return pairing_product_is_one(jac_to_affine_fast(lhs), pg->gen, jac_to_affine_fast(jac_neg(proof)), pg->s1);
 }
 
 // quotient polynomial and its commitment (eip4844.c:417-494); the 4096-term MSM runs on the GPU
@@ -321,9 +321,11 @@ G1Jac host_lincomb(const std::vector<G1Jac> &pts, const std::vector<Fr> &k) {
 
 // Below this many blobs the few G1 scalar multiplications of a verification (point validation,
 // random-linear-combination sums) stay on the host next to the pairing: a single 255-bit scalar
-// multiplication is ~0.25 ms on a CPU core but ~5 ms of dependent latency on one GPU lane.  The
+// multiplication is ~0.25 ms on a CPU core but ~1 ms of dependent latency even on four GPU lanes.  The
 // data-parallel part (bytes -> Fr, 4096-term evaluation) runs on the GPU for every n.
-constexpr uint64_t SMALL_VERIFY_N = 5;
+// Measured (tools/bench_verify_small.py): host path 1.4 / 2.0 / 2.5 / 3.1 ms for n = 1 / 2 / 3 / 4, GPU path
+// 2.6 ms for any n up to ~16 -> hand-over after 3.
+constexpr uint64_t SMALL_VERIFY_N = 3;
 
 // Shared core of verify_blob_kzg_proof and verify_blob_kzg_proof_batch (eip4844.c:537-595,
 // 697-844).  Per blob, on the GPU: point validation, bytes -> Fr, evaluation at the challenge;
@@ -489,7 +491,7 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     // sum r^i (C_i - [y_i]G) = sum r^i C_i - [sum r^i y_i]G
     G1Jac rhs = jac_add(jac_add(lc[2], jac_neg(g1_mul_fr(g1_generator(), ysum))), lc[1]);
     // e(sum r^i proof_i, [s]G2) == e(rhs, G2)
-    *ok = pairing_product_is_one(jac_to_affine(jac_neg(lc[0])), prepared_of(ctx)->s1, jac_to_affine(rhs),
+    *ok = pairing_product_is_one(jac_to_affine_fast(jac_neg(lc[0])), prepared_of(ctx)->s1, jac_to_affine_fast(rhs),
                                  prepared_of(ctx)->gen);
     tr.mark("pairing check");
     return C_KZG_OK;
@@ -503,7 +505,7 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
 
 extern "C" void compute_challenge(fr_t *eval_challenge_out, const Blob *blob, const g1_t *commitment) {
     uint8_t c48[48];
-    g1_compress_affine(c48, jac_to_affine(*as_g1(commitment)));
+    g1_compress_affine(c48, jac_to_affine_fast(*as_g1(commitment)));
     *as_fr(eval_challenge_out) = challenge_from_bytes(blob->bytes, c48);
 }
 
@@ -1073,7 +1075,7 @@ static C_KZG_RET verify_cells_on(dev::DeviceCtx *ctx, bool *ok, const Bytes48 *c
     const G1Jac &proof_lc = lc[0], &csum = lc[1], &wsum = lc[2], &interp_commit = lc[3];
     G1Jac final_sum = jac_add(jac_add(csum, jac_neg(interp_commit)), wsum);
     // e(final_sum, G2) == e(proof_lc, [s^64]G2)
-    *ok = pairing_product_is_one(jac_to_affine(final_sum), prepared_of(ctx)->gen, jac_to_affine(jac_neg(proof_lc)),
+    *ok = pairing_product_is_one(jac_to_affine_fast(final_sum), prepared_of(ctx)->gen, jac_to_affine_fast(jac_neg(proof_lc)),
                                  prepared_of(ctx)->s64);
     tr.mark("pairing check");
     return C_KZG_OK;
@@ -1126,7 +1128,7 @@ extern "C" C_KZG_RET ckzg_hip_g1_lincomb(g1_t *out, const g1_t *p, const fr_t *c
         std::vector<G1Affine> aff(len);
         std::vector<RawScalar> k(len);
         for (uint64_t i = 0; i < len; i++) {
-            aff[i] = jac_to_affine(*as_g1(&p[i]));
+            aff[i] = jac_to_affine_fast(*as_g1(&p[i]));
             k[i] = raw_of(*as_fr(&coeffs[i]));
         }
         Arena &ar = ctx->api_arena;

@@ -297,10 +297,10 @@ static C_KZG_RET build_owner(dev::DeviceCtx *ctx, const KZGSettings *s, const Op
             int rc = dev::build_fixed_base_table(ctx, &ctx->mono, ctx->d_mono, (int)NUM_G1_POINTS, wbits);
             if (rc) return (C_KZG_RET)rc;
             // Automatic hand-over point (measured, tools/bench_direct_vs_fk20.py, profiles/r02_quad_ab.txt): with the
-            // radix-4 / four-lane G1 FFT FK20 costs 8.0-8.6 ms for any batch of up to 16 blobs (it was ~28 ms with
-            // twelve dependent one-lane ladder stages), the direct path 1.9 / 2.2 / 3.2 ms for one blob plus
+            // radix-4 / four-lane G1 FFT FK20 costs 6.8-7.1 ms for any batch of up to 8 blobs (it was ~28 ms with
+            // twelve dependent one-lane ladder stages), the direct path 1.9 / 2.2 / 3.1 ms for one blob plus
             // ~1.3 / ~1.6 / ~2.3 ms per further blob with a 16 / 13 / 8-bit table.
-            if (ctx->direct_max < 0) ctx->direct_max = wbits >= 15 ? 5 : (wbits >= 11 ? 4 : 3);
+            if (ctx->direct_max < 0) ctx->direct_max = wbits >= 15 ? 4 : (wbits >= 11 ? 3 : 2);
         }
         if (ctx->direct_max < 0) ctx->direct_max = 0;
     }

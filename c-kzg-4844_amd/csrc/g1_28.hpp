@@ -1032,6 +1032,15 @@ HDNI inline bool g1_28_in_subgroup(const F28<1, 2> &x, const F28<1, 2> &y) {
 // the inversion used by the kernels: safegcd (fp28_inv.hpp), ~12x fewer instructions than the ladder
 HD F28<1, 2> f28_inv(const F28<1, 2> &a) { return f28_inv_safegcd(a); }
 
+// 1/a for the 12-limb representation through the safegcd inverse (host glue and kernels that still hold Fp values)
+HDNI inline Fp fp_inv_safegcd(const Fp &a) { return f28_to_fp(f28_inv(f28_from_fp(a))); }
+HDNI inline G1Affine jac_to_affine_fast(const G1Jac &p) {
+    if (p.is_inf()) return G1Affine::inf();
+    Fp zi = fp_inv_safegcd(p.z);
+    Fp zi2 = sqr(zi);
+    return {mul(p.x, zi2), mul(p.y, mul(zi2, zi))};
+}
+
 // affine coordinates (fully reduced, 2^384 domain) of a point in the 28-bit domain
 HDNI inline G1Affine xyzz28_to_affine(const XYZZ28 &a, bool inf) {
     if (inf) return G1Affine::inf();

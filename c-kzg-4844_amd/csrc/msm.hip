@@ -98,7 +98,7 @@ __global__ void k_batch_to_affine(G1Affine *out, const G1XYZZ *in, Fp *prefix, s
     // the run's one inversion: safegcd in the 28-bit-limb domain (fp28_inv.hpp), ~12x fewer instructions than the
     // 381-squaring Fermat ladder -- which was 1.4 ms of latency at the end of every small FK20 batch and a quarter
     // of the table-build kernel
-    Fp inv = f28_to_fp(f28_inv(f28_from_fp(acc)));
+    Fp inv = fp_inv_safegcd(acc);
     for (size_t k = e; k-- > b;) {
         G1XYZZ p = in[k];
         if (p.zz.is_zero()) {

@@ -42,12 +42,12 @@ extern "C" {
  *   "proof_wbits"   window width of the table over the 4096 monomial points used by the low-latency
  *                   (no G1 FFT) cell-proof path; default 8 (0.8 GB), 0 disables the path
  *   "direct_max"    largest batch that takes the low-latency proof path; larger batches use FK20, which
- *                   does ~10x fewer point additions but costs ~8 ms for any small batch (6 dependent
- *                   ladder launches).  -1 (default): 3 / 4 / 5 blobs for a proof table of <= 10 / <= 14 /
+ *                   does ~10x fewer point additions but costs ~7 ms for any small batch (6 dependent
+ *                   ladder launches).  -1 (default): 2 / 3 / 4 blobs for a proof table of <= 10 / <= 14 /
  *                   >= 15 bits, the measured hand-over points; 0 disables the path
  *   "gpu_sha_min"   smallest verify_blob_kzg_proof_batch size whose Fiat-Shamir challenges are hashed on
  *                   the GPU; 0 (default): never on hosts with the x86 SHA extensions (the host hash runs under the
- *                   blob copy), from 512 blobs otherwise.  Batches of at most 5 blobs always hash on the host.
+ *                   blob copy), from 512 blobs otherwise.  Batches of at most 3 blobs always hash on the host.
  *                   Takes effect immediately (every other option is read by load_trusted_setup).
  * A width that does not fit the free HBM is narrowed at load time (ckzg_hip_table_wbits reports the result).
  * Returns C_KZG_BADARGS for an unknown key or out-of-range value. */
