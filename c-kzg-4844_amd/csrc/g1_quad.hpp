@@ -269,8 +269,205 @@ __device__ __noinline__ bool g1_28_in_subgroup_quad(const F28<1, 2> &x, const F2
     return is_zero(mul(add(q.y, mul(y, mul(q.z, zz))), f28_one()));
 }
 
+// ---- the co-Z table and the mixed addition of g1_28.hpp (section "effectively affine" table) on four lanes ----
+// Two more steps go: the accumulator carries Z^2 (computed in a spare lane of the previous doubling or addition),
+// so a mixed addition is FOUR product steps (the Jacobian-table form needs five, six for a phi entry), and the
+// table costs 15 steps instead of 30.
+
+// a <- 2a, zz <- (new Z)^2: jac28_dbl_quad with the square of 2YZ in the spare lane of step 2
+__device__ __forceinline__ void jac28_dbl_quad_zz(JAC28 &a, F28<1, 2> &zz, int ql) {
+    const auto x = widen<2, 34>(a.x), y = widen<2, 34>(a.y), z = widen<2, 34>(a.z);
+    const auto p1 = mul(qsel(ql, x, y, y, x), qsel(ql, x, y, z, x));     // X*X | Y*Y | Y*Z | (X*X)
+    const auto A = qread<0>(p1), B = qread<1>(p1), YZ = qread<2>(p1);
+    const auto E = add(add(A, A), A);                                     // <3,6>
+    const auto Z3 = add(YZ, YZ);                                          // <2,4>
+    const auto e = widen<3, 34>(E), b = widen<3, 34>(B), xx = widen<3, 34>(a.x), z3 = widen<3, 34>(Z3);
+    const auto p2 = mul(qsel(ql, e, b, xx, z3), qsel(ql, e, b, b, z3));   // E*E | B*B | X*B | Z3*Z3; 14*9+15 ok
+    const auto F = qread<0>(p2), C = qread<1>(p2), XB = qread<2>(p2);
+    zz = qread<3>(p2);
+    const auto XB2 = add(XB, XB);
+    const auto D = add(XB2, XB2);                                         // <4,8>
+    const auto X3 = norm(sub(F, add(D, D)));                              // <1,34>
+    const auto dx = norm(sub(D, X3));                                     // <1,72>
+    const auto C2 = add(C, C);
+    const auto C4 = add(C2, C2);
+    const auto C8 = add(C4, C4);                                          // <8,16>
+    const auto Y3 = norm(sub(mul(E, dx), C8));                            // <1,34>
+    a.x = X3;
+    a.y = Y3;
+    a.z = Z3;
+}
+
+// a <- a + (x2, +-y2), the point affine on the curve a lives on; zz = Z(a)^2 in and out.  Four product steps.
+__device__ __forceinline__ void jac28_madd_quad_zz(JAC28 &a, F28<1, 2> &zz, bool &ainf, const F28<1, 20> &x2,
+                                                   const F28<1, 20> &y2in, bool neg, int ql) {
+    F28<1, 0> zero;
+#pragma unroll
+    for (int j = 0; j < 14; j++) zero.l[j] = 0;
+    F28<1, 41> y2;
+    {
+        const auto ny = norm(sub_k<21>(zero, y2in));                      // <1,21>
+#pragma unroll
+        for (int j = 0; j < 14; j++) y2.l[j] = neg ? ny.l[j] : y2in.l[j];
+    }
+    if (ainf) {
+        a.x = widen<1, 34>(x2);
+        a.y = widen<1, 34>(mul(y2, f28_one()));
+        a.z = widen<2, 4>(f28_one());
+        zz = widen<1, 2>(f28_one());
+        ainf = false;
+        return;
+    }
+    // step A: X2*ZZ1 | Z1*ZZ1
+    const auto x2w = widen<2, 41>(x2), azw = widen<2, 41>(a.z);
+    const auto pA = mul(qsel(ql, x2w, azw, x2w, azw), widen<2, 41>(zz));  // 14*4+15 ok; 41*41 ok
+    const auto u2 = qread<0>(pA), z1c = qread<1>(pA);
+    const auto h = sub_k<35>(u2, a.x);                                    // <4,37>
+    // step B: Y2*Z1^3 | H*H | Z1*H | (H*H)
+    const auto hw = widen<4, 41>(h);
+    const auto pB = mul(qsel(ql, widen<4, 41>(y2), hw, widen<4, 41>(a.z), hw),
+                        qsel(ql, widen<4, 37>(z1c), h, h, h));            // 14*16+15 = 239 ok; 41*37 ok
+    const auto s2 = qread<0>(pB), hh = qread<1>(pB), z3 = qread<2>(pB);
+    const auto r = sub_k<35>(s2, a.y);                                    // <4,37>
+    if (is_zero(hh)) {  // same x: the table point itself (double it) or its negative (infinity)
+        if (is_zero(mul(r, f28_one()))) {
+            a.x = widen<1, 34>(x2);
+            a.y = widen<1, 34>(mul(y2, f28_one()));
+            a.z = widen<2, 4>(f28_one());
+            jac28_dbl_quad_zz(a, zz, ql);
+        } else {
+            ainf = true;
+        }
+        return;
+    }
+    // step C: H*HH | X1*HH | R*R | Z3*Z3
+    const auto hh37 = widen<4, 37>(hh), z3w = widen<4, 37>(z3);
+    const auto pC = mul(qsel(ql, h, widen<4, 37>(a.x), r, z3w), qsel(ql, hh37, hh37, r, z3w));   // 239 ok; 37*37 ok
+    const auto hhh = qread<0>(pC), v = qread<1>(pC), rr = qread<2>(pC);
+    const auto zz3 = qread<3>(pC);
+    const auto x3 = norm(sub(rr, add(hhh, add(v, v))));                   // <6,10> -> <1,10>
+    const auto dv = sub(v, x3);                                           // <4,18>
+    const auto s1n = sub_k<35>(zero, a.y);                                // <3,35> = -Y1
+    // step D: R*(V - X3) | (-Y1)*HHH ; Y3 is their sum
+    const auto rn = widen<4, 37>(norm(r)), sn = widen<4, 37>(s1n);
+    const auto h18 = widen<4, 18>(hhh);
+    const auto pD = mul(qsel(ql, rn, sn, rn, sn), qsel(ql, dv, h18, dv, h18));   // 239 ok; 37*18 ok
+    const auto y3 = norm(add(qread<0>(pD), qread<1>(pD)));                // <2,4> -> <1,4>
+    a.x = widen<1, 34>(x3);
+    a.y = widen<1, 34>(y3);
+    a.z = widen<2, 4>(z3);
+    zz = zz3;
+}
+
+// coz28_addu on four lanes, three steps; up to two further points over the old Z follow in spare lanes (q1 fully,
+// q2's x only: its y is returned by the caller's next step through w)
+__device__ __forceinline__ void coz28_addu_quad(CoZ28 &sum, CoZ28 &p1, CoZ28 &p2, F28<1, 2> &z, F28<4, 6> &w,
+                                                CoZ28 *q1, CoZ28 *q2, int ql) {
+    const auto dX = sub_k<21>(p2.x, p1.x);                                // <4,41>
+    const auto dY = sub_k<21>(p2.y, p1.y);
+    // step 1: dX*dX | dY*dY | Z*dX | (dX*dX)
+    const auto pa = mul(qsel(ql, dX, dY, widen<4, 41>(z), dX), qsel(ql, dX, dY, dX, dX));   // 239 ok; 41*41 ok
+    const auto c = qread<0>(pa), D = qread<1>(pa);
+    z = qread<2>(pa);
+    // step 2: X1*c | X2*c | Q1.x*c | Q2.x*c
+    const auto pb = mul(qsel(ql, p1.x, p2.x, q1 ? q1->x : p1.x, q2 ? q2->x : p1.x), c);
+    const auto W1 = qread<0>(pb), W2 = qread<1>(pb), Q1x = qread<2>(pb), Q2x = qread<3>(pb);
+    w = sub(W2, W1);                                                      // <4,6> = dX^3
+    const auto X3 = norm(sub(D, add(W1, W2)));                            // <5,10> -> <1,10>
+    const auto t = sub(W1, X3);                                           // <4,18>
+    // step 3: Y1*w | Y2*w | dY*(W1 - X3) | Q1.y*w
+    const auto w18 = widen<4, 18>(w);
+    const auto pc = mul(qsel(ql, widen<4, 41>(p1.y), widen<4, 41>(p2.y), dY, widen<4, 41>(q1 ? q1->y : p1.y)),
+                        qsel(ql, w18, w18, t, w18));                      // 239 ok; 41*18 ok
+    const auto A1 = qread<0>(pc), A2 = qread<1>(pc), M = qread<2>(pc), Q1y = qread<3>(pc);
+    const auto Y3 = norm(sub(M, A1));                                     // <4,6> -> <1,6>
+    sum.x = widen<1, 20>(X3);
+    sum.y = widen<1, 20>(Y3);
+    p1.x = widen<1, 20>(W1);
+    p1.y = widen<1, 20>(A1);
+    p2.x = widen<1, 20>(W2);
+    p2.y = widen<1, 20>(A2);
+    if (q1) {
+        q1->x = widen<1, 20>(Q1x);
+        q1->y = widen<1, 20>(Q1y);
+    }
+    if (q2) q2->x = widen<1, 20>(Q2x);
+}
+
+// eat28_build on four lanes: 15 product steps
+__device__ __forceinline__ void eat28_build_quad(EAT28 (&tbl)[4], F28<1, 2> &zc, const XYZZ28 &p, int ql) {
+    // step 0: X1 = x*zz | Y1 = y*zzz
+    const auto px = p.x, py = widen<1, 10>(p.y);
+    const auto p0 = mul(qsel(ql, px, py, px, py), qsel(ql, p.zz, p.zzz, p.zz, p.zzz));
+    const auto X1 = qread<0>(p0), Y1 = qread<1>(p0);
+    // the doubling that also leaves P over 2P's Z (eat28_build): steps 1-3
+    const auto p1 = mul(qsel(ql, X1, Y1, Y1, X1), qsel(ql, X1, Y1, p.zz, X1));   // X1^2 | Y1^2 | Y1*Z1
+    const auto A = qread<0>(p1), B = qread<1>(p1), YZ = qread<2>(p1);
+    const auto E = add(add(A, A), A);                                     // <3,6>
+    const auto e = widen<3, 6>(E), b = widen<3, 6>(B), xx = widen<3, 6>(X1), zr = widen<3, 6>(add(YZ, YZ));
+    const auto one3 = widen<3, 6>(f28_one());
+    const auto p2 = mul(qsel(ql, e, b, xx, zr), qsel(ql, e, b, b, one3));  // E^2 | B^2 | X1*B | Z2 back under <1,2>
+    const auto F = qread<0>(p2), C = qread<1>(p2), XB = qread<2>(p2);
+    F28<1, 2> z = qread<3>(p2);
+    const auto XB2 = add(XB, XB);
+    const auto D = add(XB2, XB2);                                         // <4,8>
+    const auto X2 = norm(sub_k<17>(F, add(D, D)));                        // <1,19>
+    const auto dx = norm(sub_k<20>(D, X2));                               // <1,28>
+    const auto C2 = add(C, C);
+    const auto C4 = add(C2, C2);
+    const auto C8 = add(C4, C4);                                          // <8,16>
+    const auto Y2 = norm(sub_k<17>(mul(E, dx), C8));                      // <1,19>
+    CoZ28 t1, t2, t3, t5, t7;
+    t1.x = widen<1, 20>(norm(D));
+    t1.y = widen<1, 20>(norm(C8));
+    t2.x = widen<1, 20>(X2);
+    t2.y = widen<1, 20>(Y2);
+    F28<4, 6> w;
+    coz28_addu_quad(t3, t2, t1, z, w, nullptr, nullptr, ql);              // 3P = 2P + P
+    coz28_addu_quad(t5, t2, t3, z, w, &t1, nullptr, ql);                  // 5P = 2P + 3P; P follows
+    coz28_addu_quad(t7, t2, t5, z, w, &t1, &t3, ql);                      // 7P = 2P + 5P; P and 3P.x follow
+    // last step but one: 3P.y * w (the same product in every lane); last: beta * x of the four entries
+    t3.y = widen<1, 20>(mul(t3.y, w));
+    const auto bx = mul(qsel(ql, t1.x, t3.x, t5.x, t7.x), f28_const<1, 1>(FP28_BETA_LAMBDA));
+    tbl[0].x = t1.x; tbl[0].y = t1.y; tbl[0].bx = widen<1, 20>(qread<0>(bx));
+    tbl[1].x = t3.x; tbl[1].y = t3.y; tbl[1].bx = widen<1, 20>(qread<1>(bx));
+    tbl[2].x = t5.x; tbl[2].y = t5.y; tbl[2].bx = widen<1, 20>(qread<2>(bx));
+    tbl[3].x = t7.x; tbl[3].y = t7.y; tbl[3].bx = widen<1, 20>(qread<3>(bx));
+    zc = z;
+}
+
+#ifndef CKZG_QUAD_JACOBIAN_TABLE
 // [k]P = [k1]P + [k2]phi(P) with both halves in width-4 NAF: quad form of xyzz28_mul_glv_naf (the G1 FFT's
-// twiddle multiplication; the digit strings are shared by the whole wave)
+// twiddle multiplication; the digit strings are shared by the whole wave).  Co-Z table, mixed additions.
+__device__ __noinline__ void xyzz28_mul_glv_naf_quad(XYZZ28 &out, bool &out_inf, const XYZZ28 &p, bool p_inf,
+                                                     const int8_t *naf1, const int8_t *naf2, int ql) {
+    bool inf = true;
+    if (!p_inf) {
+        EAT28 tbl[4];
+        F28<1, 2> zc, zz;
+        eat28_build_quad(tbl, zc, p, ql);
+        JAC28 acc;
+        for (int i = GLV_NAF_LEN - 1; i >= 0; i--) {
+            if (!inf) jac28_dbl_quad_zz(acc, zz, ql);
+            const int d1 = naf1[i], d2 = naf2[i];
+            if (d1) {
+                const EAT28 &e = tbl[(d1 > 0 ? d1 : -d1) >> 1];
+                jac28_madd_quad_zz(acc, zz, inf, e.x, e.y, d1 < 0, ql);
+            }
+            if (d2) {
+                const EAT28 &e = tbl[(d2 > 0 ? d2 : -d2) >> 1];
+                jac28_madd_quad_zz(acc, zz, inf, e.bx, e.y, d2 < 0, ql);
+            }
+        }
+        if (!inf) {
+            acc.z = widen<2, 4>(mul(acc.z, zc));   // home from the isomorphic curve
+            out = jac28_to_xyzz(acc);
+        }
+    }
+    out_inf = inf;
+}
+#else
+// (A/B builds: Jacobian table with cached Z^2, Z^3, five-step additions, phi applied per addition)
 __device__ __noinline__ void xyzz28_mul_glv_naf_quad(XYZZ28 &out, bool &out_inf, const XYZZ28 &p, bool p_inf,
                                                      const int8_t *naf1, const int8_t *naf2, int ql) {
     JACT28 tbl[8];  // [2m] = (2m+1)P, [2m+1] = -(2m+1)P
@@ -302,6 +499,7 @@ __device__ __noinline__ void xyzz28_mul_glv_naf_quad(XYZZ28 &out, bool &out_inf,
     if (!inf) out = jac28_to_xyzz(acc);
     out_inf = inf;
 }
+#endif
 
 }  // namespace quad
 }  // namespace ckzg

@@ -42,7 +42,7 @@ extern "C" {
  *   "proof_wbits"   window width of the table over the 4096 monomial points used by the low-latency
  *                   (no G1 FFT) cell-proof path; default 8 (0.8 GB), 0 disables the path
  *   "direct_max"    largest batch that takes the low-latency proof path; larger batches use FK20, which
- *                   does ~10x fewer point additions but costs ~7 ms for any small batch (6 dependent
+ *                   does ~10x fewer point additions but costs ~6 ms for any small batch (6 dependent
  *                   ladder launches).  -1 (default): 2 / 3 / 4 blobs for a proof table of <= 10 / <= 14 /
  *                   >= 15 bits, the measured hand-over points; 0 disables the path
  *   "gpu_sha_min"   smallest verify_blob_kzg_proof_batch size whose Fiat-Shamir challenges are hashed on
