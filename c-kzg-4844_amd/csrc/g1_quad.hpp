@@ -123,7 +123,9 @@ __device__ __forceinline__ void jac28_add_quad(JAC28 &a, bool &ainf, const JACT2
 
 // [k]P for a 128-bit k (one GLV half), uniform 4-bit windows: the quad form of xyzz28_mul_w4_128.
 // Only for points of the prime-order subgroup (every multiple 1..15 is finite).  All four lanes of the quad
-// pass the same arguments and receive the same result.
+// pass the same arguments and receive the same result.  (The first form of the round, kept for A/B builds with
+// CKZG_QUAD_W4_UNSIGNED: 15-entry table, five-step additions; the signed-window form below replaces it.)
+#ifdef CKZG_QUAD_W4_UNSIGNED
 __device__ __noinline__ void xyzz28_mul_w4_128_quad(XYZZ28 &out, bool &out_inf, const XYZZ28 &p, bool p_inf,
                                                     const uint32_t *k, int ql) {
     JACT28 tbl[15];
@@ -151,6 +153,7 @@ __device__ __noinline__ void xyzz28_mul_w4_128_quad(XYZZ28 &out, bool &out_inf, 
     if (!inf) out = jac28_to_xyzz(acc);
     out_inf = inf;
 }
+#endif
 
 // a <- a + b in XYZZ coordinates (add-2008-s), both operands general: four product steps instead of fourteen
 // products.  Quad form of xyzz28_add; ainf / binf are the (replicated) infinity flags.
@@ -435,6 +438,121 @@ __device__ __forceinline__ void eat28_build_quad(EAT28 (&tbl)[4], F28<1, 2> &zc,
     tbl[3].x = t7.x; tbl[3].y = t7.y; tbl[3].bx = widen<1, 20>(qread<3>(bx));
     zc = z;
 }
+
+// a <- a + b (b finite, Jacobian with cached Z^2, Z^3), zz = Z(a)^2 in and out: with Z1^2 at hand the products
+// X2*Z1^2 and Z1^3 move up into the first step and the addition is FOUR product steps instead of five.
+__device__ __forceinline__ void jac28_add_quad_zz(JAC28 &a, F28<1, 2> &zz, bool &ainf, const JACT28 &b, int ql) {
+    if (ainf) {
+        a.x = b.x;
+        a.y = widen<1, 34>(mul(b.y, f28_one()));
+        a.z = b.z;
+        zz = b.zz;
+        ainf = false;
+        return;
+    }
+    // step 1: X1*ZZ2 | Y1*ZZZ2 | X2*ZZ1 | Z1*ZZ1
+    const auto az = widen<2, 34>(a.z);
+    const auto zz1 = widen<2, 4>(zz);
+    const auto p1 = mul(qsel(ql, widen<2, 34>(a.x), widen<2, 34>(a.y), widen<2, 34>(b.x), az),
+                        qsel(ql, widen<2, 4>(b.zz), widen<2, 4>(b.zzz), zz1, zz1));   // 14*4+15 ok; 34*4 ok
+    const auto u1 = qread<0>(p1), s1 = qread<1>(p1), u2 = qread<2>(p1), z1c = qread<3>(p1);
+    const auto h = sub(u2, u1);                                                       // <4,6>
+    // step 2: Y2*Z1^3 | H*H | Z1*Z2 | (H*H)
+    const auto h64 = widen<4, 64>(h);
+    const auto p2 = mul(qsel(ql, widen<4, 64>(b.y), h64, widen<4, 64>(a.z), h64),
+                        qsel(ql, widen<4, 6>(z1c), h, widen<4, 6>(b.z), h));          // 239 ok; 64*6 ok
+    const auto s2 = qread<0>(p2), hh = qread<1>(p2), z1z2 = qread<2>(p2);
+    if (is_zero(hh)) {  // same x: the complete one-lane routine, on every copy
+        jac28_add(a, ainf, b);
+        if (!ainf) zz = sqr(a.z);
+        return;
+    }
+    const auto r = sub(s2, s1);                                                       // <4,6>
+    // step 3: H*HH | U1*HH | R*R | Z1Z2*H
+    const auto hh46 = widen<4, 6>(hh);
+    const auto p3 = mul(qsel(ql, h, widen<4, 6>(u1), r, widen<4, 6>(z1z2)), qsel(ql, hh46, hh46, r, h));   // 239 ok; 36 ok
+    const auto hhh = qread<0>(p3), v = qread<1>(p3), rr = qread<2>(p3), z3 = qread<3>(p3);
+    const auto x3 = norm(sub(rr, add(hhh, add(v, v))));                               // <6,10> -> <1,10>
+    const auto dv = sub(v, x3);                                                       // <4,18>
+    F28<1, 0> zero;
+#pragma unroll
+    for (int j = 0; j < 14; j++) zero.l[j] = 0;
+    const auto s1n = sub(zero, s1);                                                   // <4,4> = -S1
+    // step 4: R*(V - X3) | (-S1)*HHH | Z3*Z3 | (Z3*Z3)
+    const auto rn = widen<4, 6>(norm(r)), sn = widen<4, 6>(s1n), z3l = widen<4, 6>(z3);
+    const auto h18 = widen<4, 18>(hhh), z3r = widen<4, 18>(z3);
+    const auto p4 = mul(qsel(ql, rn, sn, z3l, z3l), qsel(ql, dv, h18, z3r, z3r));     // 239 ok; 108 ok
+    const auto y3 = norm(add(qread<0>(p4), qread<1>(p4)));                            // <2,4> -> <1,4>
+    a.x = widen<1, 34>(x3);
+    a.y = widen<1, 34>(y3);
+    a.z = widen<2, 4>(z3);
+    zz = qread<2>(p4);
+}
+
+#ifndef CKZG_QUAD_W4_UNSIGNED
+// [k]P for a 128-bit k (one GLV half): uniform SIGNED 4-bit windows (digits -8..8, 33 of them), so the table is
+// P..8P (7 additions instead of 14) and every addition is the four-step form above.  ~560 dependent product steps
+// instead of ~650.  Only for points of the prime-order subgroup (every multiple 1..8 is finite).  All four lanes
+// of the quad pass the same arguments and receive the same result.
+__device__ __noinline__ void xyzz28_mul_w4_128_quad(XYZZ28 &out, bool &out_inf, const XYZZ28 &p, bool p_inf,
+                                                    const uint32_t *k, int ql) {
+    JACT28 tbl[8];
+    JAC28 acc;
+    F28<1, 2> zz;
+    bool inf = true;
+    if (!p_inf) {
+        // carries of the signed recoding: digit i = nibble i + c_i - 16 c_(i+1), c_(i+1) = [nibble i + c_i > 8]
+        uint64_t cm = 0;
+        {
+            uint32_t c = 0;
+            for (int i = 0; i < 32; i++) {
+                const uint32_t nib = ((k[i >> 3] >> ((i & 7) * 4)) & 15u) + c;
+                c = nib > 8u ? 1u : 0u;
+                cm |= (uint64_t)c << (i + 1);
+            }
+        }
+        JAC28 cur = jac28_from_xyzz(p);
+        tbl[0] = jac28_table_entry(cur);
+        F28<1, 2> czz = tbl[0].zz;
+        for (int i = 1; i < 8; i++) {
+            bool ci = false;
+            jac28_add_quad_zz(cur, czz, ci, tbl[0], ql);
+            tbl[i].x = cur.x;
+            tbl[i].y = widen<1, 64>(cur.y);
+            tbl[i].z = cur.z;
+            tbl[i].zz = czz;
+        }
+        // Z^3 of entries 2P..8P: two steps (entry 1 + 4 per step; lane 3 of the second repeats a product)
+        {
+            const auto pz = mul(qsel(ql, tbl[1].z, tbl[2].z, tbl[3].z, tbl[4].z), qsel(ql, tbl[1].zz, tbl[2].zz, tbl[3].zz, tbl[4].zz));
+            tbl[1].zzz = qread<0>(pz); tbl[2].zzz = qread<1>(pz); tbl[3].zzz = qread<2>(pz); tbl[4].zzz = qread<3>(pz);
+            const auto pw = mul(qsel(ql, tbl[5].z, tbl[6].z, tbl[7].z, tbl[7].z), qsel(ql, tbl[5].zz, tbl[6].zz, tbl[7].zz, tbl[7].zz));
+            tbl[5].zzz = qread<0>(pw); tbl[6].zzz = qread<1>(pw); tbl[7].zzz = qread<2>(pw);
+        }
+        for (int w = 32; w >= 0; w--) {
+            if (!inf) {
+                jac28_dbl_quad_zz(acc, zz, ql);
+                jac28_dbl_quad_zz(acc, zz, ql);
+                jac28_dbl_quad_zz(acc, zz, ql);
+                jac28_dbl_quad_zz(acc, zz, ql);
+            }
+            const int nib = w < 32 ? (int)((k[w >> 3] >> ((w & 7) * 4)) & 15u) : 0;
+            const int d = nib + (int)((cm >> w) & 1u) - (w < 32 ? 16 * (int)((cm >> (w + 1)) & 1u) : 0);
+            if (d != 0) {
+                // ONE call site for both signs: the quads of a wave have different digits, and two call sites
+                // would run the addition twice per window (measured: slower than the unsigned form)
+                JACT28 e = tbl[(d > 0 ? d : -d) - 1];
+                const JACT28 n = jact28_neg(e);
+#pragma unroll
+                for (int j = 0; j < 14; j++) e.y.l[j] = d < 0 ? n.y.l[j] : e.y.l[j];
+                jac28_add_quad_zz(acc, zz, inf, e, ql);
+            }
+        }
+    }
+    if (!inf) out = jac28_to_xyzz(acc);
+    out_inf = inf;
+}
+#endif
 
 #ifndef CKZG_QUAD_JACOBIAN_TABLE
 // [k]P = [k1]P + [k2]phi(P) with both halves in width-4 NAF: quad form of xyzz28_mul_glv_naf (the G1 FFT's
