@@ -67,7 +67,10 @@ C_KZG_RET ckzg_hip_blob_to_kzg_commitment_batch(KZGCommitment *out, uint8_t *sta
                                                 const Blob *blobs, uint64_t n,
                                                 const KZGSettings *s);
 
-/* Same with blobs/out/status resident in HBM (device pointers); runs on the device that holds them. */
+/* Same with blobs/out/status resident in HBM (device pointers); runs on the device that holds them and returns
+ * when the results are in HBM.  Non-canonical blobs are reported through d_status ONLY (d_status[i] = 1 =
+ * C_KZG_BADARGS): the return value does not reflect them -- deriving it would cost a copy back to the host on
+ * every call -- and is C_KZG_OK unless the call itself failed.  The same holds for the cells + proofs form below. */
 C_KZG_RET ckzg_hip_blob_to_kzg_commitment_batch_device(void *d_out48, void *d_status,
                                                        const void *d_blobs, uint64_t n,
                                                        const KZGSettings *s);

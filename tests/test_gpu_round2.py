@@ -493,6 +493,64 @@ def test_pinned_caller_memory_is_read_in_place(hip):
     assert rt.hipHostFree(pinned) == 0
 
 
+def test_device_pointer_batches_match_the_host_pointer_calls(hip):
+    """The *_batch_device entry points (what bench.py times) on buffers from hipMalloc: commitments, and cells +
+    proofs for 520 blobs -- 66,560 small MSMs in one launch, the size from which k_msm_small runs 8 lanes per
+    vector -- against the host-pointer calls on the same blobs, with one non-canonical blob flagged (in d_status
+    only: the device-pointer forms do not copy a verdict back, include/ckzg_hip.h)."""
+    rt = C.CDLL("/opt/rocm/lib/libamdhip64.so")
+    rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    rt.hipFree.argtypes = [C.c_void_p]
+    H2D, D2H = 1, 2
+    base = [rand_blob(123, i) for i in range(4)]
+    n = 520
+    blobs = [base[(i * 5 + i // 7) % 4] for i in range(n)]
+    bad = bytearray(base[0])
+    bad[64:96] = R.to_bytes(32, "big")
+    blobs[333] = bytes(bad)
+    raw = b"".join(blobs)
+
+    def dmalloc(nbytes):
+        q = C.c_void_p()
+        assert rt.hipMalloc(C.byref(q), nbytes) == 0
+        return q
+
+    d_blobs, d_out, d_st = dmalloc(len(raw)), dmalloc(48 * n), dmalloc(n)
+    d_cells, d_proofs = dmalloc(n * 262144), dmalloc(n * 6144)
+    try:
+        assert rt.hipMemcpy(d_blobs, C.cast(C.c_char_p(raw), C.c_void_p), len(raw), H2D) == 0
+        f = hip.lib.ckzg_hip_blob_to_kzg_commitment_batch_device
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        rc = f(d_out, d_st, d_blobs, n, hip.sp)
+        out, st = C.create_string_buffer(48 * n), C.create_string_buffer(n)
+        assert rt.hipMemcpy(out, d_out, 48 * n, D2H) == 0 and rt.hipMemcpy(st, d_st, n, D2H) == 0
+        assert rc == 0 and [i for i, v in enumerate(st.raw) if v] == [333]
+        single = [hip.blob_to_kzg_commitment(b) for b in base]
+        assert all(out.raw[48 * i:48 * i + 48] == single[(i * 5 + i // 7) % 4] for i in range(n) if i != 333)
+
+        g = hip.lib.ckzg_hip_compute_cells_and_kzg_proofs_batch_device
+        g.restype = C.c_int
+        g.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        rc = g(d_cells, d_proofs, d_st, d_blobs, n, hip.sp)
+        assert rt.hipMemcpy(st, d_st, n, D2H) == 0
+        assert rc == 0 and [i for i, v in enumerate(st.raw) if v] == [333]
+        proofs = C.create_string_buffer(n * 6144)
+        assert rt.hipMemcpy(proofs, d_proofs, n * 6144, D2H) == 0
+        exp = [hip.compute_cells_and_kzg_proofs(b) for b in base]
+        for i in range(n):
+            if i != 333:
+                assert proofs.raw[6144 * i:6144 * (i + 1)] == b"".join(exp[(i * 5 + i // 7) % 4][1]), i
+        cells = C.create_string_buffer(262144)
+        for i in (0, 332, 334, n - 1):
+            assert rt.hipMemcpy(cells, C.c_void_p(d_cells.value + 262144 * i), 262144, D2H) == 0
+            assert cells.raw == b"".join(exp[(i * 5 + i // 7) % 4][0]), i
+    finally:
+        for q in (d_blobs, d_out, d_st, d_cells, d_proofs):
+            rt.hipFree(q)
+
+
 def _run_bench(extra_env, args):
     import json
     import os
