@@ -346,11 +346,31 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # "nccl" is RCCL on ROCm.  CKZG_BENCH_BACKEND=gloo + CKZG_BENCH_ONE_GPU=1 exist only to exercise
         # this file's multi-rank control flow on a one-GPU box (all ranks share device 0).
-        dist.init_process_group(os.environ.get("CKZG_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
     if one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:
+        # The ranks only meet at barriers and at one MAX over their timings (the path has no data-path collective,
+        # SURVEY 8e).  RCCL carries them; if it cannot come up on this node (every rank then fails alike) the same
+        # two calls go over gloo on a second rendezvous port, and the line says so in "barrier_backend".
+        backend = os.environ.get("CKZG_BENCH_BACKEND", "nccl")
+        try:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+            t = torch.zeros(1, device=dev if backend == "nccl" else torch.device("cpu"))
+            dist.all_reduce(t)
+            if backend == "nccl":
+                torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001 -- whatever RCCL raised, the control plane can still run
+            if backend != "nccl":
+                raise
+            sys.stderr.write("bench: rank %d: RCCL did not come up (%s); barriers over gloo\n" % (rank, str(e)[:200]))
+            try:
+                dist.destroy_process_group()
+            except Exception:  # noqa: BLE001
+                pass
+            os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     red_dev = dev if (world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")
 
     import __graft_entry__ as ge
@@ -550,7 +570,8 @@ def main():
             "config": {"workload": "blob_to_kzg_commitment batch of 1024 blobs per GPU (4096-point G1 MSM per blob), "
                                    "inputs resident in HBM", "blobs_per_step_per_gpu": BLOBS_PER_STEP,
                        "table_wbits": wbits, "tables": tables_of(L, hip),
-                       "parallelism": "independent blob shards per GPU, no collective"},
+                       "parallelism": "independent blob shards per GPU, no collective",
+                       "barrier_backend": dist.get_backend() if world > 1 else None},
             "roofline": dict(roofline(ALGO_BYTES_PER_BLOB * BLOBS_PER_STEP, avg_k, "k_msm_accumulate",
                                       PMC_TRAFFIC_BYTES.get(wbits)),
                              note="integer-VALU-bound kernel (v_mad_u64_u32 chains); HBM fraction is small by nature"),
