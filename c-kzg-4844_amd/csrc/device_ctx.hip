@@ -374,6 +374,7 @@ C_KZG_RET create_settings_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affin
     host::g2_prepare(sc->prepared.gen, host::g2_to_affine(host::g2_generator()));
     host::g2_prepare(sc->prepared.s1, host::g2_to_affine(*as_g2(&s->g2_values_monomial[1])));
     host::g2_prepare(sc->prepared.s64, host::g2_to_affine(*as_g2(&s->g2_values_monomial[dev::N_CELL])));
+    (void)host::g1_gen_table();   // built once per process, here rather than inside the first verification
     for (int d : devs) {
         for (int r = 0; r < replicas; r++) {
             DevicePool *p = new DevicePool();

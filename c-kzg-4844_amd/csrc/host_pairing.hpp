@@ -642,9 +642,11 @@ inline Fp12 mul_by_prepared_line(const Fp12 &f, const Fp2 &lam, const Fp2 &c, co
     return {add(t0, mul_v(t1)), sub(sub(t2, t0), t1)};
 }
 
-// e(p1, Q1) * e(p2, Q2) == 1 ?
-inline bool pairing_product_is_one(const G1Affine &p1, const G2Prepared &q1, const G1Affine &p2,
-                                   const G2Prepared &q2) {
+// The Miller-loop value of e(p1, Q1) * e(p2, Q2) (before the final exponentiation); an infinite argument makes
+// its factor 1.  A caller whose second pair is known early can run that loop ahead of time
+// (miller_product_prepared(p2, q2, inf, q2)) and multiply the two values: the same product.
+inline Fp12 miller_product_prepared(const G1Affine &p1, const G2Prepared &q1, const G1Affine &p2,
+                                    const G2Prepared &q2) {
     const bool use1 = !p1.is_inf() && !q1.inf, use2 = !p2.is_inf() && !q2.inf;
     Fp12 f = Fp12::one();
     const uint64_t xabs = BLS_X_ABS;
@@ -660,7 +662,65 @@ inline bool pairing_product_is_one(const G1Affine &p1, const G2Prepared &q1, con
             n++;
         }
     }
-    return final_exp(f).is_one();
+    return f;
+}
+
+// e(p1, Q1) * e(p2, Q2) == 1 ?
+inline bool pairing_product_is_one(const G1Affine &p1, const G2Prepared &q1, const G1Affine &p2,
+                                   const G2Prepared &q2) {
+    return final_exp(miller_product_prepared(p1, q1, p2, q2)).is_one();
+}
+
+// ---- [k]G1 for the generator from a table: 64 windows of 4 bits, entries j * 16^w * G (j = 1..15) with Z = 1,
+// so a 255-bit multiple is at most 64 additions and no doubling (the generic GLV ladder: 128 + ~96).  Built on
+// first use (~1 ms). ----
+struct G1GenTable {
+    G1Jac e[64][15];
+};
+inline const G1GenTable &g1_gen_table() {
+    static const G1GenTable *tbl = []() {
+        G1GenTable *t = new G1GenTable;
+        G1Jac base = g1_generator();
+        for (int w = 0; w < 64; w++) {
+            G1Jac cur = base;
+            for (int j = 0; j < 15; j++) {
+                t->e[w][j] = cur;
+                cur = jac_add(cur, base);
+            }
+            base = cur;                                             // 16 * base
+        }
+        // all 960 entries to Z = 1 with ONE inversion (Montgomery's trick); no entry is at infinity
+        G1Jac *flat = &t->e[0][0];
+        const int N = 64 * 15;
+        Fp *prefix = new Fp[N];
+        Fp acc = Fp::one();
+        for (int i = 0; i < N; i++) {
+            prefix[i] = acc;
+            acc = mul(acc, flat[i].z);
+        }
+        Fp inv = fp_inv(acc);
+        for (int i = N - 1; i >= 0; i--) {
+            const Fp zi = mul(inv, prefix[i]);
+            inv = mul(inv, flat[i].z);
+            const Fp zi2 = sqr(zi);
+            flat[i].x = mul(flat[i].x, zi2);
+            flat[i].y = mul(flat[i].y, mul(zi2, zi));
+            flat[i].z = Fp::one();
+        }
+        delete[] prefix;
+        return t;
+    }();
+    return *tbl;
+}
+// k: canonical little-endian limbs of a scalar < r
+inline G1Jac g1_gen_mul(const uint32_t *k) {
+    const G1GenTable &t = g1_gen_table();
+    G1Jac acc = G1Jac::inf();
+    for (int w = 0; w < 64; w++) {
+        const uint32_t d = (k[w >> 3] >> ((w & 7) * 4)) & 15u;
+        if (d) acc = jac_add(acc, t.e[w][d - 1]);
+    }
+    return acc;
 }
 
 // e(a1, a2) == e(b1, b2)

@@ -337,6 +337,26 @@ extern "C" int hs_fp12_selftest(uint32_t seed) {
     return bad;
 }
 
+// [k]G1 from the generator table against the generic ladder; returns 1 when they agree
+extern "C" int hs_g1_gen_mul_check(const uint32_t *k) {
+    G1Jac a = g1_gen_mul(k), b = g1_mul_glv_host(g1_generator(), k);
+    G1Affine x = jac_to_affine(a), y = jac_to_affine(b);
+    return std::memcmp(&x, &y, sizeof x) == 0 ? 1 : 0;
+}
+// the product check with the second pair's Miller loop run separately (what verify_blob_kzg_proof does underneath
+// the GPU's evaluation) against the fused loop: returns verdict | (agreement << 1)
+extern "C" int hs_pairing_split(const G1Jac *a1, const G2Jac *q1, const G1Jac *a2, const G2Jac *q2) {
+    G2Prepared p1, p2;
+    g2_prepare(p1, g2_to_affine(*q1));
+    g2_prepare(p2, g2_to_affine(*q2));
+    const G1Affine x1 = jac_to_affine(*a1), x2 = jac_to_affine(*a2);
+    const Fp12 early = miller_product_prepared(x2, p2, G1Affine::inf(), p2);
+    const Fp12 late = miller_product_prepared(x1, p1, G1Affine::inf(), p1);
+    const bool split = final_exp(mul(late, early)).is_one();
+    const bool fused = pairing_product_is_one(x1, p1, x2, p2);
+    return (split ? 1 : 0) | ((split == fused) ? 2 : 0);
+}
+
 extern "C" int hs_pairing_prepared(const G1Jac *a1, const G2Jac *q1, const G1Jac *a2, const G2Jac *q2) {
     G2Prepared p1, p2;
     g2_prepare(p1, g2_to_affine(*q1));

@@ -461,6 +461,34 @@ def test_glv_split_and_glv_scalar_mul(libs):
     assert o.og1_is_inf(r)
 
 
+def test_generator_table_and_split_miller_loops(libs):
+    """host_pairing.hpp: [k]G1 from the 64 x 15 generator table against the generic ladder, and the product check
+    with the second pair's Miller loop run ahead of time against the fused loop (true and false instances)."""
+    o, h = libs
+    rnd = random.Random(91)
+    ks = [0, 1, 15, 16, 17, R - 1, R - 2, 2 ** 252, (1 << 255) % R, 0x0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f]
+    ks += [rnd.randrange(R) for _ in range(30)]
+    for k in ks:
+        kk = (C.c_uint32 * 8)(*[(k >> (32 * i)) & 0xffffffff for i in range(8)])
+        assert h.hs_g1_gen_mul_check(kk) == 1, k
+    g, g2 = _buf(144), _buf(288)
+    h.hs_g1_generator(g)
+    h.hs_g2_generator(g2)
+    k = rnd.randrange(1, R)
+    kk = (C.c_uint32 * 8)(*[(k >> (32 * i)) & 0xffffffff for i in range(8)])
+    kg2 = _buf(288)
+    h.hs_g2_mul(kg2, g2, kk, 255)
+    kg1 = _omul(o, g, k)
+    neg_g = _omul(o, g, R - 1)
+    # e(kG, Q) * e(-G, kQ) == 1 ; e(kG, Q) * e(G, kQ) != 1
+    assert h.hs_pairing_split(kg1, g2, neg_g, kg2) == 3
+    assert h.hs_pairing_split(kg1, g2, g, kg2) == 2
+    # an infinite argument on either side
+    inf = _buf(144)
+    assert h.hs_pairing_split(inf, g2, inf, kg2) == 3
+    assert h.hs_pairing_split(kg1, g2, inf, kg2) == 2
+
+
 def test_coz_table_and_mixed_addition_branches(libs):
     """g1_28.hpp: the co-Z table {P, 3P, 5P, 7P} of the G1 FFT's NAF ladder brought home from its isomorphic curve,
     and every branch of the mixed addition on that curve (from infinity, equal points -> doubling, generic,
