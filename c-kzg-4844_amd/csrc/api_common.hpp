@@ -86,7 +86,9 @@ struct DevicePool {
     std::mutex mu;
     std::condition_variable cv;
     std::vector<int> free_slots;
-    std::atomic<dev::DeviceCtx *> last{nullptr};  // slot of the most recent call (ckzg_hip_last_kernel_ms)
+    std::atomic<dev::DeviceCtx *> last{nullptr};  // slot of this pool's most recent lease
+    std::atomic<uint64_t> last_seq{0};            // ... and its number in SettingsCtx::lease_seq
+    struct SettingsCtx *owner = nullptr;
 };
 
 // Everything this library hangs off one KZGSettings.  Found through a registry keyed by the struct's
@@ -98,12 +100,35 @@ struct SettingsCtx {
     PreparedG2 prepared;
     Options opts;
     std::atomic<unsigned> next{0};
+    std::atomic<uint64_t> lease_seq{0};   // leases handed out so far, over all pools (ckzg_hip_last_kernel_ms)
 };
 SettingsCtx *settings_of(const KZGSettings *s, bool complain = true);
 
+// The library never leaves the calling thread's current HIP device changed: whatever selects a device on a
+// caller's thread (a lease, a load, a free) holds one of these, which puts the caller's device back on the way
+// out -- a host application that shares the process (torch, another HIP library) keeps allocating and launching
+// where it was.
+struct DeviceGuard {
+    int saved = -1;
+    DeviceGuard() {
+        if (hipGetDevice(&saved) != hipSuccess) {
+            (void)hipGetLastError();
+            saved = -1;
+        }
+    }
+    ~DeviceGuard() {
+        int now = -1;
+        if (saved >= 0 && hipGetDevice(&now) == hipSuccess && now != saved) (void)hipSetDevice(saved);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 // Exclusive use of one slot for the duration of a call.  Default: the first pool with a free slot (round
-// robin), waiting if every slot is busy.  Sets the calling thread's HIP device.
+// robin), waiting if every slot is busy.  Selects the slot's HIP device on the calling thread for the lifetime
+// of the lease and restores the caller's device when it ends (`guard` is destroyed after the slot is returned).
 struct Lease {
+    DeviceGuard guard;
     DevicePool *pool = nullptr;
     dev::DeviceCtx *ctx = nullptr;
     explicit Lease(const KZGSettings *s, int pool_index = -1);
@@ -137,6 +162,24 @@ C_KZG_RET guarded(F &&f) noexcept {
 
 inline C_KZG_RET worse(C_KZG_RET a, C_KZG_RET b) { return (int)a > (int)b ? a : b; }
 
+// Threads that are joined on every exit path: if constructing a later std::thread throws (EAGAIN, rlimit), the
+// ones already running are joined by the destructor instead of std::terminate() firing on a joinable thread, and
+// the exception reaches guarded() like any other.
+struct JoinThreads {
+    std::vector<std::thread> th;
+    template <class F>
+    void spawn(F &&f) {
+        th.emplace_back(std::forward<F>(f));
+    }
+    void join() {
+        for (auto &t : th) {
+            if (t.joinable()) t.join();
+        }
+        th.clear();
+    }
+    ~JoinThreads() { join(); }
+};
+
 // Host-pointer batch entry points: contiguous ranges of the n units over the pools (one host thread and
 // one leased slot per device), results written in place by each shard; the reference's equivalent is the
 // goroutine fan-out of bindings/go/main_test.go:953-971.  body(ctx, lo, hi) -> C_KZG_RET.
@@ -153,12 +196,12 @@ C_KZG_RET for_each_device_shard(const KZGSettings *s, uint64_t n, uint64_t min_s
         return body(lease.ctx, (uint64_t)0, n);
     }
     std::vector<C_KZG_RET> rets(np, C_KZG_OK);
-    std::vector<std::thread> th;
+    JoinThreads th;   // joined on every exit path, also when a later thread cannot be created
     const uint64_t base = n / np, extra = n % np;
     uint64_t lo = 0;
     for (size_t d = 0; d < np; d++) {
         const uint64_t hi = lo + base + (d < extra ? 1 : 0);
-        th.emplace_back([&, d, lo, hi]() {
+        th.spawn([&, d, lo, hi]() {
             rets[d] = guarded([&]() -> C_KZG_RET {
                 Lease lease(sc->pools[d]);
                 if (!lease.ctx) return C_KZG_ERROR;
@@ -167,14 +210,72 @@ C_KZG_RET for_each_device_shard(const KZGSettings *s, uint64_t n, uint64_t min_s
         });
         lo = hi;
     }
-    for (auto &t : th) t.join();
+    th.join();
     C_KZG_RET ret = C_KZG_OK;
     for (auto r : rets) ret = worse(ret, r);
     return ret;
 }
 
 // pageable <-> pinned staging copy.  One core moves ~10 GB/s, which would make a copy (13 ms per
-// 1024 blobs) longer than the kernels it is supposed to hide behind: large chunks are split over four threads.
+// 1024 blobs) longer than the kernels it is supposed to hide behind: large chunks are split four ways, three
+// parts going to a small process-wide set of persistent helper threads (started on first use, never per chunk;
+// if they cannot be started the caller copies everything itself).
+class CopyHelpers {
+   public:
+    static CopyHelpers &get() {
+        static CopyHelpers *h = new CopyHelpers();   // leaked on purpose: helpers may outlive static destruction
+        return *h;
+    }
+    struct Job {
+        void *dst;
+        const void *src;
+        size_t len;
+        std::atomic<int> *pending;
+    };
+    // false: no helper available, the caller does this part itself
+    bool submit(const Job &j) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!ensure_started()) return false;
+        q.push_back(j);
+        cv.notify_one();
+        return true;
+    }
+
+   private:
+    static constexpr int NHELP = 6;   // two concurrent callers are served at full width
+    bool ensure_started() {
+        if (started) return nworkers > 0;
+        started = true;
+        for (int i = 0; i < NHELP; i++) {
+            try {
+                std::thread([this]() { run(); }).detach();
+                nworkers++;
+            } catch (...) {
+                break;
+            }
+        }
+        return nworkers > 0;
+    }
+    void run() {
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> lock(mu);
+                cv.wait(lock, [&]() { return !q.empty(); });
+                j = q.front();
+                q.pop_front();
+            }
+            if (j.len) memcpy(j.dst, j.src, j.len);
+            j.pending->fetch_sub(1, std::memory_order_release);
+        }
+    }
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Job> q;
+    bool started = false;
+    int nworkers = 0;
+};
+
 inline void staged_copy(void *dst, const void *src, size_t bytes) {
     const size_t nt = 4;
     if (bytes < ((size_t)4 << 20) || std::thread::hardware_concurrency() < 8) {
@@ -182,15 +283,18 @@ inline void staged_copy(void *dst, const void *src, size_t bytes) {
         return;
     }
     const size_t part = (bytes / nt + 4095) & ~(size_t)4095;
-    std::thread th[nt - 1];
+    std::atomic<int> pending{0};
     for (size_t t = 1; t < nt; t++) {
         size_t o = t * part, len = o >= bytes ? 0 : (bytes - o < part ? bytes - o : part);
-        th[t - 1] = std::thread([=]() {
-            if (len) memcpy((uint8_t *)dst + o, (const uint8_t *)src + o, len);
-        });
+        if (!len) continue;
+        pending.fetch_add(1, std::memory_order_relaxed);
+        if (!CopyHelpers::get().submit({(uint8_t *)dst + o, (const uint8_t *)src + o, len, &pending})) {
+            pending.fetch_sub(1, std::memory_order_relaxed);
+            memcpy((uint8_t *)dst + o, (const uint8_t *)src + o, len);
+        }
     }
     memcpy(dst, src, part < bytes ? part : bytes);
-    for (auto &x : th) x.join();
+    while (pending.load(std::memory_order_acquire) != 0) std::this_thread::yield();
 }
 
 // true if the caller's host buffer is page-locked (hipHostMalloc / hipHostRegister): such a buffer is DMA'd
@@ -242,7 +346,10 @@ class OutPipe {
             if (!ctx->out_stream && hipStreamCreateWithFlags(&ctx->out_stream, hipStreamNonBlocking) != hipSuccess) return false;
             if (!ensure_pinned(ctx->h_out, ctx->h_out_bytes, PIECE)) return false;
             for (auto &e : piece_ev) {
-                if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+                if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+                    e = nullptr;
+                    return false;
+                }
             }
             worker = std::thread([this]() { run(); });
             started = true;
@@ -276,10 +383,11 @@ class OutPipe {
             cv.notify_all();
             worker.join();
             started = false;
-            for (auto &e : piece_ev) {
-                if (e) (void)hipEventDestroy(e);
-                e = nullptr;
-            }
+        }
+        // also after a push() that failed half-way through its set-up (events created, worker never started)
+        for (auto &e : piece_ev) {
+            if (e) (void)hipEventDestroy(e);
+            e = nullptr;
         }
         return failed ? C_KZG_ERROR : C_KZG_OK;
     }
@@ -351,12 +459,22 @@ struct DeviceBuffer {
 };
 
 // the same interface over a slice of a persistent arena (device.hpp: Arena): no hipMalloc/hipFree
+// up() / down() are ordered on the slot's compute stream (Arena::stream) and return when the copy is complete:
+// every slot stream is hipStreamNonBlocking, so a legacy-stream hipMemcpy would NOT wait for kernels enqueued
+// there -- a down() placed after an enqueue-only stage would read stale bytes without any error.
 template <class T>
 struct ABuf {
     T *p;
-    ABuf(dev::Arena &a, size_t count) : p(a.get<T>(count)) {}
-    bool up(const T *h, size_t count) { return hipMemcpy(p, h, count * sizeof(T), hipMemcpyHostToDevice) == hipSuccess; }
-    bool down(T *h, size_t count) const { return hipMemcpy(h, p, count * sizeof(T), hipMemcpyDeviceToHost) == hipSuccess; }
+    hipStream_t stream;
+    ABuf(dev::Arena &a, size_t count) : p(a.get<T>(count)), stream(a.stream) {}
+    bool up(const T *h, size_t count) {
+        return hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, stream) == hipSuccess &&
+               hipStreamSynchronize(stream) == hipSuccess;
+    }
+    bool down(T *h, size_t count) const {
+        return hipMemcpyAsync(h, p, count * sizeof(T), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+               hipStreamSynchronize(stream) == hipSuccess;
+    }
 };
 using dev::Arena;
 

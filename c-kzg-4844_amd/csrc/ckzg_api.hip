@@ -2,6 +2,7 @@
 // extensions).  Host-side protocol logic lives here; every MSM / NTT goes to the HIP kernels via
 // device.hpp.  There is no CPU fallback for the hot path: if no GPU context is attached to the
 // KZGSettings (or the HIP runtime fails) the call returns C_KZG_ERROR and says why on stderr.
+#include <algorithm>
 #include <atomic>
 #include <thread>
 
@@ -155,9 +156,9 @@ static C_KZG_RET load_trusted_setup_impl(KZGSettings *out, const uint8_t *g1_mon
         unsigned hw = std::thread::hardware_concurrency();
         const size_t nt = hw >= 16 ? 16 : (hw ? hw : 1);
         std::atomic<int> bad(0);
-        std::vector<std::thread> th;
+        JoinThreads th;
         for (size_t t = 0; t < nt; t++) {
-            th.emplace_back([&, t]() {
+            th.spawn([&, t]() {
                 for (size_t i = t; i < NUM_G1_POINTS; i += nt) {
                     if (g1_uncompress(mono_affine[i], g1_monomial_bytes + 48 * i) != 0 ||
                         g1_uncompress(lagr_affine[i], g1_lagrange_bytes + 48 * i) != 0) {
@@ -169,7 +170,7 @@ static C_KZG_RET load_trusted_setup_impl(KZGSettings *out, const uint8_t *g1_mon
                 }
             });
         }
-        for (auto &x : th) x.join();
+        th.join();
         if (bad.load()) {
             ret = C_KZG_BADARGS;
             goto fail;
@@ -630,18 +631,27 @@ extern "C" C_KZG_RET compute_cells_and_kzg_proofs(Cell *cells, KZGProof *proofs,
     return ckzg_hip_compute_cells_and_kzg_proofs_batch(cells, proofs, &st, blob, 1, s);
 }
 
-// the slot that served the most recent call on pool 0 (bench.py is single-threaded)
-static dev::DeviceCtx *last_slot(const KZGSettings *s) {
-    SettingsCtx *sc = settings_of(s);
-    if (!sc || sc->pools.empty()) return nullptr;
-    dev::DeviceCtx *c = sc->pools[0]->last.load();
-    return c ? c : sc->pools[0]->slots[0];
-}
-
+// Timings of the most recent call on this KZGSettings (bench.py is single-threaded): every lease is numbered
+// (SettingsCtx::lease_seq); a call that was fanned out over P pools took the last P leases, one per pool, so the
+// answer is the maximum over the pools whose latest lease is among the last P -- for a one-pool call, or a
+// single-unit call that went round robin to some pool, that is exactly the slot that served it.
 extern "C" double ckzg_hip_last_kernel_ms(const KZGSettings *s, int which) {
-    dev::DeviceCtx *ctx = last_slot(s);
-    if (!ctx || which < 0 || which > 5) return -1.0;
-    return ctx->last_ms[which];
+    SettingsCtx *sc = settings_of(s);
+    if (!sc || sc->pools.empty() || which < 0 || which > 5) return -1.0;
+    const uint64_t now = sc->lease_seq.load();
+    if (now == 0) return -1.0;
+    uint64_t newest = 0;
+    for (auto *p : sc->pools) newest = std::max(newest, p->last_seq.load());
+    // pools that took part in the newest call: consecutive lease numbers ending at `newest`
+    double best = -1.0;
+    for (auto *p : sc->pools) {
+        const uint64_t q = p->last_seq.load();
+        dev::DeviceCtx *c = p->last.load();
+        if (!c || q == 0 || newest - q >= sc->pools.size()) continue;
+        if (newest - q > 0 && sc->pools.size() == 1) continue;
+        best = std::max(best, (double)c->last_ms[which]);
+    }
+    return best;
 }
 
 extern "C" uint64_t ckzg_hip_table_bytes(const KZGSettings *s) {

@@ -234,13 +234,13 @@ void parallel_for(size_t n, const std::function<void(size_t)> &fn) {
         for (size_t i = 0; i < n; i++) fn(i);
         return;
     }
-    std::vector<std::thread> th;
+    JoinThreads th;
     for (size_t t = 0; t < nt; t++) {
-        th.emplace_back([&, t]() {
+        th.spawn([&, t]() {
             for (size_t i = t; i < n; i += nt) fn(i);
         });
     }
-    for (auto &x : th) x.join();
+    th.join();
 }
 
 // Several variable-base lincombs sum_i k_i P_i in ONE launch.  Job j takes n points starting at

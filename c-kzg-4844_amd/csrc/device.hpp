@@ -48,6 +48,7 @@ struct Scratch {
 struct Arena {
     void *base = nullptr;
     size_t cap = 0, used = 0;
+    hipStream_t stream = nullptr;   // the owning slot's compute stream: host copies of ABuf are ordered on it
     // start a call: make room for `bytes` (plus alignment slack) and forget earlier contents
     bool begin(size_t bytes) {
         bytes += 64 * 256;

@@ -49,6 +49,7 @@ void Lease::take(DevicePool *p) {
     pool = p;
     ctx = p->slots[idx];
     p->last.store(ctx, std::memory_order_relaxed);
+    if (p->owner) p->last_seq.store(p->owner->lease_seq.fetch_add(1, std::memory_order_relaxed) + 1, std::memory_order_relaxed);
     if (hipSetDevice(ctx->device) != hipSuccess) {
         fprintf(stderr, "[ckzg-hip] hipSetDevice(%d) failed\n", ctx->device);
         std::lock_guard<std::mutex> relock(p->mu);
@@ -186,6 +187,7 @@ static void destroy_pool(DevicePool *p) {
 
 static void destroy_settings(SettingsCtx *sc) {
     if (!sc) return;
+    DeviceGuard guard;   // destroy_slot selects each slot's device; the caller's comes back afterwards
     for (auto *p : sc->pools) destroy_pool(p);
     delete sc;
 }
@@ -203,6 +205,7 @@ static void destroy_settings(SettingsCtx *sc) {
 static C_KZG_RET init_slot_runtime(dev::DeviceCtx *ctx) {
     CTX_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     CTX_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    ctx->api_arena.stream = ctx->lc_arena.stream = ctx->stream;
     for (auto &e : ctx->ev) CTX_TRY(hipEventCreate(&e));
     return C_KZG_OK;
 }
@@ -331,6 +334,7 @@ static C_KZG_RET clone_slot(dev::DeviceCtx **out, const dev::DeviceCtx *owner, i
 
 C_KZG_RET create_settings_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affine, const G1Affine *monomial_affine) {
     const Options opts = options_snapshot();
+    DeviceGuard guard;   // the load selects devices on this thread (clone_slot loop); the caller's comes back
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
         fprintf(stderr, "[ckzg-hip] no HIP device available: this build has no CPU fallback for the MSM/FFT hot path\n");
@@ -379,6 +383,7 @@ C_KZG_RET create_settings_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affin
         for (int r = 0; r < replicas; r++) {
             DevicePool *p = new DevicePool();
             p->device = d;
+            p->owner = sc;
             dev::DeviceCtx *owner = new dev::DeviceCtx();
             owner->device = d;
             owner->host_prepared = &sc->prepared;
@@ -391,9 +396,9 @@ C_KZG_RET create_settings_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affin
     std::vector<G1Affine> h_xext((size_t)dev::N_CELLS_EXT * dev::N_CELL);
     std::vector<C_KZG_RET> rets(sc->pools.size(), C_KZG_OK);
     {
-        std::vector<std::thread> th;
+        JoinThreads th;
         for (size_t di = 0; di < devs.size(); di++) {
-            th.emplace_back([&, di]() {
+            th.spawn([&, di]() {
                 for (int r = 0; r < replicas; r++) {
                     const size_t pi = di * replicas + r;
                     rets[pi] = guarded([&]() {
@@ -404,7 +409,7 @@ C_KZG_RET create_settings_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affin
                 }
             });
         }
-        for (auto &t : th) t.join();
+        th.join();
     }
     C_KZG_RET ret = C_KZG_OK;
     for (auto r : rets) ret = worse(ret, r);

@@ -15,6 +15,7 @@
 // 96-byte gather per addition, 8M+2S mixed additions into an XYZZ accumulator held in VGPRs, an
 // LDS tree to fold a workgroup, no buckets, no doublings, no atomics.  Arithmetic intensity is
 // ~3000 integer multiply-adds per 96-byte gather: the kernel is VALU-bound, not HBM-bound.
+#include <vector>
 #include "device.hpp"
 #include "dev_inline.hpp"
 #include "g1_28.hpp"
@@ -324,6 +325,23 @@ __device__ __forceinline__ void msm_sum_pairs(XYZZ28 &acc28, bool &inf, bool &yn
     if (phi_pending && !inf) msm_apply_phi(acc28);
 }
 
+#ifdef CKZG_MSM_TRACE
+// Diagnostic build (tools/build_variant.sh trace -DCKZG_MSM_TRACE; never in the product): every wave of
+// k_msm_accumulate records when and where it ran -- {s_memrealtime at entry, at exit, HW_ID, XCC_ID} -- so that
+// tools/msm_trace.py can draw the occupancy of every SIMD over the launch (why SQ_WAVE_CYCLES says 1.7 waves
+// per SIMD where the register budget allows 2).  Dumped to $CKZG_HIP_MSM_TRACE_FILE by commit_blobs_device.
+__device__ uint64_t *g_msm_trace = nullptr;
+__device__ __forceinline__ void msm_trace_mark(uint32_t wave_slot, int which) {
+    if ((threadIdx.x & 63) != 0 || !g_msm_trace) return;
+    uint64_t *rec = g_msm_trace + (size_t)wave_slot * 4;
+    rec[which] = wall_clock64();
+    if (which == 0) {
+        rec[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+        rec[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+    }
+}
+#endif
+
 // grid: nvec * blocks_per_vec workgroups.  A "vector" is one MSM: ppv (points per vector) scalars
 // recoded to digits[vec][w][i], i < ppv, w < nwin = 2*twin.  Its bases are points voff..voff+ppv of a
 // table over npoints bases, voff = (vec % vecs_per_group) * ppv  (commitment: ppv = npoints = 4096,
@@ -341,6 +359,9 @@ __global__ __launch_bounds__(THREADS) void k_msm_accumulate(
     __shared__ uint32_t sh[57][THREADS];
 #else
     __shared__ uint32_t sh[57][THREADS / 2];   // A/B builds: the one-lane fold
+#endif
+#ifdef CKZG_MSM_TRACE
+    msm_trace_mark(blockIdx.x * (THREADS / 64) + threadIdx.x / 64, 0);
 #endif
     const uint32_t vec = blockIdx.x / blocks_per_vec, chunk = blockIdx.x % blocks_per_vec;
     const uint32_t q0 = chunk * pairs_per_block;
@@ -362,6 +383,9 @@ __global__ __launch_bounds__(THREADS) void k_msm_accumulate(
     block_reduce_xyzz28<THREADS>(acc28, inf, sh);
 #endif
     if (threadIdx.x == 0) partials[(size_t)vec * part_stride + chunk] = xyzz28_to_xyzz(acc28, inf);
+#ifdef CKZG_MSM_TRACE
+    msm_trace_mark(blockIdx.x * (THREADS / 64) + threadIdx.x / 64, 1);
+#endif
 }
 
 // Many small MSMs (FK20: 128 vectors of 64 points per blob).  A 64-lane workgroup serves 64/LPV
@@ -720,10 +744,36 @@ int commit_blobs_device(DeviceCtx *ctx, uint8_t *d_out48, uint8_t *d_status, con
     if (n == 0) return 0;
     int rc = scratch_reserve(ctx, commit_scratch_bytes(ctx, n));
     if (rc) return rc;
+#ifdef CKZG_MSM_TRACE
+    const char *trace_file = getenv("CKZG_HIP_MSM_TRACE_FILE");
+    uint64_t *d_trace = nullptr;
+    size_t trace_waves = 0;
+    if (trace_file && *trace_file) {
+        const FixedBaseTable &t = ctx->commit;
+        uint32_t ppv = (uint32_t)t.nwin * t.npoints, ppb = pick_pairs_per_block(n, ppv);
+        trace_waves = n * ((ppv + ppb - 1) / ppb) * 4;
+        HIP_TRY(hipMalloc(&d_trace, trace_waves * 32));
+        HIP_TRY(hipMemset(d_trace, 0, trace_waves * 32));
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_msm_trace), &d_trace, sizeof d_trace));
+    }
+#endif
     rc = commit_blobs_enqueue(ctx, d_out48, d_status, d_blobs, n);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     collect_times(ctx);
+#ifdef CKZG_MSM_TRACE
+    if (d_trace) {
+        std::vector<uint64_t> h(trace_waves * 4);
+        HIP_TRY(hipMemcpy(h.data(), d_trace, trace_waves * 32, hipMemcpyDeviceToHost));
+        uint64_t *null_ptr = nullptr;
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_msm_trace), &null_ptr, sizeof null_ptr));
+        (void)hipFree(d_trace);
+        if (FILE *f = fopen(trace_file, "wb")) {   // the last traced launch wins
+            fwrite(h.data(), 8, h.size(), f);
+            fclose(f);
+        }
+    }
+#endif
     return 0;
 }
 

@@ -12,6 +12,9 @@ for f in csrc/ckzg_api.hip csrc/device_ctx.hip csrc/msm.hip csrc/ntt.hip csrc/fk
   # (a space-separated list is accepted: ONLY="msm fk20")
   stem=$(basename $f .hip)
   if [ -z "$ONLY" ] || [[ " $ONLY " == *" $stem "* ]]; then extra=("$@"); else extra=(); fi
+  # the product's Makefile compiles the throughput units with the asm-block Montgomery product; so do variants
+  # (NOASM=1 leaves it out, for A/Bs of the product forms themselves)
+  if [ -z "$NOASM" ] && { [ "$stem" = msm ] || [ "$stem" = fk20 ]; }; then extra+=(-DCKZG_F28_ASM_BLOCKS); fi
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-pass-failed "${extra[@]}" -c $f -o $o &
 done
 wait
