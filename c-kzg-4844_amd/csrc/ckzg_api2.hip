@@ -355,9 +355,53 @@ constexpr uint64_t SMALL_VERIFY_N = 3;
 // 697-844).  Per blob, on the GPU: point validation, bytes -> Fr, evaluation at the challenge;
 // then three lincombs over all blobs; host: transcripts and the pairing check
 //   e(sum r^i proof_i, [s]G2) == e(sum r^i (C_i - [y_i]G1) + sum r^i z_i proof_i, G2).
+// Host threads that hash the blobs' Fiat-Shamir challenges IN ORDER and say how far they are: the pipelined form
+// of the batch verification enqueues chunk c's evaluation as soon as the first (c + 1) * chunk challenges exist,
+// while later blobs are still crossing PCIe.  (compute_challenge, eip4844.c:147-178)
+struct OrderedHasher {
+    std::atomic<size_t> next{0};
+    std::vector<std::atomic<uint32_t>> done;   // per chunk: blobs hashed
+    size_t n, chunk;
+    JoinThreads th;
+    OrderedHasher(size_t n_, size_t chunk_) : done((n_ + chunk_ - 1) / chunk_), n(n_), chunk(chunk_) {
+        for (auto &d : done) d.store(0);
+    }
+    void start(Fr *z, const Blob *blobs, const Bytes48 *cb) {
+        unsigned hw = std::thread::hardware_concurrency();
+        size_t nt = hw ? hw : 4;
+        if (nt > 32) nt = 32;
+        for (size_t t = 0; t < nt; t++) {
+            th.spawn([this, z, blobs, cb]() {
+                for (;;) {
+                    const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+                    if (i >= n) return;
+                    z[i] = challenge_from_bytes(blobs[i].bytes, cb[i].bytes);
+                    done[i / chunk].fetch_add(1, std::memory_order_release);
+                }
+            });
+        }
+    }
+    void wait_chunk(size_t c) const {
+        const size_t lo = c * chunk, want = (n - lo < chunk ? n - lo : chunk);
+        while (done[c].load(std::memory_order_acquire) < want) std::this_thread::yield();
+    }
+};
+
+// Shared core of verify_blob_kzg_proof and verify_blob_kzg_proof_batch (eip4844.c:537-595,
+// 697-844).  Per blob, on the GPU: point validation, bytes -> Fr, evaluation at the challenge;
+// then three lincombs over all blobs; host: transcripts and the pairing check
+//   e(sum r^i proof_i, [s]G2) == e(sum r^i (C_i - [y_i]G1) + sum r^i z_i proof_i, G2).
+// Three forms of the per-blob stage:
+//   * classic (n < 1024, or challenges hashed on the GPU): one copy of all blobs, then the kernels;
+//   * pipelined (host pointers, n >= 1024): the blobs cross PCIe in chunks on the copy stream -- DMA'd in place
+//     from page-locked caller memory, through pinned staging otherwise -- while earlier chunks are converted and
+//     evaluated and host threads hash the challenges in order, so that only the transcript, the three sums and
+//     the pairing follow the last byte;
+//   * resident (ckzg_hip_verify_blob_kzg_proof_batch_device): blobs, commitments and proofs already in HBM, the
+//     challenges hashed by k_sha256_challenges; only 96 + 64 bytes per blob travel to the host for the transcript.
 C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, const Bytes48 *pb, uint64_t n,
-                            const KZGSettings *s, dev::DeviceCtx *ctx) {
-    const bool small = n <= SMALL_VERIFY_N;
+                            const KZGSettings *s, dev::DeviceCtx *ctx, bool resident = false) {
+    const bool small = !resident && n <= SMALL_VERIFY_N;
     Trace tr("verify_blobs");
     std::vector<G1Jac> hc, hp;  // host copies of the validated points (small n)
     if (small) {
@@ -369,17 +413,38 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
         }
     }
     tr.mark("host point validation");
+    // (never for the small path: its commitments are validated on the host and are not in d_ptb)
+    const bool gpu_sha = resident || (!small && n >= gpu_sha_min_n());
+    static const size_t pipe_min = []() {
+        const char *e = getenv("CKZG_HIP_VERIFY_PIPE_MIN");
+        return e && *e ? (size_t)atol(e) : (size_t)1024;
+    }();
+    const bool piped = !resident && !small && !gpu_sha && n >= pipe_min;
     Arena &ar = ctx->api_arena;
-    OKM(ar.begin(n * BYTES_PER_BLOB + (n * FIELD_ELEMENTS_PER_BLOB + 2 * n) * sizeof(Fr) + n * 4 +
-                 2 * n * (48 + 2 + sizeof(G1Affine))));
-    ABuf<uint8_t> d_ptb(ar, 2 * n * 48), d_st(ar, 2 * n), d_st2(ar, 2 * n), d_blobs(ar, n * BYTES_PER_BLOB);
+    OKM(ar.begin((resident ? 0 : n * BYTES_PER_BLOB) + (n * FIELD_ELEMENTS_PER_BLOB + 2 * n) * sizeof(Fr) + n * 4 +
+                 2 * n * (48 + 2 + sizeof(G1Affine)) + 4096));
+    ABuf<uint8_t> d_ptb(ar, 2 * n * 48), d_st(ar, 2 * n), d_st2(ar, 2 * n), d_blobs_own(ar, resident ? 1 : n * BYTES_PER_BLOB);
     ABuf<G1Affine> d_pts(ar, 2 * n);
     ABuf<Fr> d_poly(ar, n * FIELD_ELEMENTS_PER_BLOB), d_z(ar, n), d_y(ar, n);
     ABuf<uint32_t> d_bad(ar, n);
-    OKM(d_ptb.p && d_st.p && d_st2.p && d_blobs.p && d_pts.p && d_poly.p && d_z.p && d_y.p && d_bad.p);
+    OKM(d_ptb.p && d_st.p && d_st2.p && d_blobs_own.p && d_pts.p && d_poly.p && d_z.p && d_y.p && d_bad.p);
     ArenaTrim trim(ar);
     tr.mark("arena");
-    const bool split_validation = !small && n < 1024;
+    // resident: the device copies of the inputs ARE the caller's buffers; the transcript needs the 96 bytes of
+    // commitment and proof per blob on the host
+    std::vector<uint8_t> h_cpb;
+    const uint8_t *d_blob_bytes = resident ? reinterpret_cast<const uint8_t *>(blobs) : d_blobs_own.p;
+    const Bytes48 *d_cb = cb, *d_pb = pb;
+    if (resident) {
+        h_cpb.resize(2 * n * 48);
+        OKB(hipMemcpy(h_cpb.data(), d_cb, n * 48, hipMemcpyDeviceToHost) == hipSuccess);
+        OKB(hipMemcpy(h_cpb.data() + n * 48, d_pb, n * 48, hipMemcpyDeviceToHost) == hipSuccess);
+        cb = reinterpret_cast<const Bytes48 *>(h_cpb.data());
+        pb = reinterpret_cast<const Bytes48 *>(h_cpb.data() + n * 48);
+        blobs = nullptr;   // never dereferenced on the host
+        OKB(hipEventRecord(ctx->ev[1], ctx->stream) == hipSuccess);
+    }
+    const bool split_validation = !small && !piped && !resident && n < 1024;
     if (!small) {
         // commitments [0,n), proofs [n,2n): decompress + subgroup-check on the GPU, on the second stream
         // so that the ladder kernel runs under the (host-blocking, pageable) copy of the blobs
@@ -390,8 +455,9 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
         hipStream_t vs = split_validation ? ctx->copy_stream : ctx->stream;
         if (!ctx->stage_ev[0]) OKB(hipEventCreateWithFlags(&ctx->stage_ev[0], hipEventDisableTiming) == hipSuccess);
         if (!ctx->stage_ev[1]) OKB(hipEventCreateWithFlags(&ctx->stage_ev[1], hipEventDisableTiming) == hipSuccess);
-        OKB(hipMemcpyAsync(d_ptb.p, cb, n * 48, hipMemcpyHostToDevice, vs) == hipSuccess);
-        OKB(hipMemcpyAsync(d_ptb.p + n * 48, pb, n * 48, hipMemcpyHostToDevice, vs) == hipSuccess);
+        const hipMemcpyKind kind = resident ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+        OKB(hipMemcpyAsync(d_ptb.p, d_cb, n * 48, kind, vs) == hipSuccess);
+        OKB(hipMemcpyAsync(d_ptb.p + n * 48, d_pb, n * 48, kind, vs) == hipSuccess);
         if (split_validation) {
             RC(dev::decompress_g1_batch_device(ctx, d_pts.p, d_st.p, d_ptb.p, 2 * n, vs));
             OKB(hipEventRecord(ctx->stage_ev[0], vs) == hipSuccess);
@@ -407,13 +473,72 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
         hipStream_t s;
         ~StreamDrain() { (void)hipStreamSynchronize(s); }
     } drain{ctx->copy_stream};
+    std::vector<Fr> z(n), y(n);
+    ProofSide ps;
+    if (piped) {
+        // ---- pipelined host-pointer form ----
+        const size_t CH = 256;   // 32 MB per chunk: ~0.6 ms of PCIe, 16 chunks at n = 4096
+        const size_t nch = (n + CH - 1) / CH;
+        const bool src_pinned = host_pointer_is_pinned(blobs);
+        if (!src_pinned) OKM(ensure_pinned(ctx->h_stage, ctx->h_stage_bytes, CH * (size_t)BYTES_PER_BLOB));
+        for (int i = 2; i < 4; i++) {
+            if (!ctx->stage_ev[i]) OKB(hipEventCreateWithFlags(&ctx->stage_ev[i], hipEventDisableTiming) == hipSuccess);
+        }
+        hipEvent_t *copied = ctx->stage_ev + 2;
+        OrderedHasher hasher(n, CH);
+        hasher.start(z.data(), blobs, cb);   // joined by its destructor on every exit path
+        OKB(hipMemsetAsync(d_bad.p, 0, n * 4, ctx->stream) == hipSuccess);
+        bool used[2] = {false, false};
+        for (size_t c = 0; c < nch; c++) {
+            const size_t off = c * CH, k = n - off < CH ? n - off : CH;
+            const int b = (int)(c & 1);
+            const void *h_src = blobs + off;
+            if (!src_pinned) {
+                if (used[b]) OKB(hipEventSynchronize(copied[b]) == hipSuccess);   // the DMA out of this staging buffer is done
+                staged_copy(ctx->h_stage[b], blobs + off, k * BYTES_PER_BLOB);
+                h_src = ctx->h_stage[b];
+            }
+            OKB(hipMemcpyAsync(d_blobs_own.p + off * BYTES_PER_BLOB, h_src, k * BYTES_PER_BLOB, hipMemcpyHostToDevice,
+                               ctx->copy_stream) == hipSuccess);
+            OKB(hipEventRecord(copied[b], ctx->copy_stream) == hipSuccess);
+            used[b] = true;
+            OKB(hipStreamWaitEvent(ctx->stream, copied[b], 0) == hipSuccess);
+            RC(dev::bytes_to_fr_batch(ctx, d_poly.p + off * FIELD_ELEMENTS_PER_BLOB, d_bad.p + off,
+                                      d_blobs_own.p + off * BYTES_PER_BLOB, k * FIELD_ELEMENTS_PER_BLOB, FIELD_ELEMENTS_PER_BLOB));
+            // the evaluation of chunk c - 1 is enqueued once its challenges exist: one chunk of slack, so that this
+            // thread never waits for the hashers while there is a copy to issue
+            if (c >= 1) {
+                const size_t po = (c - 1) * CH;
+                hasher.wait_chunk(c - 1);
+                OKB(hipMemcpyAsync(d_z.p + po, z.data() + po, CH * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
+                RC(dev::eval_poly_batch_device(ctx, d_y.p + po, d_poly.p + po * FIELD_ELEMENTS_PER_BLOB, d_z.p + po, CH));
+            }
+        }
+        {
+            const size_t po = (nch - 1) * CH, k = n - po;
+            hasher.wait_chunk(nch - 1);
+            OKB(hipMemcpyAsync(d_z.p + po, z.data() + po, k * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
+            RC(dev::eval_poly_batch_device(ctx, d_y.p + po, d_poly.p + po * FIELD_ELEMENTS_PER_BLOB, d_z.p + po, k));
+        }
+        tr.mark("chunked H2D + bytes_to_fr + evaluation enqueued (challenges hashed in order on host threads)");
+        OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
+        tr.mark("wait for GPU");
+        std::vector<uint8_t> st(2 * n);
+        OKB(d_st.down(st.data(), 2 * n));
+        for (size_t i = 0; i < 2 * n; i++) {
+            if (st[i]) return C_KZG_BADARGS;
+        }
+        std::vector<uint32_t> bad(n);
+        OKB(d_bad.down(bad.data(), n));
+        for (size_t i = 0; i < n; i++) {
+            if (bad[i]) return C_KZG_BADARGS;
+        }
+        OKB(d_y.down(y.data(), n));
+    } else {
     // Challenges: on host threads, started BEFORE the blob copy -- a copy from pageable memory blocks
     // this thread for its whole duration (3.5 us per blob), and with the x86 SHA extensions the hashing
     // (2 us per blob on 32 threads) finishes underneath it.  Hosts without the extensions hash large
     // batches on the GPU instead (a lane per blob; ~6 ms whatever the batch size).
-    // (never for the small path: its commitments are validated on the host and are not in d_ptb)
-    const bool gpu_sha = !small && n >= gpu_sha_min_n();
-    std::vector<Fr> z(n), y(n);
     struct Joiner {
         std::thread t;
         ~Joiner() {
@@ -425,15 +550,20 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     };
     const bool threaded = !gpu_sha && n >= 16;  // a thread costs ~0.2 ms: not for the single-blob call
     if (threaded) hasher.t = std::thread(hash_all);
-    OKB(hipMemcpyAsync(d_blobs.p, blobs, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
+    if (!resident) OKB(hipMemcpyAsync(d_blobs_own.p, blobs, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
     OKB(hipMemsetAsync(d_bad.p, 0, n * 4, ctx->stream) == hipSuccess);
-    RC(dev::bytes_to_fr_batch(ctx, d_poly.p, d_bad.p, d_blobs.p, n * FIELD_ELEMENTS_PER_BLOB, FIELD_ELEMENTS_PER_BLOB));
+    RC(dev::bytes_to_fr_batch(ctx, d_poly.p, d_bad.p, d_blob_bytes, n * FIELD_ELEMENTS_PER_BLOB, FIELD_ELEMENTS_PER_BLOB));
     if (!small) OKB(hipStreamWaitEvent(ctx->stream, ctx->stage_ev[0], 0) == hipSuccess);  // d_ptb, d_pts, d_st ready
-    if (gpu_sha) RC(dev::sha256_challenges_device(ctx, d_z.p, d_blobs.p, d_ptb.p, n));
+    if (gpu_sha) RC(dev::sha256_challenges_device(ctx, d_z.p, d_blob_bytes, d_ptb.p, n));
     tr.mark("enqueue H2D + bytes_to_fr (+ GPU validation)");
     if (hasher.t.joinable()) hasher.t.join();
     if (!gpu_sha && !threaded) hash_all();
     tr.mark("host SHA-256 challenges");
+    if (resident) {
+        // resident inputs: nothing to learn from the host before the evaluation -- enqueue it straight away
+        RC(dev::eval_poly_batch_device(ctx, d_y.p, d_poly.p, d_z.p, n));
+        OKB(hipEventRecord(ctx->ev[2], ctx->stream) == hipSuccess);
+    }
     OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
     tr.mark("wait for GPU");
     if (!small) {
@@ -453,13 +583,15 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     } else {
         OKB(d_z.up(z.data(), n));
     }
-    RC(dev::eval_poly_batch_device(ctx, d_y.p, d_poly.p, d_z.p, n));
-    ProofSide ps;
-    if (n == 1) ps = verify_proof_side(z[0], hp[0], prepared_of(ctx));   // host work underneath the GPU's evaluation
-    OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
+    if (!resident) {
+        RC(dev::eval_poly_batch_device(ctx, d_y.p, d_poly.p, d_z.p, n));
+        if (n == 1) ps = verify_proof_side(z[0], hp[0], prepared_of(ctx));   // host work underneath the GPU's evaluation
+        OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
+    }
     OKB(d_y.down(y.data(), n));
+    }
     tr.mark("GPU evaluation (+ the proof's half of the check on the host)");
-    if (n == 1) {
+    if (n == 1 && !resident) {
         // the single-blob form of the check (eip4844.c:537-595)
         *ok = verify_with_proof_side(hc[0], y[0], ps, prepared_of(ctx));
         tr.mark("[y]G1 + the commitment's Miller loop + final exponentiation");
@@ -502,8 +634,21 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
             rz[i] = raw_of(rzf[i]);
         }
         LincombJob jobs[3] = {{d_pts.p + n, &rp}, {d_pts.p + n, &rz}, {d_pts.p, &rp}};
+        if (resident) OKB(hipEventRecord(ctx->ev[3], ctx->stream) == hipSuccess);
         C_KZG_RET ret = gpu_lincomb_multi(ctx, lc, jobs, 3);
         if (ret != C_KZG_OK) return ret;
+        if (resident) {
+            // kernel-only time of the resident form (ckzg_hip_last_kernel_ms, which = 3): validation + conversion +
+            // challenges + evaluation, and the three sums; the host transcript between them is not GPU time
+            float a = 0, b = 0;
+            OKB(hipEventRecord(ctx->ev[4], ctx->stream) == hipSuccess && hipEventSynchronize(ctx->ev[4]) == hipSuccess);
+            if (hipEventElapsedTime(&a, ctx->ev[1], ctx->ev[2]) == hipSuccess &&
+                hipEventElapsedTime(&b, ctx->ev[3], ctx->ev[4]) == hipSuccess) {
+                ctx->last_ms[3] = a + b;
+                ctx->last_ms[0] = a;
+                ctx->last_ms[2] = b;
+            }
+        }
     }
     if (split_validation) {
         OKB(hipEventSynchronize(ctx->stage_ev[1]) == hipSuccess);
@@ -765,6 +910,27 @@ extern "C" C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, co
         });
         if (ret == C_KZG_OK) *ok = all_ok.load() != 0;
         return ret;
+    });
+}
+
+// verify_blob_kzg_proof_batch with blobs, commitments and proofs resident in HBM (device pointers on one GPU):
+// nothing but 96 + 64 bytes per blob (commitment, proof, challenge, evaluation -- the Fiat-Shamir transcript of
+// eip4844.c:597-680 is hashed on the host) leaves the device.  The verdict is written to the HOST bool *ok.
+extern "C" C_KZG_RET ckzg_hip_verify_blob_kzg_proof_batch_device(bool *ok, const void *d_blobs, const void *d_commitments,
+                                                                 const void *d_proofs, uint64_t n, const KZGSettings *s) {
+    if (!ok) return C_KZG_BADARGS;
+    if (n == 0) {
+        *ok = true;
+        return C_KZG_OK;
+    }
+    return guarded([&]() -> C_KZG_RET {
+        *ok = false;
+        SettingsCtx *sc = settings_of(s);
+        if (!sc) return C_KZG_ERROR;
+        Lease lease(s, pool_of_pointer(sc, d_blobs));
+        if (!lease.ctx) return C_KZG_ERROR;
+        return verify_blobs_core(ok, static_cast<const Blob *>(d_blobs), static_cast<const Bytes48 *>(d_commitments),
+                                 static_cast<const Bytes48 *>(d_proofs), n, s, lease.ctx, /*resident=*/true);
     });
 }
 

@@ -253,6 +253,26 @@ __device__ __forceinline__ void msm_apply_phi(XYZZ28 &acc28) {
     acc28.x = widen<1, 10>(mul(acc28.x, f28_const<1, 1>(FP28_BETA_LAMBDA)));
 }
 
+// Fair time slices between the two waves of a SIMD.  The per-wave trace of round 3 (tools/msm_trace.py,
+// profiles/r03_msm_trace_*.json) shows that of two resident waves the OLDER one is served first: it gets ~82 % of
+// the issue slots, finishes its 256 additions in 2.8 ms and leaves its partner (5.2 ms) to run alone, so a launch
+// of exactly two rounds of workgroups ends with a quarter of its time at one wave per SIMD (SQ_WAVE_CYCLES: 1.72).
+// s_setprio outranks age: a wave raises its priority in the time slices whose parity equals the parity of its
+// wave slot in the SIMD (two resident waves sit in different slots) and lowers it in the others, so both advance
+// at the same average rate and finish together.  slice = 2^prio_bit ticks of the 100 MHz s_memrealtime counter;
+// prio_bit = 0 switches the scheme off.
+__device__ __forceinline__ uint32_t msm_wave_slot_parity() {
+    return __builtin_amdgcn_s_getreg(4) & 1u;   // hwreg(HW_REG_HW_ID, 0, 1): bit 0 of WAVE_ID
+}
+__device__ __forceinline__ void msm_fair_prio(uint32_t prio_bit, uint32_t parity) {
+    if (prio_bit == 0) return;
+    const uint32_t slice = (uint32_t)(wall_clock64() >> prio_bit) & 1u;
+    if (slice == parity)
+        __builtin_amdgcn_s_setprio(2);
+    else
+        __builtin_amdgcn_s_setprio(0);
+}
+
 // One lane's share of a fixed-base sum: pairs q = first, first + STRIDE, ... < q1 of one vector (q = w*ppv + i;
 // pairs below phi_pairs = twin*ppv belong to the k2 half, so the accumulator goes through phi once, when the lane
 // crosses that boundary or at the end if it never does).
@@ -266,8 +286,9 @@ template <int STRIDE>
 __device__ __forceinline__ void msm_sum_pairs(XYZZ28 &acc28, bool &inf, bool &yneg, const G1Affine *table,
                                               const int16_t *dg, uint32_t first, uint32_t q1, uint32_t phi_pairs,
                                               uint32_t twin, uint32_t ppv, uint32_t npoints, uint32_t voff,
-                                              int half_shift) {
+                                              int half_shift, uint32_t prio_bit = 0) {
     bool phi_pending = first < phi_pairs;
+    const uint32_t slot_parity = prio_bit ? msm_wave_slot_parity() : 0u;
 #ifndef CKZG_MSM_NO_PREFETCH
     uint32_t qn = first;
     int d = 0, d1 = qn < q1 ? dg[qn] : 0;
@@ -275,6 +296,7 @@ __device__ __forceinline__ void msm_sum_pairs(XYZZ28 &acc28, bool &inf, bool &yn
 #pragma unroll
     for (int k = 0; k < 6; k++) e[k] = make_uint4(0, 0, 0, 0);
     for (; qn < q1 + STRIDE; qn += STRIDE) {
+        msm_fair_prio(prio_bit, slot_parity);
         uint4 nx[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) nx[k] = make_uint4(0, 0, 0, 0);
@@ -354,7 +376,7 @@ template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_msm_accumulate(
     G1XYZZ *partials, const G1Affine *table, const int16_t *digits, uint32_t pairs_per_vec,
     uint32_t pairs_per_block, int half_shift, uint32_t blocks_per_vec, uint32_t ppv,
-    uint32_t npoints, uint32_t vecs_per_group, uint32_t part_stride) {
+    uint32_t npoints, uint32_t vecs_per_group, uint32_t part_stride, uint32_t prio_bit) {
 #ifndef CKZG_NO_QUAD_TREE
     __shared__ uint32_t sh[57][THREADS];
 #else
@@ -375,7 +397,8 @@ __global__ __launch_bounds__(THREADS) void k_msm_accumulate(
     // (Measured alternatives: unrolling by two -- 14.4 ms, two copies of the ~40 KB addition body thrash the
     // instruction cache; capping VGPRs for 3 or 4 waves per SIMD -- 11.4 / 13.2 ms.)
     msm_sum_pairs<THREADS>(acc28, inf, yneg, table, dg, q0 + threadIdx.x, q1, phi_pairs, twin, ppv, npoints, voff,
-                           half_shift);
+                           half_shift, prio_bit);
+    if (prio_bit) __builtin_amdgcn_s_setprio(0);
     xyzz28_fix_sign(acc28, inf, yneg);
 #ifndef CKZG_NO_QUAD_TREE
     quad::block_reduce_xyzz28_quad<THREADS>(acc28, inf, sh);   // four lanes per pair: the fold is ~3x shorter
@@ -395,7 +418,7 @@ __global__ __launch_bounds__(THREADS) void k_msm_accumulate(
 template <int LPV>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_msm_small(G1XYZZ *out, const G1Affine *table, const int16_t *digits,
                                                  uint32_t nvec, uint32_t pairs_per_vec, int half_shift,
-                                                 uint32_t ppv, uint32_t npoints, uint32_t vecs_per_group) {
+                                                 uint32_t ppv, uint32_t npoints, uint32_t vecs_per_group, uint32_t prio_bit) {
     __shared__ uint32_t sh[57][LPV == 64 ? 64 : 32];
     constexpr int GROUPS = 64 / LPV;
     const int tid = threadIdx.x, grp = tid / LPV, l = tid % LPV;
@@ -407,8 +430,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const uint32_t voff = (vec % vecs_per_group) * ppv;
         const int16_t *dg = digits + (size_t)vec * pairs_per_vec;
         msm_sum_pairs<LPV>(acc28, inf, yneg, table, dg, (uint32_t)l, pairs_per_vec, phi_pairs, twin, ppv, npoints,
-                           voff, half_shift);
+                           voff, half_shift, prio_bit);
     }
+    if (prio_bit) __builtin_amdgcn_s_setprio(0);
     xyzz28_fix_sign(acc28, inf, yneg);
     if constexpr (LPV == 64) {
         // one wave per vector is the latency form (few vectors): fold on four lanes per pair.  (In the throughput
@@ -556,6 +580,23 @@ static uint32_t pick_pairs_per_block(size_t nvec, uint32_t pairs_per_vec) {
     return best_ppb;
 }
 
+// slice width (log2 ticks of 100 MHz) of the fair-priority scheme of msm_fair_prio; 0 = off.
+// CKZG_HIP_MSM_PRIO_BIT / CKZG_HIP_SMALL_PRIO_BIT override the defaults for A/B runs.
+static uint32_t msm_prio_bit() {
+    static const uint32_t v = []() {
+        const char *e = getenv("CKZG_HIP_MSM_PRIO_BIT");
+        return e && *e ? (uint32_t)atoi(e) : 0u;
+    }();
+    return v;
+}
+static uint32_t small_prio_bit() {
+    static const uint32_t v = []() {
+        const char *e = getenv("CKZG_HIP_SMALL_PRIO_BIT");
+        return e && *e ? (uint32_t)atoi(e) : 0u;
+    }();
+    return v;
+}
+
 // digits already in scratch; runs accumulate + finalize.  Scratch layout is owned by callers.
 static int run_msm(DeviceCtx *ctx, const FixedBaseTable &t, uint8_t *d_out48, uint8_t *d_status,
                    const int16_t *d_digits, const uint32_t *d_bad, G1XYZZ *d_partials, size_t nvec,
@@ -565,7 +606,7 @@ static int run_msm(DeviceCtx *ctx, const FixedBaseTable &t, uint8_t *d_out48, ui
     HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
     hipLaunchKernelGGL(k_msm_accumulate<256>, dim3((unsigned)(nvec * bpv)), dim3(256), 0, ctx->stream,
                        d_partials, t.d_table, d_digits, pairs_per_vec, ppb, t.wbits - 1, bpv,
-                       (uint32_t)t.npoints, (uint32_t)t.npoints, 1u, bpv);
+                       (uint32_t)t.npoints, (uint32_t)t.npoints, 1u, bpv, msm_prio_bit());
     HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
     if (bpv > 8) {
         // partials[nvec*bpv ..] is free: run_msm callers size d_partials for nvec*bpv + nvec
@@ -622,19 +663,19 @@ int msm_small_vectors_device(DeviceCtx *ctx, const FixedBaseTable &t, G1XYZZ *d_
     if (nvec >= 4096 && lpv == 4) {
         hipLaunchKernelGGL(k_msm_small<4>, dim3((unsigned)((nvec + 15) / 16)), dim3(64), 0, ctx->stream, d_out,
                            t.d_table, d_digits, (uint32_t)nvec, pairs_per_vec, t.wbits - 1, ppv,
-                           (uint32_t)t.npoints, vecs_per_group);
+                           (uint32_t)t.npoints, vecs_per_group, small_prio_bit());
     } else if (nvec >= 4096 && lpv == 8) {
         hipLaunchKernelGGL(k_msm_small<8>, dim3((unsigned)((nvec + 7) / 8)), dim3(64), 0, ctx->stream, d_out,
                            t.d_table, d_digits, (uint32_t)nvec, pairs_per_vec, t.wbits - 1, ppv,
-                           (uint32_t)t.npoints, vecs_per_group);
+                           (uint32_t)t.npoints, vecs_per_group, small_prio_bit());
     } else if (nvec >= 4096) {
         hipLaunchKernelGGL(k_msm_small<16>, dim3((unsigned)((nvec + 3) / 4)), dim3(64), 0, ctx->stream, d_out,
                            t.d_table, d_digits, (uint32_t)nvec, pairs_per_vec, t.wbits - 1, ppv,
-                           (uint32_t)t.npoints, vecs_per_group);
+                           (uint32_t)t.npoints, vecs_per_group, small_prio_bit());
     } else {
         hipLaunchKernelGGL(k_msm_small<64>, dim3((unsigned)nvec), dim3(64), 0, ctx->stream, d_out, t.d_table,
                            d_digits, (uint32_t)nvec, pairs_per_vec, t.wbits - 1, ppv, (uint32_t)t.npoints,
-                           vecs_per_group);
+                           vecs_per_group, small_prio_bit());
     }
     HIP_TRY(hipEventRecord(ctx->ev[6], ctx->stream));
     HIP_TRY(hipGetLastError());
@@ -714,7 +755,7 @@ int commit_accumulate8_enqueue(DeviceCtx *ctx, G1XYZZ *d_part8, uint32_t *d_bad,
                        d_digits, d_bad, d_blobs, total, t.wbits, t.twin);
     hipLaunchKernelGGL(k_msm_accumulate<256>, dim3((unsigned)(k * bpv)), dim3(256), 0, ctx->stream,
                        d_part8, t.d_table, d_digits, pairs_per_vec, ppb, t.wbits - 1, bpv,
-                       (uint32_t)t.npoints, (uint32_t)t.npoints, 1u, 8u);
+                       (uint32_t)t.npoints, (uint32_t)t.npoints, 1u, 8u, msm_prio_bit());
     HIP_TRY(hipGetLastError());
     return 0;
 }

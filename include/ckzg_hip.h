@@ -91,6 +91,22 @@ C_KZG_RET ckzg_hip_compute_blob_kzg_proof_batch(KZGProof *proofs, uint8_t *statu
                                                 const Bytes48 *commitments_bytes, uint64_t n,
                                                 const KZGSettings *s);
 
+/* verify_blob_kzg_proof_batch (src/eip4844/eip4844.c:775-844) with blobs, commitments and proofs resident in HBM
+ * (device pointers on one GPU: n Blob, n Bytes48, n Bytes48).  Point validation, bytes -> field elements, the
+ * Fiat-Shamir challenges (SHA-256 of every blob, on the GPU), the evaluations and the three random-linear-combination
+ * sums run on the device; 96 + 64 bytes per blob travel to the host for the batch transcript (eip4844.c:597-680)
+ * and the two-pairing check runs there.  *ok is a HOST bool.  n == 0 gives *ok = true as in the reference.
+ * Returns C_KZG_BADARGS exactly when the host-pointer call would (non-canonical field element, invalid point).
+ * ckzg_hip_last_kernel_ms(s, 3) afterwards reports the device time of the call (which = 0: validation + conversion
+ * + challenges + evaluation, which = 2: the sums).
+ * The host-pointer verify_blob_kzg_proof_batch itself pipelines batches of >= 1024 blobs: chunks are DMA'd in place
+ * when the caller's blobs are page-locked (hipHostMalloc / hipHostRegister), through pinned staging otherwise,
+ * while earlier chunks are converted and evaluated.
+ * (verify_cell_kzg_proof_batch has no resident form: its transcript is ONE SHA-256 stream over every cell,
+ * eip7594.c:390-482, which only a host core can hash at a useful rate, so the cells must visit the host anyway.) */
+C_KZG_RET ckzg_hip_verify_blob_kzg_proof_batch_device(bool *ok, const void *d_blobs, const void *d_commitments,
+                                                      const void *d_proofs, uint64_t n, const KZGSettings *s);
+
 /* recover_cells_and_kzg_proofs (src/eip7594/eip7594.c:177-304) over num_blobs rows that all hold
  * the SAME num_cells columns (the PeerDAS reconstruction case: a node has columns cell_indices[] of
  * every blob in the block).  cells is [num_blobs][num_cells], outputs are [num_blobs][128]; either

@@ -1,0 +1,156 @@
+"""GPU tests for the round-3 work: the pipelined (chunked, DMA-in-place) form of verify_blob_kzg_proof_batch for
+batches of >= 1024 blobs (src/eip4844/eip4844.c:775-844), the device-resident entry point
+ckzg_hip_verify_blob_kzg_proof_batch_device, and the library's promise to leave the caller's HIP device alone."""
+import ctypes as C
+
+import pytest
+
+from test_gpu_commitment import R, rand_blob
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def material(oracle):
+    """Expected values come from the CPU oracle, never from the library under test."""
+    blobs = [rand_blob(171, i) for i in range(8)]
+    cm = [oracle.blob_to_kzg_commitment(b) for b in blobs]
+    pr = [oracle.compute_blob_kzg_proof(b, c) for b, c in zip(blobs, cm)]
+    return blobs, cm, pr
+
+
+@pytest.fixture(scope="module")
+def rt():
+    lib = C.CDLL("/opt/rocm/lib/libamdhip64.so")
+    lib.hipHostMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+    lib.hipHostFree.argtypes = [C.c_void_p]
+    lib.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    lib.hipFree.argtypes = [C.c_void_p]
+    lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    lib.hipGetDevice.argtypes = [C.POINTER(C.c_int)]
+    return lib
+
+
+def _host(hip, bb, cc, pp, n):
+    f = hip.lib.verify_blob_kzg_proof_batch
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    ok = C.c_bool(False)
+    as_p = lambda x: x if isinstance(x, C.c_void_p) else C.cast(C.c_char_p(x), C.c_void_p)  # noqa: E731
+    rc = f(C.byref(ok), as_p(bb), as_p(cc), as_p(pp), n, C.addressof(hip.s))
+    return rc, ok.value
+
+
+def _device(hip, rt, bb, cc, pp, n):
+    f = hip.lib.ckzg_hip_verify_blob_kzg_proof_batch_device
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    d = [C.c_void_p() for _ in range(3)]
+    try:
+        for q, src in zip(d, (bb, cc, pp)):
+            assert rt.hipMalloc(C.byref(q), max(len(src), 1)) == 0
+            if src:
+                assert rt.hipMemcpy(q, C.cast(C.c_char_p(src), C.c_void_p), len(src), 1) == 0
+        ok = C.c_bool(False)
+        rc = f(C.byref(ok), d[0], d[1], d[2], n, C.addressof(hip.s))
+        return rc, ok.value
+    finally:
+        for q in d:
+            rt.hipFree(q)
+
+
+def _inputs(material, n):
+    blobs, cm, pr = material
+    order = [(3 * i + i // 11) % 8 for i in range(n)]
+    return (b"".join(blobs[k] for k in order), b"".join(cm[k] for k in order), b"".join(pr[k] for k in order), order)
+
+
+@pytest.mark.parametrize("n", [1024, 1100])
+def test_pipelined_verification_pageable_pinned_and_resident(hip, rt, material, n):
+    # 1024: exactly four chunks of 256; 1100: a ragged fifth chunk of 76 blobs
+    blobs, cm, pr = material
+    bb, cc, pp, order = _inputs(material, n)
+    assert _host(hip, bb, cc, pp, n) == (0, True)
+    pin = C.c_void_p()
+    assert rt.hipHostMalloc(C.byref(pin), len(bb), 0) == 0
+    try:
+        C.memmove(pin, bb, len(bb))
+        assert _host(hip, pin, cc, pp, n) == (0, True)
+        assert _device(hip, rt, bb, cc, pp, n) == (0, True)
+        # one wrong (but valid) proof in the first chunk, in a middle chunk, in the last blob
+        for at in (5, 600, n - 1):
+            bad = pp[:48 * at] + pr[(order[at] + 1) % 8] + pp[48 * (at + 1):]
+            assert _host(hip, bb, cc, bad, n) == (0, False), at
+            assert _host(hip, pin, cc, bad, n) == (0, False), at
+            assert _device(hip, rt, bb, cc, bad, n) == (0, False), at
+        # a commitment that belongs to another blob
+        wrong = cc[:48 * 777] + cm[(order[777] + 3) % 8] + cc[48 * 778:]
+        assert _host(hip, pin, wrong, pp, n) == (0, False)
+        assert _device(hip, rt, bb, wrong, pp, n) == (0, False)
+        # a non-canonical field element in the LAST chunk: BADARGS from every form (blob.c:31-38)
+        nb = bytearray(bb)
+        at = (n - 2) * 131072 + 32 * 4000
+        nb[at:at + 32] = R.to_bytes(32, "big")
+        assert _host(hip, bytes(nb), cc, pp, n)[0] == 1
+        C.memmove(pin, bytes(nb), len(nb))
+        assert _host(hip, pin, cc, pp, n)[0] == 1
+        assert _device(hip, rt, bytes(nb), cc, pp, n)[0] == 1
+        # an invalid point encoding (x not on the curve / flag bits) anywhere: BADARGS (bytes.c:81-95)
+        C.memmove(pin, bb, len(bb))
+        badc = cc[:48 * 300] + b"\x8f" + cc[48 * 300 + 1:]
+        rc_h = _host(hip, pin, badc, pp, n)[0]
+        assert rc_h == 1 and _device(hip, rt, bb, badc, pp, n)[0] == 1
+    finally:
+        rt.hipHostFree(pin)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 5, 64])
+def test_resident_verification_small_batches(hip, rt, material, n):
+    blobs, cm, pr = material
+    bb, cc, pp, order = _inputs(material, n)
+    assert _device(hip, rt, bb, cc, pp, n) == (0, True)
+    if n:
+        bad = pp[:48 * (n - 1)] + pr[(order[n - 1] + 1) % 8]
+        assert _device(hip, rt, bb, cc, bad, n) == (0, False)
+        assert _host(hip, bb, cc, bad, n) == (0, False)
+
+
+def test_pipe_threshold_can_be_lowered_for_every_chunk_shape(material):
+    """CKZG_HIP_VERIFY_PIPE_MIN is read once per process: a child process runs 300 / 513 blobs through the
+    pipelined form (two chunks, the second of 44 / a third chunk of one blob)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, json, sys
+sys.path.insert(0, "tests")
+from kzg_ctypes import HIP_SO, Kzg
+from test_gpu_commitment import rand_blob
+hip = Kzg(HIP_SO, "", precompute=0, options={"commit_wbits": 8, "proof_wbits": 0})
+blobs = [rand_blob(171, i) for i in range(4)]
+cm = [hip.blob_to_kzg_commitment(b) for b in blobs]
+pr = [hip.compute_blob_kzg_proof(b, c) for b, c in zip(blobs, cm)]
+out = {}
+for n in (300, 513):
+    o = [(5 * i) % 4 for i in range(n)]
+    good = hip.verify_blob_kzg_proof_batch([blobs[k] for k in o], [cm[k] for k in o], [pr[k] for k in o])
+    p2 = [pr[k] for k in o]; p2[n - 1] = pr[(o[n - 1] + 1) % 4]
+    bad = hip.verify_blob_kzg_proof_batch([blobs[k] for k in o], [cm[k] for k in o], p2)
+    out[str(n)] = [good, bad]
+print(json.dumps(out))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CKZG_HIP_VERIFY_PIPE_MIN="2")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res == {"300": [True, False], "513": [True, False]}
+
+
+def test_calls_leave_the_callers_hip_device_selected(hip, rt):
+    dev = C.c_int(-1)
+    assert rt.hipGetDevice(C.byref(dev)) == 0
+    before = dev.value
+    hip.blob_to_kzg_commitment(rand_blob(172, 0))
+    assert rt.hipGetDevice(C.byref(dev)) == 0 and dev.value == before
