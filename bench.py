@@ -33,15 +33,12 @@ BLOBS_PER_STEP = 1024
 ALGO_BYTES_PER_BLOB = 131072 + 48          # scalars in + commitment out
 ALGO_BYTES_CELLS_PROOFS = 131072 + 262144 + 6144   # blob in, cells + proofs out
 HBM_PEAK_GBS = 8000.0
-# HBM bytes per k_msm_accumulate launch (1024 blobs) from rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
-# KB units), see profiles/README.md; keyed by table window width.  The traffic is the table gathers
-# themselves (nwin*4096 x 96 B per blob), not re-reads of the algorithmic bytes.
-PMC_TRAFFIC_BYTES = {13: (7658816 + 960) * 1024, 15: (6796321 + 960) * 1024, 16: (6324011 + 192) * 1024}
 # v_mad_u64_u32 per mixed addition (g1_28.hpp: xyzz28_madd_alt): 6 products x 392, 2 squares x 301,
 # one fused two-product reduction x 588
 MADS_PER_ADDITION = 6 * 392 + 2 * 301 + 588
-# SQ_INSTS_VALU per 1024-blob launch (profiles/)
-PMC_VALU_INSTS = {16: 4.795e9}
+ALGO_BYTES_VERIFY_BLOB = 131072 + 48 + 48          # blob + commitment + proof per blob
+ALGO_BYTES_RECOVER_ROW = 131072 + 262144 + 6144    # 64 cells in, 128 cells + 128 proofs out
+PCIE_PEAK_GBS = 63.0                               # PCIe Gen5 x16, one direction (spec; the measured H2D rate is printed next to it)
 WIDE = {"commit_wbits": 16, "proof_wbits": 16, "fk20_wbits": 13}
 
 
@@ -58,6 +55,38 @@ def respawn(n):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     os.execv(sys.executable, cmd)
+
+
+def analytic_traffic(wbits, blobs):
+    """HBM bytes one k_msm_accumulate launch has to move, from the table geometry alone: every one of the
+    nwin * 4096 (window, point) pairs of a blob gathers one 96-byte table entry and reads one int16 digit; one
+    192-byte partial sum is written per workgroup.  (Zero digits skip their gather: 2^-wbits of the pairs.)"""
+    nwin = 2 * (127 // wbits + 1)
+    pairs = nwin * 4096
+    return int(blobs * (pairs * (96 * (1.0 - 2.0 ** -wbits) + 2) + 192))
+
+
+def pmc_cross_check():
+    """The newest committed PMC summaries of the headline kernel (separate rocprofv3 --pmc passes, tools/profile_bench.sh):
+    a cross-check of the analytic traffic and the instruction count, named with its file, never a constant of this script."""
+    import glob
+    out = {}
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_final_pmc_k_msm_accumulate.json")))[-1:]:
+        try:
+            d = json.load(open(f))
+            kb = d["pmc_FETCH_SIZE"]["counter_mean"]["FETCH_SIZE"] + d["pmc_WRITE_SIZE"]["counter_mean"]["WRITE_SIZE"]
+            out["traffic_bytes_per_launch"] = int(kb * 1024)
+            out["traffic_file"] = os.path.relpath(f, ROOT)
+        except Exception as e:  # noqa: BLE001
+            out["traffic_error"] = str(e)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_final_pmc_sq_k_msm_accumulate.json")))[-1:]:
+        try:
+            d = json.load(open(f))["pmc_SQ"]["counter_mean"]
+            out["valu_wave_insts_per_launch"] = d["SQ_INSTS_VALU"]
+            out["sq_file"] = os.path.relpath(f, ROOT)
+        except Exception as e:  # noqa: BLE001
+            out["sq_error"] = str(e)
+    return out or None
 
 
 def cpu_baseline(seconds_budget=12.0):
@@ -81,8 +110,8 @@ def cpu_baseline(seconds_budget=12.0):
     # the same port on many cores at once, one blob per thread (the shape of the reference's
     # ComputeCellsAndKZGProofsParallel benchmark, bindings/go/main_test.go:953-971); ctypes
     # releases the GIL during the C call
-    nthreads = min(64, os.cpu_count() or 1)
-    per_thread = 6
+    nthreads = os.cpu_count() or 1     # every logical CPU of the host (N = nproc)
+    per_thread = 6 if nthreads <= 64 else 3
     counts = [0] * nthreads
 
     def work(i):
@@ -97,10 +126,14 @@ def cpu_baseline(seconds_budget=12.0):
     for t in ths:
         t.join()
     dt_mt = time.perf_counter() - t1
-    # the other half of the metric: compute_cells_and_kzg_proofs, one call, single thread
-    t2 = time.perf_counter()
+    # the other half of the metric: compute_cells_and_kzg_proofs, single thread: one warm-up, median of three
     orc.compute_cells_and_kzg_proofs(blob)
-    dt_cells = time.perf_counter() - t2
+    cell_ts = []
+    for _ in range(3):
+        t2 = time.perf_counter()
+        orc.compute_cells_and_kzg_proofs(blob)
+        cell_ts.append(time.perf_counter() - t2)
+    dt_cells = median(cell_ts)
     orc.close()
     return {"value": round(n / dt, 3), "unit": "blobs/s", "cores": 1, "kind": "port",
             "sample": "%d x blob_to_kzg_commitment on one 4096-element blob, oracle/liboracle.so "
@@ -108,7 +141,8 @@ def cpu_baseline(seconds_budget=12.0):
                       % (n, os.cpu_count() or 0),
             "all_cores": {"value": round(sum(counts) / dt_mt, 2), "unit": "blobs/s", "cores": nthreads,
                           "sample": "%d threads x %d commitments" % (nthreads, per_thread)},
-            "compute_cells_and_kzg_proofs_ms_per_call": round(dt_cells * 1e3, 1)}
+            "compute_cells_and_kzg_proofs_ms_per_call": round(dt_cells * 1e3, 1),
+            "compute_cells_and_kzg_proofs_sample": "median of 3 calls after one warm-up, single thread"}
 
 
 class Lib:
@@ -128,6 +162,8 @@ class Lib:
         self.table_bytes = self._fn("ckzg_hip_table_bytes", [p], C.c_uint64)
         self.table_wbits = self._fn("ckzg_hip_table_wbits", [p, C.c_int])
         self.num_devices = self._fn("ckzg_hip_num_devices", [p])
+        self.verify_blobs_dev = self._fn("ckzg_hip_verify_blob_kzg_proof_batch_device", [p, p, p, p, u64, p])
+        self.load_times = self._fn("ckzg_hip_load_times", [p, C.POINTER(C.c_double), C.c_int])
 
     def _fn(self, name, argtypes, restype=C.c_int):
         f = getattr(self.lib, name)
@@ -223,11 +259,59 @@ def cells_rows(L, hip, torch, dev, blobs, label):
     return out
 
 
-def roofline(algo_bytes, kernel_ms, kernel, traffic=None):
+def roofline(algo_bytes, kernel_ms, kernel, traffic=None, bound="hbm", peak=HBM_PEAK_GBS):
     ach = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms and kernel_ms > 0 else None
-    return {"bound": "hbm", "achieved": None if ach is None else round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": None if ach is None else round(ach / HBM_PEAK_GBS, 6), "traffic": traffic, "kernel": kernel,
+    return {"bound": bound, "achieved": None if ach is None else round(ach, 3), "peak": peak, "unit": "GB/s",
+            "frac": None if ach is None else round(ach / peak, 6), "traffic": traffic, "kernel": kernel,
             "kernel_ms": None if kernel_ms is None else round(kernel_ms, 3)}
+
+
+LOAD_PHASES = ["host_parse_hex", "host_decompress_points_and_pairing_check", "hip_init_and_code_load", "small_tables_and_subgroup_check",
+               "commit_table_malloc", "commit_table_build", "fk20_x_ext_fft_columns", "fk20_table_malloc", "fk20_table_build",
+               "proof_table_malloc", "proof_table_build", "slots_and_host_mirror"]
+
+
+def load_phases(L, hip):
+    """Where the wall clock of load_trusted_setup went (ckzg_hip_load_times), seconds."""
+    buf = (C.c_double * len(LOAD_PHASES))()
+    k = L.load_times(C.addressof(hip.s), buf, len(LOAD_PHASES))
+    return {LOAD_PHASES[i]: round(buf[i] / 1e3, 3) for i in range(k)}
+
+
+class HipRt:
+    """The few HIP runtime calls the verification rows need for page-locked and device copies of their inputs."""
+
+    def __init__(self):
+        rt = C.CDLL("/opt/rocm/lib/libamdhip64.so")
+        rt.hipHostMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+        rt.hipHostFree.argtypes = [C.c_void_p]
+        rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        rt.hipFree.argtypes = [C.c_void_p]
+        rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.rt = rt
+
+    def pinned(self, data):
+        q = C.c_void_p()
+        if self.rt.hipHostMalloc(C.byref(q), len(data), 0) != 0:
+            raise RuntimeError("hipHostMalloc failed")
+        C.memmove(q, data, len(data))
+        return q
+
+    def device(self, data):
+        q = C.c_void_p()
+        if self.rt.hipMalloc(C.byref(q), len(data)) != 0:
+            raise RuntimeError("hipMalloc failed")
+        if self.rt.hipMemcpy(q, C.cast(C.c_char_p(data), C.c_void_p), len(data), 1) != 0:
+            raise RuntimeError("hipMemcpy failed")
+        return q
+
+    def h2d_rate(self, pinned_ptr, nbytes, dev_ptr):
+        ts = []
+        for _ in range(3):
+            t = time.perf_counter()
+            self.rt.hipMemcpy(dev_ptr, pinned_ptr, nbytes, 1)
+            ts.append(time.perf_counter() - t)
+        return nbytes / median(ts) / 1e9
 
 
 def verify_and_recover_rows(L, hip, base):
@@ -256,6 +340,47 @@ def verify_and_recover_rows(L, hip, base):
             raise RuntimeError("verify_blob_kzg_proof_batch rc=%d ok=%s" % (rc, ok.value))
         out["verify_blob_kzg_proof_batch_n%d" % k] = {"blobs_per_s": round(k / median(ts), 1),
                                                       "ms": round(median(ts) * 1e3, 3), "runs": 5}
+    # configs[3] in its three forms: pageable host pointers (above), page-locked host pointers (DMA'd in place,
+    # chunk by chunk under the evaluation kernels), inputs resident in HBM (kernel-only time)
+    row = out["verify_blob_kzg_proof_batch_n%d" % n]
+    row["roofline"] = roofline(ALGO_BYTES_VERIFY_BLOB * n, row["ms"], "whole call, pageable host pointers (PCIe H2D of the blobs)",
+                               bound="pcie", peak=PCIE_PEAK_GBS)
+    try:
+        hrt = HipRt()
+        pin = hrt.pinned(bb)
+        dptr = [hrt.device(x) for x in (bb, cc, pp)]
+        row["pcie_h2d_pinned_GBps_measured"] = round(hrt.h2d_rate(pin, len(bb), dptr[0]), 2)
+        vb = L._fn("verify_blob_kzg_proof_batch", [C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p, C.c_uint64, C.c_void_p])
+        vb(C.byref(ok), pin, cc, pp, n, sp)
+        ts = []
+        for _ in range(5):
+            t = time.perf_counter()
+            rc = vb(C.byref(ok), pin, cc, pp, n, sp)
+            ts.append(time.perf_counter() - t)
+        if rc != 0 or not ok.value:
+            raise RuntimeError("pinned verify rc=%d ok=%s" % (rc, ok.value))
+        row["pinned_caller_memory"] = {"ms": round(median(ts) * 1e3, 3), "blobs_per_s": round(n / median(ts), 1),
+                                       "roofline": roofline(ALGO_BYTES_VERIFY_BLOB * n, median(ts) * 1e3,
+                                                            "whole call, page-locked host pointers", bound="pcie", peak=PCIE_PEAK_GBS)}
+        L.verify_blobs_dev(C.byref(ok), dptr[0], dptr[1], dptr[2], n, sp)
+        ts, ks, k0, k2 = [], [], [], []
+        for _ in range(5):
+            t = time.perf_counter()
+            rc = L.verify_blobs_dev(C.byref(ok), dptr[0], dptr[1], dptr[2], n, sp)
+            ts.append(time.perf_counter() - t)
+            ks.append(L.kms(sp, 3)); k0.append(L.kms(sp, 0)); k2.append(L.kms(sp, 2))
+        if rc != 0 or not ok.value:
+            raise RuntimeError("resident verify rc=%d ok=%s" % (rc, ok.value))
+        row["resident_inputs"] = {"ms": round(median(ts) * 1e3, 3), "blobs_per_s": round(n / median(ts), 1),
+                                  "kernel_ms": {"total": round(median(ks), 3), "validate_convert_hash_evaluate": round(median(k0), 3),
+                                                "sums": round(median(k2), 3)},
+                                  "roofline": roofline(ALGO_BYTES_VERIFY_BLOB * n, median(ks),
+                                                       "k_sha256_challenges + k_eval_barycentric + k_validate_g1 + k_lincomb_partial (device time of the call)")}
+        for q in dptr:
+            hrt.rt.hipFree(q)
+        hrt.rt.hipHostFree(pin)
+    except Exception as e:  # noqa: BLE001 -- reported, the pageable row stands
+        row["forms_error"] = str(e)
     del bb
     cp = [hip.compute_cells_and_kzg_proofs(b) for b in ub]
     n = 8192
@@ -290,10 +415,92 @@ def verify_and_recover_rows(L, hip, base):
         ts.append(time.perf_counter() - t)
     if rc != 0 or rp_buf.raw[:128 * 48] != b"".join(cp[0][1]):
         raise RuntimeError("recover batch rc=%d or wrong proofs" % rc)
+    k_small, k_fft, k_dev = L.kms(sp, 1), L.kms(sp, 4), L.kms(sp, 3)
+    dom, dom_name = (k_small, "k_msm_small") if k_small >= k_fft else (k_fft, "k_g1_fft_twiddle* + k_g1_fft_addsub (2 G1 FFTs)")
     out["recover_cells_and_kzg_proofs_batch256"] = {
         "rows_per_s": round(nb / median(ts), 1), "ms": round(median(ts) * 1e3, 3), "runs": 3,
+        "kernel_ms": {"device_section": round(k_dev, 3), "k_msm_small": round(k_small, 3), "g1_fft": round(k_fft, 3)},
+        "roofline": roofline(ALGO_BYTES_RECOVER_ROW * nb, dom, dom_name),
+        "roofline_whole_call": roofline(ALGO_BYTES_RECOVER_ROW * nb, median(ts) * 1e3, "whole call, pageable host pointers",
+                                        bound="pcie", peak=PCIE_PEAK_GBS),
         "note": "64 of 128 cells per row (every other cell), same columns in every row; cells and proofs out"}
     return out
+
+
+def pin_to_gpu_numa_node(torch, local_rank):
+    """A rank's host threads (staging copies, transcript hashing) belong on the NUMA node its GPU hangs off:
+    sysfs gives the node of the PCI function and the node's CPU list.  Returns what was done, for the JSON line."""
+    try:
+        props = torch.cuda.get_device_properties(local_rank)
+        bdf = "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), props.pci_bus_id, props.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+        if node < 0:
+            return {"pci": bdf, "numa_node": node, "pinned": False}
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        os.sched_setaffinity(0, cpus)
+        return {"pci": bdf, "numa_node": node, "cpus": len(cpus), "pinned": True}
+    except Exception as e:  # noqa: BLE001 -- containers often hide sysfs; never fatal
+        return {"pinned": False, "error": str(e)[:120]}
+
+
+def sharded_rows(L, hip, mod, torch, dist, rank, world, red_dev, base):
+    """BASELINE configs[3] / configs[4] in their multi-GPU form (tools/run_sharded.py, c-kzg-4844_amd/multi_gpu.py):
+    4096 blobs / 256 rows in contiguous shards, one per rank, no data-path collective; the verdict is an AND over
+    the shards, the recovered proofs are all-gathered.  Every rank runs this; rank 0 reports.  Timed between
+    barriers, MAX over ranks."""
+    import importlib
+    mg = importlib.import_module("ckzg_4844_amd.multi_gpu")
+    sp = C.addressof(hip.s)
+    ub = [base[i].tobytes() for i in range(8)]
+    cm = [hip.blob_to_kzg_commitment(b) for b in ub]
+    pr = [hip.compute_blob_kzg_proof(b, c) for b, c in zip(ub, cm)]
+    cp = [hip.compute_cells_and_kzg_proofs(b) for b in ub]
+    n_verify, n_rows = 4096, 256
+    lo, hi = mg.shard_bounds(n_verify, world)[rank]
+    bb = b"".join(ub[i % 8] for i in range(lo, hi))
+    cc = b"".join(cm[i % 8] for i in range(lo, hi))
+    pp = b"".join(pr[i % 8] for i in range(lo, hi))
+    ok = C.c_bool(False)
+
+    def verify(a, b):
+        rc = L.verify_blobs(C.byref(ok), bb, cc, pp, b - a, sp)
+        return rc, ok.value
+
+    def timed(fn):
+        fn()   # warm-up: arenas, pinned staging
+        dist.barrier()
+        t = time.perf_counter()
+        res = fn()
+        dt = time.perf_counter() - t
+        tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return res, float(tt.item())
+
+    (rc, verdict), dt_v = timed(lambda: mg.sharded_verify(verify, n_verify, red_dev))
+    keep = list(range(0, 128, 2))
+    rlo, rhi = mg.shard_bounds(n_rows, world)[rank]
+    data = b"".join(b"".join(cp[b % 8][0][i] for i in keep) for b in range(rlo, rhi))
+    kidx = (C.c_uint64 * len(keep))(*keep)
+    nloc = rhi - rlo
+    rp_buf = C.create_string_buffer(max(nloc, 1) * 128 * 48)
+
+    def recover(a, b):
+        r = L.recover(None, rp_buf, None, kidx, data, C.c_uint64(len(keep)), C.c_uint64(b - a), C.c_void_p(sp))
+        if r != 0:
+            raise RuntimeError("sharded recover rc=%d" % r)
+        return torch.frombuffer(bytearray(rp_buf.raw[:(b - a) * 128 * 48]), dtype=torch.uint8).reshape(b - a, 128 * 48)
+
+    proofs, dt_r = timed(lambda: mg.sharded_map(recover, n_rows, 128 * 48, red_dev))
+    good = all(bytes(proofs[b].cpu().numpy().tobytes()) == b"".join(cp[b % 8][1]) for b in (0, n_rows // 2, n_rows - 1))
+    return {"verify_blob_kzg_proof_batch_n4096_sharded": {"ranks": world, "rc": rc, "ok": verdict, "ms": round(dt_v * 1e3, 3),
+                                                          "blobs_per_s": round(n_verify / dt_v, 1),
+                                                          "collective": "MAX/AND all-reduce of (return code, verdict): 8 bytes"},
+            "recover_cells_and_kzg_proofs_batch256_sharded": {"ranks": world, "proofs_correct": good, "ms": round(dt_r * 1e3, 3),
+                                                              "rows_per_s": round(n_rows / dt_r, 1),
+                                                              "collective": "all-gather of 6,144 B of proofs per row"}}
 
 
 def concurrency_row(hip, ub):
@@ -350,7 +557,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    numa = pin_to_gpu_numa_node(torch, local_rank) if world > 1 else None
     if world > 1:
+        # RCCL comes up BEFORE the tables are allocated: its buffers and hardware queues are claimed while the HBM
+        # is still empty, and the line records what was free on every rank before and after the load.
         # The ranks only meet at barriers and at one MAX over their timings (the path has no data-path collective,
         # SURVEY 8e).  RCCL carries them; if it cannot come up on this node (every rank then fails alike) the same
         # two calls go over gloo on a second rendezvous port, and the line says so in "barrier_backend".
@@ -380,9 +590,11 @@ def main():
     opts = dict(WIDE, device=local_rank, commit_wbits=args.wbits)
     if one_gpu and world > 1:
         opts.update(commit_wbits=min(args.wbits, 12), proof_wbits=8, fk20_wbits=8)  # ranks share one GPU's HBM
+    free_before = torch.cuda.mem_get_info(local_rank)[0]
     t_load = time.perf_counter()
     hip = mod.Kzg(mod.HIP_SO, options=opts)
     load_s = time.perf_counter() - t_load
+    free_after = torch.cuda.mem_get_info(local_rank)[0]
     L = Lib(hip.lib)
     sp = C.addressof(hip.s)
     wbits = int(L.table_wbits(sp, 0))  # what was actually built
@@ -482,7 +694,7 @@ def main():
     secondary = None
 
     def secondary_rows():
-        sec = {"load_trusted_setup_s": {"wide_tables": round(load_s, 2)}}
+        sec = {"load_trusted_setup_s": {"wide_tables": round(load_s, 2), "wide_tables_phases": load_phases(L, hip)}}
         sec["cells_and_proofs"] = cells_rows(L, hip, torch, dev, blobs, "wide tables (same KZGSettings as the headline)")
         try:
             sec.update(verify_and_recover_rows(L, hip, blobs[:8].cpu().numpy()))
@@ -496,6 +708,7 @@ def main():
         t1 = time.perf_counter()
         small = mod.Kzg(mod.HIP_SO, options={"device": local_rank, "commit_wbits": 10, "proof_wbits": 8, "fk20_wbits": 0})
         sec["load_trusted_setup_s"]["default_tables"] = round(time.perf_counter() - t1, 2)
+        sec["load_trusted_setup_s"]["default_tables_phases"] = load_phases(L, small)
         try:
             sps = C.addressof(small.s)
             L.commit_dev(out.data_ptr(), status.data_ptr(), blobs.data_ptr(), BLOBS_PER_STEP, sps)
@@ -523,6 +736,21 @@ def main():
             if isinstance(e, SystemExit) and ("disagree" in str(e) or "differs" in str(e)):
                 raise
             secondary = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    # per-rank bookkeeping and the sharded forms of configs[3] / configs[4]: every rank takes part, rank 0 reports
+    per_rank = sharded = None
+    if world > 1:
+        t = torch.tensor([load_s, free_before / 1e9, free_after / 1e9, sum(kern_ms) / len(kern_ms)], dtype=torch.float64, device=red_dev)
+        parts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        per_rank = [{"rank": r, "load_trusted_setup_s": round(float(q[0]), 2), "free_hbm_gb_before_load": round(float(q[1]), 1),
+                     "free_hbm_gb_after_load": round(float(q[2]), 1), "k_msm_accumulate_ms": round(float(q[3]), 3)}
+                    for r, q in enumerate(parts)]
+        if not args.no_secondary:
+            try:
+                sharded = sharded_rows(L, hip, mod, torch, dist, rank, world, red_dev, blobs[:8].cpu().numpy())
+            except BaseException as e:  # noqa: BLE001 -- every rank fails alike or the barrier inside times out
+                sharded = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
     # C-ABI multi-device form (one process, ckzg_hip_set_option("devices", mask), host threads fan the batch
     # out): measured by rank 0 after the timed region while the other ranks wait, on small tables that fit
@@ -573,7 +801,10 @@ def main():
                        "parallelism": "independent blob shards per GPU, no collective",
                        "barrier_backend": dist.get_backend() if world > 1 else None},
             "roofline": dict(roofline(ALGO_BYTES_PER_BLOB * BLOBS_PER_STEP, avg_k, "k_msm_accumulate",
-                                      PMC_TRAFFIC_BYTES.get(wbits)),
+                                      analytic_traffic(wbits, BLOBS_PER_STEP)),
+                             traffic_source="analytic: nwin*4096 table gathers of 96 B + int16 digits per blob, from the "
+                                            "table geometry of THIS run (bench.py: analytic_traffic)",
+                             pmc_cross_check=pmc_cross_check(),
                              note="integer-VALU-bound kernel (v_mad_u64_u32 chains); HBM fraction is small by nature"),
             # the physical bound of this kernel: integer multiply-add issue rate.  peak = measured
             # v_mad_u64_u32 rate of the chip (tools/ubench/instr_rates.hip: 32.9e12 lane-ops/s);
@@ -582,8 +813,8 @@ def main():
             "roofline_valu": {"bound": "v_mad_u64_u32 issue", "unit": "T lane-mad/s", "peak": 32.9,
                               "achieved": round(BLOBS_PER_STEP * adds_per_blob * MADS_PER_ADDITION / (avg_k * 1e-3) / 1e12, 3),
                               "frac": round(BLOBS_PER_STEP * adds_per_blob * MADS_PER_ADDITION / (avg_k * 1e-3) / 32.9e12, 4),
-                              "valu_wave_insts_per_launch": PMC_VALU_INSTS.get(wbits),
-                              "pmc": "profiles/ (SQ_INSTS_VALU, GRBM_GUI_ACTIVE, SQ_WAVES)"},
+                              "pmc": "roofline.pmc_cross_check (SQ_INSTS_VALU of the newest committed profile)"},
+            "value_host_pointer": None if host_ptr is None else host_ptr["value"],
             "host_pointer": host_ptr,
             "pcie_inclusive_blobs_per_s": None if host_ptr is None else host_ptr["value"],
             "parity_spot_check_vs_oracle": parity,
@@ -591,6 +822,11 @@ def main():
         }
         if fan_out is not None:
             line["c_abi_fan_out"] = fan_out
+        if per_rank is not None:
+            line["per_rank"] = per_rank
+            line["numa"] = numa
+        if sharded is not None:
+            line["sharded_rows"] = sharded
         if not args.no_cpu_baseline and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline()

@@ -13,6 +13,8 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <pthread.h>
+#include <sched.h>
 #include <thread>
 #include <vector>
 
@@ -95,7 +97,30 @@ struct DevicePool {
 // roots_of_unity pointer: that pointer survives the by-value copies/moves bindings make of KZGSettings
 // (Go embeds it, Rust moves it), and a struct that was not loaded by this library is simply not in the
 // registry -- nothing is read through a foreign pointer.
+// wall-clock phases of load_trusted_setup (ckzg_hip_load_times), milliseconds, first pool
+enum LoadPhase {
+    LP_HOST_PARSE = 0,     // hex text -> bytes (load_trusted_setup_file only)
+    LP_HOST_POINTS,        // decompression of the 8192 G1 + 65 G2 points, the Lagrange/monomial pairing check, roots
+    LP_HIP_INIT,           // device selection, first runtime calls: HIP initialisation + code-object load, streams
+    LP_SMALL_TABLES,       // Fr twiddles, coset factors, setup points to HBM, subgroup check of the setup points
+    LP_COMMIT_MALLOC,      // hipMalloc of the commitment table (+ its construction scratch)
+    LP_COMMIT_BUILD,       // k_window_bases / k_table_chain / k_batch_to_affine of the commitment table
+    LP_FK20_SETUP,         // the 64 G1 FFTs of x_ext_fft_columns (setup.c:238-330)
+    LP_FK20_MALLOC,
+    LP_FK20_BUILD,
+    LP_PROOF_MALLOC,
+    LP_PROOF_BUILD,
+    LP_SLOTS,              // the other slots of the pool (streams, events) + host mirror of x_ext_fft_columns
+    LP_COUNT
+};
+struct LoadTimes {
+    double ms[LP_COUNT] = {};
+};
+// the phases measured before the SettingsCtx exists (load_trusted_setup_file / _impl), per calling thread
+LoadTimes &pending_load_times();
+
 struct SettingsCtx {
+    LoadTimes load;
     std::vector<DevicePool *> pools;
     PreparedG2 prepared;
     Options opts;
@@ -180,6 +205,54 @@ struct JoinThreads {
     ~JoinThreads() { join(); }
 };
 
+// A fan-out thread (one per device: staging copies, transcript hashing, its slot's pinned buffers on first touch)
+// runs on the NUMA node its GPU hangs off: sysfs gives the node of the PCI function and the node's CPU list.
+// Only threads the library creates itself are pinned, never the caller's.  CKZG_HIP_NUMA_PIN=0 switches it off.
+inline void pin_thread_to_device_numa(int device) {
+    static const bool enabled = []() {
+        const char *e = getenv("CKZG_HIP_NUMA_PIN");
+        return !(e && *e == '0');
+    }();
+    if (!enabled) return;
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf - 1, device) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    for (char *c = bdf; *c; c++) {
+        if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+    }
+    char path[160];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
+    FILE *f = fopen(path, "r");
+    if (!f) return;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    if (node < 0) return;
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    f = fopen(path, "r");
+    if (!f) return;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    int lo, hi, count = 0;
+    while (fscanf(f, "%d", &lo) == 1) {
+        hi = lo;
+        int ch = fgetc(f);
+        if (ch == '-') {
+            if (fscanf(f, "%d", &hi) != 1) break;
+            ch = fgetc(f);
+        }
+        for (int c = lo; c <= hi && c < CPU_SETSIZE; c++) {
+            CPU_SET(c, &set);
+            count++;
+        }
+        if (ch != ',') break;
+    }
+    fclose(f);
+    if (count > 0) (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
+}
+
 // Host-pointer batch entry points: contiguous ranges of the n units over the pools (one host thread and
 // one leased slot per device), results written in place by each shard; the reference's equivalent is the
 // goroutine fan-out of bindings/go/main_test.go:953-971.  body(ctx, lo, hi) -> C_KZG_RET.
@@ -203,6 +276,7 @@ C_KZG_RET for_each_device_shard(const KZGSettings *s, uint64_t n, uint64_t min_s
         const uint64_t hi = lo + base + (d < extra ? 1 : 0);
         th.spawn([&, d, lo, hi]() {
             rets[d] = guarded([&]() -> C_KZG_RET {
+                pin_thread_to_device_numa(sc->pools[d]->device);
                 Lease lease(sc->pools[d]);
                 if (!lease.ctx) return C_KZG_ERROR;
                 return body(lease.ctx, lo, hi);

@@ -3,6 +3,7 @@
 // device.hpp.  There is no CPU fallback for the hot path: if no GPU context is attached to the
 // KZGSettings (or the HIP runtime fails) the call returns C_KZG_ERROR and says why on stderr.
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <thread>
 
@@ -129,6 +130,7 @@ static C_KZG_RET load_trusted_setup_impl(KZGSettings *out, const uint8_t *g1_mon
                                          uint64_t num_g2_monomial_bytes, uint64_t precompute) {
     // setup.c:392-505
     C_KZG_RET ret = C_KZG_OK;
+    const auto t_host = std::chrono::steady_clock::now();
     std::vector<G1Affine> lagr_affine(NUM_G1_POINTS), mono_affine(NUM_G1_POINTS);
     memset(out, 0, sizeof *out);
     if (precompute > 15) return C_KZG_BADARGS;
@@ -195,6 +197,8 @@ static C_KZG_RET load_trusted_setup_impl(KZGSettings *out, const uint8_t *g1_mon
     if (ret != C_KZG_OK) goto fail;
     bit_reversal_permutation(out->g1_values_lagrange_brp, sizeof(g1_t), NUM_G1_POINTS);
     bit_reversal_permutation(lagr_affine.data(), sizeof(G1Affine), NUM_G1_POINTS);
+    pending_load_times().ms[LP_HOST_POINTS] =
+        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host).count();
     // GPU state: commitment tables, NTT twiddles, FK20 columns and tables (setup.c:238-330)
     ret = create_settings_ctx(out, lagr_affine.data(), mono_affine.data());
     if (ret != C_KZG_OK) goto fail;
@@ -223,6 +227,8 @@ static C_KZG_RET load_trusted_setup_file_impl(KZGSettings *out, FILE *in, uint64
     // setup.c:519-600: "<n_g1> <n_g2>" then hex of: G1 Lagrange, G2 monomial, G1 monomial
     uint64_t n1 = 0, n2 = 0;
     memset(out, 0, sizeof *out);
+    const auto t_parse = std::chrono::steady_clock::now();
+    pending_load_times() = LoadTimes();
     std::vector<uint8_t> mono(NUM_G1_POINTS * 48), lagr(NUM_G1_POINTS * 48), g2(NUM_G2_POINTS * 96);
     if (fscanf(in, "%" SCNu64, &n1) != 1 || n1 != NUM_G1_POINTS) return C_KZG_BADARGS;
     if (fscanf(in, "%" SCNu64, &n2) != 1 || n2 != NUM_G2_POINTS) return C_KZG_BADARGS;
@@ -235,8 +241,12 @@ static C_KZG_RET load_trusted_setup_file_impl(KZGSettings *out, FILE *in, uint64
     for (auto &b : mono) {
         if (fscanf(in, "%2hhx", &b) != 1) return C_KZG_BADARGS;
     }
-    return load_trusted_setup(out, mono.data(), mono.size(), lagr.data(), lagr.size(), g2.data(),
-                              g2.size(), precompute);
+    const double parse_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_parse).count();
+    C_KZG_RET ret = load_trusted_setup(out, mono.data(), mono.size(), lagr.data(), lagr.size(), g2.data(), g2.size(), precompute);
+    if (ret == C_KZG_OK) {
+        if (SettingsCtx *sc = settings_of(out, false)) sc->load.ms[LP_HOST_PARSE] = parse_ms;
+    }
+    return ret;
 }
 
 extern "C" C_KZG_RET load_trusted_setup_file(KZGSettings *out, FILE *in, uint64_t precompute) {
@@ -652,6 +662,14 @@ extern "C" double ckzg_hip_last_kernel_ms(const KZGSettings *s, int which) {
         best = std::max(best, (double)c->last_ms[which]);
     }
     return best;
+}
+
+extern "C" int ckzg_hip_load_times(const KZGSettings *s, double *ms, int n) {
+    SettingsCtx *sc = settings_of(s, false);
+    if (!sc || !ms) return 0;
+    int k = n < (int)LP_COUNT ? n : (int)LP_COUNT;
+    for (int i = 0; i < k; i++) ms[i] = sc->load.ms[i];
+    return k;
 }
 
 extern "C" uint64_t ckzg_hip_table_bytes(const KZGSettings *s) {

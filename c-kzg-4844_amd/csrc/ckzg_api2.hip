@@ -285,6 +285,11 @@ C_KZG_RET gpu_lincomb_multi(dev::DeviceCtx *ctx, G1Jac *outs, const LincombJob *
             return e && *e ? atoi(e) : 0;
         }();
         algo = forced ? forced : (max_job >= bucket_min_terms() ? 2 : 1);
+        if (algo == 2 && !dev::bucket_msm_available()) algo = 1;   // the product build has no bucket kernels
+    }
+    if (algo == 2 && !dev::bucket_msm_available()) {
+        fprintf(stderr, "[ckzg-hip] algo = 2 (bucket MSM) is experimental and not in this build: make buckets\n");
+        return C_KZG_BADARGS;
     }
     // ladders: four lanes per half-term (k_lincomb_partial_quad) while 8 lanes per term still fit the chip in
     // about two waves per SIMD; beyond that the one-lane-per-half form does fewer lane-products in total
@@ -1035,6 +1040,7 @@ static C_KZG_RET recover_batch_on(dev::DeviceCtx *ctx, Cell *recovered_cells, KZ
     } drain{ctx, pipe};
     std::vector<size_t> mark;
     size_t chunk = 0;
+    OKB(hipEventRecord(ctx->ev[1], ctx->stream) == hipSuccess);
     for (size_t off = 0; off < num_blobs; off += CH, chunk++) {
         const size_t k = num_blobs - off < CH ? (size_t)(num_blobs - off) : CH;
         const size_t in_bytes = k * num_cells * BYTES_PER_CELL;
@@ -1083,7 +1089,15 @@ static C_KZG_RET recover_batch_on(dev::DeviceCtx *ctx, Cell *recovered_cells, KZ
         }
         mark.push_back(pipe.pushed_count());
     }
+    OKB(hipEventRecord(ctx->ev[4], ctx->stream) == hipSuccess);
     if (pipe.finish() != C_KZG_OK) return C_KZG_ERROR;
+    OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
+    {   // ckzg_hip_last_kernel_ms: 3 = the device section of the call, 1 / 4 = k_msm_small / G1 FFTs of the last chunk
+        float ms;
+        if (hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[4]) == hipSuccess) ctx->last_ms[3] = ms;
+        if (recovered_proofs) dev::fk20_collect_times(ctx);
+        (void)hipGetLastError();
+    }
     return result;
 }
 

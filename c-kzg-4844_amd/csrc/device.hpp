@@ -122,8 +122,9 @@ struct DeviceCtx {
 int scratch_reserve(DeviceCtx *ctx, size_t bytes);
 
 // Build a fixed-base table for `npoints` affine bases already in HBM.
+// times_ms (optional): [0] += allocation, [1] += construction kernels
 int build_fixed_base_table(DeviceCtx *ctx, FixedBaseTable *t, const G1Affine *d_bases, int npoints,
-                           int wbits);
+                           int wbits, double *times_ms = nullptr);
 
 // Commit n blobs resident in HBM: d_out48[n][48], d_status[n] (0 ok, 1 non-canonical element).
 int commit_blobs_device(DeviceCtx *ctx, uint8_t *d_out48, uint8_t *d_status, const uint8_t *d_blobs,
@@ -177,6 +178,7 @@ int proofs_stage_enqueue(DeviceCtx *ctx, uint8_t *d_proofs, const Fr *d_poly, si
 int bad_to_status_enqueue(DeviceCtx *ctx, uint8_t *d_status, const uint32_t *d_bad, size_t k);
 // FK20 proofs from monomial coefficients already on the device ([n][4096] Fr, Montgomery)
 int fk20_proofs_device(DeviceCtx *ctx, uint8_t *d_proofs, const Fr *d_poly_monomial, size_t n);
+void fk20_collect_times(DeviceCtx *ctx);
 // verify.hip
 int eval_poly_batch_device(DeviceCtx *ctx, Fr *d_y, const Fr *d_poly, const Fr *d_z, size_t n);
 int eval_quotient_batch_device(DeviceCtx *ctx, Fr *d_y, uint32_t *d_q_raw, int *d_hit, const Fr *d_poly,
@@ -194,7 +196,9 @@ int subgroup_g1_batch_device(DeviceCtx *ctx, uint8_t *d_status, const G1Affine *
 // d_off: njobs + 1 words of device scratch
 int lincomb_multi_device(DeviceCtx *ctx, G1Affine *d_out, G1XYZZ *d_partials, uint32_t *d_off, const G1Affine *d_pts,
                          const uint32_t *d_scalars, size_t total, const uint32_t *h_part_off, int njobs, bool quad);
-// pippenger.hip: the same sums by bucket accumulation (enqueue-only; see bucket_msm_enqueue)
+// pippenger.hip: the same sums by bucket accumulation (enqueue-only; see bucket_msm_enqueue).  EXPERIMENTAL: only
+// libckzg_hip_buckets.so (make buckets) holds the kernels, the product has stubs (bucket_msm_available() == false)
+bool bucket_msm_available();
 size_t bucket_msm_scratch_bytes(size_t total, int njobs, int wbits);
 int bucket_msm_wbits(size_t max_job_terms);
 int bucket_msm_enqueue(DeviceCtx *ctx, G1Affine *d_out, const G1Affine *d_pts, const uint32_t *d_scalars, size_t total,

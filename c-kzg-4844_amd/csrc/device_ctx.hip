@@ -4,6 +4,7 @@
 // This is the GPU half of load_trusted_setup (src/setup/setup.c:392-505): the reference builds
 // x_ext_fft_columns and (optionally) blst fixed-base tables on the CPU (setup.c:238-330); here the
 // 64 G1 FFTs and all tables are produced by kernels and stay resident in HBM.
+#include <chrono>
 #include <shared_mutex>
 #include <unordered_map>
 
@@ -212,12 +213,33 @@ static C_KZG_RET init_slot_runtime(dev::DeviceCtx *ctx) {
 
 // Tables of one pool, built on the calling thread's device into `ctx` (slot 0).  h_xext (optional):
 // host copy of the x_ext_fft columns for the KZGSettings mirror.
+namespace {
+struct PhaseClock {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double lap() {
+        auto t1 = std::chrono::steady_clock::now();
+        double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        t0 = t1;
+        return ms;
+    }
+};
+}  // namespace
+
+LoadTimes &pending_load_times() {
+    static thread_local LoadTimes t;
+    return t;
+}
+
 static C_KZG_RET build_owner(dev::DeviceCtx *ctx, const KZGSettings *s, const Options &opts,
                              const G1Affine *lagrange_brp_affine, const G1Affine *monomial_affine,
-                             G1Affine *h_xext) {
+                             G1Affine *h_xext, LoadTimes *lt) {
+    LoadTimes scratch_times;
+    if (!lt) lt = &scratch_times;
+    PhaseClock clk;
     CTX_TRY(hipSetDevice(ctx->device));
     C_KZG_RET r = init_slot_runtime(ctx);
     if (r != C_KZG_OK) return r;
+    lt->ms[LP_HIP_INIT] += clk.lap();
 
     // Fr twiddles
     CTX_TRY(hipMalloc(&ctx->d_roots, (dev::N_EXT + 1) * sizeof(Fr)));
@@ -271,23 +293,28 @@ static C_KZG_RET build_owner(dev::DeviceCtx *ctx, const KZGSettings *s, const Op
         }
     }
 
+    lt->ms[LP_SMALL_TABLES] += clk.lap();
     // commitment table over the bit-reversed Lagrange points
     {
         int wbits = env_int("CKZG_HIP_COMMIT_WBITS", opts.commit_wbits);
         if (wbits < 4 || wbits > 16) wbits = 10;
         wbits = fit_wbits("commit", wbits, 8, (int)NUM_G1_POINTS);
-        int rc = dev::build_fixed_base_table(ctx, &ctx->commit, (const G1Affine *)d_bases.p, (int)NUM_G1_POINTS, wbits);
+        int rc = dev::build_fixed_base_table(ctx, &ctx->commit, (const G1Affine *)d_bases.p, (int)NUM_G1_POINTS, wbits,
+                                             &lt->ms[LP_COMMIT_MALLOC]);
         if (rc) return (C_KZG_RET)rc;
     }
+    clk.lap();
     // FK20: x_ext_fft columns by 64 G1 FFTs on the GPU, then the fixed-base table over those 8192 points
     {
         int rc = dev::fk20_setup_device(ctx, ctx->d_mono, h_xext);
         if (rc) return (C_KZG_RET)rc;
+        lt->ms[LP_FK20_SETUP] += clk.lap();
         int wbits = env_int("CKZG_HIP_FK20_WBITS", opts.fk20_wbits);
         if (wbits == 0) wbits = s->wbits > 8 ? (s->wbits > 13 ? 13 : (int)s->wbits) : 8;
         if (wbits < 4 || wbits > 16) wbits = 8;
         wbits = fit_wbits("fk20", wbits, 8, dev::N_CELLS_EXT * dev::N_CELL);
-        rc = dev::build_fixed_base_table(ctx, &ctx->fk20, ctx->d_xext, dev::N_CELLS_EXT * dev::N_CELL, wbits);
+        rc = dev::build_fixed_base_table(ctx, &ctx->fk20, ctx->d_xext, dev::N_CELLS_EXT * dev::N_CELL, wbits,
+                                         &lt->ms[LP_FK20_MALLOC]);
         if (rc) return (C_KZG_RET)rc;
     }
     // table over the monomial points for the low-latency (direct) cell-proof path
@@ -297,7 +324,8 @@ static C_KZG_RET build_owner(dev::DeviceCtx *ctx, const KZGSettings *s, const Op
         if (wbits != 0 && ctx->direct_max != 0) {
             if (wbits < 4 || wbits > 16) wbits = 8;
             wbits = fit_wbits("proof", wbits, 8, (int)NUM_G1_POINTS);
-            int rc = dev::build_fixed_base_table(ctx, &ctx->mono, ctx->d_mono, (int)NUM_G1_POINTS, wbits);
+            int rc = dev::build_fixed_base_table(ctx, &ctx->mono, ctx->d_mono, (int)NUM_G1_POINTS, wbits,
+                                                 &lt->ms[LP_PROOF_MALLOC]);
             if (rc) return (C_KZG_RET)rc;
             // Automatic hand-over point (measured, tools/bench_direct_vs_fk20.py, profiles/r02_quad_ab.txt): with the
             // radix-4 / four-lane G1 FFT FK20 costs 6.8-7.1 ms for any batch of up to 8 blobs (it was ~28 ms with
@@ -375,6 +403,9 @@ C_KZG_RET create_settings_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affin
 
     SettingsCtx *sc = new SettingsCtx();
     sc->opts = opts;
+    sc->load = pending_load_times();       // host phases measured by load_trusted_setup(_file) on this thread
+    pending_load_times() = LoadTimes();
+    PhaseClock slots_clk;
     host::g2_prepare(sc->prepared.gen, host::g2_to_affine(host::g2_generator()));
     host::g2_prepare(sc->prepared.s1, host::g2_to_affine(*as_g2(&s->g2_values_monomial[1])));
     host::g2_prepare(sc->prepared.s64, host::g2_to_affine(*as_g2(&s->g2_values_monomial[dev::N_CELL])));
@@ -399,11 +430,12 @@ C_KZG_RET create_settings_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affin
         JoinThreads th;
         for (size_t di = 0; di < devs.size(); di++) {
             th.spawn([&, di]() {
+                if (devs.size() > 1) pin_thread_to_device_numa(devs[di]);
                 for (int r = 0; r < replicas; r++) {
                     const size_t pi = di * replicas + r;
                     rets[pi] = guarded([&]() {
                         return build_owner(sc->pools[pi]->slots[0], s, opts, lagrange_brp_affine, monomial_affine,
-                                           pi == 0 ? h_xext.data() : nullptr);
+                                           pi == 0 ? h_xext.data() : nullptr, pi == 0 ? &sc->load : nullptr);
                     });
                     if (rets[pi] != C_KZG_OK) break;
                 }
@@ -413,6 +445,7 @@ C_KZG_RET create_settings_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affin
     }
     C_KZG_RET ret = C_KZG_OK;
     for (auto r : rets) ret = worse(ret, r);
+    slots_clk.lap();
     for (size_t pi = 0; pi < sc->pools.size() && ret == C_KZG_OK; pi++) {
         DevicePool *p = sc->pools[pi];
         if (hipSetDevice(p->device) != hipSuccess) ret = C_KZG_ERROR;
@@ -442,6 +475,7 @@ C_KZG_RET create_settings_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affin
         destroy_settings(sc);
         return ret;
     }
+    sc->load.ms[LP_SLOTS] += slots_clk.lap();
     std::unique_lock<std::shared_mutex> lock(g_reg_mu);
     registry()[s->roots_of_unity] = sc;
     return C_KZG_OK;

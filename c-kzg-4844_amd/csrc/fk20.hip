@@ -830,5 +830,15 @@ int cells_and_proofs_device(DeviceCtx *ctx, uint8_t *d_cells, uint8_t *d_proofs,
     return 0;
 }
 
+// Kernel times of the most recent FK20 run on this slot, for callers that enqueue it themselves (the recover batch):
+// last_ms[1] = k_msm_small, last_ms[4] = the two G1 FFTs (ckzg_hip_last_kernel_ms).  Stream must be idle.
+void fk20_collect_times(DeviceCtx *ctx) {
+    float ms;
+    ctx->last_ms[1] = ctx->last_ms[4] = -1;
+    if (hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6]) == hipSuccess) ctx->last_ms[1] = ms;
+    if (hipEventElapsedTime(&ms, ctx->ev[7], ctx->ev[8]) == hipSuccess) ctx->last_ms[4] = ms;
+    (void)hipGetLastError();
+}
+
 }  // namespace dev
 }  // namespace ckzg

@@ -15,6 +15,7 @@
 // 96-byte gather per addition, 8M+2S mixed additions into an XYZZ accumulator held in VGPRs, an
 // LDS tree to fold a workgroup, no buckets, no doublings, no atomics.  Arithmetic intensity is
 // ~3000 integer multiply-adds per 96-byte gather: the kernel is VALU-bound, not HBM-bound.
+#include <chrono>
 #include <vector>
 #include "device.hpp"
 #include "dev_inline.hpp"
@@ -142,8 +143,9 @@ struct DevTmp {  // freed on every exit path of build_fixed_base_table
 }  // namespace
 
 int build_fixed_base_table(DeviceCtx *ctx, FixedBaseTable *t, const G1Affine *d_bases, int npoints,
-                           int wbits) {
+                           int wbits, double *times_ms) {
     if (wbits < 2 || wbits > 16) return 1;
+    const auto t_start = std::chrono::steady_clock::now();
     t->npoints = npoints;
     t->wbits = wbits;
     t->twin = FixedBaseTable::twin_for(wbits);
@@ -163,6 +165,7 @@ int build_fixed_base_table(DeviceCtx *ctx, FixedBaseTable *t, const G1Affine *d_
     HIP_TRY(hipMalloc(&prefix.p, slab * sizeof(Fp)));
     G1XYZZ *d_wb = static_cast<G1XYZZ *>(wb.p), *d_tmp = static_cast<G1XYZZ *>(tmp.p);
     Fp *d_prefix = static_cast<Fp *>(prefix.p);
+    const auto t_alloc = std::chrono::steady_clock::now();
     hipLaunchKernelGGL(k_window_bases, dim3((npoints + 63) / 64), dim3(64), 0, ctx->stream, d_wb,
                        d_bases, npoints, wbits, t->twin);
     const int L = 128;
@@ -181,6 +184,11 @@ int build_fixed_base_table(DeviceCtx *ctx, FixedBaseTable *t, const G1Affine *d_
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (times_ms) {
+        const auto t_end = std::chrono::steady_clock::now();
+        times_ms[0] += std::chrono::duration<double, std::milli>(t_alloc - t_start).count();
+        times_ms[1] += std::chrono::duration<double, std::milli>(t_end - t_alloc).count();
+    }
     return 0;
 }
 

@@ -135,6 +135,14 @@ C_KZG_RET ckzg_hip_g1_lincomb(g1_t *out, const g1_t *p, const fr_t *coeffs, uint
  * Returns a negative value if unavailable. */
 double ckzg_hip_last_kernel_ms(const KZGSettings *s, int which);
 
+/* Where the wall clock of the load that produced `s` went, in milliseconds (first device of the load).  Fills at
+ * most n entries and returns how many:  0 hex text -> bytes (load_trusted_setup_file only), 1 host decompression of
+ * the setup points + pairing sanity check + roots of unity, 2 HIP initialisation / code-object load / streams,
+ * 3 small tables + subgroup check of the setup points, 4 / 5 allocation / construction of the commitment table,
+ * 6 the 64 G1 FFTs of x_ext_fft_columns, 7 / 8 allocation / construction of the FK20 table, 9 / 10 the same for
+ * the proof (monomial) table, 11 the remaining slots + host mirror of x_ext_fft_columns. */
+int ckzg_hip_load_times(const KZGSettings *s, double *ms, int n);
+
 /* Bytes of HBM held by the context's tables. */
 uint64_t ckzg_hip_table_bytes(const KZGSettings *s);
 
