@@ -13,8 +13,11 @@ ROOT = os.path.dirname(HERE)
 sys.path.insert(0, HERE)
 
 ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
-HIP_SO = os.path.join(ROOT, "c-kzg-4844_amd", "libckzg_hip.so")
-SHIM_SO = os.path.join(ROOT, "c-kzg-4844_amd", "csrc", "libhost_shim.so")
+# CKZG_HIP_SO / CKZG_SHIM_SO: other builds of the same libraries (sanitizer builds: tools/run_sanitized.sh)
+HIP_SO = os.path.abspath(os.environ["CKZG_HIP_SO"]) if os.environ.get("CKZG_HIP_SO") else \
+    os.path.join(ROOT, "c-kzg-4844_amd", "libckzg_hip.so")
+SHIM_SO = os.path.abspath(os.environ["CKZG_SHIM_SO"]) if os.environ.get("CKZG_SHIM_SO") else \
+    os.path.join(ROOT, "c-kzg-4844_amd", "csrc", "libhost_shim.so")
 
 
 def pytest_configure(config):
