@@ -64,6 +64,7 @@ struct Options {
     int fk20_wbits = 0;     // 0: max(8, precompute); env CKZG_HIP_FK20_WBITS
     int proof_wbits = 8;    // monomial-point table for the direct proof path; 0 disables it
     int direct_max = -1;    // largest batch that takes the direct path (0 disables it; -1: by table width)
+    int async_tables = 0;   // 1: load with the default-width tables, widen to the requested widths in the background
 };
 // options of the NEXT load_trusted_setup; snapshotted under a lock when a load starts, so concurrent loads
 // with different options do not see each other's half-written state
@@ -81,9 +82,21 @@ inline const PreparedG2 *prepared_of(const dev::DeviceCtx *ctx) {
     return static_cast<const PreparedG2 *>(ctx->host_prepared);
 }
 
-// One device's share of a loaded KZGSettings: the tables (owned by slots[0]) and the slots that alias them.
+// The tables a pool serves calls from.  Immutable once published; a wider table replaces a narrower one by
+// publishing a new set (version + 1) under the pool's mutex, and every slot refreshes its copies when it is leased
+// -- a lease is exclusive, so a call sees one consistent set from start to end.  Replaced tables are retired, not
+// freed: a call that started before the publication may still be reading them.
+struct PublishedTables {
+    dev::FixedBaseTable commit, mono, fk20;
+    int direct_max = 0;
+    uint64_t version = 0;
+};
+
+// One device's share of a loaded KZGSettings: the tables and the slots that alias them.
 struct DevicePool {
     int device = 0;
+    PublishedTables pub;            // guarded by mu
+    std::vector<void *> retired;    // device allocations of replaced tables, freed with the pool
     std::vector<dev::DeviceCtx *> slots;
     std::mutex mu;
     std::condition_variable cv;
@@ -126,6 +139,13 @@ struct SettingsCtx {
     Options opts;
     std::atomic<unsigned> next{0};
     std::atomic<uint64_t> lease_seq{0};   // leases handed out so far, over all pools (ckzg_hip_last_kernel_ms)
+    // "async_tables": the thread that widens the tables after load_trusted_setup has returned
+    std::thread widener;
+    volatile bool cancel_widening = false;
+    std::mutex widen_mu;
+    std::condition_variable widen_cv;
+    bool widening_done = true;
+    int requested_wbits[3] = {0, 0, 0};   // commitment, FK20, proof: what the widener is to reach
 };
 SettingsCtx *settings_of(const KZGSettings *s, bool complain = true);
 
@@ -172,6 +192,9 @@ int pool_of_pointer(const SettingsCtx *sc, const void *dptr);
 C_KZG_RET create_settings_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affine,
                               const G1Affine *monomial_affine);
 void destroy_settings_ctx(const KZGSettings *s);
+// blocks until the background widening of an "async_tables" load has finished (returns at once otherwise)
+void wait_for_tables(const KZGSettings *s);
+bool tables_ready(const KZGSettings *s);
 
 // No C++ exception may cross the C ABI (the reference returns C_KZG_MALLOC where these would throw).
 template <class F>

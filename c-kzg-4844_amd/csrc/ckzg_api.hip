@@ -63,6 +63,9 @@ extern "C" C_KZG_RET ckzg_hip_set_option(const char *key, int64_t value) {
     } else if (!strcmp(key, "gpu_sha_min")) {
         if (value < 0 || value > (1 << 30)) return C_KZG_BADARGS;
         g_gpu_sha_min.store((int)value);  // read at call time, unlike the load-time options
+    } else if (!strcmp(key, "async_tables")) {
+        if (value != 0 && value != 1) return C_KZG_BADARGS;
+        g_opts.async_tables = (int)value;
     } else if (!strcmp(key, "direct_max")) {
         if (value < -1 || value > 4096) return C_KZG_BADARGS;
         g_opts.direct_max = (int)value;
@@ -664,6 +667,16 @@ extern "C" double ckzg_hip_last_kernel_ms(const KZGSettings *s, int which) {
     return best;
 }
 
+extern "C" C_KZG_RET ckzg_hip_wait_tables(const KZGSettings *s) {
+    return guarded([&]() -> C_KZG_RET {
+        if (!settings_of(s)) return C_KZG_ERROR;
+        wait_for_tables(s);
+        return C_KZG_OK;
+    });
+}
+
+extern "C" int ckzg_hip_tables_ready(const KZGSettings *s) { return tables_ready(s) ? 1 : 0; }
+
 extern "C" int ckzg_hip_load_times(const KZGSettings *s, double *ms, int n) {
     SettingsCtx *sc = settings_of(s, false);
     if (!sc || !ms) return 0;
@@ -677,8 +690,8 @@ extern "C" uint64_t ckzg_hip_table_bytes(const KZGSettings *s) {
     if (!sc) return 0;
     uint64_t total = 0;
     for (auto *p : sc->pools) {
-        const dev::DeviceCtx *ctx = p->slots[0];
-        total += ctx->commit.bytes() + ctx->fk20.bytes() + ctx->mono.bytes();
+        std::lock_guard<std::mutex> lock(p->mu);
+        total += p->pub.commit.bytes() + p->pub.fk20.bytes() + p->pub.mono.bytes();
     }
     return total;
 }
@@ -686,11 +699,12 @@ extern "C" uint64_t ckzg_hip_table_bytes(const KZGSettings *s) {
 extern "C" int ckzg_hip_table_wbits(const KZGSettings *s, int which) {
     SettingsCtx *sc = settings_of(s);
     if (!sc) return -1;
-    const dev::DeviceCtx *ctx = sc->pools[0]->slots[0];
+    DevicePool *p = sc->pools[0];
+    std::lock_guard<std::mutex> lock(p->mu);
     switch (which) {
-        case 0: return ctx->commit.wbits;
-        case 1: return ctx->fk20.wbits;
-        case 2: return ctx->mono.d_table ? ctx->mono.wbits : 0;
+        case 0: return p->pub.commit.wbits;
+        case 1: return p->pub.fk20.wbits;
+        case 2: return p->pub.mono.d_table ? p->pub.mono.wbits : 0;
         default: return -1;
     }
 }

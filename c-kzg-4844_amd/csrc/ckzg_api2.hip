@@ -457,7 +457,9 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
         // copy by more than the ~1.3 ms it hides -- n = 4096: 30 -> 37 ms; n = 64: 8.0 -> 5.6 ms)
         // Below 1024 blobs the validation is also split: event 0 marks the decompressed points, the
         // subgroup test (event 1) keeps running on the second stream underneath evaluation and sums.
-        hipStream_t vs = split_validation ? ctx->copy_stream : ctx->stream;
+        // (resident inputs: nothing blocks the host, so the validation ladders always run on the second stream,
+        // underneath the challenge hashing -- the longest kernel of that form -- and the evaluation)
+        hipStream_t vs = (split_validation || resident) ? ctx->copy_stream : ctx->stream;
         if (!ctx->stage_ev[0]) OKB(hipEventCreateWithFlags(&ctx->stage_ev[0], hipEventDisableTiming) == hipSuccess);
         if (!ctx->stage_ev[1]) OKB(hipEventCreateWithFlags(&ctx->stage_ev[1], hipEventDisableTiming) == hipSuccess);
         const hipMemcpyKind kind = resident ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
@@ -558,8 +560,9 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     if (!resident) OKB(hipMemcpyAsync(d_blobs_own.p, blobs, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
     OKB(hipMemsetAsync(d_bad.p, 0, n * 4, ctx->stream) == hipSuccess);
     RC(dev::bytes_to_fr_batch(ctx, d_poly.p, d_bad.p, d_blob_bytes, n * FIELD_ELEMENTS_PER_BLOB, FIELD_ELEMENTS_PER_BLOB));
-    if (!small) OKB(hipStreamWaitEvent(ctx->stream, ctx->stage_ev[0], 0) == hipSuccess);  // d_ptb, d_pts, d_st ready
-    if (gpu_sha) RC(dev::sha256_challenges_device(ctx, d_z.p, d_blob_bytes, d_ptb.p, n));
+    if (!small && !resident) OKB(hipStreamWaitEvent(ctx->stream, ctx->stage_ev[0], 0) == hipSuccess);  // d_ptb, d_pts, d_st ready
+    if (gpu_sha)
+        RC(dev::sha256_challenges_device(ctx, d_z.p, d_blob_bytes, resident ? reinterpret_cast<const uint8_t *>(d_cb) : d_ptb.p, n));
     tr.mark("enqueue H2D + bytes_to_fr (+ GPU validation)");
     if (hasher.t.joinable()) hasher.t.join();
     if (!gpu_sha && !threaded) hash_all();
@@ -567,6 +570,7 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     if (resident) {
         // resident inputs: nothing to learn from the host before the evaluation -- enqueue it straight away
         RC(dev::eval_poly_batch_device(ctx, d_y.p, d_poly.p, d_z.p, n));
+        OKB(hipStreamWaitEvent(ctx->stream, ctx->stage_ev[0], 0) == hipSuccess);   // the validated points and their status
         OKB(hipEventRecord(ctx->ev[2], ctx->stream) == hipSuccess);
     }
     OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);

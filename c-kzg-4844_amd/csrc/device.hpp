@@ -90,6 +90,8 @@ struct DeviceCtx {
     FixedBaseTable commit;        // over g1_values_lagrange_brp (4096 points)
     FixedBaseTable mono;          // over g1_values_monomial (4096 points): low-latency cell proofs
     int direct_max = 10;          // batches up to this many blobs use the direct proof path (set at load)
+    uint64_t tables_version = 0;  // which publication of the pool's tables the copies above are (api_common.hpp: PublishedTables)
+    G1Affine *d_lagr = nullptr;   // g1_values_lagrange_brp, affine, 4096 (bases of the commitment table; kept for widening)
     Scratch scratch;              // per slot: reused by every call that leases the slot
     Arena api_arena, lc_arena;    // temporaries of the host-pointer entry points / of gpu_lincomb_multi
     hipEvent_t stage_ev[4] = {};  // copied[2], consumed[2] of the staging pipeline (created on first use)
@@ -122,9 +124,10 @@ struct DeviceCtx {
 int scratch_reserve(DeviceCtx *ctx, size_t bytes);
 
 // Build a fixed-base table for `npoints` affine bases already in HBM.
-// times_ms (optional): [0] += allocation, [1] += construction kernels
+// times_ms (optional): [0] += allocation, [1] += construction kernels.  cancel (optional): polled between the
+// construction launches; a set flag abandons the build (return value 5, nothing left allocated).
 int build_fixed_base_table(DeviceCtx *ctx, FixedBaseTable *t, const G1Affine *d_bases, int npoints,
-                           int wbits, double *times_ms = nullptr);
+                           int wbits, double *times_ms = nullptr, const volatile bool *cancel = nullptr);
 
 // Commit n blobs resident in HBM: d_out48[n][48], d_status[n] (0 ok, 1 non-canonical element).
 int commit_blobs_device(DeviceCtx *ctx, uint8_t *d_out48, uint8_t *d_status, const uint8_t *d_blobs,

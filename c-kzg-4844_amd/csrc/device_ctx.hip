@@ -4,6 +4,7 @@
 // This is the GPU half of load_trusted_setup (src/setup/setup.c:392-505): the reference builds
 // x_ext_fft_columns and (optionally) blst fixed-base tables on the CPU (setup.c:238-330); here the
 // 64 G1 FFTs and all tables are produced by kernels and stay resident in HBM.
+#include <algorithm>
 #include <chrono>
 #include <shared_mutex>
 #include <unordered_map>
@@ -46,9 +47,16 @@ void Lease::take(DevicePool *p) {
     p->cv.wait(lock, [p]() { return !p->free_slots.empty(); });
     int idx = p->free_slots.back();
     p->free_slots.pop_back();
+    ctx = p->slots[idx];
+    if (ctx->tables_version != p->pub.version) {   // a wider table was published since this slot last ran
+        ctx->commit = p->pub.commit;
+        ctx->mono = p->pub.mono;
+        ctx->fk20 = p->pub.fk20;
+        ctx->direct_max = p->pub.direct_max;
+        ctx->tables_version = p->pub.version;
+    }
     lock.unlock();
     pool = p;
-    ctx = p->slots[idx];
     p->last.store(ctx, std::memory_order_relaxed);
     if (p->owner) p->last_seq.store(p->owner->lease_seq.fetch_add(1, std::memory_order_relaxed) + 1, std::memory_order_relaxed);
     if (hipSetDevice(ctx->device) != hipSuccess) {
@@ -146,10 +154,8 @@ static void destroy_slot(dev::DeviceCtx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
-    if (ctx->owns_tables) {
-        if (ctx->commit.d_table) (void)hipFree(ctx->commit.d_table);
-        if (ctx->fk20.d_table) (void)hipFree(ctx->fk20.d_table);
-        if (ctx->mono.d_table) (void)hipFree(ctx->mono.d_table);
+    if (ctx->owns_tables) {   // (the fixed-base tables themselves belong to the pool: destroy_pool)
+        if (ctx->d_lagr) (void)hipFree(ctx->d_lagr);
         if (ctx->d_xext) (void)hipFree(ctx->d_xext);
         if (ctx->d_roots) (void)hipFree(ctx->d_roots);
         if (ctx->d_brp_roots) (void)hipFree(ctx->d_brp_roots);
@@ -181,14 +187,22 @@ static void destroy_slot(dev::DeviceCtx *ctx) {
 
 static void destroy_pool(DevicePool *p) {
     if (!p) return;
-    // aliases first, the owner of the tables last
+    // aliases first, the owner of the shared arrays last
     for (size_t i = p->slots.size(); i-- > 0;) destroy_slot(p->slots[i]);
+    (void)hipSetDevice(p->device);
+    // every slot is idle now: the published tables and the ones they replaced can go
+    for (void *t : {(void *)p->pub.commit.d_table, (void *)p->pub.fk20.d_table, (void *)p->pub.mono.d_table}) {
+        if (t) (void)hipFree(t);
+    }
+    for (void *t : p->retired) (void)hipFree(t);
     delete p;
 }
 
 static void destroy_settings(SettingsCtx *sc) {
     if (!sc) return;
     DeviceGuard guard;   // destroy_slot selects each slot's device; the caller's comes back afterwards
+    sc->cancel_widening = true;   // a background table build stops at its next slab
+    if (sc->widener.joinable()) sc->widener.join();
     for (auto *p : sc->pools) destroy_pool(p);
     delete sc;
 }
@@ -230,9 +244,35 @@ LoadTimes &pending_load_times() {
     return t;
 }
 
-static C_KZG_RET build_owner(dev::DeviceCtx *ctx, const KZGSettings *s, const Options &opts,
+// widths asked for by the options / environment of a load (what build_owner builds, or -- "async_tables" -- what the
+// widener is to reach after the load has returned with the default widths)
+static void requested_widths(int out[3], const KZGSettings *s, const Options &opts) {
+    int cw = env_int("CKZG_HIP_COMMIT_WBITS", opts.commit_wbits);
+    if (cw < 4 || cw > 16) cw = 10;
+    int fw = env_int("CKZG_HIP_FK20_WBITS", opts.fk20_wbits);
+    if (fw == 0) fw = s->wbits > 8 ? (s->wbits > 13 ? 13 : (int)s->wbits) : 8;
+    if (fw < 4 || fw > 16) fw = 8;
+    int pw = env_int("CKZG_HIP_PROOF_WBITS", opts.proof_wbits);
+    if (pw != 0 && (pw < 4 || pw > 16)) pw = 8;
+    out[0] = cw;
+    out[1] = fw;
+    out[2] = pw;
+}
+
+static int auto_direct_max(int proof_wbits) { return proof_wbits >= 15 ? 4 : (proof_wbits >= 11 ? 3 : 2); }
+
+static C_KZG_RET build_owner(DevicePool *pool, const KZGSettings *s, const Options &opts,
                              const G1Affine *lagrange_brp_affine, const G1Affine *monomial_affine,
                              G1Affine *h_xext, LoadTimes *lt) {
+    dev::DeviceCtx *ctx = pool->slots[0];
+    int want[3];
+    requested_widths(want, s, opts);
+    const bool async = env_int("CKZG_HIP_ASYNC_TABLES", opts.async_tables) != 0;
+    if (async) {   // start with the library's default footprint; the widener takes it from there
+        want[0] = want[0] < 10 ? want[0] : 10;
+        want[1] = want[1] < 8 ? want[1] : 8;
+        want[2] = want[2] < 8 ? want[2] : 8;
+    }
     LoadTimes scratch_times;
     if (!lt) lt = &scratch_times;
     PhaseClock clk;
@@ -266,8 +306,9 @@ static C_KZG_RET build_owner(dev::DeviceCtx *ctx, const KZGSettings *s, const Op
         CTX_TRY(hipMemcpy(ctx->d_unshift, ush.data(), dev::N_EXT * sizeof(Fr), hipMemcpyHostToDevice));
     }
 
-    DeviceBuffer d_bases;
-    if (!d_bases.alloc(NUM_G1_POINTS * sizeof(G1Affine))) return C_KZG_MALLOC;
+    struct { void *p; } d_bases;
+    CTX_TRY(hipMalloc(&ctx->d_lagr, NUM_G1_POINTS * sizeof(G1Affine)));
+    d_bases.p = ctx->d_lagr;
     CTX_TRY(hipMemcpy(d_bases.p, lagrange_brp_affine, NUM_G1_POINTS * sizeof(G1Affine), hipMemcpyHostToDevice));
     CTX_TRY(hipMalloc(&ctx->d_mono, NUM_G1_POINTS * sizeof(G1Affine)));
     CTX_TRY(hipMemcpy(ctx->d_mono, monomial_affine, NUM_G1_POINTS * sizeof(G1Affine), hipMemcpyHostToDevice));
@@ -296,9 +337,7 @@ static C_KZG_RET build_owner(dev::DeviceCtx *ctx, const KZGSettings *s, const Op
     lt->ms[LP_SMALL_TABLES] += clk.lap();
     // commitment table over the bit-reversed Lagrange points
     {
-        int wbits = env_int("CKZG_HIP_COMMIT_WBITS", opts.commit_wbits);
-        if (wbits < 4 || wbits > 16) wbits = 10;
-        wbits = fit_wbits("commit", wbits, 8, (int)NUM_G1_POINTS);
+        int wbits = fit_wbits("commit", want[0], 8, (int)NUM_G1_POINTS);
         int rc = dev::build_fixed_base_table(ctx, &ctx->commit, (const G1Affine *)d_bases.p, (int)NUM_G1_POINTS, wbits,
                                              &lt->ms[LP_COMMIT_MALLOC]);
         if (rc) return (C_KZG_RET)rc;
@@ -309,20 +348,16 @@ static C_KZG_RET build_owner(dev::DeviceCtx *ctx, const KZGSettings *s, const Op
         int rc = dev::fk20_setup_device(ctx, ctx->d_mono, h_xext);
         if (rc) return (C_KZG_RET)rc;
         lt->ms[LP_FK20_SETUP] += clk.lap();
-        int wbits = env_int("CKZG_HIP_FK20_WBITS", opts.fk20_wbits);
-        if (wbits == 0) wbits = s->wbits > 8 ? (s->wbits > 13 ? 13 : (int)s->wbits) : 8;
-        if (wbits < 4 || wbits > 16) wbits = 8;
-        wbits = fit_wbits("fk20", wbits, 8, dev::N_CELLS_EXT * dev::N_CELL);
+        int wbits = fit_wbits("fk20", want[1], 8, dev::N_CELLS_EXT * dev::N_CELL);
         rc = dev::build_fixed_base_table(ctx, &ctx->fk20, ctx->d_xext, dev::N_CELLS_EXT * dev::N_CELL, wbits,
                                          &lt->ms[LP_FK20_MALLOC]);
         if (rc) return (C_KZG_RET)rc;
     }
     // table over the monomial points for the low-latency (direct) cell-proof path
     {
-        int wbits = env_int("CKZG_HIP_PROOF_WBITS", opts.proof_wbits);
+        int wbits = want[2];
         ctx->direct_max = env_int("CKZG_HIP_DIRECT_MAX", opts.direct_max);
         if (wbits != 0 && ctx->direct_max != 0) {
-            if (wbits < 4 || wbits > 16) wbits = 8;
             wbits = fit_wbits("proof", wbits, 8, (int)NUM_G1_POINTS);
             int rc = dev::build_fixed_base_table(ctx, &ctx->mono, ctx->d_mono, (int)NUM_G1_POINTS, wbits,
                                                  &lt->ms[LP_PROOF_MALLOC]);
@@ -331,11 +366,93 @@ static C_KZG_RET build_owner(dev::DeviceCtx *ctx, const KZGSettings *s, const Op
             // radix-4 / four-lane G1 FFT FK20 costs 6.8-7.1 ms for any batch of up to 8 blobs (it was ~28 ms with
             // twelve dependent one-lane ladder stages), the direct path 1.9 / 2.2 / 3.1 ms for one blob plus
             // ~1.3 / ~1.6 / ~2.3 ms per further blob with a 16 / 13 / 8-bit table.
-            if (ctx->direct_max < 0) ctx->direct_max = wbits >= 15 ? 4 : (wbits >= 11 ? 3 : 2);
+            if (ctx->direct_max < 0) ctx->direct_max = auto_direct_max(wbits);
         }
         if (ctx->direct_max < 0) ctx->direct_max = 0;
     }
+    // publication 1: what every slot of the pool serves calls from
+    {
+        std::lock_guard<std::mutex> lock(pool->mu);
+        pool->pub.commit = ctx->commit;
+        pool->pub.mono = ctx->mono;
+        pool->pub.fk20 = ctx->fk20;
+        pool->pub.direct_max = ctx->direct_max;
+        pool->pub.version = 1;
+        ctx->tables_version = 1;
+    }
     return C_KZG_OK;
+}
+
+// "async_tables": widen one pool's tables to the requested widths, one table at a time (commitment first), each
+// published as soon as it is complete.  Runs on the widener thread with its own stream; a width that does not fit,
+// an allocation failure or a cancelled build leaves the narrower table in service.
+static void widen_pool(SettingsCtx *sc, DevicePool *pool, const KZGSettings *s) {
+    if (hipSetDevice(pool->device) != hipSuccess) return;
+    dev::DeviceCtx b;   // builder context: a stream and nothing else
+    b.device = pool->device;
+    if (hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking) != hipSuccess) return;
+    const dev::DeviceCtx *owner = pool->slots[0];
+    const int user_direct_max = env_int("CKZG_HIP_DIRECT_MAX", sc->opts.direct_max);
+    struct Job {
+        int which;
+        const char *name;
+        const G1Affine *bases;
+        int npoints, phase;
+    } jobs[3] = {{0, "commit", owner->d_lagr, (int)NUM_G1_POINTS, LP_COMMIT_MALLOC},
+                 {2, "proof", owner->d_mono, (int)NUM_G1_POINTS, LP_PROOF_MALLOC},
+                 {1, "fk20", owner->d_xext, dev::N_CELLS_EXT * dev::N_CELL, LP_FK20_MALLOC}};
+    for (const Job &j : jobs) {
+        if (sc->cancel_widening) break;
+        int have;
+        {
+            std::lock_guard<std::mutex> lock(pool->mu);
+            const dev::FixedBaseTable &cur = j.which == 0 ? pool->pub.commit : (j.which == 1 ? pool->pub.fk20 : pool->pub.mono);
+            have = cur.d_table ? cur.wbits : 0;
+        }
+        if (j.which == 2 && (have == 0 || user_direct_max == 0)) continue;   // the direct path is switched off
+        int wbits = fit_wbits(j.name, sc->requested_wbits[j.which], have, j.npoints);
+        if (wbits <= have) continue;
+        dev::FixedBaseTable t;
+        int rc = dev::build_fixed_base_table(&b, &t, j.bases, j.npoints, wbits, pool == sc->pools[0] ? &sc->load.ms[j.phase] : nullptr,
+                                             &sc->cancel_widening);
+        if (rc) {
+            if (rc != 5) fprintf(stderr, "[ckzg-hip] widening the %s table to %d bits failed (rc %d): the %d-bit table stays\n", j.name, wbits, rc, have);
+            (void)hipGetLastError();
+            continue;
+        }
+        std::lock_guard<std::mutex> lock(pool->mu);
+        dev::FixedBaseTable &cur = j.which == 0 ? pool->pub.commit : (j.which == 1 ? pool->pub.fk20 : pool->pub.mono);
+        if (cur.d_table) pool->retired.push_back(cur.d_table);
+        cur = t;
+        if (j.which == 2 && user_direct_max < 0) pool->pub.direct_max = auto_direct_max(wbits);
+        pool->pub.version++;
+    }
+    (void)hipStreamSynchronize(b.stream);
+    (void)hipStreamDestroy(b.stream);
+}
+
+static void widener_main(SettingsCtx *sc, const KZGSettings *s) {
+    guarded([&]() -> C_KZG_RET {
+        JoinThreads th;   // one builder per device; pools that share a device (replicas) one after the other
+        std::vector<int> seen;
+        for (DevicePool *first : sc->pools) {
+            if (std::find(seen.begin(), seen.end(), first->device) != seen.end()) continue;
+            seen.push_back(first->device);
+            th.spawn([sc, s, first]() {
+                pin_thread_to_device_numa(first->device);
+                for (DevicePool *p : sc->pools) {
+                    if (p->device == first->device) widen_pool(sc, p, s);
+                }
+            });
+        }
+        th.join();
+        return C_KZG_OK;
+    });
+    {
+        std::lock_guard<std::mutex> lock(sc->widen_mu);
+        sc->widening_done = true;
+    }
+    sc->widen_cv.notify_all();
 }
 
 // a further slot of the same pool: own streams, events, scratch; the owner's tables
@@ -349,6 +466,8 @@ static C_KZG_RET clone_slot(dev::DeviceCtx **out, const dev::DeviceCtx *owner, i
     c->mono = owner->mono;
     c->fk20 = owner->fk20;
     c->direct_max = owner->direct_max;
+    c->tables_version = owner->tables_version;
+    c->d_lagr = owner->d_lagr;
     c->d_roots = owner->d_roots;
     c->d_brp_roots = owner->d_brp_roots;
     c->d_roots_raw = owner->d_roots_raw;
@@ -434,7 +553,7 @@ C_KZG_RET create_settings_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affin
                 for (int r = 0; r < replicas; r++) {
                     const size_t pi = di * replicas + r;
                     rets[pi] = guarded([&]() {
-                        return build_owner(sc->pools[pi]->slots[0], s, opts, lagrange_brp_affine, monomial_affine,
+                        return build_owner(sc->pools[pi], s, opts, lagrange_brp_affine, monomial_affine,
                                            pi == 0 ? h_xext.data() : nullptr, pi == 0 ? &sc->load : nullptr);
                     });
                     if (rets[pi] != C_KZG_OK) break;
@@ -476,9 +595,37 @@ C_KZG_RET create_settings_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affin
         return ret;
     }
     sc->load.ms[LP_SLOTS] += slots_clk.lap();
-    std::unique_lock<std::shared_mutex> lock(g_reg_mu);
-    registry()[s->roots_of_unity] = sc;
+    {
+        std::unique_lock<std::shared_mutex> lock(g_reg_mu);
+        registry()[s->roots_of_unity] = sc;
+    }
+    if (env_int("CKZG_HIP_ASYNC_TABLES", opts.async_tables) != 0) {
+        requested_widths(sc->requested_wbits, s, opts);
+        bool any = false;
+        for (DevicePool *p : sc->pools) {
+            any |= sc->requested_wbits[0] > p->pub.commit.wbits || sc->requested_wbits[1] > p->pub.fk20.wbits ||
+                   (p->pub.mono.d_table && sc->requested_wbits[2] > p->pub.mono.wbits);
+        }
+        if (any) {
+            sc->widening_done = false;
+            sc->widener = std::thread(widener_main, sc, (const KZGSettings *)s);
+        }
+    }
     return C_KZG_OK;
+}
+
+void wait_for_tables(const KZGSettings *s) {
+    SettingsCtx *sc = settings_of(s, false);
+    if (!sc) return;
+    std::unique_lock<std::mutex> lock(sc->widen_mu);
+    sc->widen_cv.wait(lock, [sc]() { return sc->widening_done; });
+}
+
+bool tables_ready(const KZGSettings *s) {
+    SettingsCtx *sc = settings_of(s, false);
+    if (!sc) return true;
+    std::lock_guard<std::mutex> lock(sc->widen_mu);
+    return sc->widening_done;
 }
 
 void destroy_settings_ctx(const KZGSettings *s) {

@@ -143,7 +143,7 @@ struct DevTmp {  // freed on every exit path of build_fixed_base_table
 }  // namespace
 
 int build_fixed_base_table(DeviceCtx *ctx, FixedBaseTable *t, const G1Affine *d_bases, int npoints,
-                           int wbits, double *times_ms) {
+                           int wbits, double *times_ms, const volatile bool *cancel) {
     if (wbits < 2 || wbits > 16) return 1;
     const auto t_start = std::chrono::steady_clock::now();
     t->npoints = npoints;
@@ -158,8 +158,10 @@ int build_fixed_base_table(DeviceCtx *ctx, FixedBaseTable *t, const G1Affine *d_
     if (chunk < 1) chunk = 1;
     if (chunk > npoints) chunk = npoints;
     const size_t slab = (size_t)chunk * t->half;
-    DevTmp wb, tmp, prefix;
-    HIP_TRY(hipMalloc(&t->d_table, t->bytes()));
+    DevTmp wb, tmp, prefix, table;   // `table` is handed to *t only when the build has completed
+    t->d_table = nullptr;
+    HIP_TRY(hipMalloc(&table.p, t->bytes()));
+    G1Affine *d_table = static_cast<G1Affine *>(table.p);
     HIP_TRY(hipMalloc(&wb.p, (size_t)t->twin * npoints * sizeof(G1XYZZ)));
     HIP_TRY(hipMalloc(&tmp.p, slab * sizeof(G1XYZZ)));
     HIP_TRY(hipMalloc(&prefix.p, slab * sizeof(Fp)));
@@ -172,18 +174,25 @@ int build_fixed_base_table(DeviceCtx *ctx, FixedBaseTable *t, const G1Affine *d_
     const size_t segs = (t->half + CHAIN_SEG - 1) / CHAIN_SEG;
     for (int w = 0; w < t->twin; w++) {
         for (int i0 = 0; i0 < npoints; i0 += chunk) {
+            if (cancel && *cancel) {
+                (void)hipStreamSynchronize(ctx->stream);
+                return 5;
+            }
+            if (cancel && (w || i0)) HIP_TRY(hipStreamSynchronize(ctx->stream));   // a background build yields between slabs
             const int cnt = npoints - i0 < chunk ? npoints - i0 : chunk;
             const size_t entries = (size_t)cnt * t->half;
             const size_t chain_threads = (size_t)cnt * segs, aff_threads = (entries + L - 1) / L;
             hipLaunchKernelGGL(k_table_chain, dim3((unsigned)((chain_threads + 63) / 64)), dim3(64), 0,
                                ctx->stream, d_tmp, d_wb + (size_t)w * npoints + i0, cnt, t->half);
             hipLaunchKernelGGL(k_batch_to_affine, dim3((unsigned)((aff_threads + 63) / 64)), dim3(64), 0,
-                               ctx->stream, t->d_table + ((size_t)w * npoints + i0) * t->half, d_tmp, d_prefix,
+                               ctx->stream, d_table + ((size_t)w * npoints + i0) * t->half, d_tmp, d_prefix,
                                entries, L, 1);
         }
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    t->d_table = d_table;
+    table.p = nullptr;
     if (times_ms) {
         const auto t_end = std::chrono::steady_clock::now();
         times_ms[0] += std::chrono::duration<double, std::milli>(t_alloc - t_start).count();
@@ -261,14 +270,21 @@ __device__ __forceinline__ void msm_apply_phi(XYZZ28 &acc28) {
     acc28.x = widen<1, 10>(mul(acc28.x, f28_const<1, 1>(FP28_BETA_LAMBDA)));
 }
 
-// Fair time slices between the two waves of a SIMD.  The per-wave trace of round 3 (tools/msm_trace.py,
-// profiles/r03_msm_trace_*.json) shows that of two resident waves the OLDER one is served first: it gets ~82 % of
-// the issue slots, finishes its 256 additions in 2.8 ms and leaves its partner (5.2 ms) to run alone, so a launch
-// of exactly two rounds of workgroups ends with a quarter of its time at one wave per SIMD (SQ_WAVE_CYCLES: 1.72).
-// s_setprio outranks age: a wave raises its priority in the time slices whose parity equals the parity of its
-// wave slot in the SIMD (two resident waves sit in different slots) and lowers it in the others, so both advance
-// at the same average rate and finish together.  slice = 2^prio_bit ticks of the 100 MHz s_memrealtime counter;
-// prio_bit = 0 switches the scheme off.
+// Alternating priority slices between the two waves of a SIMD.
+// What the per-wave trace of round 3 showed (tools/msm_trace.py, profiles/r03_msm_trace_*.json): of two resident
+// waves the OLDER one is served first -- it gets ~88 % of the issue slots and finishes its 256 additions in 2.8 ms,
+// its partner needs 5.3 ms -- so a launch of exactly two rounds of workgroups spends its last quarter with one wave
+// per SIMD (SQ_WAVE_CYCLES: 1.72 waves resident on average).  But that lone wave runs at 98 % of the pair's combined
+// rate (0.392 vs 0.401 wave-additions per ms and SIMD): the SIMD's issue slots are already full with one wave, and
+// residency is NOT what bounds this kernel (finer work items raise it to 1.89 and gain nothing, profiles/r03_ppb_ab.txt).
+// What does help, measurably: s_setprio slices.  A wave raises its priority in the time slices whose parity equals
+// the parity of its wave slot in the SIMD (two resident waves sit in slots 0 and 1) and lowers it in the others, so
+// the two waves take turns at running nearly alone.  Slices of 2^15..2^17 ticks of the 100 MHz s_memrealtime counter
+// (0.3-1.3 ms) give -3 % kernel time in interleaved same-box runs; 2^13 and shorter, or 2^19 and longer, give
+// nothing (profiles/r03_prio_ab.txt).  The mechanism is not established -- the likeliest is instruction-cache
+// locality: the loop body is ~37 KB of code, and two waves at unrelated positions in it compete for the cache their
+// CU pair shares, while a wave that runs nearly alone for a slice streams through it undisturbed.
+// prio_bit = log2 of the slice width in ticks; 0 switches the scheme off.
 __device__ __forceinline__ uint32_t msm_wave_slot_parity() {
     return __builtin_amdgcn_s_getreg(4) & 1u;   // hwreg(HW_REG_HW_ID, 0, 1): bit 0 of WAVE_ID
 }
@@ -590,10 +606,13 @@ static uint32_t pick_pairs_per_block(size_t nvec, uint32_t pairs_per_vec) {
 
 // slice width (log2 ticks of 100 MHz) of the fair-priority scheme of msm_fair_prio; 0 = off.
 // CKZG_HIP_MSM_PRIO_BIT / CKZG_HIP_SMALL_PRIO_BIT override the defaults for A/B runs.
+// Measured on the headline launch (1024 blobs, same box, interleaved runs, profiles/r03_prio_ab.txt): off 10.03 ms,
+// 2^9..2^13 ticks no change, 2^15 9.72-9.75 ms, 2^17 9.68 ms, 2^19 10.07 ms -> 2^16 ticks = 0.66 ms per slice.
+// (k_msm_small showed no gain at any slice width and keeps the scheme off.)
 static uint32_t msm_prio_bit() {
     static const uint32_t v = []() {
         const char *e = getenv("CKZG_HIP_MSM_PRIO_BIT");
-        return e && *e ? (uint32_t)atoi(e) : 0u;
+        return e && *e ? (uint32_t)atoi(e) : 16u;
     }();
     return v;
 }

@@ -45,6 +45,13 @@ extern "C" {
  *                   does ~10x fewer point additions but costs ~6 ms for any small batch (6 dependent
  *                   ladder launches).  -1 (default): 2 / 3 / 4 blobs for a proof table of <= 10 / <= 14 /
  *                   >= 15 bits, the measured hand-over points; 0 disables the path
+ *   "async_tables"  1: progressive widening.  load_trusted_setup builds the tables at the library's default widths
+ *                   (10 / 8 / 8 bits: ~0.4 s) and returns a fully working KZGSettings; a background thread then builds
+ *                   the requested wider tables one at a time (commitment, proof, FK20) and publishes each when it is
+ *                   complete, so calls simply get faster while it runs (every call sees one consistent set of tables;
+ *                   replaced tables stay allocated until free_trusted_setup).  ckzg_hip_wait_tables blocks until the
+ *                   widening has finished, ckzg_hip_tables_ready polls it; free_trusted_setup cancels it.  0 (default):
+ *                   the load builds the requested widths itself before it returns.  env CKZG_HIP_ASYNC_TABLES.
  *   "gpu_sha_min"   smallest verify_blob_kzg_proof_batch size whose Fiat-Shamir challenges are hashed on
  *                   the GPU; 0 (default): never on hosts with the x86 SHA extensions (the host hash runs under the
  *                   blob copy), from 512 blobs otherwise.  Batches of at most 3 blobs always hash on the host.
@@ -142,6 +149,11 @@ double ckzg_hip_last_kernel_ms(const KZGSettings *s, int which);
  * 6 the 64 G1 FFTs of x_ext_fft_columns, 7 / 8 allocation / construction of the FK20 table, 9 / 10 the same for
  * the proof (monomial) table, 11 the remaining slots + host mirror of x_ext_fft_columns. */
 int ckzg_hip_load_times(const KZGSettings *s, double *ms, int n);
+
+/* Progressive widening ("async_tables"): block until the background table builds of the load that produced `s` have
+ * finished (returns at once for an ordinary load) / 1 if they have, 0 while they run. */
+C_KZG_RET ckzg_hip_wait_tables(const KZGSettings *s);
+int ckzg_hip_tables_ready(const KZGSettings *s);
 
 /* Bytes of HBM held by the context's tables. */
 uint64_t ckzg_hip_table_bytes(const KZGSettings *s);

@@ -19,7 +19,7 @@ LAMBDA = 0xd201000000010000 ** 2 - 1
 
 def _restore(api):
     for k, v in (("commit_wbits", 10), ("fk20_wbits", 0), ("proof_wbits", 8), ("direct_max", -1),
-                 ("replicas", 1), ("streams", 8), ("devices", 0), ("gpu_sha_min", 0)):
+                 ("replicas", 1), ("streams", 8), ("devices", 0), ("gpu_sha_min", 0), ("async_tables", 0)):
         api.lib.ckzg_hip_set_option(k.encode(), v)
 
 

@@ -154,3 +154,65 @@ def test_calls_leave_the_callers_hip_device_selected(hip, rt):
     before = dev.value
     hip.blob_to_kzg_commitment(rand_blob(172, 0))
     assert rt.hipGetDevice(C.byref(dev)) == 0 and dev.value == before
+
+
+# ---------------------------------------------------------------------------------------------
+# progressive widening ("async_tables"): the load returns with default-width tables, wider ones are built in the
+# background and published one at a time; every call sees one consistent set
+# ---------------------------------------------------------------------------------------------
+
+def test_async_tables_serve_calls_while_they_widen(oracle):
+    import time
+    from kzg_ctypes import HIP_SO, Kzg
+    from test_gpu_round2 import _restore
+    blob = rand_blob(173, 0)
+    exp_c = oracle.blob_to_kzg_commitment(blob)
+    exp_cp = oracle.compute_cells_and_kzg_proofs(blob)
+    t0 = time.perf_counter()
+    api = Kzg(HIP_SO, "", precompute=0, options={"async_tables": 1, "commit_wbits": 14, "proof_wbits": 13, "fk20_wbits": 12})
+    t_load = time.perf_counter() - t0
+    _restore(api)
+    api.lib.ckzg_hip_set_option(b"async_tables", 0)
+    try:
+        wb = api.lib.ckzg_hip_table_wbits
+        wb.restype = C.c_int
+        ready = api.lib.ckzg_hip_tables_ready
+        ready.restype = C.c_int
+        seen = set()
+        rounds = 0
+        while True:
+            done = bool(ready(api.sp))
+            seen.add(tuple(int(wb(api.sp, k)) for k in range(3)))
+            assert api.blob_to_kzg_commitment(blob) == exp_c
+            got = api.compute_cells_and_kzg_proofs(blob)
+            assert got[0] == exp_cp[0] and got[1] == exp_cp[1]
+            rounds += 1
+            if done:
+                break
+        assert api.lib.ckzg_hip_wait_tables(api.sp) == 0
+        final = tuple(int(wb(api.sp, k)) for k in range(3))
+        assert final == (14, 12, 13), (final, sorted(seen))
+        assert (10, 8, 8) in seen or rounds == 1, sorted(seen)   # the first calls really ran on the narrow tables
+        # a batch on the widened FK20 table, and the widened commitment table at batch size
+        got = api.compute_cells_and_kzg_proofs(blob)
+        assert got[1] == exp_cp[1]
+        assert t_load < 5.0
+    finally:
+        api.close()
+
+
+def test_async_tables_cancelled_by_free(rt):
+    """free_trusted_setup while the wide tables are still being built: the build stops, everything is released."""
+    from kzg_ctypes import HIP_SO, Kzg
+    from test_gpu_round2 import _restore
+    rt.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    free0, total = C.c_size_t(), C.c_size_t()
+    assert rt.hipMemGetInfo(C.byref(free0), C.byref(total)) == 0
+    api = Kzg(HIP_SO, "", precompute=0, options={"async_tables": 1, "commit_wbits": 16, "proof_wbits": 0, "fk20_wbits": 8})
+    _restore(api)
+    api.lib.ckzg_hip_set_option(b"async_tables", 0)
+    assert api.blob_to_kzg_commitment(bytes(131072)) == b"\xc0" + bytes(47)
+    api.close()   # the 103 GB build is somewhere in the middle
+    free1 = C.c_size_t()
+    assert rt.hipMemGetInfo(C.byref(free1), C.byref(total)) == 0
+    assert free1.value >= free0.value - (1 << 30), (free0.value, free1.value)
