@@ -16,6 +16,7 @@
 // LDS tree to fold a workgroup, no buckets, no doublings, no atomics.  Arithmetic intensity is
 // ~3000 integer multiply-adds per 96-byte gather: the kernel is VALU-bound, not HBM-bound.
 #include <chrono>
+#include <cstring>
 #include <vector>
 #include "device.hpp"
 #include "dev_inline.hpp"
@@ -122,6 +123,174 @@ __global__ void k_batch_to_affine(G1Affine *out, const G1XYZZ *in, Fp *prefix, s
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// table construction, round 3: affine chains with a shared inversion, in the 28-bit-limb field
+//
+// The entries of one (window, point) chain are an arithmetic progression e*B, e = 1..half, and they are wanted in
+// AFFINE form.  The round-1/2 builder walked the chain in XYZZ coordinates (12M+2S per entry on 12 x 32-bit limbs)
+// and normalised afterwards (k_batch_to_affine: ~12 more products per entry and a 240-byte temporary).  Here every
+// thread owns L independent chain segments and advances all of them one entry per step directly in affine
+// coordinates: (e+1)B = eB + B costs lambda = (yB - y)/(xB - x), x3 = lambda^2 - xB - x, y3 = lambda (x - x3) - y,
+// i.e. 2M + 1S plus the share of ONE inversion of the product of the L denominators (Montgomery's trick: 3 more
+// products per entry; safegcd inversion ~40 product-equivalents per step).  ~6 + 40/L products per entry instead of
+// ~26, on the faster field, no temporaries: 238 GB of tables in ~1 s instead of ~3.6 s.  This is batch-affine
+// addition in the one place of this library where its operands are streamed exactly once (the accumulate kernels
+// cannot use it: DESIGN.md section 10).
+// Segments start from seeds (e0+1)*B computed by a short double-and-add (k_table_seeds); segment 0 also gets its
+// second entry 2B from there, so that the step kernel never meets the doubling case (e*B = +-B only for e = 1).
+// ------------------------------------------------------------------------------------------
+
+// canonical representative in [0, p) of a value < V*p with normalised limbs
+template <int V>
+__device__ __forceinline__ F28<1, 1> f28_canon(const F28<1, V> &a) {
+    static_assert(V <= 16, "value bound");
+    uint32_t t[14];
+#pragma unroll
+    for (int j = 0; j < 14; j++) t[j] = a.l[j];
+#pragma unroll
+    for (int K = f28detail::pow2_above(V - 1) / 2; K >= 1; K >>= 1) {
+        const f28detail::Limbs14 m = f28detail::spread_multiple(K, 0);   // K*p, normalised limbs
+        uint32_t d[14], br = 0;
+#pragma unroll
+        for (int j = 0; j < 14; j++) {
+            uint32_t v = t[j] - m.v[j] - br;
+            br = v >> 31;   // limbs < 2^28: a negative difference sets bit 31
+            d[j] = (j == 13) ? v : (v & M28);
+        }
+#pragma unroll
+        for (int j = 0; j < 14; j++) t[j] = br ? t[j] : d[j];
+    }
+    F28<1, 1> r;
+#pragma unroll
+    for (int j = 0; j < 14; j++) r.l[j] = t[j];
+    return r;
+}
+
+__device__ __forceinline__ void tb_load12(uint32_t *w, const Fp *src) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(src);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        uint4 v = q[k];
+        w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+    }
+}
+__device__ __forceinline__ void tb_store_point(G1Affine *dst, const F28<1, 1> &x, const F28<1, 1> &y) {
+    uint32_t w[24];
+    f28_pack<1>(w, x);
+    f28_pack<1>(w + 12, y);
+    uint4 *q = reinterpret_cast<uint4 *>(dst);
+#pragma unroll
+    for (int k = 0; k < 6; k++) q[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+}
+
+// bases[c] (affine, 2^392 domain, canonical; (0,0) = infinity) -> table[c*half + e0] = (e0+1)*B for every segment
+// start e0 = s*seg, and table[c*half + 1] = 2B.  One thread per (chain, segment).
+__global__ void k_table_seeds(G1Affine *table, const G1Affine *bases, uint32_t nchains, uint32_t half, uint32_t seg) {
+    const uint32_t nseg = half / seg;
+    const size_t u = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (u >= (size_t)nchains * nseg) return;
+    const uint32_t c = (uint32_t)(u / nseg), sgm = (uint32_t)(u % nseg);
+    uint32_t wx[12], wy[12];
+    tb_load12(wx, &bases[c].x);
+    tb_load12(wy, &bases[c].y);
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) any |= wx[k] | wy[k];
+    G1Affine *row = table + (size_t)c * half;
+    if (any == 0) {   // a base at infinity: its whole row is infinity; the step kernel skips it
+        G1Affine z = G1Affine::inf();
+        row[(size_t)sgm * seg] = z;
+        if (sgm == 0 && half > 1) row[1] = z;
+        return;
+    }
+    const F28<1, 1> xb = f28_unpack<1>(wx), yb = f28_unpack<1>(wy);
+    const F28<4, 2> yb4 = cneg_reduced(yb, false);
+    for (int pass = 0; pass < 2; pass++) {
+        const uint32_t m = pass == 0 ? sgm * seg + 1 : 2u;
+        if (pass == 1 && !(sgm == 0 && half > 1 && seg > 1)) break;
+        XYZZ28 acc;
+        bool inf = true;
+        for (int bit = 31 - __builtin_clz(m); bit >= 0; bit--) {
+            if (!inf) xyzz28_dbl(acc);
+            if ((m >> bit) & 1u) xyzz28_madd(acc, inf, xb, yb4);
+        }
+        // m*B is never infinity (the base has prime order r > m)
+        auto t = f28_inv(acc.zzz);   // 1/z^3
+        auto zi = mul(acc.zz, t);    // 1/z
+        auto ax = mul(acc.x, sqr(zi));
+        auto ay = mul(acc.y, t);
+        tb_store_point(row + (m - 1), f28_canon<2>(ax), f28_canon<2>(ay));
+    }
+}
+
+// Every thread advances L chain segments by seg - 1 entries (segment 0: seg - 2, its first two entries are seeds).
+template <int L>
+__global__ __launch_bounds__(64) void k_table_steps(G1Affine *table, const G1Affine *bases, uint32_t nchains, uint32_t half,
+                                                    uint32_t seg) {
+    const uint32_t nseg = half / seg;
+    const size_t total = (size_t)nchains * nseg;
+    const size_t u0 = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) * L;
+    if (u0 >= total) return;
+    G1Affine *cur[L];          // the last entry written for unit k
+    const G1Affine *base[L];
+    uint32_t left[L];          // entries still to write
+#pragma unroll
+    for (int k = 0; k < L; k++) {
+        const size_t u = u0 + k;
+        left[k] = 0;
+        cur[k] = table;
+        base[k] = bases;
+        if (u < total) {
+            const uint32_t c = (uint32_t)(u / nseg), sgm = (uint32_t)(u % nseg);
+            const uint32_t first = sgm == 0 && seg > 1 ? 1u : 0u;   // entries [e0, e0 + first] exist already
+            base[k] = bases + c;
+            cur[k] = table + (size_t)c * half + (size_t)sgm * seg + first;
+            uint32_t wb[12], wy[12], any = 0;
+            tb_load12(wb, &bases[c].x);
+            tb_load12(wy, &bases[c].y);
+#pragma unroll
+            for (int j = 0; j < 12; j++) any |= wb[j] | wy[j];
+            left[k] = any ? seg - 1 - first : 0;   // a row at infinity: zero-filled by the caller's memset
+        }
+    }
+    for (uint32_t step = 0; step + 1 < seg; step++) {
+        F28<1, 2> pre[L];
+        // forward: running product of the denominators xB - x
+#pragma unroll
+        for (int k = 0; k < L; k++) {
+            F28<4, 3> d = widen<4, 3>(f28_one());
+            if (step < left[k]) {
+                uint32_t wx[12], wb[12];
+                tb_load12(wx, &cur[k]->x);
+                tb_load12(wb, &base[k]->x);
+                d = sub(f28_unpack<1>(wb), f28_unpack<1>(wx));
+            }
+            pre[k] = k == 0 ? mul(d, f28_one()) : mul(pre[k - 1], d);
+        }
+        F28<1, 2> inv = f28_inv(pre[L - 1]);
+        // backward: peel the inverses off, finish each addition, write the next entry
+#pragma unroll
+        for (int k = L - 1; k >= 0; k--) {
+            if (step < left[k]) {   // (inactive units contributed d = 1: nothing to peel)
+                uint32_t wx[12], wy[12], wbx[12], wby[12];
+                tb_load12(wx, &cur[k]->x);
+                tb_load12(wy, &cur[k]->y);
+                tb_load12(wbx, &base[k]->x);
+                tb_load12(wby, &base[k]->y);
+                const F28<1, 1> x = f28_unpack<1>(wx), y = f28_unpack<1>(wy), xb = f28_unpack<1>(wbx), yb = f28_unpack<1>(wby);
+                const F28<4, 3> d = sub(xb, x);
+                const F28<1, 2> dinv = k == 0 ? inv : mul(inv, pre[k - 1]);
+                if (k > 0) inv = mul(inv, d);
+                const F28<1, 2> lam = mul(sub(yb, y), dinv);             // (yB - y) / (xB - x)
+                const F28<1, 1> x3 = f28_canon<6>(norm(sub(sub(sqr(lam), xb), x)));   // <7,6> -> [0, p)
+                const F28<1, 1> y3 = f28_canon<4>(norm(sub(mul(lam, sub(x, x3)), y)));   // <4,4> -> [0, p)
+                cur[k] += 1;
+                tb_store_point(cur[k], x3, y3);
+            }
+        }
+    }
+}
+
 int batch_to_affine_device(DeviceCtx *ctx, G1Affine *d_out, const G1XYZZ *d_in, Fp *d_prefix, size_t n) {
     if (n == 0) return 0;
     // short runs when there are few points (latency), long runs when there are many (throughput)
@@ -151,6 +320,56 @@ int build_fixed_base_table(DeviceCtx *ctx, FixedBaseTable *t, const G1Affine *d_
     t->twin = FixedBaseTable::twin_for(wbits);
     t->nwin = 2 * t->twin;
     t->half = (size_t)1 << (wbits - 1);
+    static const bool old_builder = []() {
+        const char *e = getenv("CKZG_HIP_TABLE_BUILDER");
+        return e && !strcmp(e, "old");
+    }();
+    DevTmp wb, tmp, prefix, table, wba;   // `table` is handed to *t only when the build has completed
+    t->d_table = nullptr;
+    HIP_TRY(hipMalloc(&table.p, t->bytes()));
+    G1Affine *d_table = static_cast<G1Affine *>(table.p);
+    HIP_TRY(hipMalloc(&wb.p, (size_t)t->twin * npoints * sizeof(G1XYZZ)));
+    G1XYZZ *d_wb = static_cast<G1XYZZ *>(wb.p);
+    const auto t_alloc = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(k_window_bases, dim3((npoints + 63) / 64), dim3(64), 0, ctx->stream, d_wb,
+                       d_bases, npoints, wbits, t->twin);
+    if (!old_builder) {
+        // affine chains (k_table_seeds / k_table_steps): window bases to affine in the 2^392 domain, then segments
+        const size_t nchains = (size_t)t->twin * npoints;
+        HIP_TRY(hipMalloc(&wba.p, nchains * sizeof(G1Affine)));
+        HIP_TRY(hipMalloc(&prefix.p, nchains * sizeof(Fp)));
+        G1Affine *d_wba = static_cast<G1Affine *>(wba.p);
+        {
+            const int Lb = 16;
+            const size_t th = (nchains + Lb - 1) / Lb;
+            hipLaunchKernelGGL(k_batch_to_affine, dim3((unsigned)((th + 63) / 64)), dim3(64), 0, ctx->stream, d_wba, d_wb,
+                               static_cast<Fp *>(prefix.p), nchains, Lb, 1);
+        }
+        // segment length: ~4096 waves of 8-segment threads when the table is large enough, 16..512 entries
+        constexpr int LSEG = 8;
+        const size_t entries = nchains * t->half;
+        size_t seg = entries / ((size_t)262144 * LSEG);
+        uint32_t seg2 = 16;
+        while (seg2 < 512 && seg2 * 2 <= seg) seg2 *= 2;
+        if (seg2 > t->half) seg2 = (uint32_t)t->half;
+        const uint32_t nseg = (uint32_t)(t->half / seg2);
+        // windows one at a time when a background build may be cancelled (a launch of the whole table cannot be)
+        const size_t chains_per_launch = cancel ? (size_t)npoints : nchains;
+        for (size_t c0 = 0; c0 < nchains; c0 += chains_per_launch) {
+            if (cancel && *cancel) {
+                (void)hipStreamSynchronize(ctx->stream);
+                return 5;
+            }
+            if (cancel && c0) HIP_TRY(hipStreamSynchronize(ctx->stream));
+            const size_t nc = nchains - c0 < chains_per_launch ? nchains - c0 : chains_per_launch;
+            const size_t units = nc * nseg, threads = (units + LSEG - 1) / LSEG;
+            hipLaunchKernelGGL(k_table_seeds, dim3((unsigned)((units + 63) / 64)), dim3(64), 0, ctx->stream,
+                               d_table + c0 * t->half, d_wba + c0, (uint32_t)nc, (uint32_t)t->half, seg2);
+            if (seg2 > 1)
+                hipLaunchKernelGGL(k_table_steps<LSEG>, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, ctx->stream,
+                                   d_table + c0 * t->half, d_wba + c0, (uint32_t)nc, (uint32_t)t->half, seg2);
+        }
+    } else {
     // one window of a chunk of points at a time, so that the construction scratch (240 B per entry) stays
     // below ~2 GiB whatever the table width
     size_t per_point = t->half * (sizeof(G1XYZZ) + sizeof(Fp));
@@ -158,18 +377,10 @@ int build_fixed_base_table(DeviceCtx *ctx, FixedBaseTable *t, const G1Affine *d_
     if (chunk < 1) chunk = 1;
     if (chunk > npoints) chunk = npoints;
     const size_t slab = (size_t)chunk * t->half;
-    DevTmp wb, tmp, prefix, table;   // `table` is handed to *t only when the build has completed
-    t->d_table = nullptr;
-    HIP_TRY(hipMalloc(&table.p, t->bytes()));
-    G1Affine *d_table = static_cast<G1Affine *>(table.p);
-    HIP_TRY(hipMalloc(&wb.p, (size_t)t->twin * npoints * sizeof(G1XYZZ)));
     HIP_TRY(hipMalloc(&tmp.p, slab * sizeof(G1XYZZ)));
     HIP_TRY(hipMalloc(&prefix.p, slab * sizeof(Fp)));
-    G1XYZZ *d_wb = static_cast<G1XYZZ *>(wb.p), *d_tmp = static_cast<G1XYZZ *>(tmp.p);
+    G1XYZZ *d_tmp = static_cast<G1XYZZ *>(tmp.p);
     Fp *d_prefix = static_cast<Fp *>(prefix.p);
-    const auto t_alloc = std::chrono::steady_clock::now();
-    hipLaunchKernelGGL(k_window_bases, dim3((npoints + 63) / 64), dim3(64), 0, ctx->stream, d_wb,
-                       d_bases, npoints, wbits, t->twin);
     const int L = 128;
     const size_t segs = (t->half + CHAIN_SEG - 1) / CHAIN_SEG;
     for (int w = 0; w < t->twin; w++) {
@@ -188,6 +399,7 @@ int build_fixed_base_table(DeviceCtx *ctx, FixedBaseTable *t, const G1Affine *d_
                                ctx->stream, d_table + ((size_t)w * npoints + i0) * t->half, d_tmp, d_prefix,
                                entries, L, 1);
         }
+    }
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -11,22 +11,23 @@ mode=${1:-cpu}
 mkdir -p gpurun_out
 LOG=gpurun_out/sanitize_$mode.log
 : > $LOG
-CLANG_RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
-GCC_RT=$(gcc -print-file-name=libasan.so)
+# GCC's runtimes for both libraries (c-kzg-4844_amd/Makefile says why not clang's on a GPU box)
+GCC_RT="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)"
+CLANG_RT=$GCC_RT
 export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0:halt_on_error=0:detect_odr_violation=0
 export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=0
 if [ "$mode" = cpu ]; then
   echo "== host shim under gcc ASan+UBSan: tests/test_host_arith.py tests/test_fk20_edge_builder.py" >> $LOG
-  LD_PRELOAD=$GCC_RT CKZG_SHIM_SO=c-kzg-4844_amd/csrc/libhost_shim_san.so CKZG_TESTS_NO_AUTOBUILD=1 \
+  LD_PRELOAD="$GCC_RT" CKZG_SHIM_SO=c-kzg-4844_amd/csrc/libhost_shim_san.so CKZG_TESTS_NO_AUTOBUILD=1 \
     timeout 3000 python -m pytest tests/test_host_arith.py tests/test_fk20_edge_builder.py -q -x -p no:cacheprovider >> $LOG 2>&1
   echo "rc=$?" >> $LOG
-  echo "== product (host half sanitized) under clang ASan+UBSan: tests/test_abi_exports.py" >> $LOG
-  LD_PRELOAD=$CLANG_RT CKZG_HIP_SO=c-kzg-4844_amd/libckzg_hip_san.so CKZG_TESTS_NO_AUTOBUILD=1 \
+  echo "== product (host half sanitized) under ASan+UBSan: tests/test_abi_exports.py" >> $LOG
+  LD_PRELOAD="$CLANG_RT" CKZG_HIP_SO=c-kzg-4844_amd/libckzg_hip_san.so CKZG_TESTS_NO_AUTOBUILD=1 \
     timeout 600 python -m pytest tests/test_abi_exports.py -q -x -p no:cacheprovider >> $LOG 2>&1
   echo "rc=$?" >> $LOG
 else
   echo "== product (host half sanitized) on the GPU: vectors, fuzz, round-3 verification forms" >> $LOG
-  LD_PRELOAD=$CLANG_RT CKZG_HIP_SO=c-kzg-4844_amd/libckzg_hip_san.so CKZG_TESTS_NO_AUTOBUILD=1 HSA_XNACK=0 \
+  LD_PRELOAD="$CLANG_RT" CKZG_HIP_SO=c-kzg-4844_amd/libckzg_hip_san.so CKZG_TESTS_NO_AUTOBUILD=1 HSA_XNACK=0 \
     timeout 1500 python -m pytest tests/test_gpu_vectors.py tests/test_gpu_fuzz.py tests/test_gpu_round3.py -m gpu -q -x -p no:cacheprovider >> $LOG 2>&1
   echo "rc=$?" >> $LOG
 fi
