@@ -250,7 +250,11 @@ __global__ __launch_bounds__(64) void k_table_steps(G1Affine *table, const G1Aff
             tb_load12(wy, &bases[c].y);
 #pragma unroll
             for (int j = 0; j < 12; j++) any |= wb[j] | wy[j];
-            left[k] = any ? seg - 1 - first : 0;   // a row at infinity: zero-filled by the caller's memset
+            left[k] = any ? seg - 1 - first : 0;
+            if (!any) {   // a base at infinity (never in a ceremony file, legal in the format): its row is all infinity
+                const G1Affine z = G1Affine::inf();
+                for (uint32_t e = first + 1; e < seg; e++) cur[k][e - first] = z;
+            }
         }
     }
     for (uint32_t step = 0; step + 1 < seg; step++) {

@@ -216,3 +216,36 @@ def test_async_tables_cancelled_by_free(rt):
     free1 = C.c_size_t()
     assert rt.hipMemGetInfo(C.byref(free1), C.byref(total)) == 0
     assert free1.value >= free0.value - (1 << 30), (free0.value, free1.value)
+
+
+def test_setup_points_at_infinity_give_infinity_table_rows(tmp_path):
+    """A setup file may hold the point at infinity (the reference checks curve membership only, setup.c:447-477): the
+    table rows of such a base are all infinity and every sum simply skips them.  Oracle and product load the same
+    doctored file (Lagrange point 5 and monomial point 100 replaced) and must agree on commitments, cells and proofs."""
+    from conftest import ORACLE_SO
+    from kzg_ctypes import HIP_SO, TRUSTED_SETUP, Kzg
+    from oracle_binding import OracleKzg
+    from test_gpu_round2 import _restore
+    lines = open(TRUSTED_SETUP).read().split("\n")
+    inf = "c0" + "00" * 47
+    assert lines[0].strip() == "4096" and lines[1].strip() == "65" and len(lines[2]) == 96
+    lines[2 + 5] = inf
+    lines[2 + 4096 + 65 + 100] = inf
+    path = tmp_path / "setup_with_infinity.txt"
+    path.write_text("\n".join(lines))
+    blob = rand_blob(174, 0)
+    orc = OracleKzg(ORACLE_SO, precompute=0, setup_path=str(path))
+    try:
+        exp_c = orc.blob_to_kzg_commitment(blob)
+        exp_cp = orc.compute_cells_and_kzg_proofs(blob)
+    finally:
+        orc.close()
+    for opts in ({"commit_wbits": 9, "proof_wbits": 6, "fk20_wbits": 8}, {"commit_wbits": 12, "proof_wbits": 0, "direct_max": 0, "fk20_wbits": 10}):
+        api = Kzg(HIP_SO, "", precompute=0, setup_path=str(path), options=opts)
+        _restore(api)
+        try:
+            assert api.blob_to_kzg_commitment(blob) == exp_c
+            got = api.compute_cells_and_kzg_proofs(blob)
+            assert got[0] == exp_cp[0] and got[1] == exp_cp[1]
+        finally:
+            api.close()

@@ -1,0 +1,29 @@
+"""The sanitizer passes of tools/run_sanitized.sh as tests (the reference's counterpart: src/Makefile:214-238).
+They need the sanitizer builds (`make -C c-kzg-4844_amd sanitize`: ~3 min for the product, ~11 min for the host shim
+under g++ -O1 -g with ASan+UBSan), which are not part of the ordinary build; a checkout without them skips."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SAN_LIB = os.path.join(ROOT, "c-kzg-4844_amd", "libckzg_hip_san.so")
+SAN_SHIM = os.path.join(ROOT, "c-kzg-4844_amd", "csrc", "libhost_shim_san.so")
+
+
+def _run(mode):
+    env = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "CKZG_HIP_SO", "CKZG_SHIM_SO")}
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "run_sanitized.sh"), mode], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=3000)
+    assert r.returncode == 0 and "sanitizers: clean" in r.stdout, (r.stdout[-3000:], r.stderr[-1000:])
+
+
+@pytest.mark.skipif(not (os.path.exists(SAN_LIB) and os.path.exists(SAN_SHIM)), reason="sanitizer builds absent: make -C c-kzg-4844_amd sanitize")
+def test_host_arithmetic_and_abi_under_asan_ubsan():
+    _run("cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(SAN_LIB), reason="sanitizer build absent: make -C c-kzg-4844_amd sanitize")
+def test_vectors_fuzz_and_verification_forms_under_asan_ubsan_on_the_gpu():
+    _run("gpu")

@@ -2,7 +2,7 @@
 # where does the sanitized product stop on the GPU box?  incremental steps, unbuffered
 export TMPDIR=/tmp PYTHONUNBUFFERED=1
 CLANG_RT="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)"
-export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0:detect_odr_violation=0:verbosity=0
+export ASAN_OPTIONS=detect_leaks=0:use_sigaltstack=0:abort_on_error=0:detect_odr_violation=0
 export CKZG_HIP_SO=c-kzg-4844_amd/libckzg_hip_san.so CKZG_TESTS_NO_AUTOBUILD=1
 echo "-- step 1: python under the ASan runtime"; LD_PRELOAD="$CLANG_RT" python -c "print('py ok')"; echo "rc=$?"
 echo "-- step 2: HIP runtime"; LD_PRELOAD="$CLANG_RT" python -c "

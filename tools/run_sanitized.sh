@@ -14,7 +14,7 @@ LOG=gpurun_out/sanitize_$mode.log
 # GCC's runtimes for both libraries (c-kzg-4844_amd/Makefile says why not clang's on a GPU box)
 GCC_RT="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)"
 CLANG_RT=$GCC_RT
-export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0:halt_on_error=0:detect_odr_violation=0
+export ASAN_OPTIONS=detect_leaks=0:use_sigaltstack=0:abort_on_error=0:detect_odr_violation=0   # use_sigaltstack=0: the HIP runtime's threads trip ASan's alternate-stack teardown
 export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=0
 if [ "$mode" = cpu ]; then
   echo "== host shim under gcc ASan+UBSan: tests/test_host_arith.py tests/test_fk20_edge_builder.py" >> $LOG
