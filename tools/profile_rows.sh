@@ -6,7 +6,7 @@
 export TMPDIR=/tmp
 O=gpurun_out/prof_rows
 rm -rf $O && mkdir -p $O
-for spec in "cells wide" "cells default" "verify default"; do
+for spec in "cells wide" "cells default" "verify default" "verify wide"; do
   set -- $spec
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$1_$2 -- python tools/row_driver.py $1 $2 > $O/$1_$2.json 2> $O/$1_$2.err
   tail -c 600 $O/$1_$2.json

@@ -1,6 +1,8 @@
 """Summarise rocprofv3 output directories (csv format) for one kernel: per-launch counter values from
 *counter_collection.csv and per-launch durations from *kernel_trace.csv.
-usage: python tools/summarize_pmc.py <kernel-substring> <dir> [<dir> ...] > summary.json"""
+usage: python tools/summarize_pmc.py <kernel-substring> <dir> [<dir> ...] > summary.json
+GRID=<threads> keeps only the launches of that grid size (the bench's 1024-blob steps are 262144 threads; the
+one-blob commitments around the load use the same kernel with another shape)."""
 import csv
 import glob
 import json
@@ -15,6 +17,9 @@ def rows(d, suffix):
                 yield r
 
 
+GRID = os.environ.get("GRID")
+
+
 def main():
     key = sys.argv[1]
     out = {}
@@ -22,6 +27,8 @@ def main():
         entry = {"counters": {}, "kernel_ms": []}
         for r in rows(d, "counter_collection.csv"):
             if key not in r.get("Kernel_Name", ""):
+                continue
+            if GRID and r.get("Grid_Size") != GRID:
                 continue
             c = entry["counters"].setdefault(r["Counter_Name"], [])
             c.append(float(r["Counter_Value"]))
@@ -31,6 +38,8 @@ def main():
                 if k_src in r:
                     entry[k_dst] = r[k_src]
         for r in rows(d, "kernel_trace.csv"):
+            if GRID and r.get("Grid_Size_X", r.get("Grid_Size")) != GRID:
+                continue
             if key in r.get("Kernel_Name", ""):
                 entry["kernel_ms"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
         entry["counter_mean"] = {k: sum(v) / len(v) for k, v in entry["counters"].items() if v}
