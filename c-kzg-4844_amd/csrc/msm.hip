@@ -357,8 +357,9 @@ int build_fixed_base_table(DeviceCtx *ctx, FixedBaseTable *t, const G1Affine *d_
         while (seg2 < 512 && seg2 * 2 <= seg) seg2 *= 2;
         if (seg2 > t->half) seg2 = (uint32_t)t->half;
         const uint32_t nseg = (uint32_t)(t->half / seg2);
-        // windows one at a time when a background build may be cancelled (a launch of the whole table cannot be)
-        const size_t chains_per_launch = cancel ? (size_t)npoints : nchains;
+        // a background build that may be cancelled goes four windows at a time (a launch of the whole table cannot be
+        // abandoned; one window alone -- 512 waves at 16 bits -- leaves half the chip idle)
+        const size_t chains_per_launch = cancel ? (size_t)4 * npoints : nchains;
         for (size_t c0 = 0; c0 < nchains; c0 += chains_per_launch) {
             if (cancel && *cancel) {
                 (void)hipStreamSynchronize(ctx->stream);
