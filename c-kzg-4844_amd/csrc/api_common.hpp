@@ -192,6 +192,7 @@ int pool_of_pointer(const SettingsCtx *sc, const void *dptr);
 C_KZG_RET create_settings_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affine,
                               const G1Affine *monomial_affine);
 void destroy_settings_ctx(const KZGSettings *s);
+void start_widening(const KZGSettings *s);   // "async_tables": after the warm-up calls of the load
 // blocks until the background widening of an "async_tables" load has finished (returns at once otherwise)
 void wait_for_tables(const KZGSettings *s);
 bool tables_ready(const KZGSettings *s);

@@ -205,6 +205,17 @@ static C_KZG_RET load_trusted_setup_impl(KZGSettings *out, const uint8_t *g1_mon
     // GPU state: commitment tables, NTT twiddles, FK20 columns and tables (setup.c:238-330)
     ret = create_settings_ctx(out, lagr_affine.data(), mono_affine.data());
     if (ret != C_KZG_OK) goto fail;
+    if (!tables_ready(out)) {
+        // "async_tables": one commitment and one cells+proofs call on the default tables leave the first slot's
+        // arena, scratch and pinned staging allocated, so that the caller's first calls need no allocation while the
+        // widener's large ones are in flight (results ignored: a failure here is a failure of the caller's call later)
+        std::vector<uint8_t> zero(BYTES_PER_BLOB, 0), cells((size_t)CELLS_PER_EXT_BLOB * BYTES_PER_CELL), proofs((size_t)CELLS_PER_EXT_BLOB * 48);
+        KZGCommitment c;
+        (void)blob_to_kzg_commitment(&c, reinterpret_cast<const Blob *>(zero.data()), out);
+        (void)compute_cells_and_kzg_proofs(reinterpret_cast<Cell *>(cells.data()), reinterpret_cast<KZGProof *>(proofs.data()),
+                                           reinterpret_cast<const Blob *>(zero.data()), out);
+        start_widening(out);
+    }
     return C_KZG_OK;
 fail:
     free_trusted_setup(out);

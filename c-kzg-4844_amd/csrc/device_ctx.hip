@@ -601,17 +601,28 @@ C_KZG_RET create_settings_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affin
     }
     if (env_int("CKZG_HIP_ASYNC_TABLES", opts.async_tables) != 0) {
         requested_widths(sc->requested_wbits, s, opts);
-        bool any = false;
+        sc->widening_done = true;
         for (DevicePool *p : sc->pools) {
-            any |= sc->requested_wbits[0] > p->pub.commit.wbits || sc->requested_wbits[1] > p->pub.fk20.wbits ||
-                   (p->pub.mono.d_table && sc->requested_wbits[2] > p->pub.mono.wbits);
-        }
-        if (any) {
-            sc->widening_done = false;
-            sc->widener = std::thread(widener_main, sc, (const KZGSettings *)s);
+            if (sc->requested_wbits[0] > p->pub.commit.wbits || sc->requested_wbits[1] > p->pub.fk20.wbits ||
+                (p->pub.mono.d_table && sc->requested_wbits[2] > p->pub.mono.wbits))
+                sc->widening_done = false;   // start_widening() has work to do
         }
     }
     return C_KZG_OK;
+}
+
+// Second half of an "async_tables" load, called by load_trusted_setup once the new KZGSettings has served its warm-up
+// calls: from here on the widener's 100 GB allocations may hold the runtime's allocator for seconds (the kernel driver
+// scrubs VRAM another process has just released), and a first call that still had to allocate its own arena or
+// pinned staging would wait behind them.
+void start_widening(const KZGSettings *s) {
+    SettingsCtx *sc = settings_of(s, false);
+    if (!sc) return;
+    {
+        std::lock_guard<std::mutex> lock(sc->widen_mu);
+        if (sc->widening_done || sc->widener.joinable()) return;
+    }
+    sc->widener = std::thread(widener_main, sc, s);
 }
 
 void wait_for_tables(const KZGSettings *s) {
