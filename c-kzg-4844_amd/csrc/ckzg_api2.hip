@@ -375,6 +375,11 @@ struct OrderedHasher {
         unsigned hw = std::thread::hardware_concurrency();
         size_t nt = hw ? hw : 4;
         if (nt > 32) nt = 32;
+        static const size_t forced = []() {
+            const char *e = getenv("CKZG_HIP_HASH_THREADS");   // A/B knob
+            return e && *e ? (size_t)atol(e) : (size_t)0;
+        }();
+        if (forced) nt = forced;
         for (size_t t = 0; t < nt; t++) {
             th.spawn([this, z, blobs, cb]() {
                 for (;;) {
@@ -484,7 +489,11 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     ProofSide ps;
     if (piped) {
         // ---- pipelined host-pointer form ----
-        const size_t CH = 256;   // 32 MB per chunk: ~0.6 ms of PCIe, 16 chunks at n = 4096
+        static const size_t CH = []() {   // 256 blobs = 32 MB per chunk: ~0.6 ms of PCIe, 16 chunks at n = 4096
+            const char *e = getenv("CKZG_HIP_VERIFY_CHUNK");   // A/B knob
+            size_t v = e && *e ? (size_t)atol(e) : (size_t)256;
+            return v < 16 ? (size_t)16 : v;
+        }();
         const size_t nch = (n + CH - 1) / CH;
         const bool src_pinned = host_pointer_is_pinned(blobs);
         if (!src_pinned) OKM(ensure_pinned(ctx->h_stage, ctx->h_stage_bytes, CH * (size_t)BYTES_PER_BLOB));

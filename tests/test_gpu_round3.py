@@ -249,3 +249,35 @@ def test_setup_points_at_infinity_give_infinity_table_rows(tmp_path):
             assert got[0] == exp_cp[0] and got[1] == exp_cp[1]
         finally:
             api.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# the round-3 paths behind the C-ABI multi-device fan-out (two table replicas on the one GPU stand in for two devices)
+# ---------------------------------------------------------------------------------------------
+
+def test_fan_out_of_pipelined_verification_and_async_tables_over_two_replicas(material):
+    from kzg_ctypes import HIP_SO, Kzg
+    from test_gpu_round2 import _restore
+    blobs, cm, pr = material
+    api = Kzg(HIP_SO, "", precompute=0, options={"replicas": 2, "async_tables": 1, "commit_wbits": 12, "proof_wbits": 0, "fk20_wbits": 9})
+    _restore(api)
+    try:
+        nd = api.lib.ckzg_hip_num_devices
+        nd.restype = C.c_int
+        assert nd(api.sp) == 2
+        n = 2304   # two shards of 1152 blobs: each takes the pipelined form
+        bb, cc, pp, order = _inputs(material, n)
+        assert _host(api, bb, cc, pp, n) == (0, True)
+        for at in (7, 1151, 1152, n - 1):   # either shard, and both sides of the boundary
+            bad = pp[:48 * at] + pr[(order[at] + 1) % 8] + pp[48 * (at + 1):]
+            assert _host(api, bb, cc, bad, n) == (0, False), at
+        assert api.lib.ckzg_hip_wait_tables(api.sp) == 0
+        wb = api.lib.ckzg_hip_table_wbits
+        wb.restype = C.c_int
+        assert (int(wb(api.sp, 0)), int(wb(api.sp, 1))) == (12, 9)
+        # both replicas were widened: commitments from either pool (single calls go round robin) match the oracle's
+        for i in range(4):
+            assert api.blob_to_kzg_commitment(blobs[i]) == cm[i]
+        assert _host(api, bb, cc, pp, n) == (0, True)
+    finally:
+        api.close()
