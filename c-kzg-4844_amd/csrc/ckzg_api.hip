@@ -318,15 +318,17 @@ extern "C" C_KZG_RET ckzg_hip_blob_to_kzg_commitment_batch_device(void *d_out48,
 // Host buffers are pageable, and a pageable hipMemcpyAsync serialises with everything.  So chunk
 // i+1 is memcpy'd by this thread into a pinned staging buffer and DMA'd on the copy stream while
 // the kernels of chunk i execute on the compute stream.  Two staging/device buffers, events
-// both ways.  Chunks grow geometrically (64, 192, 512, 512, ...): the first one is small so that
+// both ways.  Chunks grow geometrically (64, 192, 256, 256, ...): the first one is small so that
 // the GPU starts after ~0.5 ms, and since a chunk computes ~3x longer than the next one takes to
-// stage, the following ones can be large enough to run the kernels at full-batch efficiency.
+// stage, the following ones can be large enough to run the kernels at full-batch efficiency -- but not larger
+// than 256 blobs: the staging copy of a 512-blob chunk (64 MB on four threads) outlasts the kernels of a 192-blob
+// chunk before it and the GPU waits (profiles/r03_commit_chunk_ab.txt).
 static C_KZG_RET commit_batch_on(dev::DeviceCtx *ctx, KZGCommitment *out, uint8_t *status, const Blob *blobs,
                                  uint64_t n) {
     if (n == 0) return C_KZG_OK;
     static const uint64_t CH = []() {
         const char *v = getenv("CKZG_HIP_COMMIT_CHUNK");
-        long c = v && *v ? atol(v) : 512;
+        long c = v && *v ? atol(v) : 256;   // measured: profiles/r03_commit_chunk_ab.txt (512: -11 % from pageable memory)
         return (uint64_t)(c < 16 ? 16 : (c > 1024 ? 1024 : c));
     }();
     const uint64_t FIRST = CH < 64 ? CH : 64;
