@@ -180,15 +180,34 @@ def test_async_tables_serve_calls_while_they_widen(oracle):
         ready.restype = C.c_int
         seen = set()
         rounds = 0
-        while True:
-            done = bool(ready(api.sp))
-            seen.add(tuple(int(wb(api.sp, k)) for k in range(3)))
-            assert api.blob_to_kzg_commitment(blob) == exp_c
-            got = api.compute_cells_and_kzg_proofs(blob)
-            assert got[0] == exp_cp[0] and got[1] == exp_cp[1]
-            rounds += 1
-            if done:
-                break
+        # four more callers hammer the same KZGSettings while the tables change underneath them
+        import threading
+        errs, stop = [], threading.Event()
+
+        def hammer():
+            while not stop.is_set():
+                if api.blob_to_kzg_commitment(blob) != exp_c:
+                    errs.append("commitment")
+                    return
+
+        th = [threading.Thread(target=hammer) for _ in range(4)]
+        for t in th:
+            t.start()
+        try:
+            while True:
+                done = bool(ready(api.sp))
+                seen.add(tuple(int(wb(api.sp, k)) for k in range(3)))
+                assert api.blob_to_kzg_commitment(blob) == exp_c
+                got = api.compute_cells_and_kzg_proofs(blob)
+                assert got[0] == exp_cp[0] and got[1] == exp_cp[1]
+                rounds += 1
+                if done:
+                    break
+        finally:
+            stop.set()
+            for t in th:
+                t.join()
+        assert not errs
         assert api.lib.ckzg_hip_wait_tables(api.sp) == 0
         final = tuple(int(wb(api.sp, k)) for k in range(3))
         assert final == (14, 12, 13), (final, sorted(seen))
