@@ -386,7 +386,7 @@ static C_KZG_RET build_owner(DevicePool *pool, const KZGSettings *s, const Optio
 // "async_tables": widen one pool's tables to the requested widths, one table at a time (commitment first), each
 // published as soon as it is complete.  Runs on the widener thread with its own stream; a width that does not fit,
 // an allocation failure or a cancelled build leaves the narrower table in service.
-static void widen_pool(SettingsCtx *sc, DevicePool *pool, const KZGSettings *s) {
+static void widen_pool(SettingsCtx *sc, DevicePool *pool) {
     if (hipSetDevice(pool->device) != hipSuccess) return;
     dev::DeviceCtx b;   // builder context: a stream and nothing else
     b.device = pool->device;
@@ -431,17 +431,17 @@ static void widen_pool(SettingsCtx *sc, DevicePool *pool, const KZGSettings *s) 
     (void)hipStreamDestroy(b.stream);
 }
 
-static void widener_main(SettingsCtx *sc, const KZGSettings *s) {
+static void widener_main(SettingsCtx *sc) {
     guarded([&]() -> C_KZG_RET {
         JoinThreads th;   // one builder per device; pools that share a device (replicas) one after the other
         std::vector<int> seen;
         for (DevicePool *first : sc->pools) {
             if (std::find(seen.begin(), seen.end(), first->device) != seen.end()) continue;
             seen.push_back(first->device);
-            th.spawn([sc, s, first]() {
+            th.spawn([sc, first]() {
                 pin_thread_to_device_numa(first->device);
                 for (DevicePool *p : sc->pools) {
-                    if (p->device == first->device) widen_pool(sc, p, s);
+                    if (p->device == first->device) widen_pool(sc, p);
                 }
             });
         }
@@ -622,7 +622,13 @@ void start_widening(const KZGSettings *s) {
         std::lock_guard<std::mutex> lock(sc->widen_mu);
         if (sc->widening_done || sc->widener.joinable()) return;
     }
-    sc->widener = std::thread(widener_main, sc, s);
+    try {
+        // (the thread gets the SettingsCtx, never the caller's KZGSettings: bindings move that struct around)
+        sc->widener = std::thread(widener_main, sc);
+    } catch (...) {   // no thread, no widening: the default-width tables stay in service
+        std::lock_guard<std::mutex> lock(sc->widen_mu);
+        sc->widening_done = true;
+    }
 }
 
 void wait_for_tables(const KZGSettings *s) {

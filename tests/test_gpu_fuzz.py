@@ -229,3 +229,52 @@ def test_fuzz_compute_kzg_proof_and_commitment(hip, oracle, material, data):
     c = outcome(oracle.blob_to_kzg_commitment, blob)
     if c[0] == "ok":
         assert outcome(hip.compute_blob_kzg_proof, blob, c[1]) == outcome(oracle.compute_blob_kzg_proof, blob, c[1])
+
+
+@settings(max_examples=12, **FUZZ)
+@given(st.data())
+def test_fuzz_batch_entry_points_against_single_calls(hip, material, data):
+    """The additive batch forms over sizes that straddle their chunk schedules (64 / 192 / 256-blob staging chunks of
+    the commitment batch, the 64-blob latency path and 256-blob sub-chunks of cells+proofs), with non-canonical blobs
+    at generated positions: per-blob status and outputs must equal the one-blob calls'."""
+    import ctypes as C
+    blobs = material[0]
+    rnd = random.Random(data.draw(st.integers(0, 2 ** 32)))
+    n = data.draw(st.sampled_from([1, 2, 63, 64, 65, 191, 256, 257, 320, 511, 513, 1025]))
+    order = [rnd.randrange(4) for _ in range(n)]
+    bad_at = sorted(set(rnd.randrange(n) for _ in range(data.draw(st.integers(0, 3)))))
+    raw = bytearray(b"".join(blobs[k] for k in order))
+    for at in bad_at:
+        pos = at * 131072 + 32 * rnd.randrange(4096)
+        raw[pos:pos + 32] = _noncanonical(rnd)
+    raw = bytes(raw)
+    single_c = [hip.blob_to_kzg_commitment(b) for b in blobs]
+    out = C.create_string_buffer(48 * n)
+    status = C.create_string_buffer(n)
+    f = hip.lib.ckzg_hip_blob_to_kzg_commitment_batch
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p]
+    rc = f(out, status, raw, n, C.addressof(hip.s))
+    assert rc == (1 if bad_at else 0)
+    assert [i for i, v in enumerate(status.raw) if v] == bad_at
+    for i in range(n):
+        if i not in bad_at:
+            assert out.raw[48 * i:48 * i + 48] == single_c[order[i]], i
+    if n <= 320:   # cells + proofs: 268 KB of output per blob
+        g = hip.lib.ckzg_hip_compute_cells_and_kzg_proofs_batch
+        g.restype = C.c_int
+        g.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p]
+        proofs = C.create_string_buffer(n * 6144)
+        want_cells = data.draw(st.booleans())
+        cells = C.create_string_buffer(n * 262144) if want_cells else None
+        rc = g(cells, proofs, status, raw, n, C.addressof(hip.s))
+        assert rc == (1 if bad_at else 0)
+        assert [i for i, v in enumerate(status.raw) if v] == bad_at
+        cp = material[3]
+        praw = proofs.raw
+        craw = cells.raw if want_cells else None
+        for i in range(n):
+            if i not in bad_at:
+                assert praw[6144 * i:6144 * (i + 1)] == b"".join(cp[order[i]][1]), i
+                if want_cells and i % 7 == 0:
+                    assert craw[262144 * i:262144 * (i + 1)] == b"".join(cp[order[i]][0]), i
