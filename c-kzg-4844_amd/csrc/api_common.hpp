@@ -141,8 +141,8 @@ struct SettingsCtx {
     std::atomic<uint64_t> lease_seq{0};   // leases handed out so far, over all pools (ckzg_hip_last_kernel_ms)
     // "async_tables": the thread that widens the tables after load_trusted_setup has returned
     std::thread widener;
-    volatile bool cancel_widening = false;
-    std::mutex widen_mu;
+    std::atomic<bool> cancel_widening{false};
+    std::mutex widen_mu;              // guards widening_done and, while the widener runs, `load`
     std::condition_variable widen_cv;
     bool widening_done = true;
     int requested_wbits[3] = {0, 0, 0};   // commitment, FK20, proof: what the widener is to reach

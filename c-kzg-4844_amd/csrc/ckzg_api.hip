@@ -258,7 +258,10 @@ static C_KZG_RET load_trusted_setup_file_impl(KZGSettings *out, FILE *in, uint64
     const double parse_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_parse).count();
     C_KZG_RET ret = load_trusted_setup(out, mono.data(), mono.size(), lagr.data(), lagr.size(), g2.data(), g2.size(), precompute);
     if (ret == C_KZG_OK) {
-        if (SettingsCtx *sc = settings_of(out, false)) sc->load.ms[LP_HOST_PARSE] = parse_ms;
+        if (SettingsCtx *sc = settings_of(out, false)) {
+            std::lock_guard<std::mutex> lock(sc->widen_mu);
+            sc->load.ms[LP_HOST_PARSE] = parse_ms;
+        }
     }
     return ret;
 }
@@ -694,6 +697,7 @@ extern "C" int ckzg_hip_load_times(const KZGSettings *s, double *ms, int n) {
     SettingsCtx *sc = settings_of(s, false);
     if (!sc || !ms) return 0;
     int k = n < (int)LP_COUNT ? n : (int)LP_COUNT;
+    std::lock_guard<std::mutex> lock(sc->widen_mu);   // a running widener adds its phases under this lock
     for (int i = 0; i < k; i++) ms[i] = sc->load.ms[i];
     return k;
 }

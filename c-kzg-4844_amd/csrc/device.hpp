@@ -6,6 +6,7 @@
 // slot and overlap on the GPU instead of serialising (api_common.hpp: DevicePool, Lease).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include "g1.hpp"
@@ -127,7 +128,7 @@ int scratch_reserve(DeviceCtx *ctx, size_t bytes);
 // times_ms (optional): [0] += allocation, [1] += construction kernels.  cancel (optional): polled between the
 // construction launches; a set flag abandons the build (return value 5, nothing left allocated).
 int build_fixed_base_table(DeviceCtx *ctx, FixedBaseTable *t, const G1Affine *d_bases, int npoints,
-                           int wbits, double *times_ms = nullptr, const volatile bool *cancel = nullptr);
+                           int wbits, double *times_ms = nullptr, const std::atomic<bool> *cancel = nullptr);
 
 // Commit n blobs resident in HBM: d_out48[n][48], d_status[n] (0 ok, 1 non-canonical element).
 int commit_blobs_device(DeviceCtx *ctx, uint8_t *d_out48, uint8_t *d_status, const uint8_t *d_blobs,

@@ -201,7 +201,7 @@ static void destroy_pool(DevicePool *p) {
 static void destroy_settings(SettingsCtx *sc) {
     if (!sc) return;
     DeviceGuard guard;   // destroy_slot selects each slot's device; the caller's comes back afterwards
-    sc->cancel_widening = true;   // a background table build stops at its next slab
+    sc->cancel_widening.store(true);   // a background table build stops at its next launch
     if (sc->widener.joinable()) sc->widener.join();
     for (auto *p : sc->pools) destroy_pool(p);
     delete sc;
@@ -402,7 +402,7 @@ static void widen_pool(SettingsCtx *sc, DevicePool *pool) {
                  {2, "proof", owner->d_mono, (int)NUM_G1_POINTS, LP_PROOF_MALLOC},
                  {1, "fk20", owner->d_xext, dev::N_CELLS_EXT * dev::N_CELL, LP_FK20_MALLOC}};
     for (const Job &j : jobs) {
-        if (sc->cancel_widening) break;
+        if (sc->cancel_widening.load()) break;
         int have;
         {
             std::lock_guard<std::mutex> lock(pool->mu);
@@ -413,8 +413,13 @@ static void widen_pool(SettingsCtx *sc, DevicePool *pool) {
         int wbits = fit_wbits(j.name, sc->requested_wbits[j.which], have, j.npoints);
         if (wbits <= have) continue;
         dev::FixedBaseTable t;
-        int rc = dev::build_fixed_base_table(&b, &t, j.bases, j.npoints, wbits, pool == sc->pools[0] ? &sc->load.ms[j.phase] : nullptr,
-                                             &sc->cancel_widening);
+        double times[2] = {0, 0};   // allocation, construction: merged into the load's phases under the lock
+        int rc = dev::build_fixed_base_table(&b, &t, j.bases, j.npoints, wbits, times, &sc->cancel_widening);
+        if (pool == sc->pools[0]) {
+            std::lock_guard<std::mutex> lock(sc->widen_mu);
+            sc->load.ms[j.phase] += times[0];
+            sc->load.ms[j.phase + 1] += times[1];
+        }
         if (rc) {
             if (rc != 5) fprintf(stderr, "[ckzg-hip] widening the %s table to %d bits failed (rc %d): the %d-bit table stays\n", j.name, wbits, rc, have);
             (void)hipGetLastError();

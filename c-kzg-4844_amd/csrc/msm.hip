@@ -316,7 +316,7 @@ struct DevTmp {  // freed on every exit path of build_fixed_base_table
 }  // namespace
 
 int build_fixed_base_table(DeviceCtx *ctx, FixedBaseTable *t, const G1Affine *d_bases, int npoints,
-                           int wbits, double *times_ms, const volatile bool *cancel) {
+                           int wbits, double *times_ms, const std::atomic<bool> *cancel) {
     if (wbits < 2 || wbits > 16) return 1;
     const auto t_start = std::chrono::steady_clock::now();
     t->npoints = npoints;
@@ -361,7 +361,7 @@ int build_fixed_base_table(DeviceCtx *ctx, FixedBaseTable *t, const G1Affine *d_
         // abandoned; one window alone -- 512 waves at 16 bits -- leaves half the chip idle)
         const size_t chains_per_launch = cancel ? (size_t)4 * npoints : nchains;
         for (size_t c0 = 0; c0 < nchains; c0 += chains_per_launch) {
-            if (cancel && *cancel) {
+            if (cancel && cancel->load(std::memory_order_relaxed)) {
                 (void)hipStreamSynchronize(ctx->stream);
                 return 5;
             }
@@ -390,7 +390,7 @@ int build_fixed_base_table(DeviceCtx *ctx, FixedBaseTable *t, const G1Affine *d_
     const size_t segs = (t->half + CHAIN_SEG - 1) / CHAIN_SEG;
     for (int w = 0; w < t->twin; w++) {
         for (int i0 = 0; i0 < npoints; i0 += chunk) {
-            if (cancel && *cancel) {
+            if (cancel && cancel->load(std::memory_order_relaxed)) {
                 (void)hipStreamSynchronize(ctx->stream);
                 return 5;
             }
