@@ -406,6 +406,19 @@ inline bool host_pointer_is_pinned(const void *p) {
     return at.type == hipMemoryTypeHost;
 }
 
+// ThreadSanitizer builds (make tsan): the HIP runtime maps pinned host memory behind the tool's back, often at the
+// address of a finished helper thread's stack; telling the tool that the range is new memory keeps it from pairing our
+// first accesses with that dead thread's writes.
+#if defined(__has_feature)
+#if __has_feature(thread_sanitizer)
+extern "C" void AnnotateNewMemory(const char *file, int line, const volatile void *mem, long size);
+#define CKZG_TSAN_NEW_MEMORY(p, n) AnnotateNewMemory(__FILE__, __LINE__, (p), (long)(n))
+#endif
+#endif
+#ifndef CKZG_TSAN_NEW_MEMORY
+#define CKZG_TSAN_NEW_MEMORY(p, n) ((void)0)
+#endif
+
 // pinned staging of a slot, grown on demand: h_stage[2] (towards the device), h_out[2] (back)
 inline bool ensure_pinned(void **bufs, size_t &have, size_t want) {
     if (have >= want) return true;
@@ -420,6 +433,7 @@ inline bool ensure_pinned(void **bufs, size_t &have, size_t want) {
             (void)hipGetLastError();
             return false;
         }
+        CKZG_TSAN_NEW_MEMORY(bufs[i], want);
     }
     have = want;
     return true;

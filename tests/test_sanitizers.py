@@ -9,6 +9,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SAN_LIB = os.path.join(ROOT, "c-kzg-4844_amd", "libckzg_hip_san.so")
 SAN_SHIM = os.path.join(ROOT, "c-kzg-4844_amd", "csrc", "libhost_shim_san.so")
+TSAN_LIB = os.path.join(ROOT, "c-kzg-4844_amd", "libckzg_hip_tsan.so")
 
 
 def _run(mode):
@@ -27,3 +28,9 @@ def test_host_arithmetic_and_abi_under_asan_ubsan():
 @pytest.mark.skipif(not os.path.exists(SAN_LIB), reason="sanitizer build absent: make -C c-kzg-4844_amd sanitize")
 def test_vectors_fuzz_and_verification_forms_under_asan_ubsan_on_the_gpu():
     _run("gpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(TSAN_LIB), reason="ThreadSanitizer build absent: make -C c-kzg-4844_amd tsan")
+def test_concurrent_callers_and_background_threads_under_tsan_on_the_gpu():
+    _run("tsan")
