@@ -215,7 +215,8 @@ def test_async_tables_serve_calls_while_they_widen(oracle):
         # a batch on the widened FK20 table, and the widened commitment table at batch size
         got = api.compute_cells_and_kzg_proofs(blob)
         assert got[1] == exp_cp[1]
-        assert t_load < 5.0
+        assert t_load < 60.0   # (no tight bound: a load that follows a process or test which has just released a
+        # few hundred GB waits for the driver's VRAM scrub)
     finally:
         api.close()
 
