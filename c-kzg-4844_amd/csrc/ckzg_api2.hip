@@ -430,14 +430,42 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
         return e && *e ? (size_t)atol(e) : (size_t)1024;
     }();
     const bool piped = !resident && !small && !gpu_sha && n >= pipe_min;
+    // Call-time table (msm.hip): while the chunked copy of a large pipelined batch is in flight the GPU is mostly idle
+    // and the batch challenge does not exist yet, so the 128 doublings per term of the three sums are done early, as a
+    // narrow fixed-base table over the 2n validated points built on a side stream.  The build is ~4 ms of side-stream
+    // work at n = 4096 (window bases: 126 sequential doublings; 5.8 M entries), so it only pays when the copy is
+    // longer than that: measured (profiles/r03_verify_call_table.txt) n = 4096 page-locked 15.1 -> 14.0 ms, pageable
+    // 15.9 -> 15.0 ms; n = 1024 (a 2.8 ms copy) 6.3 -> 8.4 ms and the resident form (nothing to hide under but the
+    // hashing kernel it competes with) 12.4 -> 15.3 ms: those keep the ladders.
+    static const int call_table_wbits = []() {
+        const char *e = getenv("CKZG_HIP_VERIFY_TABLE_WBITS");   // 0 switches the call-time table off (A/B)
+        return e && *e ? atoi(e) : 6;
+    }();
+    static const size_t call_table_min = []() {
+        const char *e = getenv("CKZG_HIP_VERIFY_TABLE_MIN");
+        return e && *e ? (size_t)atol(e) : (size_t)2560;   // blobs: a copy of >= ~6 ms
+    }();
+    const bool use_table = call_table_wbits >= 4 && call_table_wbits <= 10 && piped && n >= call_table_min;
+    dev::FixedBaseTable tbl;
+    size_t tbl_bytes = 0, tbl_tmp = 0, sums_scratch = 0;
+    if (use_table) {
+        dev::call_table_geometry(&tbl, (int)(2 * n), call_table_wbits);
+        tbl_bytes = tbl.bytes();
+        tbl_tmp = dev::call_table_tmp_bytes(tbl);
+        sums_scratch = dev::table_sums_scratch_bytes(tbl, 3);
+    }
     Arena &ar = ctx->api_arena;
     OKM(ar.begin((resident ? 0 : n * BYTES_PER_BLOB) + (n * FIELD_ELEMENTS_PER_BLOB + 2 * n) * sizeof(Fr) + n * 4 +
-                 2 * n * (48 + 2 + sizeof(G1Affine)) + 4096));
+                 2 * n * (48 + 2 + sizeof(G1Affine)) + tbl_bytes + tbl_tmp + sums_scratch + (use_table ? 6 * n * 32 + 1024 : 0) + 8192));
     ABuf<uint8_t> d_ptb(ar, 2 * n * 48), d_st(ar, 2 * n), d_st2(ar, 2 * n), d_blobs_own(ar, resident ? 1 : n * BYTES_PER_BLOB);
     ABuf<G1Affine> d_pts(ar, 2 * n);
     ABuf<Fr> d_poly(ar, n * FIELD_ELEMENTS_PER_BLOB), d_z(ar, n), d_y(ar, n);
     ABuf<uint32_t> d_bad(ar, n);
     OKM(d_ptb.p && d_st.p && d_st2.p && d_blobs_own.p && d_pts.p && d_poly.p && d_z.p && d_y.p && d_bad.p);
+    ABuf<uint8_t> d_tbl(ar, use_table ? tbl_bytes : 1), d_tbl_tmp(ar, use_table ? tbl_tmp : 1), d_sums_scr(ar, use_table ? sums_scratch : 1);
+    ABuf<uint32_t> d_sc(ar, use_table ? 6 * n * 8 : 1);
+    ABuf<G1XYZZ> d_sums(ar, 3);
+    OKM(d_tbl.p && d_tbl_tmp.p && d_sums_scr.p && d_sc.p && d_sums.p);
     ArenaTrim trim(ar);
     tr.mark("arena");
     // resident: the device copies of the inputs ARE the caller's buffers; the transcript needs the 96 bytes of
@@ -483,8 +511,17 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     // whatever path leaves this function, the second stream must be idle before the arena is reused
     struct StreamDrain {
         hipStream_t s;
-        ~StreamDrain() { (void)hipStreamSynchronize(s); }
+        ~StreamDrain() {
+            if (s) (void)hipStreamSynchronize(s);
+        }
     } drain{ctx->copy_stream};
+    if (use_table) {
+        if (!ctx->aux_stream) OKB(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) == hipSuccess);
+        OKB(hipStreamWaitEvent(ctx->aux_stream, ctx->stage_ev[0], 0) == hipSuccess);   // the validated points
+        RC(dev::call_table_enqueue(ctx->aux_stream, &tbl, reinterpret_cast<G1Affine *>(d_tbl.p), d_tbl_tmp.p, d_pts.p));
+        OKB(hipEventRecord(ctx->stage_ev[1], ctx->aux_stream) == hipSuccess);           // (free: the validation is not split here)
+    }
+    StreamDrain drain_aux{use_table ? ctx->aux_stream : nullptr};
     std::vector<Fr> z(n), y(n);
     ProofSide ps;
     if (piped) {
@@ -672,10 +709,27 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
             rp[i] = raw_of(rpf[i]);
             rz[i] = raw_of(rzf[i]);
         }
-        LincombJob jobs[3] = {{d_pts.p + n, &rp}, {d_pts.p + n, &rz}, {d_pts.p, &rp}};
         if (resident) OKB(hipEventRecord(ctx->ev[3], ctx->stream) == hipSuccess);
-        C_KZG_RET ret = gpu_lincomb_multi(ctx, lc, jobs, 3);
-        if (ret != C_KZG_OK) return ret;
+        if (use_table) {
+            // three scalar vectors over the 2n table points (commitments [0, n), proofs [n, 2n)): zeros select nothing
+            std::vector<RawScalar> sc(6 * n);
+            memset(sc.data(), 0, sc.size() * sizeof(RawScalar));
+            for (size_t i = 0; i < n; i++) {
+                sc[0 * 2 * n + n + i] = rp[i];   // sum r^i proof_i
+                sc[1 * 2 * n + n + i] = rz[i];   // sum r^i z_i proof_i
+                sc[2 * 2 * n + i] = rp[i];       // sum r^i C_i
+            }
+            OKB(hipMemcpyAsync(d_sc.p, sc.data(), sc.size() * sizeof(RawScalar), hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
+            OKB(hipStreamWaitEvent(ctx->stream, ctx->stage_ev[1], 0) == hipSuccess);   // the table is complete
+            RC(dev::table_sums_enqueue(ctx->stream, tbl, d_sums.p, d_sc.p, 3, d_sums_scr.p));
+            G1XYZZ hs[3];
+            OKB(d_sums.down(hs, 3));
+            for (int j = 0; j < 3; j++) lc[j] = jac_from_xyzz(hs[j]);
+        } else {
+            LincombJob jobs[3] = {{d_pts.p + n, &rp}, {d_pts.p + n, &rz}, {d_pts.p, &rp}};
+            C_KZG_RET ret = gpu_lincomb_multi(ctx, lc, jobs, 3);
+            if (ret != C_KZG_OK) return ret;
+        }
         if (resident) {
             // kernel-only time of the resident form (ckzg_hip_last_kernel_ms, which = 3): validation + conversion +
             // challenges + evaluation, and the three sums; the host transcript between them is not GPU time

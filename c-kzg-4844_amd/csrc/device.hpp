@@ -84,6 +84,7 @@ struct DeviceCtx {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;  // host-to-device staging, overlapped with `stream`
     hipStream_t out_stream = nullptr;   // device-to-host draining of results (OutPipe), created on first use
+    hipStream_t aux_stream = nullptr;   // call-time table construction under a long copy (verification), created on first use
     void *h_stage[2] = {nullptr, nullptr};  // pinned host staging buffers (allocated on first use)
     size_t h_stage_bytes = 0;
     void *h_out[2] = {nullptr, nullptr};    // pinned device-to-host staging (cells+proofs / recover pipelines)
@@ -149,6 +150,14 @@ int commit_finalize8_enqueue(DeviceCtx *ctx, uint8_t *d_out48, uint8_t *d_status
 // are already canonical little-endian 8xu32 integers in HBM ([n][4096][8]); writes n compressed
 // points.  Used by compute_kzg_proof (quotient polynomial) and friends.
 int msm_commit_table_raw_device(DeviceCtx *ctx, uint8_t *d_out48, const uint32_t *d_scalars, size_t n);
+
+// call-time tables (msm.hip): a fixed-base table over points that arrive with the call, and sums over it
+void call_table_geometry(FixedBaseTable *t, int npoints, int wbits);
+size_t call_table_tmp_bytes(const FixedBaseTable &t);
+int call_table_enqueue(hipStream_t stream, FixedBaseTable *t, G1Affine *d_table, uint8_t *d_tmp, const G1Affine *d_bases);
+size_t table_sums_scratch_bytes(const FixedBaseTable &t, size_t nvec);
+int table_sums_enqueue(hipStream_t stream, const FixedBaseTable &t, G1XYZZ *d_sums, const uint32_t *d_scalars, size_t nvec,
+                       uint8_t *scratch);
 
 size_t msm_partials_needed(const FixedBaseTable &t, size_t nvec);
 int msm_from_digits_device(DeviceCtx *ctx, const FixedBaseTable &t, uint8_t *d_out48,

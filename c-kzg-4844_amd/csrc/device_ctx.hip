@@ -176,6 +176,7 @@ static void destroy_slot(dev::DeviceCtx *ctx) {
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->out_stream) (void)hipStreamDestroy(ctx->out_stream);
+    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     for (auto &h : ctx->h_stage) {
         if (h) (void)hipHostFree(h);
     }

@@ -315,6 +315,46 @@ struct DevTmp {  // freed on every exit path of build_fixed_base_table
 };
 }  // namespace
 
+// The launches of the affine-chain builder on an explicit stream: window bases (already in d_wb, XYZZ) to affine in
+// the 2^392 domain, segment seeds, segment steps.  d_wba: twin*npoints affine points, d_prefix: as many Fp.
+static int enqueue_affine_chain_table(hipStream_t stream, const FixedBaseTable &t, G1Affine *d_table, const G1XYZZ *d_wb,
+                                      G1Affine *d_wba, Fp *d_prefix, const std::atomic<bool> *cancel) {
+    const size_t nchains = (size_t)t.twin * t.npoints;
+    {
+        const int Lb = 16;
+        const size_t th = (nchains + Lb - 1) / Lb;
+        hipLaunchKernelGGL(k_batch_to_affine, dim3((unsigned)((th + 63) / 64)), dim3(64), 0, stream, d_wba, d_wb, d_prefix,
+                           nchains, Lb, 1);
+    }
+    // segment length: ~4096 waves of 8-segment threads when the table is large enough, 16..512 entries
+    constexpr int LSEG = 8;
+    const size_t entries = nchains * t.half;
+    size_t seg = entries / ((size_t)262144 * LSEG);
+    uint32_t seg2 = 16;
+    while (seg2 < 512 && seg2 * 2 <= seg) seg2 *= 2;
+    if (seg2 > t.half) seg2 = (uint32_t)t.half;
+    const uint32_t nseg = (uint32_t)(t.half / seg2);
+    // a background build that may be cancelled goes four windows at a time (a launch of the whole table cannot be
+    // abandoned; one window alone -- 512 waves at 16 bits -- leaves half the chip idle)
+    const size_t chains_per_launch = cancel ? (size_t)4 * t.npoints : nchains;
+    for (size_t c0 = 0; c0 < nchains; c0 += chains_per_launch) {
+        if (cancel && cancel->load(std::memory_order_relaxed)) {
+            (void)hipStreamSynchronize(stream);
+            return 5;
+        }
+        if (cancel && c0) HIP_TRY(hipStreamSynchronize(stream));
+        const size_t nc = nchains - c0 < chains_per_launch ? nchains - c0 : chains_per_launch;
+        const size_t units = nc * nseg, threads = (units + LSEG - 1) / LSEG;
+        hipLaunchKernelGGL(k_table_seeds, dim3((unsigned)((units + 63) / 64)), dim3(64), 0, stream, d_table + c0 * t.half,
+                           d_wba + c0, (uint32_t)nc, (uint32_t)t.half, seg2);
+        if (seg2 > 1)
+            hipLaunchKernelGGL(k_table_steps<LSEG>, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, stream,
+                               d_table + c0 * t.half, d_wba + c0, (uint32_t)nc, (uint32_t)t.half, seg2);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int build_fixed_base_table(DeviceCtx *ctx, FixedBaseTable *t, const G1Affine *d_bases, int npoints,
                            int wbits, double *times_ms, const std::atomic<bool> *cancel) {
     if (wbits < 2 || wbits > 16) return 1;
@@ -338,42 +378,12 @@ int build_fixed_base_table(DeviceCtx *ctx, FixedBaseTable *t, const G1Affine *d_
     hipLaunchKernelGGL(k_window_bases, dim3((npoints + 63) / 64), dim3(64), 0, ctx->stream, d_wb,
                        d_bases, npoints, wbits, t->twin);
     if (!old_builder) {
-        // affine chains (k_table_seeds / k_table_steps): window bases to affine in the 2^392 domain, then segments
         const size_t nchains = (size_t)t->twin * npoints;
         HIP_TRY(hipMalloc(&wba.p, nchains * sizeof(G1Affine)));
         HIP_TRY(hipMalloc(&prefix.p, nchains * sizeof(Fp)));
-        G1Affine *d_wba = static_cast<G1Affine *>(wba.p);
-        {
-            const int Lb = 16;
-            const size_t th = (nchains + Lb - 1) / Lb;
-            hipLaunchKernelGGL(k_batch_to_affine, dim3((unsigned)((th + 63) / 64)), dim3(64), 0, ctx->stream, d_wba, d_wb,
-                               static_cast<Fp *>(prefix.p), nchains, Lb, 1);
-        }
-        // segment length: ~4096 waves of 8-segment threads when the table is large enough, 16..512 entries
-        constexpr int LSEG = 8;
-        const size_t entries = nchains * t->half;
-        size_t seg = entries / ((size_t)262144 * LSEG);
-        uint32_t seg2 = 16;
-        while (seg2 < 512 && seg2 * 2 <= seg) seg2 *= 2;
-        if (seg2 > t->half) seg2 = (uint32_t)t->half;
-        const uint32_t nseg = (uint32_t)(t->half / seg2);
-        // a background build that may be cancelled goes four windows at a time (a launch of the whole table cannot be
-        // abandoned; one window alone -- 512 waves at 16 bits -- leaves half the chip idle)
-        const size_t chains_per_launch = cancel ? (size_t)4 * npoints : nchains;
-        for (size_t c0 = 0; c0 < nchains; c0 += chains_per_launch) {
-            if (cancel && cancel->load(std::memory_order_relaxed)) {
-                (void)hipStreamSynchronize(ctx->stream);
-                return 5;
-            }
-            if (cancel && c0) HIP_TRY(hipStreamSynchronize(ctx->stream));
-            const size_t nc = nchains - c0 < chains_per_launch ? nchains - c0 : chains_per_launch;
-            const size_t units = nc * nseg, threads = (units + LSEG - 1) / LSEG;
-            hipLaunchKernelGGL(k_table_seeds, dim3((unsigned)((units + 63) / 64)), dim3(64), 0, ctx->stream,
-                               d_table + c0 * t->half, d_wba + c0, (uint32_t)nc, (uint32_t)t->half, seg2);
-            if (seg2 > 1)
-                hipLaunchKernelGGL(k_table_steps<LSEG>, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, ctx->stream,
-                                   d_table + c0 * t->half, d_wba + c0, (uint32_t)nc, (uint32_t)t->half, seg2);
-        }
+        int rc = enqueue_affine_chain_table(ctx->stream, *t, d_table, d_wb, static_cast<G1Affine *>(wba.p),
+                                            static_cast<Fp *>(prefix.p), cancel);
+        if (rc) return rc;
     } else {
     // one window of a chunk of points at a time, so that the construction scratch (240 B per entry) stays
     // below ~2 GiB whatever the table width
@@ -1084,6 +1094,90 @@ int msm_commit_table_raw_device(DeviceCtx *ctx, uint8_t *d_out48, const uint32_t
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     collect_times(ctx);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// call-time tables: fixed-base sums over points that are only known when the call arrives
+//
+// The random-linear-combination sums of a large verification batch (sum r^i proof_i, sum r^i z_i proof_i,
+// sum r^i C_i; eip4844.c:731-746) are variable-base sums -- 128 sequential doublings per term on a ladder -- but their
+// POINTS are known long before their scalars: the commitments and proofs are 96 bytes per blob and validated while
+// the blobs (128 KB each) are still crossing PCIe, whereas r hashes every evaluation and arrives last.  So the
+// doublings are done early: a narrow fixed-base table over the 2n validated points is built on a side stream under the
+// copy (the same affine-chain builder as the setup tables, 22 windows of 6 bits: ~4 ms of otherwise idle GPU for
+// n = 4096), and once r exists the three sums are three digit vectors through k_msm_accumulate: 1.1 M table
+// additions instead of 12,288 ladders, 0.4 ms instead of 2.45 ms after the last byte.  Only worth it when the copy
+// is long enough to hide the build (ckzg_api2.hip: verify_blobs_core decides).
+// ------------------------------------------------------------------------------------------
+
+// Same as k_raw_digits for vectors of any length: scalars[vec][i][8] (canonical, little-endian words), i < npoints
+__global__ void k_raw_digits_n(int16_t *digits, const uint32_t *scalars, uint32_t npoints, size_t total, int wbits, int twin) {
+    size_t gid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    size_t vec = gid / npoints;
+    uint32_t i = (uint32_t)(gid - vec * npoints);
+    uint32_t s[8];
+    const uint4 *q = reinterpret_cast<const uint4 *>(scalars + gid * 8);
+    uint4 a = q[0], b = q[1];
+    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
+    s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+    glv_digits(digits + vec * (size_t)(2 * twin) * npoints + i, npoints, s, wbits, twin);
+}
+
+void call_table_geometry(FixedBaseTable *t, int npoints, int wbits) {
+    t->d_table = nullptr;
+    t->npoints = npoints;
+    t->wbits = wbits;
+    t->twin = FixedBaseTable::twin_for(wbits);
+    t->nwin = 2 * t->twin;
+    t->half = (size_t)1 << (wbits - 1);
+}
+
+// temporaries of call_table_enqueue: window bases (XYZZ), their affine form, prefix products
+size_t call_table_tmp_bytes(const FixedBaseTable &t) {
+    const size_t nchains = (size_t)t.twin * t.npoints;
+    return align_up(nchains * sizeof(G1XYZZ), 256) + align_up(nchains * sizeof(G1Affine), 256) + align_up(nchains * sizeof(Fp), 256);
+}
+
+// Enqueue the construction of t (geometry set by call_table_geometry) into d_table (t->bytes()) on `stream`.  d_bases:
+// npoints affine points (2^384 domain, (0,0) = infinity) that must lie in the prime-order subgroup.
+int call_table_enqueue(hipStream_t stream, FixedBaseTable *t, G1Affine *d_table, uint8_t *d_tmp, const G1Affine *d_bases) {
+    const size_t nchains = (size_t)t->twin * t->npoints;
+    G1XYZZ *d_wb = reinterpret_cast<G1XYZZ *>(d_tmp);
+    G1Affine *d_wba = reinterpret_cast<G1Affine *>(d_tmp + align_up(nchains * sizeof(G1XYZZ), 256));
+    Fp *d_prefix = reinterpret_cast<Fp *>(d_tmp + align_up(nchains * sizeof(G1XYZZ), 256) + align_up(nchains * sizeof(G1Affine), 256));
+    hipLaunchKernelGGL(k_window_bases, dim3((t->npoints + 63) / 64), dim3(64), 0, stream, d_wb, d_bases, t->npoints, t->wbits,
+                       t->twin);
+    int rc = enqueue_affine_chain_table(stream, *t, d_table, d_wb, d_wba, d_prefix, nullptr);
+    if (rc) return rc;
+    t->d_table = d_table;
+    return 0;
+}
+
+size_t table_sums_scratch_bytes(const FixedBaseTable &t, size_t nvec) {
+    const uint32_t pairs_per_vec = (uint32_t)t.nwin * t.npoints;
+    const uint32_t ppb = pick_pairs_per_block(nvec, pairs_per_vec);
+    const uint32_t bpv = (pairs_per_vec + ppb - 1) / ppb;
+    return align_up(nvec * (size_t)pairs_per_vec * sizeof(int16_t), 256) + align_up(nvec * (size_t)bpv * sizeof(G1XYZZ), 256);
+}
+
+// d_sums[v] = sum_i scalars[v][i] * base_i over the whole table, v < nvec, as fully reduced XYZZ points.  Enqueue-only.
+int table_sums_enqueue(hipStream_t stream, const FixedBaseTable &t, G1XYZZ *d_sums, const uint32_t *d_scalars, size_t nvec,
+                       uint8_t *scratch) {
+    if (!t.d_table || nvec == 0) return 2;
+    const uint32_t pairs_per_vec = (uint32_t)t.nwin * t.npoints;
+    const uint32_t ppb = pick_pairs_per_block(nvec, pairs_per_vec);
+    const uint32_t bpv = (pairs_per_vec + ppb - 1) / ppb;
+    int16_t *d_digits = reinterpret_cast<int16_t *>(scratch);
+    G1XYZZ *d_partials = reinterpret_cast<G1XYZZ *>(scratch + align_up(nvec * (size_t)pairs_per_vec * sizeof(int16_t), 256));
+    const size_t total = nvec * (size_t)t.npoints;
+    hipLaunchKernelGGL(k_raw_digits_n, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, d_digits, d_scalars,
+                       (uint32_t)t.npoints, total, t.wbits, t.twin);
+    hipLaunchKernelGGL(k_msm_accumulate<256>, dim3((unsigned)(nvec * bpv)), dim3(256), 0, stream, d_partials, t.d_table, d_digits,
+                       pairs_per_vec, ppb, t.wbits - 1, bpv, (uint32_t)t.npoints, (uint32_t)t.npoints, 1u, bpv, 0u);
+    hipLaunchKernelGGL(k_msm_reduce_partials, dim3((unsigned)nvec), dim3(64), 0, stream, d_sums, d_partials, bpv);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 

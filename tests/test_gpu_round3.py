@@ -301,3 +301,32 @@ def test_fan_out_of_pipelined_verification_and_async_tables_over_two_replicas(ma
         assert _host(api, bb, cc, pp, n) == (0, True)
     finally:
         api.close()
+
+
+def test_call_time_table_sums_with_points_at_infinity(hip, rt, material):
+    """Host-pointer batches of >= 2560 blobs take their three random-linear-combination sums from a fixed-base table
+    built over the batch's own commitments and proofs while the blobs are copied (msm.hip: call-time tables).  The
+    all-zero blob has the point at infinity as commitment AND proof: its table rows are all infinity."""
+    blobs, cm, pr = material
+    n = 2600
+    inf48 = b"\xc0" + bytes(47)
+    zero = bytes(131072)
+    assert hip.blob_to_kzg_commitment(zero) == inf48 and hip.compute_blob_kzg_proof(zero, inf48) == inf48
+    order = [(3 * i + i // 11) % 8 for i in range(n)]
+    zeros = set(range(5, n, 9)) | {0, n - 1}
+    bb = b"".join(zero if i in zeros else blobs[order[i]] for i in range(n))
+    cc = b"".join(inf48 if i in zeros else cm[order[i]] for i in range(n))
+    pp = b"".join(inf48 if i in zeros else pr[order[i]] for i in range(n))
+    assert _host(hip, bb, cc, pp, n) == (0, True)
+    for at in (1, 1300, n - 2):          # a wrong (valid) proof for a non-zero blob
+        assert at not in zeros
+        bad = pp[:48 * at] + pr[(order[at] + 1) % 8] + pp[48 * (at + 1):]
+        assert _host(hip, bb, cc, bad, n) == (0, False), at
+    # a non-trivial proof claimed for the zero blob, and infinity claimed for a real one
+    bad = pp[:48 * 5] + pr[0] + pp[48 * 6:]
+    assert _host(hip, bb, cc, bad, n) == (0, False)
+    bad = pp[:48 * 6] + inf48 + pp[48 * 7:]
+    assert 6 not in zeros and _host(hip, bb, cc, bad, n) == (0, False)
+    # the same verdicts from the resident form (per-term ladders)
+    assert _device(hip, rt, bb, cc, pp, n) == (0, True)
+    assert _device(hip, rt, bb, cc, bad, n) == (0, False)
