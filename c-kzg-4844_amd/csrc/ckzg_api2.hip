@@ -1268,11 +1268,39 @@ static C_KZG_RET verify_cells_on(dev::DeviceCtx *ctx, bool *ok, const Bytes48 *c
         cidx[i] = j;
     }
     const size_t nc = uniq.size();
+    // Call-time table (msm.hip), as in verify_blobs_core: the transcript of a large cell batch is ONE SHA-256 stream
+    // over every cell (1 us per cell on a SHA-NI core) during which the GPU has nothing to do once the points are
+    // decompressed -- time enough to build a 6-bit fixed-base table over the batch's proofs, its distinct commitments
+    // and the 64 setup points of the interpolation commitment, so that the four sums that follow the challenge are
+    // table sums (0.4 ms) instead of ladders (2.2 ms).  From 4096 cells (a 4 ms hash) upwards.
+    static const int call_table_wbits = []() {
+        const char *e = getenv("CKZG_HIP_VERIFY_TABLE_WBITS");   // 0 switches the call-time table off (A/B)
+        return e && *e ? atoi(e) : 6;
+    }();
+    static const size_t cell_table_min = []() {
+        const char *e = getenv("CKZG_HIP_VERIFY_CELL_TABLE_MIN");
+        return e && *e ? (size_t)atol(e) : (size_t)4096;
+    }();
+    const bool use_table = call_table_wbits >= 4 && call_table_wbits <= 10 && n >= cell_table_min;
+    const size_t npts = n + nc + (use_table ? l : 0);   // proofs, distinct commitments [, g1_values_monomial[0..63]]
+    dev::FixedBaseTable tbl;
+    size_t tbl_bytes = 0, tbl_tmp = 0, sums_scratch = 0;
+    if (use_table) {
+        dev::call_table_geometry(&tbl, (int)npts, call_table_wbits);
+        tbl_bytes = tbl.bytes();
+        tbl_tmp = dev::call_table_tmp_bytes(tbl);
+        sums_scratch = dev::table_sums_scratch_bytes(tbl, 4);
+    }
     Arena &ar = ctx->api_arena;
-    OKM(ar.begin((n + nc) * (48 + 2 + sizeof(G1Affine)) + ((size_t)CELLS_PER_EXT_BLOB * l + l + n * l + n) * sizeof(Fr) +
-                 n * BYTES_PER_CELL + (n + CELLS_PER_EXT_BLOB + 1 + n) * 4));
+    OKM(ar.begin(npts * (48 + 2 + sizeof(G1Affine)) + ((size_t)CELLS_PER_EXT_BLOB * l + l + n * l + n) * sizeof(Fr) +
+                 n * BYTES_PER_CELL + (n + CELLS_PER_EXT_BLOB + 1 + n) * 4 + tbl_bytes + tbl_tmp + sums_scratch +
+                 (use_table ? 4 * npts * 32 + 2048 : 0) + 4096));
     ABuf<uint8_t> d_ptb(ar, (n + nc) * 48), d_st(ar, n + nc), d_st2(ar, n + nc), d_cells(ar, n * BYTES_PER_CELL);
-    ABuf<G1Affine> d_pts(ar, n + nc);
+    ABuf<G1Affine> d_pts(ar, npts);
+    ABuf<uint8_t> d_tbl(ar, use_table ? tbl_bytes : 1), d_tbl_tmp(ar, use_table ? tbl_tmp : 1), d_sums_scr(ar, use_table ? sums_scratch : 1);
+    ABuf<uint32_t> d_sc(ar, use_table ? 4 * npts * 8 : 1);
+    ABuf<G1XYZZ> d_sums(ar, 4);
+    OKM(d_tbl.p && d_tbl_tmp.p && d_sums_scr.p && d_sc.p && d_sums.p);
     ABuf<Fr> d_agg(ar, (size_t)CELLS_PER_EXT_BLOB * l), d_interp(ar, l), d_cellfr(ar, n * l), d_rp(ar, n);
     ABuf<uint32_t> d_bad(ar, n), d_csr(ar, CELLS_PER_EXT_BLOB + 1 + n);
     OKM(d_ptb.p && d_st.p && d_st2.p && d_cells.p && d_pts.p && d_agg.p && d_interp.p && d_cellfr.p && d_rp.p &&
@@ -1291,17 +1319,30 @@ static C_KZG_RET verify_cells_on(dev::DeviceCtx *ctx, bool *ok, const Bytes48 *c
     // (~1 ms of dependent doublings) on the second stream, next to the sums that already use the points.
     // A point outside the subgroup makes those sums meaningless, not unsafe; they are discarded below.
     RC(dev::decompress_g1_batch_device(ctx, d_pts.p, d_st.p, d_ptb.p, n + nc));
-    if (!ctx->stage_ev[0]) OKB(hipEventCreateWithFlags(&ctx->stage_ev[0], hipEventDisableTiming) == hipSuccess);
-    if (!ctx->stage_ev[1]) OKB(hipEventCreateWithFlags(&ctx->stage_ev[1], hipEventDisableTiming) == hipSuccess);
+    if (use_table)
+        OKB(hipMemcpyAsync(d_pts.p + n + nc, ctx->d_mono, l * sizeof(G1Affine), hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess);
+    for (int i = 0; i < 3; i++) {
+        if (!ctx->stage_ev[i]) OKB(hipEventCreateWithFlags(&ctx->stage_ev[i], hipEventDisableTiming) == hipSuccess);
+    }
     OKB(hipEventRecord(ctx->stage_ev[0], ctx->stream) == hipSuccess);
     OKB(hipStreamWaitEvent(ctx->copy_stream, ctx->stage_ev[0], 0) == hipSuccess);
     RC(dev::subgroup_g1_batch_device(ctx, d_st2.p, d_pts.p, n + nc, ctx->copy_stream));
     OKB(hipEventRecord(ctx->stage_ev[1], ctx->copy_stream) == hipSuccess);
-    // whatever path leaves this function, the second stream must be idle before the arena is reused
+    // whatever path leaves this function, the other streams must be idle before the arena is reused
     struct StreamDrain {
         hipStream_t s;
-        ~StreamDrain() { (void)hipStreamSynchronize(s); }
+        ~StreamDrain() {
+            if (s) (void)hipStreamSynchronize(s);
+        }
     } drain{ctx->copy_stream};
+    if (use_table) {
+        // (a point outside the subgroup makes the table meaningless, not unsafe: the call ends in BADARGS below)
+        if (!ctx->aux_stream) OKB(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) == hipSuccess);
+        OKB(hipStreamWaitEvent(ctx->aux_stream, ctx->stage_ev[0], 0) == hipSuccess);
+        RC(dev::call_table_enqueue(ctx->aux_stream, &tbl, reinterpret_cast<G1Affine *>(d_tbl.p), d_tbl_tmp.p, d_pts.p));
+        OKB(hipEventRecord(ctx->stage_ev[2], ctx->aux_stream) == hipSuccess);
+    }
+    StreamDrain drain_aux{use_table ? ctx->aux_stream : nullptr};
     tr.mark("dedup + enqueue validation");
     Fr r;
     compute_verify_cell_kzg_proof_batch_challenge((fr_t *)&r, uniq.data(), nc, cidx.data(), cell_indices, cells,
@@ -1346,7 +1387,20 @@ static C_KZG_RET verify_cells_on(dev::DeviceCtx *ctx, bool *ok, const Bytes48 *c
     // all four lincombs (eip7594.c:926, :530, :807 and the commitment to the aggregated interpolation
     // polynomial over the first 64 monomial setup points, :758) in one launch
     G1Jac lc[4];
-    {
+    if (use_table) {
+        // four scalar vectors over the npts table points: [proofs | distinct commitments | 64 monomial setup points]
+        const size_t row = npts * 8;   // words per vector
+        OKB(hipMemsetAsync(d_sc.p, 0, 4 * npts * 32, ctx->stream) == hipSuccess);
+        OKB(hipMemcpyAsync(d_sc.p + 0 * row, rp_raw.data(), n * 32, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
+        OKB(hipMemcpyAsync(d_sc.p + 1 * row + n * 8, wts_raw.data(), nc * 32, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
+        OKB(hipMemcpyAsync(d_sc.p + 2 * row, wrp_raw.data(), n * 32, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
+        OKB(hipMemcpyAsync(d_sc.p + 3 * row + (n + nc) * 8, d_interp.p, l * 32, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess);
+        OKB(hipStreamWaitEvent(ctx->stream, ctx->stage_ev[2], 0) == hipSuccess);   // the table is complete
+        RC(dev::table_sums_enqueue(ctx->stream, tbl, d_sums.p, d_sc.p, 4, d_sums_scr.p));
+        G1XYZZ hs[4];
+        OKB(d_sums.down(hs, 4));
+        for (int j = 0; j < 4; j++) lc[j] = jac_from_xyzz(hs[j]);
+    } else {
         LincombJob jobs[4] = {{d_pts.p, &rp_raw}, {d_pts.p + n, &wts_raw}, {d_pts.p, &wrp_raw},
                               {ctx->d_mono, nullptr, (const RawScalar *)d_interp.p, l}};
         C_KZG_RET ret = gpu_lincomb_multi(ctx, lc, jobs, 4);
