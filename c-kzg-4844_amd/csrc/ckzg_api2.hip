@@ -1272,14 +1272,16 @@ static C_KZG_RET verify_cells_on(dev::DeviceCtx *ctx, bool *ok, const Bytes48 *c
     // over every cell (1 us per cell on a SHA-NI core) during which the GPU has nothing to do once the points are
     // decompressed -- time enough to build a 6-bit fixed-base table over the batch's proofs, its distinct commitments
     // and the 64 setup points of the interpolation commitment, so that the four sums that follow the challenge are
-    // table sums (0.4 ms) instead of ladders (2.2 ms).  From 4096 cells (a 4 ms hash) upwards.
+    // table sums (0.4 ms) instead of ladders (2.2 ms).  Measured (tools/bench_verify_cells.py, same box): n = 8192
+    // 13.12 -> 10.96 ms, n = 16384 23.9 -> 20.4 ms, n = 4096 8.17 -> 8.40 ms (a 4 ms hash does not hide the build):
+    // from 6144 cells upwards.
     static const int call_table_wbits = []() {
         const char *e = getenv("CKZG_HIP_VERIFY_TABLE_WBITS");   // 0 switches the call-time table off (A/B)
         return e && *e ? atoi(e) : 6;
     }();
     static const size_t cell_table_min = []() {
         const char *e = getenv("CKZG_HIP_VERIFY_CELL_TABLE_MIN");
-        return e && *e ? (size_t)atol(e) : (size_t)4096;
+        return e && *e ? (size_t)atol(e) : (size_t)6144;
     }();
     const bool use_table = call_table_wbits >= 4 && call_table_wbits <= 10 && n >= cell_table_min;
     const size_t npts = n + nc + (use_table ? l : 0);   // proofs, distinct commitments [, g1_values_monomial[0..63]]

@@ -333,7 +333,7 @@ def test_call_time_table_sums_with_points_at_infinity(hip, rt, material):
 
 
 def test_call_time_table_sums_in_cell_batch_verification(hip, oracle, material):
-    """verify_cell_kzg_proof_batch over >= 4096 cells takes its four sums from a table built over the batch's proofs,
+    """verify_cell_kzg_proof_batch over >= 6144 cells takes its four sums from a table built over the batch's proofs,
     its distinct commitments and the 64 monomial setup points while the host hashes the transcript (eip7594.c:825-974).
     Cells of the all-zero blob carry the point at infinity as commitment and as proof; unsorted, duplicated cells."""
     blobs, cm, pr = material
@@ -341,25 +341,31 @@ def test_call_time_table_sums_in_cell_batch_verification(hip, oracle, material):
     inf48 = b"\xc0" + bytes(47)
     zero_cells, zero_proofs = hip.compute_cells_and_kzg_proofs(bytes(131072))
     assert all(p == inf48 for p in zero_proofs)
-    n = 4300
+    n = 6200
     ent = [((7 * i + i // 13) % 4, (31 * i + 5) % 128) for i in range(n)]   # blob 3 = the zero blob; duplicates occur
     com = [inf48 if b == 3 else cm[b] for b, _ in ent]
     cells = [zero_cells[c] if b == 3 else cp[b][0][c] for b, c in ent]
     proofs = [inf48 if b == 3 else cp[b][1][c] for b, c in ent]
     idx = [c for _, c in ent]
     assert hip.verify_cell_kzg_proof_batch(com, idx, cells, proofs) is True
-    assert hip.verify_cell_kzg_proof_batch(com[:4095], idx[:4095], cells[:4095], proofs[:4095]) is True   # ladders: same verdict
+    assert hip.verify_cell_kzg_proof_batch(com[:6143], idx[:6143], cells[:6143], proofs[:6143]) is True   # ladders: same verdict
     for at in (0, 2222, n - 1):
         b, c = ent[at]
         p2 = list(proofs)
         p2[at] = cp[(b + 1) % 3][1][c]       # a valid point, the wrong proof
         assert hip.verify_cell_kzg_proof_batch(com, idx, cells, p2) is False, at
     c2 = list(com)
+    assert ent[17][0] != 3
     c2[17] = cm[(ent[17][0] + 1) % 3]
     assert hip.verify_cell_kzg_proof_batch(c2, idx, cells, proofs) is False
     i2 = list(idx)
-    i2[100] = (i2[100] + 1) % 128
+    at = next(i for i in range(100, n) if ent[i][0] != 3)   # (for the zero blob every index is a true statement)
+    i2[at] = (i2[at] + 1) % 128
     assert hip.verify_cell_kzg_proof_batch(com, i2, cells, proofs) is False
+    zi = next(i for i in range(100, n) if ent[i][0] == 3)
+    i3 = list(idx)
+    i3[zi] = (i3[zi] + 1) % 128
+    assert hip.verify_cell_kzg_proof_batch(com, i3, cells, proofs) is True
     # a small cross-check of the whole construction against the oracle on a prefix that it can afford
     m = 300
     assert oracle.verify_cell_kzg_proof_batch(com[:m], idx[:m], cells[:m], proofs[:m]) is True
