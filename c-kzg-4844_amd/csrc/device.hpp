@@ -122,6 +122,17 @@ struct DeviceCtx {
         }                                                                                      \
     } while (0)
 
+// a device allocation that is freed on every exit path of the function holding it
+struct DevTmp {
+    void *p = nullptr;
+    DevTmp() = default;
+    DevTmp(const DevTmp &) = delete;
+    DevTmp &operator=(const DevTmp &) = delete;
+    ~DevTmp() {
+        if (p) (void)hipFree(p);
+    }
+};
+
 // returns 0 ok / 2 error / 3 out of memory (C_KZG_RET values)
 int scratch_reserve(DeviceCtx *ctx, size_t bytes);
 

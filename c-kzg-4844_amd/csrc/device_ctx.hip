@@ -277,6 +277,19 @@ static C_KZG_RET build_owner(DevicePool *pool, const KZGSettings *s, const Optio
     LoadTimes scratch_times;
     if (!lt) lt = &scratch_times;
     PhaseClock clk;
+    // The tables belong to the pool once they are published (destroy_pool frees them); a load that fails before
+    // that -- the third table does not fit, say -- must not leave the first two behind.
+    struct UnpublishedTables {
+        dev::DeviceCtx *c;
+        bool published = false;
+        ~UnpublishedTables() {
+            if (published) return;
+            for (dev::FixedBaseTable *t : {&c->commit, &c->fk20, &c->mono}) {
+                if (t->d_table) (void)hipFree(t->d_table);
+                t->d_table = nullptr;
+            }
+        }
+    } unpublished{ctx};
     CTX_TRY(hipSetDevice(ctx->device));
     C_KZG_RET r = init_slot_runtime(ctx);
     if (r != C_KZG_OK) return r;
@@ -380,6 +393,7 @@ static C_KZG_RET build_owner(DevicePool *pool, const KZGSettings *s, const Optio
         pool->pub.direct_max = ctx->direct_max;
         pool->pub.version = 1;
         ctx->tables_version = 1;
+        unpublished.published = true;
     }
     return C_KZG_OK;
 }

@@ -505,25 +505,25 @@ int fk20_setup_device(DeviceCtx *ctx, const G1Affine *d_monomial, G1Affine *h_xe
     uint32_t *d_rr = nullptr;
     int rc = ensure_roots_raw(ctx, &d_rr);
     if (rc) return rc;
-    G1XYZZ *d_xin = nullptr, *d_cols = nullptr;
-    Fp *d_prefix = nullptr;
+    DevTmp xin, cols, prefix;   // construction scratch: gone on every exit path
     const size_t npts = 64 * 128;
-    HIP_TRY(hipMalloc(&d_xin, npts * sizeof(G1XYZZ)));
-    HIP_TRY(hipMalloc(&d_cols, npts * sizeof(G1XYZZ)));
-    HIP_TRY(hipMalloc(&d_prefix, npts * sizeof(Fp)));
+    HIP_TRY(hipMalloc(&xin.p, npts * sizeof(G1XYZZ)));
+    HIP_TRY(hipMalloc(&cols.p, npts * sizeof(G1XYZZ)));
+    HIP_TRY(hipMalloc(&prefix.p, npts * sizeof(Fp)));
+    G1XYZZ *d_xin = static_cast<G1XYZZ *>(xin.p), *d_cols = static_cast<G1XYZZ *>(cols.p);
+    Fp *d_prefix = static_cast<Fp *>(prefix.p);
     if (!ctx->d_xext) HIP_TRY(hipMalloc(&ctx->d_xext, npts * sizeof(G1Affine)));
     hipLaunchKernelGGL(k_xext_gather, dim3(npts / 256), dim3(256), 0, ctx->stream, d_xin, d_monomial);
     rc = g1_fft_stages(ctx, d_xin, d_rr, 64, /*dif=*/true, 7, 1, /*inverse=*/0);
+    if (!rc) {
+        hipLaunchKernelGGL(k_xext_transpose, dim3(npts / 256), dim3(256), 0, ctx->stream, d_cols, d_xin);
+        if (hipGetLastError() != hipSuccess) rc = 2;
+    }
+    if (!rc) rc = batch_to_affine_device(ctx, ctx->d_xext, d_cols, d_prefix, npts);
+    // the scratch is freed when this function returns: nothing may still be running on it, error or not
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = 2;
     if (rc) return rc;
-    hipLaunchKernelGGL(k_xext_transpose, dim3(npts / 256), dim3(256), 0, ctx->stream, d_cols, d_xin);
-    HIP_TRY(hipGetLastError());
-    rc = batch_to_affine_device(ctx, ctx->d_xext, d_cols, d_prefix, npts);
-    if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (h_xext) HIP_TRY(hipMemcpy(h_xext, ctx->d_xext, npts * sizeof(G1Affine), hipMemcpyDeviceToHost));
-    HIP_TRY(hipFree(d_xin));
-    HIP_TRY(hipFree(d_cols));
-    HIP_TRY(hipFree(d_prefix));
     return 0;
 }
 

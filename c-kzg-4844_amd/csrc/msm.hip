@@ -306,14 +306,6 @@ int batch_to_affine_device(DeviceCtx *ctx, G1Affine *d_out, const G1XYZZ *d_in, 
     return 0;
 }
 
-namespace {
-struct DevTmp {  // freed on every exit path of build_fixed_base_table
-    void *p = nullptr;
-    ~DevTmp() {
-        if (p) (void)hipFree(p);
-    }
-};
-}  // namespace
 
 // The launches of the affine-chain builder on an explicit stream: window bases (already in d_wb, XYZZ) to affine in
 // the 2^392 domain, segment seeds, segment steps.  d_wba: twin*npoints affine points, d_prefix: as many Fp.

@@ -1,0 +1,260 @@
+"""Runs under LD_PRELOAD=failalloc.so (tests/test_gpu_alloc_failures.py starts it): every device / page-locked
+allocation of every entry point is made to fail in turn.  What must hold each time (the reference's error
+convention, src/common/ret.h:24-29): the call returns C_KZG_MALLOC -- or succeeds with the right bytes, where the
+library has a smaller fallback --, never another code, never a crash; nothing is leaked; the same call right after
+is fine.  Prints one JSON line."""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from kzg_ctypes import Kzg, KzgError, HIP_SO  # noqa: E402
+
+LIB = os.environ.get("CKZG_HIP_SO") or HIP_SO
+fa = C.CDLL(os.environ["FAILALLOC_SO"])
+fa.failalloc_arm.argtypes = [C.c_long, C.c_int]
+fa.failalloc_fired.restype = C.c_long
+fa.failalloc_seen.restype = C.c_long
+fa.failalloc_free_bytes.restype = C.c_longlong
+C_KZG_MALLOC = 3
+
+
+def blobs(n, seed):
+    a = np.random.default_rng(seed).integers(0, 256, size=(n, 4096, 32), dtype=np.uint8)
+    a[:, :, 0] = 0
+    return a.reshape(n, -1).tobytes()
+
+
+def ret_code(e):
+    s = str(e)
+    return int(s.rsplit(" ", 1)[1]) if "C_KZG_RET" in s or "->" in s else None
+
+
+def load(options=None, precompute=0):
+    return Kzg(LIB, "", precompute=precompute, options=options or {})
+
+
+report = {"ops": {}, "load": {}}
+k0 = load()
+blob = blobs(1, 1)
+_many = blobs(40, 2)
+many = [_many[i * 131072:(i + 1) * 131072] for i in range(40)]
+commitment = k0.blob_to_kzg_commitment(blob)
+proof = k0.compute_blob_kzg_proof(blob, commitment)
+cells, cproofs = k0.compute_cells_and_kzg_proofs(blob)
+many_c = [k0.blob_to_kzg_commitment(b) for b in many]
+many_p = [k0.compute_blob_kzg_proof(b, c) for b, c in zip(many, many_c)]
+half = list(range(0, 128, 2))
+half_cells = [cells[i] for i in half]
+z = (7).to_bytes(32, "big")
+kproof, ky = k0.compute_kzg_proof(blob, z)
+k0.close()
+
+OPS = {
+    "blob_to_kzg_commitment": lambda k: k.blob_to_kzg_commitment(blob),
+    "compute_kzg_proof": lambda k: k.compute_kzg_proof(blob, z),
+    "compute_blob_kzg_proof": lambda k: k.compute_blob_kzg_proof(blob, commitment),
+    "verify_kzg_proof": lambda k: k.verify_kzg_proof(commitment, z, ky, kproof),
+    "verify_blob_kzg_proof": lambda k: k.verify_blob_kzg_proof(blob, commitment, proof),
+    "verify_blob_kzg_proof_batch": lambda k: k.verify_blob_kzg_proof_batch(many, many_c, many_p),
+    "compute_cells_and_kzg_proofs": lambda k: k.compute_cells_and_kzg_proofs(blob),
+    "compute_cells": lambda k: k.compute_cells(blob),
+    "recover_cells_and_kzg_proofs": lambda k: k.recover_cells_and_kzg_proofs(half, half_cells),
+    "verify_cell_kzg_proof_batch": lambda k: k.verify_cell_kzg_proof_batch([commitment] * 128, list(range(128)),
+                                                                           cells, cproofs),
+}
+
+
+# the additive batch entry points (include/ckzg_hip.h), host pointers: staging buffers, pipelines, result drains
+def commit_batch(k, n=40):
+    out, st = C.create_string_buffer(48 * n), C.create_string_buffer(n)
+    k._call("ckzg_hip_blob_to_kzg_commitment_batch", out, st, b"".join(many[:n]), C.c_uint64(n), k.sp)
+    return out.raw, st.raw
+
+
+def cells_batch(k, n=9):   # more blobs than the low-latency proof path takes: the FK20 pipeline
+    cl, pr, st = C.create_string_buffer(128 * 2048 * n), C.create_string_buffer(128 * 48 * n), C.create_string_buffer(n)
+    k._call("ckzg_hip_compute_cells_and_kzg_proofs_batch", cl, pr, st, b"".join(many[:n]), C.c_uint64(n), k.sp)
+    return cl.raw, pr.raw, st.raw
+
+
+def proof_batch(k, n=5):
+    pr, st = C.create_string_buffer(48 * n), C.create_string_buffer(n)
+    k._call("ckzg_hip_compute_blob_kzg_proof_batch", pr, st, b"".join(many[:n]), b"".join(many_c[:n]), C.c_uint64(n), k.sp)
+    return pr.raw, st.raw
+
+
+def recover_batch(k, rows=3):
+    idx = (C.c_uint64 * 64)(*half)
+    cl, pr, st = (C.create_string_buffer(128 * 2048 * rows), C.create_string_buffer(128 * 48 * rows),
+                  C.create_string_buffer(rows))
+    k._call("ckzg_hip_recover_cells_and_kzg_proofs_batch", cl, pr, st, idx, b"".join(half_cells) * rows,
+            C.c_uint64(64), C.c_uint64(rows), k.sp)
+    return cl.raw, pr.raw, st.raw
+
+
+OPS.update({
+    "ckzg_hip_blob_to_kzg_commitment_batch": commit_batch,
+    "ckzg_hip_compute_cells_and_kzg_proofs_batch": cells_batch,
+    "ckzg_hip_compute_blob_kzg_proof_batch": proof_batch,
+    "ckzg_hip_recover_cells_and_kzg_proofs_batch": recover_batch,
+})
+only = os.environ.get("FAILALLOC_ONLY")
+if only:
+    OPS = {n: f for n, f in OPS.items() if n in only.split(",")}
+
+problems = []
+# Leak checks compare hipMemGetInfo's free figure with the one taken after a SUCCESSFUL run of the same thing: the
+# runtime keeps pools of its own (hundreds of MB after the first kernels, constant afterwards) that are no leak.
+LEAK = 4 << 20
+max_delta = 0
+
+
+def check_leak(what, free_before):
+    global max_delta
+    d = free_before - fa.failalloc_free_bytes()
+    max_delta = max(max_delta, d)
+    if d > LEAK:
+        problems.append("%s: %d bytes of device memory not returned" % (what, d))
+    return d
+
+# ---- every allocation of the FIRST call of each entry point on a fresh KZGSettings (that is where the arenas,
+# ---- the page-locked staging buffers and the lazily built tables are allocated), one failure and sticky failure
+for name, op in OPS.items():
+    k = load()
+    want = op(k)
+    k.close()
+    free0 = fa.failalloc_free_bytes()
+    for sticky in (0, 1):
+        fired_total = 0
+        n_alloc = None
+        for nth in range(0, 64):
+            k = load()
+            fa.failalloc_arm(nth, sticky)
+            got, code = None, 0
+            try:
+                got = op(k)
+            except KzgError as e:
+                code = ret_code(e)
+            fired = fa.failalloc_fired()
+            seen = fa.failalloc_seen()
+            fa.failalloc_disarm()
+            if not fired:
+                n_alloc = seen
+                if got != want:
+                    problems.append("%s: unarmed result differs" % name)
+                k.close()
+                break
+            fired_total += 1
+            if code not in (0, C_KZG_MALLOC):
+                problems.append("%s: allocation %d failed (sticky=%d) -> C_KZG_RET %s" % (name, nth, sticky, code))
+            if code == 0 and got != want:
+                problems.append("%s: allocation %d failed (sticky=%d) -> OK with WRONG result" % (name, nth, sticky))
+            try:   # the same settings, the same call, right after the failure
+                if op(k) != want:
+                    problems.append("%s: wrong result on the call after failed allocation %d" % (name, nth))
+            except KzgError as e:
+                problems.append("%s: call after failed allocation %d -> %s" % (name, nth, e))
+            k.close()
+            check_leak("%s, failed allocation %d (sticky=%d)" % (name, nth, sticky), free0)
+        report["ops"].setdefault(name, {})["sticky" if sticky else "single"] = {"allocations": n_alloc,
+                                                                                "failures_injected": fired_total}
+
+# ---- load_trusted_setup itself: C_KZG_MALLOC, the struct left freeable, device memory back where it was
+k = load()
+assert k.blob_to_kzg_commitment(blob) == commitment
+k.close()
+free0 = fa.failalloc_free_bytes()
+for sticky in (0, 1):
+    injected, n_alloc, leaked = 0, None, 0
+    nth = 0
+    while nth < 4000:
+        fa.failalloc_arm(nth, sticky)
+        code, k = 0, None
+        try:
+            k = load()
+        except KzgError as e:
+            code = ret_code(e)
+        fired, seen = fa.failalloc_fired(), fa.failalloc_seen()
+        fa.failalloc_disarm()
+        if k is not None:
+            if k.blob_to_kzg_commitment(blob) != commitment:
+                problems.append("load: settings loaded around failed allocation %d commit wrongly" % nth)
+            k.close()
+        if not fired:
+            n_alloc = seen
+            break
+        injected += 1
+        if code not in (0, C_KZG_MALLOC):
+            problems.append("load: allocation %d failed (sticky=%d) -> %s" % (nth, sticky, code))
+        leaked = max(leaked, check_leak("load, failed allocation %d (sticky=%d)" % (nth, sticky), free0))
+        nth += 1 if nth < 48 else 7
+    report["load"]["sticky" if sticky else "single"] = {"allocations": n_alloc, "failures_injected": injected,
+                                                        "leaked_bytes": leaked}
+
+# ---- two table sets ("replicas": the one-GPU stand-in for "devices"): the load builds both, a batch fans out over
+# ---- both with one worker thread each, and a failure on either side must come back as C_KZG_MALLOC just the same
+k = load(options={"replicas": 2})
+want_fan = (commit_batch(k, 40), k.verify_blob_kzg_proof_batch(many, many_c, many_p))
+k.close()
+free0 = fa.failalloc_free_bytes()
+injected = 0
+for nth in range(0, 96):
+    fa.failalloc_arm(nth, 0)
+    code, k = 0, None
+    try:
+        k = load(options={"replicas": 2})
+    except KzgError as e:
+        code = ret_code(e)
+    load_fired = fa.failalloc_fired()
+    if k is not None and not load_fired:   # the load is through: the failure lands in the fanned-out calls
+        got = None
+        try:
+            got = (commit_batch(k, 40), k.verify_blob_kzg_proof_batch(many, many_c, many_p))
+        except KzgError as e:
+            code = ret_code(e)
+        if got is not None and got != want_fan:
+            problems.append("fan-out: wrong result with failed allocation %d" % nth)
+    fired = fa.failalloc_fired()
+    fa.failalloc_disarm()
+    if k is not None:
+        try:
+            if (commit_batch(k, 40), k.verify_blob_kzg_proof_batch(many, many_c, many_p)) != want_fan:
+                problems.append("fan-out: wrong result on the calls after failed allocation %d" % nth)
+        except KzgError as e:
+            problems.append("fan-out: calls after failed allocation %d -> %s" % (nth, e))
+        k.close()
+    if not fired:
+        break
+    injected += 1
+    if code not in (0, C_KZG_MALLOC):
+        problems.append("fan-out: allocation %d failed -> C_KZG_RET %s" % (nth, code))
+    check_leak("fan-out, failed allocation %d" % nth, free0)
+k0.lib.ckzg_hip_set_option(b"replicas", 1)
+report["fan_out"] = {"failures_injected": injected}
+
+# ---- background widening under an exhausted device: the tables stay at whatever width was reached, calls go on
+k = load(options={"async_tables": 1, "commit_wbits": 13, "proof_wbits": 11, "fk20_wbits": 10})
+fa.failalloc_arm(0, 1)
+k.lib.ckzg_hip_wait_tables.argtypes = [C.c_void_p]
+k.lib.ckzg_hip_wait_tables(k.sp)
+fa.failalloc_disarm()
+try:
+    if k.blob_to_kzg_commitment(blob) != commitment:
+        problems.append("widening: wrong commitment after the widener ran out of memory")
+    if k.compute_cells_and_kzg_proofs(blob) != (cells, cproofs):
+        problems.append("widening: wrong cells/proofs after the widener ran out of memory")
+except KzgError as e:
+    problems.append("widening: %s" % e)
+for o, v in (("async_tables", 0), ("commit_wbits", 10), ("proof_wbits", 8), ("fk20_wbits", 0)):
+    k.lib.ckzg_hip_set_option(o.encode(), v)
+k.close()
+check_leak("after the widening run", free0)
+report["max_free_delta_bytes"] = max_delta
+report["problems"] = problems
+print(json.dumps(report))
+sys.exit(1 if problems else 0)
