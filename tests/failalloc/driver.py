@@ -38,7 +38,7 @@ def load(options=None, precompute=0):
     return Kzg(LIB, "", precompute=precompute, options=options or {})
 
 
-report = {"ops": {}, "load": {}}
+report = {"load": {}}
 k0 = load()
 blob = blobs(1, 1)
 _many = blobs(40, 2)
@@ -122,79 +122,103 @@ def check_leak(what, free_before):
         problems.append("%s: %d bytes of device memory not returned" % (what, d))
     return d
 
-# ---- every allocation of the FIRST call of each entry point on a fresh KZGSettings (that is where the arenas,
-# ---- the page-locked staging buffers and the lazily built tables are allocated), one failure and sticky failure
-for name, op in OPS.items():
+C_KZG_ERROR = 2
+fa.failalloc_class.argtypes = [C.c_int]
+
+
+def walk_ops(cls, allowed, stickies, key):
+    """every allocation of the FIRST call of each entry point on a fresh KZGSettings (that is where the arenas, the
+    page-locked staging buffers, the events and the lazily built tables are created)"""
+    fa.failalloc_class(cls)
+    for name, op in OPS.items():
+        k = load()
+        want = op(k)
+        k.close()
+        free0 = fa.failalloc_free_bytes()
+        for sticky in stickies:
+            fired_total = 0
+            n_alloc = None
+            for nth in range(0, 64):
+                k = load()
+                fa.failalloc_arm(nth, sticky)
+                got, code = None, 0
+                try:
+                    got = op(k)
+                except KzgError as e:
+                    code = ret_code(e)
+                fired = fa.failalloc_fired()
+                seen = fa.failalloc_seen()
+                fa.failalloc_disarm()
+                if not fired:
+                    n_alloc = seen
+                    if got != want:
+                        problems.append("%s: unarmed result differs" % name)
+                    k.close()
+                    break
+                fired_total += 1
+                what = "%s, %s %d failed (sticky=%d)" % (name, key, nth, sticky)
+                if code not in allowed:
+                    problems.append("%s -> C_KZG_RET %s" % (what, code))
+                if code == 0 and got != want:
+                    problems.append("%s -> OK with WRONG result" % what)
+                try:   # the same settings, the same call, right after the failure
+                    if op(k) != want:
+                        problems.append("%s: wrong result on the call after" % what)
+                except KzgError as e:
+                    problems.append("%s: call after -> %s" % (what, e))
+                k.close()
+                check_leak(what, free0)
+            report[key].setdefault(name, {})["sticky" if sticky else "single"] = {"seen": n_alloc,
+                                                                                  "failures_injected": fired_total}
+    fa.failalloc_class(0)
+
+
+def walk_load(cls, allowed, stickies, key):
+    """load_trusted_setup itself: the error code, the struct left freeable, device memory back where it was"""
+    fa.failalloc_class(cls)
     k = load()
-    want = op(k)
+    assert k.blob_to_kzg_commitment(blob) == commitment
     k.close()
     free0 = fa.failalloc_free_bytes()
-    for sticky in (0, 1):
-        fired_total = 0
-        n_alloc = None
-        for nth in range(0, 64):
-            k = load()
+    for sticky in stickies:
+        injected, n_alloc, leaked = 0, None, 0
+        nth = 0
+        while nth < 4000:
             fa.failalloc_arm(nth, sticky)
-            got, code = None, 0
+            code, k = 0, None
             try:
-                got = op(k)
+                k = load()
             except KzgError as e:
                 code = ret_code(e)
-            fired = fa.failalloc_fired()
-            seen = fa.failalloc_seen()
+            fired, seen = fa.failalloc_fired(), fa.failalloc_seen()
             fa.failalloc_disarm()
+            if k is not None:
+                try:
+                    if k.blob_to_kzg_commitment(blob) != commitment:
+                        problems.append("load: settings loaded around failed %s %d commit wrongly" % (key, nth))
+                except KzgError as e:
+                    problems.append("load: commitment after a load around failed %s %d -> %s" % (key, nth, e))
+                k.close()
             if not fired:
                 n_alloc = seen
-                if got != want:
-                    problems.append("%s: unarmed result differs" % name)
-                k.close()
                 break
-            fired_total += 1
-            if code not in (0, C_KZG_MALLOC):
-                problems.append("%s: allocation %d failed (sticky=%d) -> C_KZG_RET %s" % (name, nth, sticky, code))
-            if code == 0 and got != want:
-                problems.append("%s: allocation %d failed (sticky=%d) -> OK with WRONG result" % (name, nth, sticky))
-            try:   # the same settings, the same call, right after the failure
-                if op(k) != want:
-                    problems.append("%s: wrong result on the call after failed allocation %d" % (name, nth))
-            except KzgError as e:
-                problems.append("%s: call after failed allocation %d -> %s" % (name, nth, e))
-            k.close()
-            check_leak("%s, failed allocation %d (sticky=%d)" % (name, nth, sticky), free0)
-        report["ops"].setdefault(name, {})["sticky" if sticky else "single"] = {"allocations": n_alloc,
-                                                                                "failures_injected": fired_total}
+            injected += 1
+            if code not in allowed:
+                problems.append("load: %s %d failed (sticky=%d) -> %s" % (key, nth, sticky, code))
+            leaked = max(leaked, check_leak("load, failed %s %d (sticky=%d)" % (key, nth, sticky), free0))
+            nth += 1 if nth < 48 else 7
+        report["load"].setdefault(key, {})["sticky" if sticky else "single"] = {"seen": n_alloc, "failures_injected": injected,
+                                                                               "leaked_bytes": leaked}
+    fa.failalloc_class(0)
 
-# ---- load_trusted_setup itself: C_KZG_MALLOC, the struct left freeable, device memory back where it was
-k = load()
-assert k.blob_to_kzg_commitment(blob) == commitment
-k.close()
-free0 = fa.failalloc_free_bytes()
-for sticky in (0, 1):
-    injected, n_alloc, leaked = 0, None, 0
-    nth = 0
-    while nth < 4000:
-        fa.failalloc_arm(nth, sticky)
-        code, k = 0, None
-        try:
-            k = load()
-        except KzgError as e:
-            code = ret_code(e)
-        fired, seen = fa.failalloc_fired(), fa.failalloc_seen()
-        fa.failalloc_disarm()
-        if k is not None:
-            if k.blob_to_kzg_commitment(blob) != commitment:
-                problems.append("load: settings loaded around failed allocation %d commit wrongly" % nth)
-            k.close()
-        if not fired:
-            n_alloc = seen
-            break
-        injected += 1
-        if code not in (0, C_KZG_MALLOC):
-            problems.append("load: allocation %d failed (sticky=%d) -> %s" % (nth, sticky, code))
-        leaked = max(leaked, check_leak("load, failed allocation %d (sticky=%d)" % (nth, sticky), free0))
-        nth += 1 if nth < 48 else 7
-    report["load"]["sticky" if sticky else "single"] = {"allocations": n_alloc, "failures_injected": injected,
-                                                        "leaked_bytes": leaked}
+
+report["ops"], report["ops_streams_events"] = {}, {}
+walk_ops(0, (0, C_KZG_MALLOC), (0, 1), "ops")
+walk_load(0, (0, C_KZG_MALLOC), (0, 1), "ops")
+# streams and events that cannot be created: an internal error (C_KZG_ERROR) or, as the runtime reports it here,
+# out of memory; same rules otherwise
+walk_ops(1, (0, C_KZG_ERROR, C_KZG_MALLOC), (0,), "ops_streams_events")
+walk_load(1, (0, C_KZG_ERROR, C_KZG_MALLOC), (0,), "ops_streams_events")
 
 # ---- two table sets ("replicas": the one-GPU stand-in for "devices"): the load builds both, a batch fans out over
 # ---- both with one worker thread each, and a failure on either side must come back as C_KZG_MALLOC just the same

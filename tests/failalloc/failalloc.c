@@ -5,6 +5,8 @@
 // are plain calloc).
 //
 //   failalloc_arm(n, sticky)   the n-th allocation from now (0-based) fails; sticky: so does every later one
+//   failalloc_class(c)         what "allocation" means: 0 device / page-locked memory (default), 1 streams and events
+//                              (those fail with hipErrorOutOfMemory too; the library reports C_KZG_ERROR or _MALLOC)
 //   failalloc_disarm()
 //   failalloc_fired()          allocations failed since the last arm
 //   failalloc_seen()           allocations seen since the last arm
@@ -21,7 +23,7 @@
 #define HIP_ERROR_OUT_OF_MEMORY 2
 
 static atomic_long g_countdown = -1;  // < 0: disarmed
-static atomic_int g_sticky = 0;
+static atomic_int g_sticky = 0, g_class = 0;
 static atomic_long g_fired = 0, g_seen = 0;
 
 void failalloc_arm(long nth, int sticky) {
@@ -30,11 +32,13 @@ void failalloc_arm(long nth, int sticky) {
     atomic_store(&g_sticky, sticky);
     atomic_store(&g_countdown, nth);
 }
+void failalloc_class(int c) { atomic_store(&g_class, c); }
 void failalloc_disarm(void) { atomic_store(&g_countdown, -1); }
 long failalloc_fired(void) { return atomic_load(&g_fired); }
 long failalloc_seen(void) { return atomic_load(&g_seen); }
 
-static int this_one_fails(void) {
+static int this_one_fails(int cls) {
+    if (cls != atomic_load(&g_class)) return 0;
     atomic_fetch_add(&g_seen, 1);
     long c = atomic_load(&g_countdown);
     for (;;) {
@@ -77,7 +81,7 @@ static void *next_symbol(const char *name) {
 int hipMalloc(void **p, size_t bytes) {
     static int (*real)(void **, size_t);
     if (!real) real = (int (*)(void **, size_t))next_symbol("hipMalloc");
-    if (this_one_fails()) {
+    if (this_one_fails(0)) {
         if (p) *p = NULL;
         return HIP_ERROR_OUT_OF_MEMORY;
     }
@@ -87,11 +91,41 @@ int hipMalloc(void **p, size_t bytes) {
 int hipHostMalloc(void **p, size_t bytes, unsigned flags) {
     static int (*real)(void **, size_t, unsigned);
     if (!real) real = (int (*)(void **, size_t, unsigned))next_symbol("hipHostMalloc");
-    if (this_one_fails()) {
+    if (this_one_fails(0)) {
         if (p) *p = NULL;
         return HIP_ERROR_OUT_OF_MEMORY;
     }
     return real(p, bytes, flags);
+}
+
+int hipStreamCreateWithFlags(void **stream, unsigned flags) {
+    static int (*real)(void **, unsigned);
+    if (!real) real = (int (*)(void **, unsigned))next_symbol("hipStreamCreateWithFlags");
+    if (this_one_fails(1)) {
+        if (stream) *stream = NULL;
+        return HIP_ERROR_OUT_OF_MEMORY;
+    }
+    return real(stream, flags);
+}
+
+int hipEventCreateWithFlags(void **event, unsigned flags) {
+    static int (*real)(void **, unsigned);
+    if (!real) real = (int (*)(void **, unsigned))next_symbol("hipEventCreateWithFlags");
+    if (this_one_fails(1)) {
+        if (event) *event = NULL;
+        return HIP_ERROR_OUT_OF_MEMORY;
+    }
+    return real(event, flags);
+}
+
+int hipEventCreate(void **event) {
+    static int (*real)(void **);
+    if (!real) real = (int (*)(void **))next_symbol("hipEventCreate");
+    if (this_one_fails(1)) {
+        if (event) *event = NULL;
+        return HIP_ERROR_OUT_OF_MEMORY;
+    }
+    return real(event);
 }
 
 long long failalloc_free_bytes(void) {
