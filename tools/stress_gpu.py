@@ -2,8 +2,12 @@
 """Soak test of the re-entrant C-ABI: T threads share ONE KZGSettings (loaded with async_tables, so the tables change
 underneath them for the first seconds) and issue a random mix of calls -- single and batch commitments, cells + proofs,
 blob-batch verification (small, mid-size and pipelined), cell-batch verification, recovery -- for a given time; every
-result is compared with values computed once by the CPU oracle.  Prints one JSON line; exit code 1 on any mismatch.
-usage: python tools/stress_gpu.py [seconds=60] [threads=8]"""
+result is compared with values computed once by the CPU oracle.  One more thread ("churn", on by default) meanwhile
+loads and frees OTHER KZGSettings in the same process -- plain loads, progressive loads freed while their tables are
+still being widened, progressive loads waited for -- and checks a commitment and a cells + proofs call on each: the
+registry of GPU contexts, the widener threads and the device allocator are shared with the callers above.
+Prints one JSON line; exit code 1 on any mismatch.
+usage: python tools/stress_gpu.py [seconds=60] [threads=8] [churn=1]"""
 import ctypes as C
 import json
 import os
@@ -23,6 +27,7 @@ from test_gpu_commitment import rand_blob  # noqa: E402
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     nthreads = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    churn = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     mod = ge.load_package()
     orc = mod.Kzg(os.path.join(ROOT, "oracle", "liboracle.so"), "okzg_")
     blobs = [rand_blob(555, i) for i in range(4)]
@@ -107,7 +112,30 @@ def main():
                 fail("%s raised %s" % (op, e))
             note(op)
 
+    def churner():
+        rnd = random.Random(77)
+        while time.perf_counter() < t_end and not errors:
+            mode = rnd.choice(["plain", "freed_while_widening", "widened"])
+            try:
+                opts = {"async_tables": 0 if mode == "plain" else 1, "commit_wbits": rnd.choice([10, 12]),
+                        "proof_wbits": rnd.choice([8, 10]), "fk20_wbits": rnd.choice([8, 9]), "streams": 2}
+                other = mod.Kzg(mod.HIP_SO, options=opts)
+                if mode == "widened":
+                    other.lib.ckzg_hip_wait_tables(C.c_void_p(C.addressof(other.s)))
+                k = rnd.randrange(4)
+                if other.blob_to_kzg_commitment(blobs[k]) != cm[k]:
+                    fail("churn %s: commitment" % mode)
+                got = other.compute_cells_and_kzg_proofs(blobs[k])
+                if got[0] != cp[k][0] or got[1] != cp[k][1]:
+                    fail("churn %s: cells" % mode)
+                other.close()
+            except Exception as e:  # noqa: BLE001
+                fail("churn %s raised %s" % (mode, e))
+            note("load_free_" + mode)
+
     th = [threading.Thread(target=worker, args=(i,)) for i in range(nthreads)]
+    if churn:
+        th.append(threading.Thread(target=churner))
     t0 = time.perf_counter()
     for t in th:
         t.start()
