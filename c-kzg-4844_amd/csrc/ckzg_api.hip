@@ -389,6 +389,7 @@ static C_KZG_RET commit_batch_on(dev::DeviceCtx *ctx, KZGCommitment *out, uint8_
         if (rc) return (C_KZG_RET)rc;
         if (hipMemcpyAsync(h_res, d_out.p, n * 49, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return C_KZG_ERROR;
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) return C_KZG_ERROR;
+        dev::commit_collect_times(ctx);
         tr.mark("copy in + kernels + copy out");
         memcpy(out, h_res, n * 48);
         for (uint64_t i = 0; i < n; i++) {

@@ -203,6 +203,8 @@ int bad_to_status_enqueue(DeviceCtx *ctx, uint8_t *d_status, const uint32_t *d_b
 // FK20 proofs from monomial coefficients already on the device ([n][4096] Fr, Montgomery)
 int fk20_proofs_device(DeviceCtx *ctx, uint8_t *d_proofs, const Fr *d_poly_monomial, size_t n);
 void fk20_collect_times(DeviceCtx *ctx);
+// after a synchronised commit_blobs_enqueue: its event pairs -> ctx->last_ms[0..3] (digits, accumulate, finalize, all)
+void commit_collect_times(DeviceCtx *ctx);
 // verify.hip
 int eval_poly_batch_device(DeviceCtx *ctx, Fr *d_y, const Fr *d_poly, const Fr *d_z, size_t n);
 int eval_quotient_batch_device(DeviceCtx *ctx, Fr *d_y, uint32_t *d_q_raw, int *d_hit, const Fr *d_poly,

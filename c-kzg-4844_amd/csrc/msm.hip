@@ -883,7 +883,7 @@ static int run_msm(DeviceCtx *ctx, const FixedBaseTable &t, uint8_t *d_out48, ui
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-static void collect_times(DeviceCtx *ctx) {
+void commit_collect_times(DeviceCtx *ctx) {
     float ms;
     if (hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]) == hipSuccess) ctx->last_ms[0] = ms;
     if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_ms[1] = ms;
@@ -1047,7 +1047,7 @@ int commit_blobs_device(DeviceCtx *ctx, uint8_t *d_out48, uint8_t *d_status, con
     rc = commit_blobs_enqueue(ctx, d_out48, d_status, d_blobs, n);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    collect_times(ctx);
+    commit_collect_times(ctx);
 #ifdef CKZG_MSM_TRACE
     if (d_trace) {
         std::vector<uint64_t> h(trace_waves * 4);
@@ -1085,7 +1085,7 @@ int msm_commit_table_raw_device(DeviceCtx *ctx, uint8_t *d_out48, const uint32_t
     rc = run_msm(ctx, t, d_out48, nullptr, d_digits, nullptr, d_partials, n, ppb);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    collect_times(ctx);
+    commit_collect_times(ctx);
     return 0;
 }
 
