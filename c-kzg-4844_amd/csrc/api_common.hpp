@@ -8,6 +8,7 @@
 #include <cinttypes>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -370,6 +371,67 @@ class CopyHelpers {
     std::mutex mu;
     std::condition_variable cv;
     std::deque<Job> q;
+    bool started = false;
+    int nworkers = 0;
+};
+
+// Persistent worker threads for the per-call host work that used to start its own (the challenge hashers of a
+// pipelined verification: 32 thread creations before the first byte moved and 32 joins after the last -- 0.3-0.5 ms
+// and 0.15 ms of a 12 ms call).  Same life cycle as CopyHelpers: started on first use, parked on a condition variable,
+// leaked at exit.  A job is any callable; completion is the submitter's business (an atomic it counts down).
+class WorkerPool {
+   public:
+    static WorkerPool &get() {
+        static WorkerPool *p = new WorkerPool();
+        return *p;
+    }
+    // false: no worker could be started; the caller runs the job some other way
+    bool submit(std::function<void()> job) {
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            if (!ensure_started()) return false;
+            q.push_back(std::move(job));
+        }
+        cv.notify_one();
+        return true;
+    }
+    int workers() {
+        std::lock_guard<std::mutex> lock(mu);
+        return ensure_started() ? nworkers : 0;
+    }
+
+   private:
+    bool ensure_started() {
+        if (started) return nworkers > 0;
+        started = true;
+        unsigned hw = std::thread::hardware_concurrency();
+        int want = hw ? (int)hw : 4;
+        if (want > 64) want = 64;   // two concurrent verifications at full width
+        for (int i = 0; i < want; i++) {
+            try {
+                std::thread([this]() { run(); }).detach();
+                nworkers++;
+            } catch (...) {
+                break;
+            }
+        }
+        return nworkers > 0;
+    }
+    void run() {
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> lock(mu);
+                cv.wait(lock, [&]() { return !q.empty(); });
+                job = std::move(q.front());
+                q.pop_front();
+            }
+            job();
+        }
+    }
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> q;
     bool started = false;
     int nworkers = 0;
 };

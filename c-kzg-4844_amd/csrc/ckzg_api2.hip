@@ -356,20 +356,85 @@ G1Jac host_lincomb(const std::vector<G1Jac> &pts, const std::vector<Fr> &k) {
 // 2.6 ms for any n up to ~16 -> hand-over after 3.
 constexpr uint64_t SMALL_VERIFY_N = 3;
 
-// Shared core of verify_blob_kzg_proof and verify_blob_kzg_proof_batch (eip4844.c:537-595,
-// 697-844).  Per blob, on the GPU: point validation, bytes -> Fr, evaluation at the challenge;
-// then three lincombs over all blobs; host: transcripts and the pairing check
-//   e(sum r^i proof_i, [s]G2) == e(sum r^i (C_i - [y_i]G1) + sum r^i z_i proof_i, G2).
+// The batch challenge's transcript (eip4844.c:637-664: one SHA-256 stream over every C_i, z_i, y_i, proof_i) hashed
+// while the batch is still in flight: the pipelined form downloads each chunk's evaluations into page-locked memory
+// right behind the kernel that produced them, and this thread feeds them to the hash in order as they land.  When
+// the last chunk has been evaluated only its own 256 entries are left to hash (~0.03 ms) instead of all of them
+// (0.49 ms at n = 4096, after the last byte and before everything that needs r).
+struct TranscriptHasher {
+    Sha256 h;
+    std::atomic<size_t> published{0};   // chunks whose download has been enqueued (its event recorded)
+    std::atomic<bool> abort{false};
+    bool failed = false;
+    std::thread t;
+    TranscriptHasher() = default;
+    TranscriptHasher(const TranscriptHasher &) = delete;
+    TranscriptHasher &operator=(const TranscriptHasher &) = delete;
+    ~TranscriptHasher() {
+        abort.store(true);
+        if (t.joinable()) t.join();
+    }
+    void start(int device, size_t n, size_t chunk, const hipEvent_t *landed, const Bytes48 *cb, const Bytes48 *pb,
+               const Fr *z, const Fr *h_y) {
+        uint8_t head[32];
+        memcpy(head, "RCKZGBATCH___V1_", 16);
+        be64(head + 16, FIELD_ELEMENTS_PER_BLOB);
+        be64(head + 24, n);
+        h.update(head, 32);
+        t = std::thread([=]() {
+            if (hipSetDevice(device) != hipSuccess) {
+                failed = true;
+                return;
+            }
+            const size_t nch = (n + chunk - 1) / chunk;
+            uint8_t zb[64];
+            for (size_t c = 0; c < nch; c++) {
+                while (published.load(std::memory_order_acquire) <= c) {
+                    if (abort.load()) return;
+                    std::this_thread::yield();
+                }
+                if (hipEventSynchronize(landed[c]) != hipSuccess) {
+                    failed = true;
+                    return;
+                }
+                const size_t lo = c * chunk, hi = lo + chunk < n ? lo + chunk : n;
+                for (size_t i = lo; i < hi; i++) {
+                    h.update(cb[i].bytes, 48);
+                    fr_to_bytes(zb, z[i]);
+                    fr_to_bytes(zb + 32, h_y[i]);
+                    h.update(zb, 64);
+                    h.update(pb[i].bytes, 48);
+                }
+            }
+        });
+    }
+    void publish(size_t chunks) { published.store(chunks, std::memory_order_release); }
+    bool finish(uint8_t digest[32]) {
+        if (t.joinable()) t.join();
+        if (failed) return false;
+        h.finish(digest);
+        return true;
+    }
+};
+
 // Host threads that hash the blobs' Fiat-Shamir challenges IN ORDER and say how far they are: the pipelined form
 // of the batch verification enqueues chunk c's evaluation as soon as the first (c + 1) * chunk challenges exist,
 // while later blobs are still crossing PCIe.  (compute_challenge, eip4844.c:147-178)
 struct OrderedHasher {
     std::atomic<size_t> next{0};
     std::vector<std::atomic<uint32_t>> done;   // per chunk: blobs hashed
+    std::atomic<int> active{0};                // pool jobs of this call that have not returned yet
     size_t n, chunk;
-    JoinThreads th;
+    JoinThreads th;                            // only when the process-wide pool could not be used
     OrderedHasher(size_t n_, size_t chunk_) : done((n_ + chunk_ - 1) / chunk_), n(n_), chunk(chunk_) {
         for (auto &d : done) d.store(0);
+    }
+    OrderedHasher(const OrderedHasher &) = delete;
+    OrderedHasher &operator=(const OrderedHasher &) = delete;
+    // nothing of this object (or of z / blobs / cb) may be touched by a worker once the call has returned
+    ~OrderedHasher() {
+        next.store(n, std::memory_order_relaxed);   // an abandoned call: the workers stop at their next blob
+        while (active.load(std::memory_order_acquire) != 0) std::this_thread::yield();
     }
     void start(Fr *z, const Blob *blobs, const Bytes48 *cb) {
         unsigned hw = std::thread::hardware_concurrency();
@@ -380,15 +445,23 @@ struct OrderedHasher {
             return e && *e ? (size_t)atol(e) : (size_t)0;
         }();
         if (forced) nt = forced;
+        auto loop = [this, z, blobs, cb]() {
+            for (;;) {
+                const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+                if (i >= n) return;
+                z[i] = challenge_from_bytes(blobs[i].bytes, cb[i].bytes);
+                done[i / chunk].fetch_add(1, std::memory_order_release);
+            }
+        };
         for (size_t t = 0; t < nt; t++) {
-            th.spawn([this, z, blobs, cb]() {
-                for (;;) {
-                    const size_t i = next.fetch_add(1, std::memory_order_relaxed);
-                    if (i >= n) return;
-                    z[i] = challenge_from_bytes(blobs[i].bytes, cb[i].bytes);
-                    done[i / chunk].fetch_add(1, std::memory_order_release);
-                }
-            });
+            active.fetch_add(1, std::memory_order_relaxed);
+            if (!WorkerPool::get().submit([this, loop]() {
+                    loop();
+                    active.fetch_sub(1, std::memory_order_release);
+                })) {
+                active.fetch_sub(1, std::memory_order_relaxed);
+                th.spawn(loop);
+            }
         }
     }
     void wait_chunk(size_t c) const {
@@ -522,8 +595,11 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
         OKB(hipEventRecord(ctx->stage_ev[1], ctx->aux_stream) == hipSuccess);           // (free: the validation is not split here)
     }
     StreamDrain drain_aux{use_table ? ctx->aux_stream : nullptr};
+    tr.mark("validation (+ call-time table) enqueued");
     std::vector<Fr> z(n), y(n);
     ProofSide ps;
+    uint8_t digest[32];
+    bool have_digest = false;   // the pipelined form hashes the batch transcript while the batch is in flight
     if (piped) {
         // ---- pipelined host-pointer form ----
         static const size_t CH = []() {   // 256 blobs = 32 MB per chunk: ~0.6 ms of PCIe, 16 chunks at n = 4096
@@ -538,36 +614,44 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
             if (!ctx->stage_ev[i]) OKB(hipEventCreateWithFlags(&ctx->stage_ev[i], hipEventDisableTiming) == hipSuccess);
         }
         hipEvent_t *copied = ctx->stage_ev + 2;
-        OrderedHasher hasher(n, CH);
-        hasher.start(z.data(), blobs, cb);   // joined by its destructor on every exit path
+        // what the host needs back -- evaluations per chunk, the flags of the blobs and of the points at the end --
+        // lands in page-locked memory behind the kernels that produce it, never through a blocking copy
+        OKM(ensure_pinned(ctx->h_out, ctx->h_out_bytes, n * sizeof(Fr)));
+        const Fr *h_y = static_cast<const Fr *>(ctx->h_out[0]);
+        uint8_t *h_y_bytes = static_cast<uint8_t *>(ctx->h_out[0]);
+        uint32_t *h_bad = static_cast<uint32_t *>(ctx->h_out[1]);
+        uint8_t *h_st = static_cast<uint8_t *>(ctx->h_out[1]) + n * 4;
+        // one event per chunk for "copied" and one for "evaluations landed": kept in the slot, not created per call
+        while (ctx->chunk_ev.size() < 2 * nch) {
+            hipEvent_t e;
+            OKB(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess);
+            ctx->chunk_ev.push_back(e);
+        }
+        hipEvent_t *const chunk_copied = ctx->chunk_ev.data(), *const landed = ctx->chunk_ev.data() + nch;
         OKB(hipMemsetAsync(d_bad.p, 0, n * 4, ctx->stream) == hipSuccess);
         // Page-locked source: every chunk's DMA is enqueued up front, each with its own event, so that the copy engine
         // runs at link speed from the first microsecond instead of at the pace this loop is allowed to advance by the
         // hashers (n = 4096: GPU idle again 1.5 ms earlier).  Pageable source: the staging copy IS the pace.
-        struct ChunkEvents {
-            std::vector<hipEvent_t> ev;
-            ~ChunkEvents() {
-                for (auto e : ev) (void)hipEventDestroy(e);
-            }
-        } chunk_ev;
         if (src_pinned) {
-            chunk_ev.ev.reserve(nch);
             for (size_t c = 0; c < nch; c++) {
                 const size_t off = c * CH, k = n - off < CH ? n - off : CH;
-                hipEvent_t e;
-                OKB(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess);
-                chunk_ev.ev.push_back(e);
                 OKB(hipMemcpyAsync(d_blobs_own.p + off * BYTES_PER_BLOB, blobs + off, k * BYTES_PER_BLOB, hipMemcpyHostToDevice,
                                    ctx->copy_stream) == hipSuccess);
-                OKB(hipEventRecord(e, ctx->copy_stream) == hipSuccess);
+                OKB(hipEventRecord(chunk_copied[c], ctx->copy_stream) == hipSuccess);
             }
         }
+        // (started after the DMAs of a page-locked source are on their way: waking the workers is host time the copy
+        // engine need not wait for)
+        OrderedHasher hasher(n, CH);
+        hasher.start(z.data(), blobs, cb);   // its destructor waits for the workers on every exit path
+        TranscriptHasher transcript;         // likewise
+        transcript.start(ctx->device, n, CH, landed, cb, pb, z.data(), h_y);
         bool used[2] = {false, false};
         for (size_t c = 0; c < nch; c++) {
             const size_t off = c * CH, k = n - off < CH ? n - off : CH;
             const int b = (int)(c & 1);
             if (src_pinned) {
-                OKB(hipStreamWaitEvent(ctx->stream, chunk_ev.ev[c], 0) == hipSuccess);
+                OKB(hipStreamWaitEvent(ctx->stream, chunk_copied[c], 0) == hipSuccess);
             } else {
                 if (used[b]) OKB(hipEventSynchronize(copied[b]) == hipSuccess);   // the DMA out of this staging buffer is done
                 staged_copy(ctx->h_stage[b], blobs + off, k * BYTES_PER_BLOB);
@@ -586,6 +670,9 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
                 hasher.wait_chunk(c - 1);
                 OKB(hipMemcpyAsync(d_z.p + po, z.data() + po, CH * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
                 RC(dev::eval_poly_batch_device(ctx, d_y.p + po, d_poly.p + po * FIELD_ELEMENTS_PER_BLOB, d_z.p + po, CH));
+                OKB(hipMemcpyAsync(h_y_bytes + po * sizeof(Fr), d_y.p + po, CH * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess);
+                OKB(hipEventRecord(landed[c - 1], ctx->stream) == hipSuccess);
+                transcript.publish(c);
             }
         }
         {
@@ -593,21 +680,26 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
             hasher.wait_chunk(nch - 1);
             OKB(hipMemcpyAsync(d_z.p + po, z.data() + po, k * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
             RC(dev::eval_poly_batch_device(ctx, d_y.p + po, d_poly.p + po * FIELD_ELEMENTS_PER_BLOB, d_z.p + po, k));
+            OKB(hipMemcpyAsync(h_y_bytes + po * sizeof(Fr), d_y.p + po, k * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess);
+            OKB(hipEventRecord(landed[nch - 1], ctx->stream) == hipSuccess);
+            transcript.publish(nch);
         }
+        OKB(hipMemcpyAsync(h_bad, d_bad.p, n * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess);
+        OKB(hipMemcpyAsync(h_st, d_st.p, 2 * n, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess);
         tr.mark("chunked H2D + bytes_to_fr + evaluation enqueued (challenges hashed in order on host threads)");
         OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
         tr.mark("wait for GPU");
-        std::vector<uint8_t> st(2 * n);
-        OKB(d_st.down(st.data(), 2 * n));
         for (size_t i = 0; i < 2 * n; i++) {
-            if (st[i]) return C_KZG_BADARGS;
+            if (h_st[i]) return C_KZG_BADARGS;
         }
-        std::vector<uint32_t> bad(n);
-        OKB(d_bad.down(bad.data(), n));
         for (size_t i = 0; i < n; i++) {
-            if (bad[i]) return C_KZG_BADARGS;
+            if (h_bad[i]) return C_KZG_BADARGS;
         }
-        OKB(d_y.down(y.data(), n));
+        memcpy(y.data(), h_y, n * sizeof(Fr));
+        tr.mark("flags checked");
+        OKB(transcript.finish(digest));
+        have_digest = true;
+        tr.mark("transcript thread joined");
     } else {
     // Challenges: on host threads, started BEFORE the blob copy -- a copy from pageable memory blocks
     // this thread for its whole duration (3.5 us per blob), and with the x86 SHA extensions the hashing
@@ -675,30 +767,52 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     }
     // r = H("RCKZGBATCH___V1_" | u64be 4096 | u64be n | (C_i | z_i | y_i | proof_i)*)  (eip4844.c:597-680);
     // valid compressed encodings are canonical, so the input bytes are the re-compressed bytes
-    Sha256 h;
-    uint8_t head[32], zb[64], digest[32];
-    memcpy(head, "RCKZGBATCH___V1_", 16);
-    be64(head + 16, FIELD_ELEMENTS_PER_BLOB);
-    be64(head + 24, n);
-    h.update(head, 32);
-    for (size_t i = 0; i < n; i++) {
-        h.update(cb[i].bytes, 48);
-        fr_to_bytes(zb, z[i]);
-        fr_to_bytes(zb + 32, y[i]);
-        h.update(zb, 64);
-        h.update(pb[i].bytes, 48);
+    if (!have_digest) {
+        Sha256 h;
+        uint8_t head[32], zb[64];
+        memcpy(head, "RCKZGBATCH___V1_", 16);
+        be64(head + 16, FIELD_ELEMENTS_PER_BLOB);
+        be64(head + 24, n);
+        h.update(head, 32);
+        for (size_t i = 0; i < n; i++) {
+            h.update(cb[i].bytes, 48);
+            fr_to_bytes(zb, z[i]);
+            fr_to_bytes(zb + 32, y[i]);
+            h.update(zb, 64);
+            h.update(pb[i].bytes, 48);
+        }
+        h.finish(digest);
     }
-    h.finish(digest);
     Fr r = fr_from_bytes_reduce(digest);
+    tr.mark("batch challenge r (one SHA-256 stream over every C, z, y, proof)");
+    G1Jac lc[3];  // sum r^i proof_i, sum r^i z_i proof_i, sum r^i C_i
+    Fr ysum = Fr::zero();
+    if (use_table) {
+        // The sums over the call-time table.  Their scalars are made where their digits are needed: one lane per blob
+        // raises r to its index (k_rlc_scalars; the challenges z are in d_z since their chunks were evaluated), so only
+        // r crosses PCIe, and while the GPU recodes and accumulates the host adds up sum r^i y_i for its side of the check.
+        OKB(hipStreamWaitEvent(ctx->stream, ctx->stage_ev[1], 0) == hipSuccess);   // the table is complete
+        RC(dev::rlc_scalars_enqueue(ctx->stream, d_sc.p, d_z.p, r, n));
+        RC(dev::table_sums_enqueue(ctx->stream, tbl, d_sums.p, d_sc.p, 3, d_sums_scr.p));
+        Fr pw = Fr::one();
+        for (size_t i = 0; i < n; i++) {
+            ysum = add(ysum, mul(pw, y[i]));
+            pw = mul(pw, r);
+        }
+        tr.mark("powers of r (host: sum r^i y_i; GPU: the scalars of the sums)");
+        G1XYZZ hs[3];
+        OKB(d_sums.down(hs, 3));
+        for (int j = 0; j < 3; j++) lc[j] = jac_from_xyzz(hs[j]);
+    } else {
     std::vector<Fr> rpf(n), rzf(n);
-    Fr pw = Fr::one(), ysum = Fr::zero();
+    Fr pw = Fr::one();
     for (size_t i = 0; i < n; i++) {
         rpf[i] = pw;
         rzf[i] = mul(pw, z[i]);
         ysum = add(ysum, mul(pw, y[i]));
         pw = mul(pw, r);
     }
-    G1Jac lc[3];  // sum r^i proof_i, sum r^i z_i proof_i, sum r^i C_i
+    tr.mark("powers of r");
     if (small) {
         lc[0] = host_lincomb(hp, rpf);
         lc[1] = host_lincomb(hp, rzf);
@@ -710,26 +824,9 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
             rz[i] = raw_of(rzf[i]);
         }
         if (resident) OKB(hipEventRecord(ctx->ev[3], ctx->stream) == hipSuccess);
-        if (use_table) {
-            // three scalar vectors over the 2n table points (commitments [0, n), proofs [n, 2n)): zeros select nothing
-            std::vector<RawScalar> sc(6 * n);
-            memset(sc.data(), 0, sc.size() * sizeof(RawScalar));
-            for (size_t i = 0; i < n; i++) {
-                sc[0 * 2 * n + n + i] = rp[i];   // sum r^i proof_i
-                sc[1 * 2 * n + n + i] = rz[i];   // sum r^i z_i proof_i
-                sc[2 * 2 * n + i] = rp[i];       // sum r^i C_i
-            }
-            OKB(hipMemcpyAsync(d_sc.p, sc.data(), sc.size() * sizeof(RawScalar), hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
-            OKB(hipStreamWaitEvent(ctx->stream, ctx->stage_ev[1], 0) == hipSuccess);   // the table is complete
-            RC(dev::table_sums_enqueue(ctx->stream, tbl, d_sums.p, d_sc.p, 3, d_sums_scr.p));
-            G1XYZZ hs[3];
-            OKB(d_sums.down(hs, 3));
-            for (int j = 0; j < 3; j++) lc[j] = jac_from_xyzz(hs[j]);
-        } else {
-            LincombJob jobs[3] = {{d_pts.p + n, &rp}, {d_pts.p + n, &rz}, {d_pts.p, &rp}};
-            C_KZG_RET ret = gpu_lincomb_multi(ctx, lc, jobs, 3);
-            if (ret != C_KZG_OK) return ret;
-        }
+        LincombJob jobs[3] = {{d_pts.p + n, &rp}, {d_pts.p + n, &rz}, {d_pts.p, &rp}};
+        C_KZG_RET ret = gpu_lincomb_multi(ctx, lc, jobs, 3);
+        if (ret != C_KZG_OK) return ret;
         if (resident) {
             // kernel-only time of the resident form (ckzg_hip_last_kernel_ms, which = 3): validation + conversion +
             // challenges + evaluation, and the three sums; the host transcript between them is not GPU time
@@ -742,6 +839,7 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
                 ctx->last_ms[2] = b;
             }
         }
+    }
     }
     if (split_validation) {
         OKB(hipEventSynchronize(ctx->stage_ev[1]) == hipSuccess);

@@ -5,6 +5,7 @@
 // reference: bindings/rust/src/bindings/mod.rs:910-913, bindings/go/main_test.go:953-971) each lease a
 // slot and overlap on the GPU instead of serialising (api_common.hpp: DevicePool, Lease).
 #pragma once
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <cstdint>
@@ -58,7 +59,11 @@ struct Arena {
         if (base) (void)hipFree(base);
         base = nullptr;
         cap = 0;
-        size_t want = bytes + (bytes >> 1);
+        // growth slack: half again for small arenas, at most 256 MB for large ones -- a 4096-blob verification with its
+        // call-time table needs 1.65 GB, and half again on top of that put it over the limit above which ArenaTrim
+        // gives the block back after every call (a hipMalloc + a synchronising hipFree per call: ~0.5-0.8 ms)
+        const size_t slack = (bytes >> 1) < ((size_t)256 << 20) ? (bytes >> 1) : ((size_t)256 << 20);
+        size_t want = bytes + slack;
         if (hipMalloc(&base, want) != hipSuccess) return false;
         cap = want;
         return true;
@@ -97,6 +102,7 @@ struct DeviceCtx {
     Scratch scratch;              // per slot: reused by every call that leases the slot
     Arena api_arena, lc_arena;    // temporaries of the host-pointer entry points / of gpu_lincomb_multi
     hipEvent_t stage_ev[4] = {};  // copied[2], consumed[2] of the staging pipeline (created on first use)
+    std::vector<hipEvent_t> chunk_ev;   // per-chunk events of the pipelined verification (grown on demand, kept)
     hipEvent_t ev[12] = {};       // timing events
     float last_ms[6] = {-1, -1, -1, -1, -1, -1};  // see ckzg_hip_last_kernel_ms
     // Fr tables for NTTs and evaluation (Montgomery form, 8 x u32)
@@ -207,6 +213,9 @@ void fk20_collect_times(DeviceCtx *ctx);
 void commit_collect_times(DeviceCtx *ctx);
 // verify.hip
 int eval_poly_batch_device(DeviceCtx *ctx, Fr *d_y, const Fr *d_poly, const Fr *d_z, size_t n);
+// d_sc[3][2n][8] <- the scalar vectors of a blob batch's three sums over a call-time table of (commitments, proofs),
+// from the batch challenge r and the blobs' challenges d_z (verify.hip: k_rlc_scalars).  Enqueue-only.
+int rlc_scalars_enqueue(hipStream_t stream, uint32_t *d_sc, const Fr *d_z, const Fr &r, size_t n);
 int eval_quotient_batch_device(DeviceCtx *ctx, Fr *d_y, uint32_t *d_q_raw, int *d_hit, const Fr *d_poly,
                                const Fr *d_z, size_t n);
 // stream: nullptr = the context's compute stream

@@ -173,6 +173,7 @@ static void destroy_slot(dev::DeviceCtx *ctx) {
     for (auto &e : ctx->stage_ev) {
         if (e) (void)hipEventDestroy(e);
     }
+    for (auto e : ctx->chunk_ev) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->out_stream) (void)hipStreamDestroy(ctx->out_stream);

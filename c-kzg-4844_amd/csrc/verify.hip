@@ -156,6 +156,40 @@ int eval_poly_batch_device(DeviceCtx *ctx, Fr *d_y, const Fr *d_poly, const Fr *
     return 0;
 }
 
+// The scalars of the three sums of a blob batch (eip4844.c:697-758: sum r^i proof_i, sum r^i z_i proof_i,
+// sum r^i C_i) as digit-ready vectors over the 2n points of a call-time table (commitments [0, n), proofs [n, 2n);
+// the caller zeroed sc): one lane per blob raises the batch challenge to its own index -- <= 2 log2(n) products --
+// so that nothing but r itself (32 bytes, a kernel argument) crosses PCIe between the transcript and the sums.
+__global__ void k_rlc_scalars(uint32_t *sc, const Fr *z, Fr r, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr pw = Fr::one(), b = r;
+    for (uint32_t e = i; e; e >>= 1) {
+        if (e & 1u) pw = mul(pw, b);
+        b = mul(b, b);
+    }
+    uint32_t a[8], c[8];
+    to_raw<FrParams>(a, pw);
+    to_raw<FrParams>(c, mul(pw, z[i]));
+    uint32_t *v0 = sc + ((size_t)0 * 2 * n + n + i) * 8;   // r^i        on proof_i
+    uint32_t *v1 = sc + ((size_t)1 * 2 * n + n + i) * 8;   // r^i z_i    on proof_i
+    uint32_t *v2 = sc + ((size_t)2 * 2 * n + i) * 8;       // r^i        on C_i
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        v0[k] = a[k];
+        v1[k] = c[k];
+        v2[k] = a[k];
+    }
+}
+
+int rlc_scalars_enqueue(hipStream_t stream, uint32_t *d_sc, const Fr *d_z, const Fr &r, size_t n) {
+    if (!n) return 0;
+    HIP_TRY(hipMemsetAsync(d_sc, 0, 6 * n * 8 * sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(k_rlc_scalars, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_sc, d_z, r, (uint32_t)n);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // y_i = p_i(z_i) and the quotient scalars q (canonical limbs, [n][4096][8]); d_hit[i] >= 0 flags a
 // blob whose z lies in the evaluation domain
 int eval_quotient_batch_device(DeviceCtx *ctx, Fr *d_y, uint32_t *d_q_raw, int *d_hit, const Fr *d_poly,
