@@ -1394,20 +1394,50 @@ static C_KZG_RET verify_cells_on(dev::DeviceCtx *ctx, bool *ok, const Bytes48 *c
     Arena &ar = ctx->api_arena;
     OKM(ar.begin(npts * (48 + 2 + sizeof(G1Affine)) + ((size_t)CELLS_PER_EXT_BLOB * l + l + n * l + n) * sizeof(Fr) +
                  n * BYTES_PER_CELL + (n + CELLS_PER_EXT_BLOB + 1 + n) * 4 + tbl_bytes + tbl_tmp + sums_scratch +
-                 (use_table ? 4 * npts * 32 + 2048 : 0) + 4096));
+                 (use_table ? 4 * npts * 32 + (2 * n + nc + 1) * 4 + 4096 : 0) + 4096));
     ABuf<uint8_t> d_ptb(ar, (n + nc) * 48), d_st(ar, n + nc), d_st2(ar, n + nc), d_cells(ar, n * BYTES_PER_CELL);
     ABuf<G1Affine> d_pts(ar, npts);
     ABuf<uint8_t> d_tbl(ar, use_table ? tbl_bytes : 1), d_tbl_tmp(ar, use_table ? tbl_tmp : 1), d_sums_scr(ar, use_table ? sums_scratch : 1);
     ABuf<uint32_t> d_sc(ar, use_table ? 4 * npts * 8 : 1);
+    ABuf<uint32_t> d_grp(ar, use_table ? 2 * n + nc + 1 : 1);   // column of each cell [n] | commitment groups: start [nc + 1], members [n]
     ABuf<G1XYZZ> d_sums(ar, 4);
-    OKM(d_tbl.p && d_tbl_tmp.p && d_sums_scr.p && d_sc.p && d_sums.p);
+    OKM(d_tbl.p && d_tbl_tmp.p && d_sums_scr.p && d_sc.p && d_grp.p && d_sums.p);
     ABuf<Fr> d_agg(ar, (size_t)CELLS_PER_EXT_BLOB * l), d_interp(ar, l), d_cellfr(ar, n * l), d_rp(ar, n);
     ABuf<uint32_t> d_bad(ar, n), d_csr(ar, CELLS_PER_EXT_BLOB + 1 + n);
     OKM(d_ptb.p && d_st.p && d_st2.p && d_cells.p && d_pts.p && d_agg.p && d_interp.p && d_cellfr.p && d_rp.p &&
         d_bad.p && d_csr.p);
     ArenaTrim trim(ar);
+    tr.mark("dedup");
+    // The transcript is ONE SHA-256 stream over every cell (eip7594.c:390-482): the longest thing in this call, on one
+    // host core.  It starts now, on a worker thread, and everything below that does not need the challenge -- the
+    // copies (blocking, from pageable memory), the GPU validation, the grouping of cells by column and by commitment,
+    // the check of the validation flags -- happens underneath it.
+    Fr r;
+    struct HashJob {
+        std::atomic<bool> done{false};
+        bool submitted = false;
+        void wait() {
+            while (submitted && !done.load(std::memory_order_acquire)) std::this_thread::yield();
+        }
+        ~HashJob() { wait(); }   // nothing the worker reads or writes may die before it is through
+    } hash_job;
+    const uint64_t *cidx_p = cidx.data();
+    const Bytes48 *uniq_p = uniq.data();
+    auto hash_all = [&r, uniq_p, nc, cidx_p, cell_indices, cells, proofs_bytes, n]() {
+        compute_verify_cell_kzg_proof_batch_challenge((fr_t *)&r, uniq_p, nc, cidx_p, cell_indices, cells, proofs_bytes, n);
+    };
+    if (n >= 256) {
+        HashJob *hj = &hash_job;
+        hash_job.submitted = WorkerPool::get().submit([hash_all, hj]() {
+            hash_all();
+            hj->done.store(true, std::memory_order_release);
+        });
+    }
+    OKM(ensure_pinned(ctx->h_out, ctx->h_out_bytes, 2 * (n + nc) + n * 4));
+    uint8_t *h_st = static_cast<uint8_t *>(ctx->h_out[0]), *h_st2 = h_st + (n + nc);
+    uint32_t *h_bad = static_cast<uint32_t *>(ctx->h_out[1]);
     // proofs [0,n), unique commitments [n, n+nc): decompression and subgroup checks start on the GPU,
-    // followed by the cells' bytes -> Fr conversion, while the host hashes the transcript
+    // followed by the cells' bytes -> Fr conversion, while the transcript is being hashed
     // (all copies from pageable memory first: such a copy returns only when it is done, so it must not
     // queue behind the validation kernel)
     OKB(hipMemcpyAsync(d_ptb.p, proofs_bytes, n * 48, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
@@ -1415,18 +1445,21 @@ static C_KZG_RET verify_cells_on(dev::DeviceCtx *ctx, bool *ok, const Bytes48 *c
     OKB(hipMemcpyAsync(d_cells.p, cells, n * BYTES_PER_CELL, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
     OKB(hipMemsetAsync(d_bad.p, 0, n * 4, ctx->stream) == hipSuccess);
     RC(dev::bytes_to_fr_batch(ctx, d_cellfr.p, d_bad.p, d_cells.p, n * l, (uint32_t)l));
+    OKB(hipMemcpyAsync(h_bad, d_bad.p, n * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess);
     // Validation in two launches: decompression (a square root, ~0.35 ms) here, the subgroup test
-    // (~1 ms of dependent doublings) on the second stream, next to the sums that already use the points.
-    // A point outside the subgroup makes those sums meaningless, not unsafe; they are discarded below.
+    // (~1 ms of dependent doublings) on the second stream, next to the table build that already uses the points.
+    // A point outside the subgroup makes table and sums meaningless, not unsafe; the call ends in BADARGS below.
     RC(dev::decompress_g1_batch_device(ctx, d_pts.p, d_st.p, d_ptb.p, n + nc));
+    OKB(hipMemcpyAsync(h_st, d_st.p, n + nc, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess);
     if (use_table)
         OKB(hipMemcpyAsync(d_pts.p + n + nc, ctx->d_mono, l * sizeof(G1Affine), hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess);
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < 4; i++) {
         if (!ctx->stage_ev[i]) OKB(hipEventCreateWithFlags(&ctx->stage_ev[i], hipEventDisableTiming) == hipSuccess);
     }
     OKB(hipEventRecord(ctx->stage_ev[0], ctx->stream) == hipSuccess);
     OKB(hipStreamWaitEvent(ctx->copy_stream, ctx->stage_ev[0], 0) == hipSuccess);
     RC(dev::subgroup_g1_batch_device(ctx, d_st2.p, d_pts.p, n + nc, ctx->copy_stream));
+    OKB(hipMemcpyAsync(h_st2, d_st2.p, n + nc, hipMemcpyDeviceToHost, ctx->copy_stream) == hipSuccess);
     OKB(hipEventRecord(ctx->stage_ev[1], ctx->copy_stream) == hipSuccess);
     // whatever path leaves this function, the other streams must be idle before the arena is reused
     struct StreamDrain {
@@ -1436,26 +1469,12 @@ static C_KZG_RET verify_cells_on(dev::DeviceCtx *ctx, bool *ok, const Bytes48 *c
         }
     } drain{ctx->copy_stream};
     if (use_table) {
-        // (a point outside the subgroup makes the table meaningless, not unsafe: the call ends in BADARGS below)
         if (!ctx->aux_stream) OKB(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) == hipSuccess);
         OKB(hipStreamWaitEvent(ctx->aux_stream, ctx->stage_ev[0], 0) == hipSuccess);
         RC(dev::call_table_enqueue(ctx->aux_stream, &tbl, reinterpret_cast<G1Affine *>(d_tbl.p), d_tbl_tmp.p, d_pts.p));
         OKB(hipEventRecord(ctx->stage_ev[2], ctx->aux_stream) == hipSuccess);
     }
     StreamDrain drain_aux{use_table ? ctx->aux_stream : nullptr};
-    tr.mark("dedup + enqueue validation");
-    Fr r;
-    compute_verify_cell_kzg_proof_batch_challenge((fr_t *)&r, uniq.data(), nc, cidx.data(), cell_indices, cells,
-                                                  proofs_bytes, n);
-    tr.mark("transcript hash");
-    std::vector<Fr> rp(n);
-    {
-        Fr pw = Fr::one();
-        for (size_t i = 0; i < n; i++) {
-            rp[i] = pw;
-            pw = mul(pw, r);
-        }
-    }
     // cells grouped by column (counting sort) for the aggregation kernel
     std::vector<uint32_t> csr(CELLS_PER_EXT_BLOB + 1 + n, 0);
     for (size_t i = 0; i < n; i++) csr[cell_indices[i] + 1]++;
@@ -1464,8 +1483,60 @@ static C_KZG_RET verify_cells_on(dev::DeviceCtx *ctx, bool *ok, const Bytes48 *c
         std::vector<uint32_t> fill(csr.begin(), csr.begin() + CELLS_PER_EXT_BLOB);
         for (size_t i = 0; i < n; i++) csr[CELLS_PER_EXT_BLOB + 1 + fill[cell_indices[i]]++] = (uint32_t)i;
     }
-    std::vector<RawScalar> rp_raw(n), wrp_raw(n), wts_raw(nc);
-    {
+    OKB(hipMemcpyAsync(d_csr.p, csr.data(), csr.size() * 4, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
+    if (use_table) {
+        // ... and by commitment, for the weights; the column of each cell, for its coset factor (k_cell_rlc_scalars)
+        std::vector<uint32_t> grp(2 * n + nc + 1, 0);
+        uint32_t *col = grp.data(), *start = grp.data() + n, *members = grp.data() + n + nc + 1;
+        for (size_t i = 0; i < n; i++) {
+            col[i] = (uint32_t)cell_indices[i];
+            start[cidx[i] + 1]++;
+        }
+        for (size_t j = 0; j < nc; j++) start[j + 1] += start[j];
+        std::vector<uint32_t> fill(start, start + nc);
+        for (size_t i = 0; i < n; i++) members[fill[cidx[i]]++] = (uint32_t)i;
+        OKB(hipMemcpyAsync(d_grp.p, grp.data(), grp.size() * 4, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
+        OKB(hipMemsetAsync(d_sc.p, 0, 4 * npts * 32, ctx->stream) == hipSuccess);
+    }
+    // The validation flags.  A large batch: both streams are through long before the transcript is, so they are
+    // checked here, underneath it.  A small one (ladder sums): the subgroup test (~1 ms of dependent doublings) keeps
+    // running on the second stream next to the sums, and the flags are checked after those.
+    auto flags_ok = [&]() -> C_KZG_RET {
+        OKB(hipEventSynchronize(ctx->stage_ev[3]) == hipSuccess && hipEventSynchronize(ctx->stage_ev[1]) == hipSuccess);
+        for (size_t i = 0; i < n + nc; i++) {
+            if (h_st[i] || h_st2[i]) return C_KZG_BADARGS;  // bad encoding / off the curve / outside G1
+        }
+        for (size_t i = 0; i < n; i++) {
+            if (h_bad[i]) return C_KZG_BADARGS;  // a non-canonical field element in a cell (bytes.c:67)
+        }
+        return C_KZG_OK;
+    };
+    OKB(hipEventRecord(ctx->stage_ev[3], ctx->stream) == hipSuccess);
+    if (use_table) RC(flags_ok());
+    tr.mark("copies, validation, grouping (underneath the transcript hash)");
+    if (hash_job.submitted)
+        hash_job.wait();
+    else
+        hash_all();
+    tr.mark("transcript hash");
+    const size_t row = npts * 8;   // words per scalar vector of the table path
+    std::vector<RawScalar> rp_raw, wrp_raw, wts_raw;
+    if (use_table) {
+        // scalars made on the GPU from r: [proofs | distinct commitments | 64 monomial setup points] x 4 vectors
+        RC(dev::cell_rlc_scalars_enqueue(ctx, d_rp.p, d_sc.p + 0 * row, d_sc.p + 2 * row, d_sc.p + 1 * row + n * 8, d_grp.p,
+                                         d_grp.p + n, d_grp.p + n + nc + 1, r, n, nc));
+    } else {
+        std::vector<Fr> rp(n);
+        {
+            Fr pw = Fr::one();
+            for (size_t i = 0; i < n; i++) {
+                rp[i] = pw;
+                pw = mul(pw, r);
+            }
+        }
+        rp_raw.resize(n);
+        wrp_raw.resize(n);
+        wts_raw.resize(nc);
         std::vector<Fr> wts(nc, Fr::zero());
         for (size_t i = 0; i < n; i++) {
             rp_raw[i] = raw_of(rp[i]);
@@ -1474,12 +1545,11 @@ static C_KZG_RET verify_cells_on(dev::DeviceCtx *ctx, bool *ok, const Bytes48 *c
             wrp_raw[i] = raw_of(mul(rp[i], rou[rb * l]));  // r^i * h_k^64 (eip7594.c:784-812)
         }
         for (size_t j = 0; j < nc; j++) wts_raw[j] = raw_of(wts[j]);
+        OKB(d_rp.up(rp.data(), n));
     }
     tr.mark("powers of r + weights");
-    OKB(hipMemcpyAsync(d_rp.p, rp.data(), n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
-    OKB(hipMemcpyAsync(d_csr.p, csr.data(), csr.size() * 4, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
     // aggregated column data: sum of r^i * cell_i per column (eip7594.c:661-683)
-    RC(dev::cell_aggregate_device(ctx, d_agg.p, d_cellfr.p, d_rp.p, d_csr.p, d_csr.p + CELLS_PER_EXT_BLOB + 1));
+    RC(dev::cell_aggregate_device(ctx, d_agg.p, d_cellfr.p, d_rp.p, d_csr.p, d_csr.p + CELLS_PER_EXT_BLOB + 1, n));
     // per column: cell data is in bit-reversed order -> DIT inverse NTT(64) gives the interpolation
     // polynomial over the coset; unused columns are all-zero and stay zero
     RC(dev::fr_ntt_batch(ctx, d_agg.p, CELLS_PER_EXT_BLOB, 6, false, true, true));
@@ -1488,12 +1558,6 @@ static C_KZG_RET verify_cells_on(dev::DeviceCtx *ctx, bool *ok, const Bytes48 *c
     // polynomial over the first 64 monomial setup points, :758) in one launch
     G1Jac lc[4];
     if (use_table) {
-        // four scalar vectors over the npts table points: [proofs | distinct commitments | 64 monomial setup points]
-        const size_t row = npts * 8;   // words per vector
-        OKB(hipMemsetAsync(d_sc.p, 0, 4 * npts * 32, ctx->stream) == hipSuccess);
-        OKB(hipMemcpyAsync(d_sc.p + 0 * row, rp_raw.data(), n * 32, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
-        OKB(hipMemcpyAsync(d_sc.p + 1 * row + n * 8, wts_raw.data(), nc * 32, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
-        OKB(hipMemcpyAsync(d_sc.p + 2 * row, wrp_raw.data(), n * 32, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
         OKB(hipMemcpyAsync(d_sc.p + 3 * row + (n + nc) * 8, d_interp.p, l * 32, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess);
         OKB(hipStreamWaitEvent(ctx->stream, ctx->stage_ev[2], 0) == hipSuccess);   // the table is complete
         RC(dev::table_sums_enqueue(ctx->stream, tbl, d_sums.p, d_sc.p, 4, d_sums_scr.p));
@@ -1505,19 +1569,7 @@ static C_KZG_RET verify_cells_on(dev::DeviceCtx *ctx, bool *ok, const Bytes48 *c
                               {ctx->d_mono, nullptr, (const RawScalar *)d_interp.p, l}};
         C_KZG_RET ret = gpu_lincomb_multi(ctx, lc, jobs, 4);
         if (ret != C_KZG_OK) return ret;
-    }
-    OKB(hipEventSynchronize(ctx->stage_ev[1]) == hipSuccess);  // the subgroup test on the second stream
-    std::vector<uint8_t> st(n + nc), st2(n + nc);
-    OKB(d_st.down(st.data(), n + nc) && d_st2.down(st2.data(), n + nc));
-    for (size_t i = 0; i < n + nc; i++) {
-        if (st[i] || st2[i]) return C_KZG_BADARGS;  // bad encoding / off the curve / outside G1: sums discarded
-    }
-    {
-        std::vector<uint32_t> bad(n);
-        OKB(d_bad.down(bad.data(), n));
-        for (auto b : bad) {
-            if (b) return C_KZG_BADARGS;  // a non-canonical field element in a cell (bytes.c:67)
-        }
+        RC(flags_ok());   // a point outside G1 makes the sums above meaningless, not unsafe: discarded
     }
     tr.mark("aggregation + IFFTs + four lincombs");
     const G1Jac &proof_lc = lc[0], &csum = lc[1], &wsum = lc[2], &interp_commit = lc[3];

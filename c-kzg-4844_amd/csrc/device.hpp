@@ -215,6 +215,12 @@ void commit_collect_times(DeviceCtx *ctx);
 int eval_poly_batch_device(DeviceCtx *ctx, Fr *d_y, const Fr *d_poly, const Fr *d_z, size_t n);
 // d_sc[3][2n][8] <- the scalar vectors of a blob batch's three sums over a call-time table of (commitments, proofs),
 // from the batch challenge r and the blobs' challenges d_z (verify.hip: k_rlc_scalars).  Enqueue-only.
+// the same for a cell batch (verify.hip: k_cell_rlc_scalars, k_commit_weights): d_rp[n] <- r^i (Montgomery),
+// d_vec_rp[n][8] <- r^i, d_vec_wrp[n][8] <- r^i * h_k^64, d_vec_w[nc][8] <- per-commitment sums of r^i over the member
+// lists (d_grp_start[nc + 1], d_members[n]); on ctx->stream.  Enqueue-only.
+int cell_rlc_scalars_enqueue(DeviceCtx *ctx, Fr *d_rp, uint32_t *d_vec_rp, uint32_t *d_vec_wrp, uint32_t *d_vec_w,
+                             const uint32_t *d_cell_idx, const uint32_t *d_grp_start, const uint32_t *d_members,
+                             const Fr &r, size_t n, size_t nc);
 int rlc_scalars_enqueue(hipStream_t stream, uint32_t *d_sc, const Fr *d_z, const Fr &r, size_t n);
 int eval_quotient_batch_device(DeviceCtx *ctx, Fr *d_y, uint32_t *d_q_raw, int *d_hit, const Fr *d_poly,
                                const Fr *d_z, size_t n);
@@ -245,7 +251,7 @@ int scatter_cells_device(DeviceCtx *ctx, uint8_t *d_image, const uint8_t *d_cell
                          uint32_t num_cells, size_t num_rows);
 // agg[c][j] = sum over the cells i of column c (CSR: col_start[129], order[n]) of rp[i] * cell_fr[i][j]
 int cell_aggregate_device(DeviceCtx *ctx, Fr *d_agg, const Fr *d_cell_fr, const Fr *d_rp, const uint32_t *d_col_start,
-                          const uint32_t *d_order);
+                          const uint32_t *d_order, size_t n_cells);
 // interpolation-polynomial coefficients summed over the 128 columns, as canonical MSM scalars
 int interp_sum_device(DeviceCtx *ctx, Fr *d_interp, const Fr *d_cols);
 int fr_mul_inplace_device(DeviceCtx *ctx, Fr *d_a, const Fr *d_b, size_t n, size_t period);

@@ -160,14 +160,34 @@ int eval_poly_batch_device(DeviceCtx *ctx, Fr *d_y, const Fr *d_poly, const Fr *
 // sum r^i C_i) as digit-ready vectors over the 2n points of a call-time table (commitments [0, n), proofs [n, 2n);
 // the caller zeroed sc): one lane per blob raises the batch challenge to its own index -- <= 2 log2(n) products --
 // so that nothing but r itself (32 bytes, a kernel argument) crosses PCIe between the transcript and the sums.
-__global__ void k_rlc_scalars(uint32_t *sc, const Fr *z, Fr r, uint32_t n) {
+// r^(2^k), k < 24, made on the host (23 squarings) and passed by value: a lane's power of r is then the product of
+// the entries its index selects -- <= 13 products for n = 8192, ~6 on average, and no squarings of its own.
+struct RPow2 {
+    Fr p[24];
+};
+__device__ __forceinline__ Fr rpow_at(const RPow2 &t, uint32_t i) {
+    Fr pw = Fr::one();
+    bool first = true;
+#pragma unroll 1
+    for (int k = 0; k < 24 && (i >> k); k++) {
+        if ((i >> k) & 1u) {
+            pw = first ? t.p[k] : mul(pw, t.p[k]);
+            first = false;
+        }
+    }
+    return pw;
+}
+static RPow2 rpow2_of(const Fr &r) {
+    RPow2 t;
+    t.p[0] = r;
+    for (int k = 1; k < 24; k++) t.p[k] = mul(t.p[k - 1], t.p[k - 1]);
+    return t;
+}
+
+__global__ void k_rlc_scalars(uint32_t *sc, const Fr *z, RPow2 rp2, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Fr pw = Fr::one(), b = r;
-    for (uint32_t e = i; e; e >>= 1) {
-        if (e & 1u) pw = mul(pw, b);
-        b = mul(b, b);
-    }
+    Fr pw = rpow_at(rp2, i);
     uint32_t a[8], c[8];
     to_raw<FrParams>(a, pw);
     to_raw<FrParams>(c, mul(pw, z[i]));
@@ -185,7 +205,8 @@ __global__ void k_rlc_scalars(uint32_t *sc, const Fr *z, Fr r, uint32_t n) {
 int rlc_scalars_enqueue(hipStream_t stream, uint32_t *d_sc, const Fr *d_z, const Fr &r, size_t n) {
     if (!n) return 0;
     HIP_TRY(hipMemsetAsync(d_sc, 0, 6 * n * 8 * sizeof(uint32_t), stream));
-    hipLaunchKernelGGL(k_rlc_scalars, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_sc, d_z, r, (uint32_t)n);
+    if (n >= ((size_t)1 << 24)) return 2;
+    hipLaunchKernelGGL(k_rlc_scalars, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_sc, d_z, rpow2_of(r), (uint32_t)n);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -471,46 +492,49 @@ __global__ void k_scatter_cells(uint4 *image, const uint4 *cells, const uint32_t
 }
 
 // interp[k] = sum_c col[c][k] * (h_c^-1)^k with h_c^-1 = w^(8192 - brp7(c))  (eip7594.c:549-566,
-// 713-752): one thread per coefficient k
-__global__ void k_interp_sum(Fr *interp, const Fr *cols, const Fr *roots) {
-    int k = threadIdx.x;
-    Fr acc = Fr::zero();
-    for (int c = 0; c < 128; c++) {
-        uint32_t rb = __brev((uint32_t)c) >> 25;
-        uint32_t idx = ((8192u - rb) * (uint32_t)k) & 8191u;
-        const uint4 *q = reinterpret_cast<const uint4 *>(cols + c * 64 + k);
-        const uint4 *w = reinterpret_cast<const uint4 *>(roots + idx);
-        uint4 a = q[0], b = q[1], wa = w[0], wb = w[1];
-        Fr v, r;
-        v.l[0] = a.x; v.l[1] = a.y; v.l[2] = a.z; v.l[3] = a.w; v.l[4] = b.x; v.l[5] = b.y; v.l[6] = b.z; v.l[7] = b.w;
-        r.l[0] = wa.x; r.l[1] = wa.y; r.l[2] = wa.z; r.l[3] = wa.w; r.l[4] = wb.x; r.l[5] = wb.y; r.l[6] = wb.z; r.l[7] = wb.w;
-        acc = add(acc, mul(v, r));
+// 713-752).  One workgroup per coefficient k, one thread per column: a product each and a seven-level fold in LDS --
+// the one-thread-per-coefficient form was 128 dependent multiply-adds (225 us of every cell verification).
+__global__ __launch_bounds__(128) void k_interp_sum(Fr *interp, const Fr *cols, const Fr *roots) {
+    __shared__ Fr sh[128];
+    const uint32_t k = blockIdx.x, c = threadIdx.x;
+    const uint32_t rb = __brev(c) >> 25;
+    const uint32_t idx = ((8192u - rb) * k) & 8191u;
+    sh[c] = mul(vld_fr(cols + c * 64 + k), vld_fr(roots + idx));
+    __syncthreads();
+    for (uint32_t s2 = 64; s2 >= 1; s2 >>= 1) {
+        if (c < s2) sh[c] = add(sh[c], sh[c + s2]);
+        __syncthreads();
     }
-    uint32_t raw[8];
-    to_raw<FrParams>(raw, acc);  // canonical limbs: this vector is used as MSM scalars
-    for (int i = 0; i < 8; i++) reinterpret_cast<uint32_t *>(interp + k)[i] = raw[i];
+    if (c == 0) {
+        uint32_t raw[8];
+        to_raw<FrParams>(raw, sh[0]);  // canonical limbs: this vector is used as MSM scalars
+        for (int i = 0; i < 8; i++) reinterpret_cast<uint32_t *>(interp + k)[i] = raw[i];
+    }
 }
 
 // agg[c][j] = sum over the cells i of column c of r^i * cell_i[j]  (eip7594.c:661-683).
-// order[col_start[c] .. col_start[c+1]) lists the cells of column c; thread = (c, j).
+// order[col_start[c] .. col_start[c+1]) lists the cells of column c.  One workgroup per column, thread (j, p): position
+// j over every parts-th cell of the list, then a fold over the parts in LDS (a large batch has 64+ cells per column:
+// that many dependent multiply-adds per thread in the one-part form).
 __global__ void k_cell_aggregate(Fr *agg, const Fr *cell_fr, const Fr *rp, const uint32_t *col_start,
-                                 const uint32_t *order) {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;  // < 128 * 64
-    const uint32_t c = g >> 6, j = g & 63u;
+                                 const uint32_t *order, uint32_t parts) {
+    extern __shared__ Fr sh_agg[];   // [parts][64]
+    const uint32_t c = blockIdx.x, j = threadIdx.x & 63u, p = threadIdx.x >> 6;
     Fr acc = Fr::zero();
-    for (uint32_t t = col_start[c]; t < col_start[c + 1]; t++) {
+    for (uint32_t t = col_start[c] + p; t < col_start[c + 1]; t += parts) {
         const uint32_t i = order[t];
-        const uint4 *q = reinterpret_cast<const uint4 *>(cell_fr + (size_t)i * 64 + j);
-        const uint4 *w = reinterpret_cast<const uint4 *>(rp + i);
-        uint4 a = q[0], b = q[1], wa = w[0], wb = w[1];
-        Fr v, r;
-        v.l[0] = a.x; v.l[1] = a.y; v.l[2] = a.z; v.l[3] = a.w; v.l[4] = b.x; v.l[5] = b.y; v.l[6] = b.z; v.l[7] = b.w;
-        r.l[0] = wa.x; r.l[1] = wa.y; r.l[2] = wa.z; r.l[3] = wa.w; r.l[4] = wb.x; r.l[5] = wb.y; r.l[6] = wb.z; r.l[7] = wb.w;
-        acc = add(acc, mul(v, r));
+        acc = add(acc, mul(vld_fr(cell_fr + (size_t)i * 64 + j), vld_fr(rp + i)));
     }
-    uint4 *o = reinterpret_cast<uint4 *>(agg + g);
-    o[0] = make_uint4(acc.l[0], acc.l[1], acc.l[2], acc.l[3]);
-    o[1] = make_uint4(acc.l[4], acc.l[5], acc.l[6], acc.l[7]);
+    if (parts > 1) {
+        sh_agg[p * 64 + j] = acc;
+        __syncthreads();
+        for (uint32_t s2 = parts >> 1; s2 >= 1; s2 >>= 1) {
+            if (p < s2) sh_agg[p * 64 + j] = add(sh_agg[p * 64 + j], sh_agg[(p + s2) * 64 + j]);
+            __syncthreads();
+        }
+        acc = sh_agg[j];
+    }
+    if (p == 0) vst_fr(agg + c * 64 + j, acc);
 }
 
 int scatter_cells_device(DeviceCtx *ctx, uint8_t *d_image, const uint8_t *d_cells, const uint32_t *d_idx,
@@ -523,16 +547,74 @@ int scatter_cells_device(DeviceCtx *ctx, uint8_t *d_image, const uint8_t *d_cell
     return 0;
 }
 
+// The scalars of a cell batch's sums over its call-time table, made from the batch challenge where their digits are
+// needed (eip7594.c:926 sum r^i proof_i, :784-812 sum r^i h_k^64 proof_i): lane i raises r to its index, leaves it in
+// Montgomery form for k_cell_aggregate and in canonical limbs -- plain and times the coset factor of its cell's
+// column -- in the two scalar vectors.  Only r (a kernel argument) crosses PCIe after the transcript.
+__global__ void k_cell_rlc_scalars(Fr *rp, uint32_t *vec_rp, uint32_t *vec_wrp, const uint32_t *cell_idx, const Fr *roots,
+                                   RPow2 rp2, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr pw = rpow_at(rp2, i);
+    rp[i] = pw;
+    const uint32_t rb = __brev(cell_idx[i]) >> 25;   // 7-bit reversal of the column index (128 columns)
+    uint32_t a[8], c[8];
+    to_raw<FrParams>(a, pw);
+    to_raw<FrParams>(c, mul(pw, roots[(size_t)rb * N_CELL]));
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        vec_rp[(size_t)i * 8 + k] = a[k];
+        vec_wrp[(size_t)i * 8 + k] = c[k];
+    }
+}
+
+// Weight of each distinct commitment (eip7594.c:494-539): the sum of r^i over the cells that name it.  One 64-lane
+// workgroup per commitment over the member list the host grouped while the transcript was being hashed.
+__global__ __launch_bounds__(64) void k_commit_weights(uint32_t *vec_w, const Fr *rp, const uint32_t *grp_start,
+                                                      const uint32_t *members) {
+    __shared__ Fr sh[64];
+    const uint32_t j = blockIdx.x, tid = threadIdx.x;
+    Fr acc = Fr::zero();
+    for (uint32_t m = grp_start[j] + tid; m < grp_start[j + 1]; m += 64) acc = add(acc, rp[members[m]]);
+    sh[tid] = acc;
+    __syncthreads();
+    for (uint32_t s2 = 32; s2 >= 1; s2 >>= 1) {
+        if (tid < s2) sh[tid] = add(sh[tid], sh[tid + s2]);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        uint32_t a[8];
+        to_raw<FrParams>(a, sh[0]);
+#pragma unroll
+        for (int k = 0; k < 8; k++) vec_w[(size_t)j * 8 + k] = a[k];
+    }
+}
+
+int cell_rlc_scalars_enqueue(DeviceCtx *ctx, Fr *d_rp, uint32_t *d_vec_rp, uint32_t *d_vec_wrp, uint32_t *d_vec_w,
+                             const uint32_t *d_cell_idx, const uint32_t *d_grp_start, const uint32_t *d_members,
+                             const Fr &r, size_t n, size_t nc) {
+    if (!n) return 0;
+    if (n >= ((size_t)1 << 24)) return 2;
+    hipLaunchKernelGGL(k_cell_rlc_scalars, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, d_rp, d_vec_rp, d_vec_wrp,
+                       d_cell_idx, ctx->d_roots, rpow2_of(r), (uint32_t)n);
+    hipLaunchKernelGGL(k_commit_weights, dim3((unsigned)nc), dim3(64), 0, ctx->stream, d_vec_w, d_rp, d_grp_start, d_members);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int cell_aggregate_device(DeviceCtx *ctx, Fr *d_agg, const Fr *d_cell_fr, const Fr *d_rp, const uint32_t *d_col_start,
-                          const uint32_t *d_order) {
-    hipLaunchKernelGGL(k_cell_aggregate, dim3(128 * 64 / 256), dim3(256), 0, ctx->stream, d_agg, d_cell_fr, d_rp,
-                       d_col_start, d_order);
+                          const uint32_t *d_order, size_t n_cells) {
+    // parts: a power of two, ~4 cells per thread, at most 16 (1024 threads, 32 KB of LDS)
+    uint32_t parts = 1;
+    while (parts < 16 && (size_t)parts * 128 * 4 < n_cells) parts <<= 1;
+    hipLaunchKernelGGL(k_cell_aggregate, dim3(128), dim3(64 * parts), parts > 1 ? parts * 64 * sizeof(Fr) : 0, ctx->stream, d_agg,
+                       d_cell_fr, d_rp, d_col_start, d_order, parts);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 int interp_sum_device(DeviceCtx *ctx, Fr *d_interp, const Fr *d_cols) {
-    hipLaunchKernelGGL(k_interp_sum, dim3(1), dim3(64), 0, ctx->stream, d_interp, d_cols, ctx->d_roots);
+    hipLaunchKernelGGL(k_interp_sum, dim3(64), dim3(128), 0, ctx->stream, d_interp, d_cols, ctx->d_roots);
     HIP_TRY(hipGetLastError());
     return 0;
 }
