@@ -225,6 +225,9 @@ C_KZG_RET compute_kzg_proof_impl(KZGProof *proof_out, Fr &y_out, const Fr *poly,
     return C_KZG_OK;
 }
 
+// fn(0) ... fn(n - 1) on up to 32 threads: the caller takes part, the rest are jobs on the process-wide worker pool
+// (no thread is created or joined per call).  fn must not throw and must not itself wait for pool jobs -- a pool
+// worker never blocks on another pool job; the callers of this function are never pool workers.
 void parallel_for(size_t n, const std::function<void(size_t)> &fn) {
     unsigned hw = std::thread::hardware_concurrency();
     size_t nt = hw ? hw : 4;
@@ -234,13 +237,27 @@ void parallel_for(size_t n, const std::function<void(size_t)> &fn) {
         for (size_t i = 0; i < n; i++) fn(i);
         return;
     }
-    JoinThreads th;
-    for (size_t t = 0; t < nt; t++) {
-        th.spawn([&, t]() {
-            for (size_t i = t; i < n; i += nt) fn(i);
-        });
+    struct Shared {
+        std::atomic<size_t> next{0};
+        std::atomic<int> active{0};
+    } sh;
+    auto loop = [&sh, &fn, n]() {
+        for (;;) {
+            const size_t i = sh.next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= n) return;
+            fn(i);
+        }
+    };
+    for (size_t t = 1; t < nt; t++) {
+        sh.active.fetch_add(1, std::memory_order_relaxed);
+        if (!WorkerPool::get().submit([&sh, loop]() {
+                loop();
+                sh.active.fetch_sub(1, std::memory_order_release);
+            }))
+            sh.active.fetch_sub(1, std::memory_order_relaxed);
     }
-    th.join();
+    loop();
+    while (sh.active.load(std::memory_order_acquire) != 0) std::this_thread::yield();
 }
 
 // Several variable-base lincombs sum_i k_i P_i in ONE launch.  Job j takes n points starting at
