@@ -522,9 +522,9 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     const bool piped = !resident && !small && !gpu_sha && n >= pipe_min;
     // Call-time table (msm.hip): while the chunked copy of a large pipelined batch is in flight the GPU is mostly idle
     // and the batch challenge does not exist yet, so the 128 doublings per term of the three sums are done early, as a
-    // narrow fixed-base table over the 2n validated points built on a side stream.  The build is ~4 ms of side-stream
-    // work at n = 4096 (window bases: 126 sequential doublings; 5.8 M entries), so it only pays when the copy is
-    // longer than that: measured (profiles/r03_verify_call_table.txt) n = 4096 page-locked 15.1 -> 14.0 ms, pageable
+    // narrow fixed-base table over the 2n validated points built on a side stream.  The build is 7.7 ms of side-stream
+    // work at n = 4096 (window bases, 126 sequential doublings: 2.4 ms; 5.8 M entries: 5.3 ms), so it only pays when
+    // the copy is about that long: measured (profiles/r03_verify_call_table.txt) n = 4096 page-locked 15.1 -> 14.0 ms, pageable
     // 15.9 -> 15.0 ms; n = 1024 (a 2.8 ms copy) 6.3 -> 8.4 ms and the resident form (nothing to hide under but the
     // hashing kernel it competes with) 12.4 -> 15.3 ms: those keep the ladders.
     static const int call_table_wbits = []() {
@@ -535,7 +535,15 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
         const char *e = getenv("CKZG_HIP_VERIFY_TABLE_MIN");
         return e && *e ? (size_t)atol(e) : (size_t)2560;   // blobs: a copy of >= ~6 ms
     }();
-    const bool use_table = call_table_wbits >= 4 && call_table_wbits <= 10 && piped && n >= call_table_min;
+    // CKZG_HIP_VERIFY_TABLE_RESIDENT=1 tries the table in the resident form too (A/B only: the build -- 7.7 ms alone for
+    // 8192 points, its 126-doubling window-base ladders 3x slower while they share the chip with the hashing kernel --
+    // does not fit under the 8.3 ms of hash + evaluation: profiles/r03_verify_resident_table_timeline.txt)
+    static const bool table_for_resident = []() {
+        const char *e = getenv("CKZG_HIP_VERIFY_TABLE_RESIDENT");
+        return e && *e == '1';
+    }();
+    const bool use_table = call_table_wbits >= 4 && call_table_wbits <= 10 && n >= call_table_min &&
+                           (piped || (resident && table_for_resident));
     dev::FixedBaseTable tbl;
     size_t tbl_bytes = 0, tbl_tmp = 0, sums_scratch = 0;
     if (use_table) {
@@ -808,6 +816,7 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
         // The sums over the call-time table.  Their scalars are made where their digits are needed: one lane per blob
         // raises r to its index (k_rlc_scalars; the challenges z are in d_z since their chunks were evaluated), so only
         // r crosses PCIe, and while the GPU recodes and accumulates the host adds up sum r^i y_i for its side of the check.
+        if (resident) OKB(hipEventRecord(ctx->ev[3], ctx->stream) == hipSuccess);
         OKB(hipStreamWaitEvent(ctx->stream, ctx->stage_ev[1], 0) == hipSuccess);   // the table is complete
         RC(dev::rlc_scalars_enqueue(ctx->stream, d_sc.p, d_z.p, r, n));
         RC(dev::table_sums_enqueue(ctx->stream, tbl, d_sums.p, d_sc.p, 3, d_sums_scr.p));
@@ -820,6 +829,16 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
         G1XYZZ hs[3];
         OKB(d_sums.down(hs, 3));
         for (int j = 0; j < 3; j++) lc[j] = jac_from_xyzz(hs[j]);
+        if (resident) {
+            float a = 0, b = 0;
+            OKB(hipEventRecord(ctx->ev[4], ctx->stream) == hipSuccess && hipEventSynchronize(ctx->ev[4]) == hipSuccess);
+            if (hipEventElapsedTime(&a, ctx->ev[1], ctx->ev[2]) == hipSuccess &&
+                hipEventElapsedTime(&b, ctx->ev[3], ctx->ev[4]) == hipSuccess) {
+                ctx->last_ms[3] = a + b;
+                ctx->last_ms[0] = a;
+                ctx->last_ms[2] = b;
+            }
+        }
     } else {
     std::vector<Fr> rpf(n), rzf(n);
     Fr pw = Fr::one();
