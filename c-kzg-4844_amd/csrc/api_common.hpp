@@ -658,7 +658,7 @@ struct ArenaTrim {
     Arena &a;
     explicit ArenaTrim(Arena &ar) : a(ar) {}
     ~ArenaTrim() {
-        if (a.cap > ((size_t)2 << 30)) a.release();
+        if (a.cap > ((size_t)3 << 30)) a.release();
     }
 };
 

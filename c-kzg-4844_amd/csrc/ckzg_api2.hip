@@ -520,35 +520,30 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
         return e && *e ? (size_t)atol(e) : (size_t)1024;
     }();
     const bool piped = !resident && !small && !gpu_sha && n >= pipe_min;
-    // Call-time table (msm.hip): while the chunked copy of a large pipelined batch is in flight the GPU is mostly idle
-    // and the batch challenge does not exist yet, so the 128 doublings per term of the three sums are done early, as a
-    // narrow fixed-base table over the 2n validated points built on a side stream.  The build is 7.7 ms of side-stream
-    // work at n = 4096 (window bases, 126 sequential doublings: 2.4 ms; 5.8 M entries: 5.3 ms), so it only pays when
-    // the copy is about that long: measured (profiles/r03_verify_call_table.txt) n = 4096 page-locked 15.1 -> 14.0 ms, pageable
-    // 15.9 -> 15.0 ms; n = 1024 (a 2.8 ms copy) 6.3 -> 8.4 ms and the resident form (nothing to hide under but the
-    // hashing kernel it competes with) 12.4 -> 15.3 ms: those keep the ladders.
+    // Call-time table (msm.hip): while the blobs of a batch cross PCIe (or, in the resident form, while one lane per
+    // blob hashes them) the GPU is mostly idle and the batch challenge does not exist yet, so the 128 doublings per
+    // term of the three sums are done early, as a narrow fixed-base table over the 2n validated points built on a side
+    // stream.  In accumulator form (X28: no inversions) the build is the window-base ladders on quad lanes, ~1 ms of
+    // latency whatever n, plus one chain of full additions per (window, point): 2.3 ms for n = 4096, where the affine
+    // form it replaced took 7.7 ms and only paid from 2560 blobs.  Measured with the table off / on
+    // (profiles/r03_verify_x28_sweep.txt), page-locked source: n = 1024 5.30 -> 4.41 ms, 2048 8.09 -> 7.17,
+    // 4096 13.8 -> 11.9, and in the one-copy form of smaller batches n = 8 2.48 -> 2.25, 64 3.00 -> 2.33,
+    // 512 3.81 -> 3.29, 768 4.76 -> 3.70; resident: 1024 9.4 -> 8.4, 4096 12.6 -> 11.4.  From 8 blobs upwards (below
+    // that: the host path of SMALL_VERIFY_N, or ladders).
     static const int call_table_wbits = []() {
         const char *e = getenv("CKZG_HIP_VERIFY_TABLE_WBITS");   // 0 switches the call-time table off (A/B)
         return e && *e ? atoi(e) : 6;
     }();
     static const size_t call_table_min = []() {
         const char *e = getenv("CKZG_HIP_VERIFY_TABLE_MIN");
-        return e && *e ? (size_t)atol(e) : (size_t)2560;   // blobs: a copy of >= ~6 ms
+        return e && *e ? (size_t)atol(e) : (size_t)8;
     }();
-    // CKZG_HIP_VERIFY_TABLE_RESIDENT=1 tries the table in the resident form too (A/B only: the build -- 7.7 ms alone for
-    // 8192 points, its 126-doubling window-base ladders 3x slower while they share the chip with the hashing kernel --
-    // does not fit under the 8.3 ms of hash + evaluation: profiles/r03_verify_resident_table_timeline.txt)
-    static const bool table_for_resident = []() {
-        const char *e = getenv("CKZG_HIP_VERIFY_TABLE_RESIDENT");
-        return e && *e == '1';
-    }();
-    const bool use_table = call_table_wbits >= 4 && call_table_wbits <= 10 && n >= call_table_min &&
-                           (piped || (resident && table_for_resident));
+    const bool use_table = call_table_wbits >= 4 && call_table_wbits <= 10 && n >= call_table_min && !small;
     dev::FixedBaseTable tbl;
     size_t tbl_bytes = 0, tbl_tmp = 0, sums_scratch = 0;
     if (use_table) {
         dev::call_table_geometry(&tbl, (int)(2 * n), call_table_wbits);
-        tbl_bytes = tbl.bytes();
+        tbl_bytes = dev::call_table_bytes(tbl);
         tbl_tmp = dev::call_table_tmp_bytes(tbl);
         sums_scratch = dev::table_sums_scratch_bytes(tbl, 3);
     }
@@ -616,8 +611,9 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     if (use_table) {
         if (!ctx->aux_stream) OKB(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) == hipSuccess);
         OKB(hipStreamWaitEvent(ctx->aux_stream, ctx->stage_ev[0], 0) == hipSuccess);   // the validated points
-        RC(dev::call_table_enqueue(ctx->aux_stream, &tbl, reinterpret_cast<G1Affine *>(d_tbl.p), d_tbl_tmp.p, d_pts.p));
-        OKB(hipEventRecord(ctx->stage_ev[1], ctx->aux_stream) == hipSuccess);           // (free: the validation is not split here)
+        RC(dev::call_table_enqueue(ctx->aux_stream, &tbl, d_tbl.p, d_tbl_tmp.p, d_pts.p));
+        if (!ctx->table_ev) OKB(hipEventCreateWithFlags(&ctx->table_ev, hipEventDisableTiming) == hipSuccess);
+        OKB(hipEventRecord(ctx->table_ev, ctx->aux_stream) == hipSuccess);
     }
     StreamDrain drain_aux{use_table ? ctx->aux_stream : nullptr};
     tr.mark("validation (+ call-time table) enqueued");
@@ -817,7 +813,7 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
         // raises r to its index (k_rlc_scalars; the challenges z are in d_z since their chunks were evaluated), so only
         // r crosses PCIe, and while the GPU recodes and accumulates the host adds up sum r^i y_i for its side of the check.
         if (resident) OKB(hipEventRecord(ctx->ev[3], ctx->stream) == hipSuccess);
-        OKB(hipStreamWaitEvent(ctx->stream, ctx->stage_ev[1], 0) == hipSuccess);   // the table is complete
+        OKB(hipStreamWaitEvent(ctx->stream, ctx->table_ev, 0) == hipSuccess);   // the table is complete
         RC(dev::rlc_scalars_enqueue(ctx->stream, d_sc.p, d_z.p, r, n));
         RC(dev::table_sums_enqueue(ctx->stream, tbl, d_sums.p, d_sc.p, 3, d_sums_scr.p));
         Fr pw = Fr::one();
@@ -1402,20 +1398,22 @@ static C_KZG_RET verify_cells_on(dev::DeviceCtx *ctx, bool *ok, const Bytes48 *c
         cidx[i] = j;
     }
     const size_t nc = uniq.size();
-    // Call-time table (msm.hip), as in verify_blobs_core: the transcript of a large cell batch is ONE SHA-256 stream
-    // over every cell (1 us per cell on a SHA-NI core) during which the GPU has nothing to do once the points are
-    // decompressed -- time enough to build a 6-bit fixed-base table over the batch's proofs, its distinct commitments
-    // and the 64 setup points of the interpolation commitment, so that the four sums that follow the challenge are
-    // table sums (0.4 ms) instead of ladders (2.2 ms).  Measured (tools/bench_verify_cells.py, same box): n = 8192
-    // 13.12 -> 10.96 ms, n = 16384 23.9 -> 20.4 ms, n = 4096 8.17 -> 8.40 ms (a 4 ms hash does not hide the build):
-    // from 6144 cells upwards.
+    // Call-time table (msm.hip), as in verify_blobs_core: the transcript of a cell batch is ONE SHA-256 stream over
+    // every cell (1 us per cell on a SHA-NI core) during which the GPU has nothing to do once the points are
+    // decompressed -- time enough to build a 6-bit fixed-base table (accumulator form, ~1.2 ms of latency + 0.15 us per
+    // point) over the batch's proofs, its distinct commitments and the 64 setup points of the interpolation
+    // commitment, so that the four sums that follow the challenge are table sums (0.45 ms) instead of ladders
+    // (1.0-2.2 ms).  Measured with the table off / on (tools/bench_verify_cells.py, same box,
+    // profiles/r03_verify_x28_sweep.txt): n = 1024 3.20 -> 2.88 ms, 2048 4.56 -> 3.20, 4096 7.54 -> 5.50,
+    // 6144 9.81 -> 7.67, and n = 128 2.38 -> 2.31, 256 2.42 -> 2.32, 384 2.55 -> 2.36, 768 2.91 -> 2.49; below a
+    // blob's worth of cells the two forms tie at the 2.3 ms latency floor of the call: from 128 cells upwards.
     static const int call_table_wbits = []() {
         const char *e = getenv("CKZG_HIP_VERIFY_TABLE_WBITS");   // 0 switches the call-time table off (A/B)
         return e && *e ? atoi(e) : 6;
     }();
     static const size_t cell_table_min = []() {
         const char *e = getenv("CKZG_HIP_VERIFY_CELL_TABLE_MIN");
-        return e && *e ? (size_t)atol(e) : (size_t)6144;
+        return e && *e ? (size_t)atol(e) : (size_t)128;
     }();
     const bool use_table = call_table_wbits >= 4 && call_table_wbits <= 10 && n >= cell_table_min;
     const size_t npts = n + nc + (use_table ? l : 0);   // proofs, distinct commitments [, g1_values_monomial[0..63]]
@@ -1423,7 +1421,7 @@ static C_KZG_RET verify_cells_on(dev::DeviceCtx *ctx, bool *ok, const Bytes48 *c
     size_t tbl_bytes = 0, tbl_tmp = 0, sums_scratch = 0;
     if (use_table) {
         dev::call_table_geometry(&tbl, (int)npts, call_table_wbits);
-        tbl_bytes = tbl.bytes();
+        tbl_bytes = dev::call_table_bytes(tbl);
         tbl_tmp = dev::call_table_tmp_bytes(tbl);
         sums_scratch = dev::table_sums_scratch_bytes(tbl, 4);
     }
@@ -1507,7 +1505,7 @@ static C_KZG_RET verify_cells_on(dev::DeviceCtx *ctx, bool *ok, const Bytes48 *c
     if (use_table) {
         if (!ctx->aux_stream) OKB(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) == hipSuccess);
         OKB(hipStreamWaitEvent(ctx->aux_stream, ctx->stage_ev[0], 0) == hipSuccess);
-        RC(dev::call_table_enqueue(ctx->aux_stream, &tbl, reinterpret_cast<G1Affine *>(d_tbl.p), d_tbl_tmp.p, d_pts.p));
+        RC(dev::call_table_enqueue(ctx->aux_stream, &tbl, d_tbl.p, d_tbl_tmp.p, d_pts.p));
         OKB(hipEventRecord(ctx->stage_ev[2], ctx->aux_stream) == hipSuccess);
     }
     StreamDrain drain_aux{use_table ? ctx->aux_stream : nullptr};

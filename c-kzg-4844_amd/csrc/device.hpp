@@ -102,6 +102,7 @@ struct DeviceCtx {
     Scratch scratch;              // per slot: reused by every call that leases the slot
     Arena api_arena, lc_arena;    // temporaries of the host-pointer entry points / of gpu_lincomb_multi
     hipEvent_t stage_ev[4] = {};  // copied[2], consumed[2] of the staging pipeline (created on first use)
+    hipEvent_t table_ev = nullptr;      // "the call-time table is complete" (verification; created on first use)
     std::vector<hipEvent_t> chunk_ev;   // per-chunk events of the pipelined verification (grown on demand, kept)
     hipEvent_t ev[12] = {};       // timing events
     float last_ms[6] = {-1, -1, -1, -1, -1, -1};  // see ckzg_hip_last_kernel_ms
@@ -170,8 +171,9 @@ int msm_commit_table_raw_device(DeviceCtx *ctx, uint8_t *d_out48, const uint32_t
 
 // call-time tables (msm.hip): a fixed-base table over points that arrive with the call, and sums over it
 void call_table_geometry(FixedBaseTable *t, int npoints, int wbits);
+size_t call_table_bytes(const FixedBaseTable &t);       // (accumulator-form entries: not FixedBaseTable::bytes())
 size_t call_table_tmp_bytes(const FixedBaseTable &t);
-int call_table_enqueue(hipStream_t stream, FixedBaseTable *t, G1Affine *d_table, uint8_t *d_tmp, const G1Affine *d_bases);
+int call_table_enqueue(hipStream_t stream, FixedBaseTable *t, void *d_table, uint8_t *d_tmp, const G1Affine *d_bases);
 size_t table_sums_scratch_bytes(const FixedBaseTable &t, size_t nvec);
 int table_sums_enqueue(hipStream_t stream, const FixedBaseTable &t, G1XYZZ *d_sums, const uint32_t *d_scalars, size_t nvec,
                        uint8_t *scratch);

@@ -174,6 +174,7 @@ static void destroy_slot(dev::DeviceCtx *ctx) {
         if (e) (void)hipEventDestroy(e);
     }
     for (auto e : ctx->chunk_ev) (void)hipEventDestroy(e);
+    if (ctx->table_ev) (void)hipEventDestroy(ctx->table_ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->out_stream) (void)hipStreamDestroy(ctx->out_stream);

@@ -466,10 +466,16 @@ HD F28<1, 2> f28_from_fp(const Fp &x) {
     return mul(f28_unpack<1>(x.l), f28_const<1, 1>(FP28_FROM384));
 }
 
+// the tail of f28_to_fp: a value < 2p that already carries the 2^384-domain factor -> [0, p), packed
+HD Fp f28_finish_fp(const F28<1, 2> &t);
+
 // full reduction to [0, p) in the 2^384 domain
 template <int LA, int VA>
 HD Fp f28_to_fp(const F28<LA, VA> &a) {
-    F28<1, 2> t = mul(a, f28_const<1, 1>(FP28_TO384));
+    return f28_finish_fp(mul(a, f28_const<1, 1>(FP28_TO384)));
+}
+
+HD Fp f28_finish_fp(const F28<1, 2> &t) {
     // conditional subtraction of p in 28-bit limbs
     uint32_t s[14];
     uint32_t br = 0;

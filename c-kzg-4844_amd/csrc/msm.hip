@@ -60,6 +60,56 @@ __global__ void k_window_bases(G1XYZZ *wb, const G1Affine *bases, int npoints, i
     }
 }
 
+// The same on the four lanes of a DPP quad per point (g1_quad.hpp), in the 28-bit field: the (nwin - 1) * wbits
+// sequential doublings are the latency floor of every call-time table build (126 of them for a 6-bit table: 2.4 ms in
+// the one-lane form above whatever the number of points).  A doubling is three product steps on four lanes instead of
+// seven products on one; the conversion of a window base to the XYZZ form the chain builder reads is three more steps,
+// each lane finishing one coordinate: zz = z^2 | x | y | zzz = z^3, all multiplied into the 2^384 domain on the way.
+__global__ __launch_bounds__(64) void k_window_bases_quad(G1XYZZ *wb, const G1Affine *bases, int npoints, int wbits, int nwin) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = gid >> 2, ql = gid & 3;
+    if (i >= npoints) return;   // (whole quads leave together)
+    const G1Affine b = bases[i];
+    const bool inf = b.is_inf();
+    JAC28 a;
+    a.x = widen<1, 34>(f28_from_fp(b.x));
+    a.y = widen<1, 34>(f28_from_fp(b.y));
+    a.z = widen<2, 4>(f28_one());
+    const auto to384 = f28_const<1, 1>(FP28_TO384);
+    const int field = ql == 1 ? 0 : (ql == 2 ? 1 : (ql == 0 ? 2 : 3));   // x, y, zz, zzz of G1XYZZ
+    for (int w = 0; w < nwin; w++) {
+        {
+            const auto x = widen<2, 34>(a.x), y = widen<2, 34>(a.y), z = widen<2, 34>(a.z), t = widen<2, 34>(to384);
+            const auto p1 = mul(quad::qsel(ql, z, x, y, z), quad::qsel(ql, z, t, t, z));          // zz | x' | y' | zz
+            const auto z4 = widen<2, 4>(a.z), t4 = widen<2, 4>(to384);
+            const auto p2 = mul(p1, quad::qsel(ql, t4, t4, t4, z4));                               // zz' | - | - | zzz
+            const auto p3 = mul(p2, to384);                                                       // -   | - | - | zzz'
+            F28<1, 2> mine;
+#pragma unroll
+            for (int j = 0; j < 14; j++) mine.l[j] = ql == 0 ? p2.l[j] : (ql == 3 ? p3.l[j] : p1.l[j]);
+            const Fp out = f28_finish_fp(mine);
+            uint32_t *dst = reinterpret_cast<uint32_t *>(wb + (size_t)w * npoints + i) + field * 12;
+#pragma unroll
+            for (int k = 0; k < 12; k++) dst[k] = inf ? 0u : out.l[k];
+        }
+        if (w + 1 < nwin) {
+            for (int k = 0; k < wbits; k++) quad::jac28_dbl_quad(a, ql);
+        }
+    }
+}
+
+static void enqueue_window_bases(hipStream_t stream, G1XYZZ *d_wb, const G1Affine *d_bases, int npoints, int wbits, int nwin) {
+    static const bool one_lane = []() {
+        const char *e = getenv("CKZG_HIP_WINDOW_BASES");   // "old": the one-lane kernel (A/B)
+        return e && !strcmp(e, "old");
+    }();
+    if (one_lane)
+        hipLaunchKernelGGL(k_window_bases, dim3((npoints + 63) / 64), dim3(64), 0, stream, d_wb, d_bases, npoints, wbits, nwin);
+    else
+        hipLaunchKernelGGL(k_window_bases_quad, dim3((unsigned)(((size_t)npoints * 4 + 63) / 64)), dim3(64), 0, stream, d_wb,
+                           d_bases, npoints, wbits, nwin);
+}
+
 constexpr int CHAIN_SEG = 64;
 
 // tmp[i*half + e] = (e+1) * B_i for one window; each thread owns a run of CHAIN_SEG multiples
@@ -367,8 +417,7 @@ int build_fixed_base_table(DeviceCtx *ctx, FixedBaseTable *t, const G1Affine *d_
     HIP_TRY(hipMalloc(&wb.p, (size_t)t->twin * npoints * sizeof(G1XYZZ)));
     G1XYZZ *d_wb = static_cast<G1XYZZ *>(wb.p);
     const auto t_alloc = std::chrono::steady_clock::now();
-    hipLaunchKernelGGL(k_window_bases, dim3((npoints + 63) / 64), dim3(64), 0, ctx->stream, d_wb,
-                       d_bases, npoints, wbits, t->twin);
+    enqueue_window_bases(ctx->stream, d_wb, d_bases, npoints, wbits, t->twin);
     if (!old_builder) {
         const size_t nchains = (size_t)t->twin * npoints;
         HIP_TRY(hipMalloc(&wba.p, nchains * sizeof(G1Affine)));
@@ -1117,6 +1166,119 @@ __global__ void k_raw_digits_n(int16_t *digits, const uint32_t *scalars, uint32_
     glv_digits(digits + vec * (size_t)(2 * twin) * npoints + i, npoints, s, wbits, twin);
 }
 
+// ---- the call-time table is kept in ACCUMULATOR form ("X28": XYZZ28 -- x, y, zz, zzz as 14 limbs of 28 bits in the
+// 2^392 domain, 224 bytes an entry; zz all-zero = infinity).  The setup tables are affine because they are built
+// once and read for ever; a call-time table is built and read once, and what its affine form costs -- an inversion
+// per entry, shared by Montgomery's trick or not: 5.3 of the 7.7 ms of an 8192-point 6-bit build -- buys a 9-product
+// mixed addition instead of a 14-product full one in sums that are 0.1 ms of arithmetic either way.  In this form
+// the build is the window-base ladders on quad lanes (0.75 ms) and one chain of full additions per (window, point).
+struct X28Entry {
+    uint4 q[14];
+};
+
+__device__ __forceinline__ void x28_store(X28Entry *dst, const XYZZ28 &p, bool inf) {
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(&p);
+#pragma unroll
+    for (int k = 0; k < 14; k++)
+        dst->q[k] = inf ? make_uint4(0, 0, 0, 0) : make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+}
+__device__ __forceinline__ XYZZ28 x28_load(const X28Entry *src, bool &inf) {
+    XYZZ28 p;
+    uint32_t *w = reinterpret_cast<uint32_t *>(&p);
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+        const uint4 v = src->q[k];
+        w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+        if (k >= 7 && k < 11) any |= v.x | v.y | v.z | v.w;   // words 28..41 are zz (42, 43: the first limbs of zzz)
+    }
+    inf = any == 0;
+    return p;
+}
+static_assert(sizeof(XYZZ28) == 224 && sizeof(X28Entry) == 224, "XYZZ28 is 4 x 14 words");
+
+// wb[w][i] = 2^(wbits*w) * P_i in X28 form, four lanes per point (k_window_bases_quad without the way back to the
+// 2^384 domain): after each window's doublings the lanes make z^2 | x | y | z^2 and then z^3, and lane k stores
+// coordinate k.
+__global__ __launch_bounds__(64) void k_window_bases_quad_x28(X28Entry *wb, const G1Affine *bases, int npoints, int wbits, int nwin) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = gid >> 2, ql = gid & 3;
+    if (i >= npoints) return;   // (whole quads leave together)
+    const G1Affine b = bases[i];
+    const bool inf = b.is_inf();
+    JAC28 a;
+    a.x = widen<1, 34>(f28_from_fp(b.x));
+    a.y = widen<1, 34>(f28_from_fp(b.y));
+    a.z = widen<2, 4>(f28_one());
+    const int field = ql == 1 ? 0 : (ql == 2 ? 1 : (ql == 0 ? 2 : 3));   // x, y, zz, zzz
+    for (int w = 0; w < nwin; w++) {
+        {
+            const auto x = widen<2, 34>(a.x), y = widen<2, 34>(a.y), z = widen<2, 34>(a.z), one = widen<2, 34>(f28_one());
+            const auto p1 = mul(quad::qsel(ql, z, x, y, z), quad::qsel(ql, z, one, one, z));       // zz | x | y | zz
+            const auto p2 = mul(p1, widen<2, 4>(a.z));                                             // -  | - | - | zzz
+            uint32_t *dst = reinterpret_cast<uint32_t *>(wb + (size_t)w * npoints + i) + field * 14;
+#pragma unroll
+            for (int j = 0; j < 14; j++) dst[j] = inf ? 0u : (ql == 3 ? p2.l[j] : p1.l[j]);
+        }
+        if (w + 1 < nwin) {
+            for (int k = 0; k < wbits; k++) quad::jac28_dbl_quad(a, ql);
+        }
+    }
+}
+
+// table[c][e] = (e + 1) * B_c, c = window * npoints + point: one lane per chain, `half` entries, full additions
+__global__ __launch_bounds__(64) void k_table_chain_x28(X28Entry *table, const X28Entry *wb, uint32_t nchains, uint32_t half) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchains) return;
+    bool binf;
+    const XYZZ28 b = x28_load(wb + c, binf);
+    X28Entry *out = table + (size_t)c * half;
+    XYZZ28 acc = b;
+    bool inf = binf;
+    x28_store(out, acc, inf);
+    for (uint32_t e = 1; e < half; e++) {
+        xyzz28_add(acc, inf, b, binf);
+        x28_store(out + e, acc, inf);
+    }
+}
+
+// k_msm_accumulate over an X28 table: the same pair walk (k2 half first, phi when the boundary is crossed), full
+// additions, plain loads -- the three or four vectors of a verification are a few additions per lane and the fold.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_msm_accumulate_x28(G1XYZZ *partials, const X28Entry *table, const int16_t *digits,
+                                                               uint32_t pairs_per_vec, uint32_t pairs_per_block, int half_shift,
+                                                               uint32_t blocks_per_vec, uint32_t npoints) {
+    __shared__ uint32_t sh[57][THREADS];
+    const uint32_t vec = blockIdx.x / blocks_per_vec, chunk = blockIdx.x % blocks_per_vec;
+    const uint32_t q0 = chunk * pairs_per_block;
+    const uint32_t q1 = q0 + pairs_per_block < pairs_per_vec ? q0 + pairs_per_block : pairs_per_vec;
+    const uint32_t phi_pairs = pairs_per_vec >> 1, twin = phi_pairs / npoints;
+    const int16_t *dg = digits + (size_t)vec * pairs_per_vec;
+    XYZZ28 acc;
+    bool inf = true;
+    const uint32_t first = q0 + threadIdx.x;
+    bool phi_pending = first < phi_pairs;
+    for (uint32_t q = first; q < q1; q += THREADS) {
+        if (phi_pending && q >= phi_pairs) {
+            if (!inf) msm_apply_phi(acc);
+            phi_pending = false;
+        }
+        const int d = dg[q];
+        if (d == 0) continue;
+        const uint32_t w = q / npoints, i = q - w * npoints;
+        const uint32_t tw = w >= twin ? w - twin : w;
+        const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+        bool oinf;
+        XYZZ28 o = x28_load(table + ((((size_t)tw * npoints + i) << half_shift) + (mag - 1)), oinf);
+        if (oinf) continue;
+        if (d < 0) o = xyzz28_neg(o);
+        xyzz28_add(acc, inf, o, false);
+    }
+    if (phi_pending && !inf) msm_apply_phi(acc);
+    quad::block_reduce_xyzz28_quad<THREADS>(acc, inf, sh);
+    if (threadIdx.x == 0) partials[(size_t)vec * blocks_per_vec + chunk] = xyzz28_to_xyzz(acc, inf);
+}
+
 void call_table_geometry(FixedBaseTable *t, int npoints, int wbits) {
     t->d_table = nullptr;
     t->npoints = npoints;
@@ -1126,24 +1288,24 @@ void call_table_geometry(FixedBaseTable *t, int npoints, int wbits) {
     t->half = (size_t)1 << (wbits - 1);
 }
 
-// temporaries of call_table_enqueue: window bases (XYZZ), their affine form, prefix products
+size_t call_table_bytes(const FixedBaseTable &t) { return (size_t)t.twin * t.npoints * t.half * sizeof(X28Entry); }
+
+// temporaries of call_table_enqueue: the window bases
 size_t call_table_tmp_bytes(const FixedBaseTable &t) {
-    const size_t nchains = (size_t)t.twin * t.npoints;
-    return align_up(nchains * sizeof(G1XYZZ), 256) + align_up(nchains * sizeof(G1Affine), 256) + align_up(nchains * sizeof(Fp), 256);
+    return align_up((size_t)t.twin * t.npoints * sizeof(X28Entry), 256);
 }
 
-// Enqueue the construction of t (geometry set by call_table_geometry) into d_table (t->bytes()) on `stream`.  d_bases:
-// npoints affine points (2^384 domain, (0,0) = infinity) that must lie in the prime-order subgroup.
-int call_table_enqueue(hipStream_t stream, FixedBaseTable *t, G1Affine *d_table, uint8_t *d_tmp, const G1Affine *d_bases) {
+// Enqueue the construction of t (geometry set by call_table_geometry) into d_table (call_table_bytes(t)) on `stream`.
+// d_bases: npoints affine points (2^384 domain, (0,0) = infinity) that must lie in the prime-order subgroup.
+int call_table_enqueue(hipStream_t stream, FixedBaseTable *t, void *d_table, uint8_t *d_tmp, const G1Affine *d_bases) {
     const size_t nchains = (size_t)t->twin * t->npoints;
-    G1XYZZ *d_wb = reinterpret_cast<G1XYZZ *>(d_tmp);
-    G1Affine *d_wba = reinterpret_cast<G1Affine *>(d_tmp + align_up(nchains * sizeof(G1XYZZ), 256));
-    Fp *d_prefix = reinterpret_cast<Fp *>(d_tmp + align_up(nchains * sizeof(G1XYZZ), 256) + align_up(nchains * sizeof(G1Affine), 256));
-    hipLaunchKernelGGL(k_window_bases, dim3((t->npoints + 63) / 64), dim3(64), 0, stream, d_wb, d_bases, t->npoints, t->wbits,
-                       t->twin);
-    int rc = enqueue_affine_chain_table(stream, *t, d_table, d_wb, d_wba, d_prefix, nullptr);
-    if (rc) return rc;
-    t->d_table = d_table;
+    X28Entry *d_wb = reinterpret_cast<X28Entry *>(d_tmp);
+    hipLaunchKernelGGL(k_window_bases_quad_x28, dim3((unsigned)(((size_t)t->npoints * 4 + 63) / 64)), dim3(64), 0, stream, d_wb,
+                       d_bases, t->npoints, t->wbits, t->twin);
+    hipLaunchKernelGGL(k_table_chain_x28, dim3((unsigned)((nchains + 63) / 64)), dim3(64), 0, stream,
+                       static_cast<X28Entry *>(d_table), d_wb, (uint32_t)nchains, (uint32_t)t->half);
+    HIP_TRY(hipGetLastError());
+    t->d_table = static_cast<G1Affine *>(d_table);   // (an X28 table: only table_sums_enqueue reads it)
     return 0;
 }
 
@@ -1154,7 +1316,8 @@ size_t table_sums_scratch_bytes(const FixedBaseTable &t, size_t nvec) {
     return align_up(nvec * (size_t)pairs_per_vec * sizeof(int16_t), 256) + align_up(nvec * (size_t)bpv * sizeof(G1XYZZ), 256);
 }
 
-// d_sums[v] = sum_i scalars[v][i] * base_i over the whole table, v < nvec, as fully reduced XYZZ points.  Enqueue-only.
+// d_sums[v] = sum_i scalars[v][i] * base_i over the whole (call-time, X28) table, v < nvec, as fully reduced XYZZ
+// points.  Enqueue-only.
 int table_sums_enqueue(hipStream_t stream, const FixedBaseTable &t, G1XYZZ *d_sums, const uint32_t *d_scalars, size_t nvec,
                        uint8_t *scratch) {
     if (!t.d_table || nvec == 0) return 2;
@@ -1166,8 +1329,9 @@ int table_sums_enqueue(hipStream_t stream, const FixedBaseTable &t, G1XYZZ *d_su
     const size_t total = nvec * (size_t)t.npoints;
     hipLaunchKernelGGL(k_raw_digits_n, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, d_digits, d_scalars,
                        (uint32_t)t.npoints, total, t.wbits, t.twin);
-    hipLaunchKernelGGL(k_msm_accumulate<256>, dim3((unsigned)(nvec * bpv)), dim3(256), 0, stream, d_partials, t.d_table, d_digits,
-                       pairs_per_vec, ppb, t.wbits - 1, bpv, (uint32_t)t.npoints, (uint32_t)t.npoints, 1u, bpv, 0u);
+    hipLaunchKernelGGL(k_msm_accumulate_x28<256>, dim3((unsigned)(nvec * bpv)), dim3(256), 0, stream, d_partials,
+                       reinterpret_cast<const X28Entry *>(t.d_table), d_digits, pairs_per_vec, ppb, t.wbits - 1, bpv,
+                       (uint32_t)t.npoints);
     hipLaunchKernelGGL(k_msm_reduce_partials, dim3((unsigned)nvec), dim3(64), 0, stream, d_sums, d_partials, bpv);
     HIP_TRY(hipGetLastError());
     return 0;
