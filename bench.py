@@ -382,7 +382,7 @@ def verify_and_recover_rows(L, hip, base):
                                   "kernel_ms": {"total": round(median(ks), 3), "validate_convert_hash_evaluate": round(median(k0), 3),
                                                 "sums": round(median(k2), 3)},
                                   "roofline": roofline(ALGO_BYTES_VERIFY_BLOB * n, median(ks),
-                                                       "k_sha256_challenges + k_eval_barycentric + k_validate_g1 + k_lincomb_partial (device time of the call)")}
+                                                       "k_sha256_challenges + k_eval_barycentric + k_validate_g1 + k_msm_accumulate_x28 over the call-time table (device time of the call)")}
         del hb, pin_t, dev_t
     except Exception as e:  # noqa: BLE001 -- reported, the pageable row stands
         row["forms_error"] = str(e)

@@ -538,18 +538,24 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
         const char *e = getenv("CKZG_HIP_VERIFY_TABLE_MIN");
         return e && *e ? (size_t)atol(e) : (size_t)8;
     }();
-    const bool use_table = call_table_wbits >= 4 && call_table_wbits <= 10 && n >= call_table_min && !small;
+    bool use_table = call_table_wbits >= 4 && call_table_wbits <= 10 && n >= call_table_min && !small;
     dev::FixedBaseTable tbl;
     size_t tbl_bytes = 0, tbl_tmp = 0, sums_scratch = 0;
+    Arena &ar = ctx->api_arena;
+    const size_t plain_bytes = (resident ? 0 : n * BYTES_PER_BLOB) + (n * FIELD_ELEMENTS_PER_BLOB + 2 * n) * sizeof(Fr) + n * 4 +
+                               2 * n * (48 + 2 + sizeof(G1Affine)) + 8192;
     if (use_table) {
         dev::call_table_geometry(&tbl, (int)(2 * n), call_table_wbits);
         tbl_bytes = dev::call_table_bytes(tbl);
         tbl_tmp = dev::call_table_tmp_bytes(tbl);
         sums_scratch = dev::table_sums_scratch_bytes(tbl, 3);
+        // the table is an optimisation (1.3 GB at n = 4096): a device too full for it still verifies, by ladders
+        if (!ar.begin(plain_bytes + tbl_bytes + tbl_tmp + sums_scratch + 6 * n * 32 + 1024)) {
+            use_table = false;
+            tbl_bytes = tbl_tmp = sums_scratch = 0;
+        }
     }
-    Arena &ar = ctx->api_arena;
-    OKM(ar.begin((resident ? 0 : n * BYTES_PER_BLOB) + (n * FIELD_ELEMENTS_PER_BLOB + 2 * n) * sizeof(Fr) + n * 4 +
-                 2 * n * (48 + 2 + sizeof(G1Affine)) + tbl_bytes + tbl_tmp + sums_scratch + (use_table ? 6 * n * 32 + 1024 : 0) + 8192));
+    if (!use_table) OKM(ar.begin(plain_bytes));
     ABuf<uint8_t> d_ptb(ar, 2 * n * 48), d_st(ar, 2 * n), d_st2(ar, 2 * n), d_blobs_own(ar, resident ? 1 : n * BYTES_PER_BLOB);
     ABuf<G1Affine> d_pts(ar, 2 * n);
     ABuf<Fr> d_poly(ar, n * FIELD_ELEMENTS_PER_BLOB), d_z(ar, n), d_y(ar, n);
@@ -1415,20 +1421,26 @@ static C_KZG_RET verify_cells_on(dev::DeviceCtx *ctx, bool *ok, const Bytes48 *c
         const char *e = getenv("CKZG_HIP_VERIFY_CELL_TABLE_MIN");
         return e && *e ? (size_t)atol(e) : (size_t)128;
     }();
-    const bool use_table = call_table_wbits >= 4 && call_table_wbits <= 10 && n >= cell_table_min;
-    const size_t npts = n + nc + (use_table ? l : 0);   // proofs, distinct commitments [, g1_values_monomial[0..63]]
+    bool use_table = call_table_wbits >= 4 && call_table_wbits <= 10 && n >= cell_table_min;
+    size_t npts = n + nc + (use_table ? l : 0);   // proofs, distinct commitments [, g1_values_monomial[0..63]]
     dev::FixedBaseTable tbl;
     size_t tbl_bytes = 0, tbl_tmp = 0, sums_scratch = 0;
+    Arena &ar = ctx->api_arena;
+    const size_t plain_bytes = (n + nc + l) * (48 + 2 + sizeof(G1Affine)) + ((size_t)CELLS_PER_EXT_BLOB * l + l + n * l + n) * sizeof(Fr) +
+                               n * BYTES_PER_CELL + (n + CELLS_PER_EXT_BLOB + 1 + n) * 4 + 4096;
     if (use_table) {
         dev::call_table_geometry(&tbl, (int)npts, call_table_wbits);
         tbl_bytes = dev::call_table_bytes(tbl);
         tbl_tmp = dev::call_table_tmp_bytes(tbl);
         sums_scratch = dev::table_sums_scratch_bytes(tbl, 4);
+        // the table is an optimisation: a device too full for it still verifies, by ladders
+        if (!ar.begin(plain_bytes + tbl_bytes + tbl_tmp + sums_scratch + 4 * npts * 32 + (2 * n + nc + 1) * 4 + 4096)) {
+            use_table = false;
+            tbl_bytes = tbl_tmp = sums_scratch = 0;
+            npts = n + nc;
+        }
     }
-    Arena &ar = ctx->api_arena;
-    OKM(ar.begin(npts * (48 + 2 + sizeof(G1Affine)) + ((size_t)CELLS_PER_EXT_BLOB * l + l + n * l + n) * sizeof(Fr) +
-                 n * BYTES_PER_CELL + (n + CELLS_PER_EXT_BLOB + 1 + n) * 4 + tbl_bytes + tbl_tmp + sums_scratch +
-                 (use_table ? 4 * npts * 32 + (2 * n + nc + 1) * 4 + 4096 : 0) + 4096));
+    if (!use_table) OKM(ar.begin(plain_bytes));
     ABuf<uint8_t> d_ptb(ar, (n + nc) * 48), d_st(ar, n + nc), d_st2(ar, n + nc), d_cells(ar, n * BYTES_PER_CELL);
     ABuf<G1Affine> d_pts(ar, npts);
     ABuf<uint8_t> d_tbl(ar, use_table ? tbl_bytes : 1), d_tbl_tmp(ar, use_table ? tbl_tmp : 1), d_sums_scr(ar, use_table ? sums_scratch : 1);
