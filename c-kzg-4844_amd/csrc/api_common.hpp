@@ -341,7 +341,7 @@ class CopyHelpers {
     }
 
    private:
-    static constexpr int NHELP = 6;   // two concurrent callers are served at full width
+    static constexpr int NHELP = 14;  // two concurrent callers are served at full width (staged_copy: up to 8 ways)
     bool ensure_started() {
         if (started) return nworkers > 0;
         started = true;
@@ -437,8 +437,12 @@ class WorkerPool {
 };
 
 inline void staged_copy(void *dst, const void *src, size_t bytes) {
-    const size_t nt = 4;
-    if (bytes < ((size_t)4 << 20) || std::thread::hardware_concurrency() < 8) {
+    static const size_t nt = []() {
+        const char *e = getenv("CKZG_HIP_COPY_THREADS");   // ways a staging copy is split (the caller is one of them)
+        long v = e && *e ? atol(e) : 4;
+        return (size_t)(v < 1 ? 1 : (v > 8 ? 8 : v));
+    }();
+    if (nt == 1 || bytes < ((size_t)4 << 20) || std::thread::hardware_concurrency() < 8) {
         memcpy(dst, src, bytes);
         return;
     }
