@@ -385,12 +385,16 @@ class WorkerPool {
         static WorkerPool *p = new WorkerPool();
         return *p;
     }
-    // false: no worker could be started; the caller runs the job some other way
-    bool submit(std::function<void()> job) {
-        {
+    // false: the job was NOT taken (no worker could be started, or no memory for the queue entry) and the caller
+    // runs it some other way.  Never throws: the submitters keep counters of outstanding jobs that an exception
+    // between the increment and the hand-over would leave wrong for ever.
+    bool submit(std::function<void()> job) noexcept {
+        try {
             std::lock_guard<std::mutex> lock(mu);
             if (!ensure_started()) return false;
             q.push_back(std::move(job));
+        } catch (...) {
+            return false;
         }
         cv.notify_one();
         return true;

@@ -383,13 +383,22 @@ struct TranscriptHasher {
     std::atomic<size_t> published{0};   // chunks whose download has been enqueued (its event recorded)
     std::atomic<bool> abort{false};
     bool failed = false;
-    std::thread t;
+    std::atomic<bool> done{false};      // the pool job has returned
+    bool on_pool = false;
+    std::thread t;                      // only when the worker pool did not take the job
     TranscriptHasher() = default;
     TranscriptHasher(const TranscriptHasher &) = delete;
     TranscriptHasher &operator=(const TranscriptHasher &) = delete;
+    void wait() {
+        if (on_pool) {
+            while (!done.load(std::memory_order_acquire)) std::this_thread::yield();
+        } else if (t.joinable()) {
+            t.join();
+        }
+    }
     ~TranscriptHasher() {
         abort.store(true);
-        if (t.joinable()) t.join();
+        wait();
     }
     void start(int device, size_t n, size_t chunk, const hipEvent_t *landed, const Bytes48 *cb, const Bytes48 *pb,
                const Fr *z, const Fr *h_y) {
@@ -398,7 +407,7 @@ struct TranscriptHasher {
         be64(head + 16, FIELD_ELEMENTS_PER_BLOB);
         be64(head + 24, n);
         h.update(head, 32);
-        t = std::thread([=]() {
+        auto body = [=]() {
             if (hipSetDevice(device) != hipSuccess) {
                 failed = true;
                 return;
@@ -423,11 +432,17 @@ struct TranscriptHasher {
                     h.update(pb[i].bytes, 48);
                 }
             }
+        };
+        // (a pool job may wait for the GPU and for the publishing caller, never for another pool job)
+        on_pool = WorkerPool::get().submit([this, body]() {
+            body();
+            done.store(true, std::memory_order_release);
         });
+        if (!on_pool) t = std::thread(body);
     }
     void publish(size_t chunks) { published.store(chunks, std::memory_order_release); }
     bool finish(uint8_t digest[32]) {
-        if (t.joinable()) t.join();
+        wait();
         if (failed) return false;
         h.finish(digest);
         return true;
@@ -477,7 +492,11 @@ struct OrderedHasher {
                     active.fetch_sub(1, std::memory_order_release);
                 })) {
                 active.fetch_sub(1, std::memory_order_relaxed);
-                th.spawn(loop);
+                try {
+                    th.spawn(loop);
+                } catch (...) {   // no pool and no thread: the last resort hashes here, before the pipeline starts
+                    if (t == 0) loop();
+                }
             }
         }
     }

@@ -369,3 +369,52 @@ def test_call_time_table_sums_in_cell_batch_verification(hip, oracle, material):
     # a small cross-check of the whole construction against the oracle on a prefix that it can afford
     m = 300
     assert oracle.verify_cell_kzg_proof_batch(com[:m], idx[:m], cells[:m], proofs[:m]) is True
+
+
+# ---------------------------------------------------------------------------------------------
+# the ladder sums stay a supported path (CKZG_HIP_VERIFY_TABLE_WBITS=0, and the fallback of a device too full for
+# the call-time table): the same batches, table off, in a child process (the knob is read once per process)
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.gpu
+def test_ladder_sums_without_the_call_time_table(oracle):
+    import json
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, json, sys
+sys.path.insert(0, "tests")
+from kzg_ctypes import HIP_SO, Kzg
+from test_gpu_commitment import rand_blob
+hip = Kzg(HIP_SO, "", precompute=0, options={"commit_wbits": 8})
+blobs = [rand_blob(173, i) for i in range(3)] + [bytes(131072)]     # the zero blob: commitment and proofs at infinity
+cm = [hip.blob_to_kzg_commitment(b) for b in blobs]
+pr = [hip.compute_blob_kzg_proof(b, c) for b, c in zip(blobs, cm)]
+cp = [hip.compute_cells_and_kzg_proofs(b) for b in blobs]
+out = {"commitments": [c.hex() for c in cm]}
+for n in (9, 300, 1100):
+    o = [(5 * i) % 4 for i in range(n)]
+    good = hip.verify_blob_kzg_proof_batch([blobs[k] for k in o], [cm[k] for k in o], [pr[k] for k in o])
+    p2 = [pr[k] for k in o]; p2[n - 1] = pr[(o[n - 1] + 1) % 4]
+    bad = hip.verify_blob_kzg_proof_batch([blobs[k] for k in o], [cm[k] for k in o], p2)
+    out["blobs_%d" % n] = [good, bad]
+for n in (130, 700):
+    ent = [((7 * i) % 4, (11 * i) % 128) for i in range(n)]
+    args = ([cm[b] for b, _ in ent], [c for _, c in ent], [cp[b][0][c] for b, c in ent])
+    good = hip.verify_cell_kzg_proof_batch(*args, [cp[b][1][c] for b, c in ent])
+    prf = [cp[b][1][c] for b, c in ent]; prf[3] = cp[(ent[3][0] + 1) % 3][1][ent[3][1]]
+    bad = hip.verify_cell_kzg_proof_batch(*args, prf)
+    out["cells_%d" % n] = [good, bad]
+print(json.dumps(out))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CKZG_HIP_VERIFY_TABLE_WBITS="0")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    from test_gpu_commitment import rand_blob
+    want_cm = [oracle.blob_to_kzg_commitment(rand_blob(173, i)).hex() for i in range(3)] + ["c0" + "00" * 47]
+    assert res.pop("commitments") == want_cm
+    assert res == {"blobs_9": [True, False], "blobs_300": [True, False], "blobs_1100": [True, False],
+                   "cells_130": [True, False], "cells_700": [True, False]}
