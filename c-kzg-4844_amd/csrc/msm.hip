@@ -1141,15 +1141,15 @@ int msm_commit_table_raw_device(DeviceCtx *ctx, uint8_t *d_out48, const uint32_t
 // ------------------------------------------------------------------------------------------
 // call-time tables: fixed-base sums over points that are only known when the call arrives
 //
-// The random-linear-combination sums of a large verification batch (sum r^i proof_i, sum r^i z_i proof_i,
-// sum r^i C_i; eip4844.c:731-746) are variable-base sums -- 128 sequential doublings per term on a ladder -- but their
-// POINTS are known long before their scalars: the commitments and proofs are 96 bytes per blob and validated while
-// the blobs (128 KB each) are still crossing PCIe, whereas r hashes every evaluation and arrives last.  So the
-// doublings are done early: a narrow fixed-base table over the 2n validated points is built on a side stream under the
-// copy (the same affine-chain builder as the setup tables, 22 windows of 6 bits: ~4 ms of otherwise idle GPU for
-// n = 4096), and once r exists the three sums are three digit vectors through k_msm_accumulate: 1.1 M table
-// additions instead of 12,288 ladders, 0.4 ms instead of 2.45 ms after the last byte.  Only worth it when the copy
-// is long enough to hide the build (ckzg_api2.hip: verify_blobs_core decides).
+// The random-linear-combination sums of a verification batch (sum r^i proof_i, sum r^i z_i proof_i, sum r^i C_i;
+// eip4844.c:731-746; the four sums of eip7594.c:926,530,807,758) are variable-base sums -- 128 sequential doublings per
+// term on a ladder -- but their POINTS are known long before their scalars: the commitments and proofs are 96 bytes
+// per blob and validated while the blobs (128 KB each) are still crossing PCIe, whereas r hashes every evaluation and
+// arrives last.  So the doublings are done early: a narrow fixed-base table over the validated points (22 windows of
+// 6 bits) is built on a side stream under the copy / the transcript hash, and once r exists the sums are digit vectors
+// over that table: 0.45 ms instead of 1.0-2.45 ms after the last byte.  The table is in accumulator form (below): its
+// build is ~1 ms of latency plus 0.15 us per point, short enough to pay from 8 blobs / 128 cells upwards
+// (ckzg_api2.hip: verify_blobs_core, verify_cells_on decide; a table that does not fit the arena is simply not built).
 // ------------------------------------------------------------------------------------------
 
 // Same as k_raw_digits for vectors of any length: scalars[vec][i][8] (canonical, little-endian words), i < npoints
