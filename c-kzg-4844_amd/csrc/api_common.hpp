@@ -316,7 +316,7 @@ C_KZG_RET for_each_device_shard(const KZGSettings *s, uint64_t n, uint64_t min_s
 }
 
 // pageable <-> pinned staging copy.  One core moves ~10 GB/s, which would make a copy (13 ms per
-// 1024 blobs) longer than the kernels it is supposed to hide behind: large chunks are split four ways, three
+// 1024 blobs) longer than the kernels it is supposed to hide behind: large chunks are split eight ways, seven
 // parts going to a small process-wide set of persistent helper threads (started on first use, never per chunk;
 // if they cannot be started the caller copies everything itself).
 class CopyHelpers {
@@ -443,7 +443,8 @@ class WorkerPool {
 inline void staged_copy(void *dst, const void *src, size_t bytes) {
     static const size_t nt = []() {
         const char *e = getenv("CKZG_HIP_COPY_THREADS");   // ways a staging copy is split (the caller is one of them)
-        long v = e && *e ? atol(e) : 4;
+        long v = e && *e ? atol(e) : 8;   // measured (profiles/r03_copy_threads_ab.txt): 4 ways make the pageable source of a
+                                           // 4096-blob verification memcpy-bound (median 15.8 ms), 8 ways DMA-bound (12.5 ms)
         return (size_t)(v < 1 ? 1 : (v > 8 ? 8 : v));
     }();
     if (nt == 1 || bytes < ((size_t)4 << 20) || std::thread::hardware_concurrency() < 8) {
