@@ -410,7 +410,7 @@ class WorkerPool {
         started = true;
         unsigned hw = std::thread::hardware_concurrency();
         int want = hw ? (int)hw : 4;
-        if (want > 64) want = 64;   // two concurrent verifications at full width
+        if (want > 256) want = 256;   // eight concurrent verifications at full width (a fan-out over 8 GPUs in one process)
         for (int i = 0; i < want; i++) {
             try {
                 std::thread([this]() { run(); }).detach();
