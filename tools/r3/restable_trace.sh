@@ -1,3 +1,4 @@
+# (historical: CKZG_HIP_VERIFY_TABLE_RESIDENT was an A/B knob of commits b2ebe19..81b6cba; the table is now the default in the resident form)
 export TMPDIR=/tmp; O=gpurun_out/prof_restable; rm -rf $O; mkdir -p $O
 CKZG_HIP_VERIFY_TABLE_RESIDENT=1 timeout 250 rocprofv3 --kernel-trace --output-format csv -d $O -- python tools/bench_verify_forms.py 4096 2 > $O/out.txt 2>$O/err.txt
 python - <<'PY'
