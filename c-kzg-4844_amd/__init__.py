@@ -3,3 +3,4 @@
 The directory name contains '-', so import it by path (see __graft_entry__.load_package()).
 """
 from .ckzg import Kzg, KzgError, KZGSettings, HIP_SO, TRUSTED_SETUP  # noqa: F401
+from . import fanout  # noqa: F401

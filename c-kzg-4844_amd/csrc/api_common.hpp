@@ -66,6 +66,8 @@ struct Options {
     int proof_wbits = 8;    // monomial-point table for the direct proof path; 0 disables it
     int direct_max = -1;    // largest batch that takes the direct path (0 disables it; -1: by table width)
     int async_tables = 0;   // 1: load with the default-width tables, widen to the requested widths in the background
+    int coalesce = 1;       // 1: concurrent one-unit callers of the ckzg.h functions share batch launches (combiner.hpp)
+    int coalesce_active = 2;  // launches of one operation in flight per device before callers start to queue
 };
 // options of the NEXT load_trusted_setup; snapshotted under a lock when a load starts, so concurrent loads
 // with different options do not see each other's half-written state
@@ -133,8 +135,14 @@ struct LoadTimes {
 // the phases measured before the SettingsCtx exists (load_trusted_setup_file / _impl), per calling thread
 LoadTimes &pending_load_times();
 
+// the ckzg.h entry points whose concurrent callers are coalesced (combiner.hpp); the three output forms of
+// compute_cells_and_kzg_proofs are separate operations because they run different batch paths
+enum CombinedOp { CB_COMMIT = 0, CB_CELLS, CB_PROOFS, CB_CELLS_PROOFS, CB_BLOB_PROOF, CB_RECOVER, CB_COUNT };
+class Combiner;
+
 struct SettingsCtx {
     LoadTimes load;
+    Combiner *comb[CB_COUNT] = {};    // nullptr: "coalesce" = 0
     std::vector<DevicePool *> pools;
     PreparedG2 prepared;
     Options opts;

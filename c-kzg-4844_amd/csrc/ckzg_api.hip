@@ -8,6 +8,7 @@
 #include <thread>
 
 #include "api_common.hpp"
+#include "combiner.hpp"
 
 using namespace ckzg;
 using namespace ckzg::host;
@@ -66,6 +67,12 @@ extern "C" C_KZG_RET ckzg_hip_set_option(const char *key, int64_t value) {
     } else if (!strcmp(key, "async_tables")) {
         if (value != 0 && value != 1) return C_KZG_BADARGS;
         g_opts.async_tables = (int)value;
+    } else if (!strcmp(key, "coalesce")) {
+        if (value != 0 && value != 1) return C_KZG_BADARGS;
+        g_opts.coalesce = (int)value;
+    } else if (!strcmp(key, "coalesce_active")) {
+        if (value < 1 || value > 8) return C_KZG_BADARGS;
+        g_opts.coalesce_active = (int)value;
     } else if (!strcmp(key, "direct_max")) {
         if (value < -1 || value > 4096) return C_KZG_BADARGS;
         g_opts.direct_max = (int)value;
@@ -326,8 +333,9 @@ extern "C" C_KZG_RET ckzg_hip_blob_to_kzg_commitment_batch_device(void *d_out48,
 // stage, the following ones can be large enough to run the kernels at full-batch efficiency -- but not larger
 // than 256 blobs: the staging copy of a 512-blob chunk (64 MB on four threads) outlasts the kernels of a 192-blob
 // chunk before it and the GPU waits (profiles/r03_commit_chunk_ab.txt).
+// pinned_io: the caller vouches that `blobs` is page-locked (the combiner's batch buffer): DMA'd from in place.
 static C_KZG_RET commit_batch_on(dev::DeviceCtx *ctx, KZGCommitment *out, uint8_t *status, const Blob *blobs,
-                                 uint64_t n) {
+                                 uint64_t n, bool pinned_io = false) {
     if (n == 0) return C_KZG_OK;
     static const uint64_t CH = []() {
         const char *v = getenv("CKZG_HIP_COMMIT_CHUNK");
@@ -370,7 +378,7 @@ static C_KZG_RET commit_batch_on(dev::DeviceCtx *ctx, KZGCommitment *out, uint8_
     if (dev::scratch_reserve(ctx, dev::commit_scratch_bytes(ctx, m)) != 0) return C_KZG_MALLOC;
     // pinned staging: two input buffers of up to CH blobs; the results come back through the first 49 n
     // bytes of a third one (a pageable destination would make the final copy a blocking staged copy)
-    if (!ensure_pinned(ctx->h_stage, ctx->h_stage_bytes, n == 1 ? (size_t)BYTES_PER_BLOB : CH * BYTES_PER_BLOB)) return C_KZG_MALLOC;
+    if (!ensure_pinned(ctx->h_stage, ctx->h_stage_bytes, n == 1 || pinned_io ? (size_t)BYTES_PER_BLOB : CH * BYTES_PER_BLOB)) return C_KZG_MALLOC;
     for (int i = 0; i < 4; i++) {
         if (!ctx->stage_ev[i] && hipEventCreateWithFlags(&ctx->stage_ev[i], hipEventDisableTiming) != hipSuccess) {
             ctx->stage_ev[i] = nullptr;
@@ -381,8 +389,12 @@ static C_KZG_RET commit_batch_on(dev::DeviceCtx *ctx, KZGCommitment *out, uint8_
     if (n <= FIRST && ret == C_KZG_OK) {
         // one small chunk (the reference-shaped single-blob call among them): nothing to overlap, so the
         // copy in, the kernels and the copy out run on the one compute stream with a single wait
-        uint8_t *h_in = static_cast<uint8_t *>(ctx->h_stage[0]), *h_res = static_cast<uint8_t *>(ctx->h_stage[1]);
-        memcpy(h_in, blobs, n * BYTES_PER_BLOB);
+        const uint8_t *h_in = reinterpret_cast<const uint8_t *>(blobs);
+        uint8_t *h_res = static_cast<uint8_t *>(ctx->h_stage[1]);
+        if (!pinned_io) {
+            memcpy(ctx->h_stage[0], blobs, n * BYTES_PER_BLOB);
+            h_in = static_cast<const uint8_t *>(ctx->h_stage[0]);
+        }
         if (hipMemcpyAsync(d_blobs[0].p, h_in, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
             return C_KZG_ERROR;
         int rc = dev::commit_blobs_enqueue(ctx, d_out.p, d_status, (const uint8_t *)d_blobs[0].p, n);
@@ -398,7 +410,7 @@ static C_KZG_RET commit_batch_on(dev::DeviceCtx *ctx, KZGCommitment *out, uint8_
         }
         return ret;
     }
-    const bool src_pinned = host_pointer_is_pinned(blobs);  // page-locked caller memory: no staging copy
+    const bool src_pinned = pinned_io || host_pointer_is_pinned(blobs);  // page-locked caller memory: no staging copy
     uint64_t chunk = 0, k = 0, want = FIRST;
     for (uint64_t off = 0; off < n && ret == C_KZG_OK; off += k, chunk++) {
         const int b = (int)(chunk & 1);
@@ -473,9 +485,30 @@ extern "C" C_KZG_RET ckzg_hip_blob_to_kzg_commitment_batch(KZGCommitment *out, u
     });
 }
 
+// src/eip4844/eip4844.c:264-280.  One blob per call is all the reference API offers; threads that call it
+// concurrently on one KZGSettings (bindings/go/main_test.go:953-971) are served by shared batch launches
+// (combiner.hpp), a lone caller by its own launch as before.
 extern "C" C_KZG_RET blob_to_kzg_commitment(KZGCommitment *out, const Blob *blob, const KZGSettings *s) {
-    uint8_t st = 0;
-    return ckzg_hip_blob_to_kzg_commitment_batch(out, &st, blob, 1, s);
+    return guarded([&]() -> C_KZG_RET {
+        SettingsCtx *sc = settings_of(s);
+        if (!sc) return C_KZG_ERROR;
+        auto solo = [&]() -> C_KZG_RET {
+            uint8_t st = 0;
+            return ckzg_hip_blob_to_kzg_commitment_batch(out, &st, blob, 1, s);
+        };
+        Combiner *cb = sc->comb[CB_COMMIT];
+        if (!cb) return solo();
+        return cb->submit(
+            nullptr, 0, solo,
+            [&](uint8_t *h_in, size_t idx) { memcpy(h_in + idx * BYTES_PER_BLOB, blob, BYTES_PER_BLOB); },
+            [&](const uint8_t *h_in, uint8_t *h_out, uint8_t *st, size_t n) -> C_KZG_RET {
+                Lease lease(s);
+                if (!lease.ctx) return C_KZG_ERROR;
+                return commit_batch_on(lease.ctx, reinterpret_cast<KZGCommitment *>(h_out), st,
+                                       reinterpret_cast<const Blob *>(h_in), n, true);
+            },
+            [&](const uint8_t *h_out, size_t idx, size_t) { memcpy(out, h_out + idx * 48, 48); });
+    });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -511,8 +544,11 @@ static bool ensure_stage_events(dev::DeviceCtx *ctx) {
 static size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 
 // One device's share of a host-pointer compute_cells_and_kzg_proofs batch.
+// pinned_io (n <= 64 only): the caller vouches that blobs and the outputs are page-locked and that the outputs
+// are laid out [cells of n blobs][proofs of n blobs][n spare bytes] (the forms wanted only): the combiner's batch
+// buffers, DMA'd from and into in place.
 static C_KZG_RET cells_and_proofs_batch_on(dev::DeviceCtx *ctx, Cell *cells, KZGProof *proofs, uint8_t *status,
-                                           const Blob *blobs, uint64_t n) {
+                                           const Blob *blobs, uint64_t n, bool pinned_io = false) {
     if (n == 0) return C_KZG_OK;
     const size_t cells_per = (size_t)CELLS_PER_EXT_BLOB * BYTES_PER_CELL, proofs_per = (size_t)CELLS_PER_EXT_BLOB * 48;
     Arena &ar = ctx->api_arena;
@@ -524,22 +560,31 @@ static C_KZG_RET cells_and_proofs_batch_on(dev::DeviceCtx *ctx, Cell *cells, KZG
         if (!ar.begin(n * (BYTES_PER_BLOB + out_per) + 1024)) return C_KZG_MALLOC;
         ABuf<uint8_t> d_blobs(ar, n * BYTES_PER_BLOB), d_out(ar, n * out_per);
         if (!d_blobs.p || !d_out.p) return C_KZG_MALLOC;
-        if (!ensure_pinned(ctx->h_stage, ctx->h_stage_bytes, n == 1 ? (size_t)BYTES_PER_BLOB : 64 * (size_t)BYTES_PER_BLOB))
-            return C_KZG_MALLOC;
-        if (!ensure_pinned(ctx->h_out, ctx->h_out_bytes, n == 1 ? cells_per + proofs_per + 64 : OutPipe::PIECE)) return C_KZG_MALLOC;
         uint8_t *d_cells = cells ? d_out.p : nullptr;
         uint8_t *d_proofs = proofs ? d_out.p + (cells ? n * cells_per : 0) : nullptr;
         uint8_t *d_status = d_out.p + n * (out_per - 1);
-        memcpy(ctx->h_stage[0], blobs, n * BYTES_PER_BLOB);
-        if (hipMemcpyAsync(d_blobs.p, ctx->h_stage[0], n * BYTES_PER_BLOB, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        const uint8_t *h_in = reinterpret_cast<const uint8_t *>(blobs);
+        uint8_t *h = reinterpret_cast<uint8_t *>(cells ? (void *)cells : (void *)proofs);
+        if (pinned_io) {
+            if (cells && proofs && reinterpret_cast<uint8_t *>(proofs) != h + n * cells_per) return C_KZG_ERROR;   // not the promised layout
+        } else {
+            if (!ensure_pinned(ctx->h_stage, ctx->h_stage_bytes, n == 1 ? (size_t)BYTES_PER_BLOB : 64 * (size_t)BYTES_PER_BLOB))
+                return C_KZG_MALLOC;
+            if (!ensure_pinned(ctx->h_out, ctx->h_out_bytes, n == 1 ? cells_per + proofs_per + 64 : OutPipe::PIECE)) return C_KZG_MALLOC;
+            memcpy(ctx->h_stage[0], blobs, n * BYTES_PER_BLOB);
+            h_in = static_cast<const uint8_t *>(ctx->h_stage[0]);
+            h = static_cast<uint8_t *>(ctx->h_out[0]);
+        }
+        if (hipMemcpyAsync(d_blobs.p, h_in, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
             return C_KZG_ERROR;
         int rc = dev::cells_and_proofs_device(ctx, d_cells, d_proofs, d_status, d_blobs.p, n);
         if (rc) return (C_KZG_RET)rc;
-        uint8_t *h = static_cast<uint8_t *>(ctx->h_out[0]);
         if (hipMemcpyAsync(h, d_out.p, n * out_per, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return C_KZG_ERROR;
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) return C_KZG_ERROR;
-        if (cells) memcpy(cells, h, n * cells_per);
-        if (proofs) memcpy(proofs, h + (cells ? n * cells_per : 0), n * proofs_per);
+        if (!pinned_io) {
+            if (cells) memcpy(cells, h, n * cells_per);
+            if (proofs) memcpy(proofs, h + (cells ? n * cells_per : 0), n * proofs_per);
+        }
         const uint8_t *st = h + n * (out_per - 1);
         for (uint64_t i = 0; i < n; i++) {
             if (status) status[i] = st[i];
@@ -655,10 +700,37 @@ extern "C" C_KZG_RET ckzg_hip_compute_cells_and_kzg_proofs_batch(Cell *cells, KZ
     });
 }
 
+// src/eip7594/eip7594.c:61-157.  Concurrent callers share launches of the batch path (combiner.hpp): from the
+// hand-over point of the two proof algorithms upwards that is ONE FK20 pass over all of them instead of a
+// chip-filling direct pass each.
 extern "C" C_KZG_RET compute_cells_and_kzg_proofs(Cell *cells, KZGProof *proofs, const Blob *blob,
                                                   const KZGSettings *s) {
-    uint8_t st = 0;
-    return ckzg_hip_compute_cells_and_kzg_proofs_batch(cells, proofs, &st, blob, 1, s);
+    return guarded([&]() -> C_KZG_RET {
+        if (cells == NULL && proofs == NULL) return C_KZG_BADARGS;  // eip7594.c:72-74
+        SettingsCtx *sc = settings_of(s);
+        if (!sc) return C_KZG_ERROR;
+        auto solo = [&]() -> C_KZG_RET {
+            uint8_t st = 0;
+            return ckzg_hip_compute_cells_and_kzg_proofs_batch(cells, proofs, &st, blob, 1, s);
+        };
+        Combiner *cb = sc->comb[cells && proofs ? CB_CELLS_PROOFS : (cells ? CB_CELLS : CB_PROOFS)];
+        if (!cb) return solo();
+        const size_t cells_per = (size_t)CELLS_PER_EXT_BLOB * BYTES_PER_CELL, proofs_per = (size_t)CELLS_PER_EXT_BLOB * 48;
+        return cb->submit(
+            nullptr, 0, solo,
+            [&](uint8_t *h_in, size_t idx) { memcpy(h_in + idx * BYTES_PER_BLOB, blob, BYTES_PER_BLOB); },
+            [&](const uint8_t *h_in, uint8_t *h_out, uint8_t *st, size_t n) -> C_KZG_RET {
+                Lease lease(s);
+                if (!lease.ctx) return C_KZG_ERROR;
+                return cells_and_proofs_batch_on(lease.ctx, cells ? reinterpret_cast<Cell *>(h_out) : nullptr,
+                                                 proofs ? reinterpret_cast<KZGProof *>(h_out + (cells ? n * cells_per : 0)) : nullptr,
+                                                 st, reinterpret_cast<const Blob *>(h_in), n, true);
+            },
+            [&](const uint8_t *h_out, size_t idx, size_t n) {
+                if (cells) memcpy(cells, h_out + idx * cells_per, cells_per);
+                if (proofs) memcpy(proofs, h_out + (cells ? n * cells_per : 0) + idx * proofs_per, proofs_per);
+            });
+    });
 }
 
 // Timings of the most recent call on this KZGSettings (bench.py is single-threaded): every lease is numbered
@@ -725,6 +797,16 @@ extern "C" int ckzg_hip_table_wbits(const KZGSettings *s, int which) {
         case 2: return p->pub.mono.d_table ? p->pub.mono.wbits : 0;
         default: return -1;
     }
+}
+
+extern "C" int ckzg_hip_coalesce_stats(const KZGSettings *s, int op, uint64_t *out, int n) {
+    SettingsCtx *sc = settings_of(s, false);
+    if (!sc || !out || op < 0 || op >= (int)CB_COUNT || !sc->comb[op]) return 0;
+    const Combiner::Stats st = sc->comb[op]->stats();
+    const uint64_t v[6] = {st.calls, st.solo, st.batches, st.batched, st.largest, st.run_us};
+    int k = n < 6 ? n : 6;
+    for (int i = 0; i < k; i++) out[i] = v[i];
+    return k;
 }
 
 extern "C" int ckzg_hip_num_devices(const KZGSettings *s) {

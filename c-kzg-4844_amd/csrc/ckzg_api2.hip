@@ -8,6 +8,7 @@
 #include <thread>
 
 #include "api_common.hpp"
+#include "combiner.hpp"
 
 using namespace ckzg;
 using namespace ckzg::host;
@@ -1101,9 +1102,32 @@ extern "C" C_KZG_RET ckzg_hip_compute_blob_kzg_proof_batch(KZGProof *proofs, uin
 
 extern "C" C_KZG_RET compute_blob_kzg_proof(KZGProof *out, const Blob *blob, const Bytes48 *commitment_bytes,
                                             const KZGSettings *s) {
-    // eip4844.c:496-535; evaluation, quotient and MSM on the GPU (a batch of one)
-    uint8_t st = 0;
-    return ckzg_hip_compute_blob_kzg_proof_batch(out, &st, blob, commitment_bytes, 1, s);
+    // eip4844.c:496-535; evaluation, quotient and MSM on the GPU: a batch of one for a lone caller, one batch
+    // launch for callers that arrive while others are in flight (combiner.hpp)
+    return guarded([&]() -> C_KZG_RET {
+        SettingsCtx *sc = settings_of(s);
+        if (!sc) return C_KZG_ERROR;
+        auto solo = [&]() -> C_KZG_RET {
+            uint8_t st = 0;
+            return ckzg_hip_compute_blob_kzg_proof_batch(out, &st, blob, commitment_bytes, 1, s);
+        };
+        Combiner *cb = sc->comb[CB_BLOB_PROOF];
+        if (!cb) return solo();
+        const size_t UNITS = 256;   // device_ctx.hip: create_settings_ctx
+        return cb->submit(
+            nullptr, 0, solo,
+            [&](uint8_t *h_in, size_t idx) {
+                memcpy(h_in + idx * BYTES_PER_BLOB, blob, BYTES_PER_BLOB);
+                memcpy(h_in + UNITS * BYTES_PER_BLOB + idx * 48, commitment_bytes, 48);
+            },
+            [&](const uint8_t *h_in, uint8_t *h_out, uint8_t *st, size_t n) -> C_KZG_RET {
+                Lease lease(s);
+                if (!lease.ctx) return C_KZG_ERROR;
+                return blob_proof_batch_on(lease.ctx, reinterpret_cast<KZGProof *>(h_out), st, reinterpret_cast<const Blob *>(h_in),
+                                           reinterpret_cast<const Bytes48 *>(h_in + UNITS * BYTES_PER_BLOB), n, s);
+            },
+            [&](const uint8_t *h_out, size_t idx, size_t) { memcpy(out, h_out + idx * 48, 48); });
+    });
 }
 
 extern "C" C_KZG_RET verify_kzg_proof(bool *ok, const Bytes48 *commitment_bytes, const Bytes32 *z_bytes,
@@ -1367,11 +1391,44 @@ extern "C" C_KZG_RET ckzg_hip_recover_cells_and_kzg_proofs_batch(Cell *recovered
     });
 }
 
+// eip7594.c:177-304.  Concurrent callers that hold the SAME set of columns (the PeerDAS case: a node
+// reconstructs every blob of a block from the columns it custodies) share one launch of the batch path, which
+// builds the vanishing polynomial of the missing set once (combiner.hpp; the key is the index list + the outputs
+// wanted).
 extern "C" C_KZG_RET recover_cells_and_kzg_proofs(Cell *recovered_cells, KZGProof *recovered_proofs,
                                                   const uint64_t *cell_indices, const Cell *cells,
                                                   uint64_t num_cells, const KZGSettings *s) {
-    return ckzg_hip_recover_cells_and_kzg_proofs_batch(recovered_cells, recovered_proofs, NULL, cell_indices,
-                                                       cells, num_cells, 1, s);
+    return guarded([&]() -> C_KZG_RET {
+        auto solo = [&]() -> C_KZG_RET {
+            return ckzg_hip_recover_cells_and_kzg_proofs_batch(recovered_cells, recovered_proofs, NULL, cell_indices,
+                                                               cells, num_cells, 1, s);
+        };
+        SettingsCtx *sc = settings_of(s, false);
+        Combiner *cb = sc ? sc->comb[CB_RECOVER] : nullptr;
+        // arguments the batch entry point rejects outright never queue (eip7594.c:191-213)
+        if (!cb || (recovered_cells == NULL && recovered_proofs == NULL) || num_cells > CELLS_PER_EXT_BLOB ||
+            num_cells < CELLS_PER_BLOB || cell_indices == NULL || cells == NULL)
+            return solo();
+        std::vector<uint64_t> key(num_cells + 1);
+        key[0] = (recovered_cells ? 1u : 0u) | (recovered_proofs ? 2u : 0u);
+        memcpy(key.data() + 1, cell_indices, num_cells * sizeof(uint64_t));
+        const size_t in_per = (size_t)num_cells * BYTES_PER_CELL;
+        const size_t cells_per = (size_t)CELLS_PER_EXT_BLOB * BYTES_PER_CELL, proofs_per = (size_t)CELLS_PER_EXT_BLOB * 48;
+        return cb->submit(
+            key.data(), key.size() * sizeof(uint64_t), solo,
+            [&](uint8_t *h_in, size_t idx) { memcpy(h_in + idx * in_per, cells, in_per); },
+            [&](const uint8_t *h_in, uint8_t *h_out, uint8_t *st, size_t n) -> C_KZG_RET {
+                return ckzg_hip_recover_cells_and_kzg_proofs_batch(
+                    recovered_cells ? reinterpret_cast<Cell *>(h_out) : nullptr,
+                    recovered_proofs ? reinterpret_cast<KZGProof *>(h_out + (recovered_cells ? n * cells_per : 0)) : nullptr, st,
+                    cell_indices, reinterpret_cast<const Cell *>(h_in), num_cells, n, s);
+            },
+            [&](const uint8_t *h_out, size_t idx, size_t n) {
+                if (recovered_cells) memcpy(recovered_cells, h_out + idx * cells_per, cells_per);
+                if (recovered_proofs)
+                    memcpy(recovered_proofs, h_out + (recovered_cells ? n * cells_per : 0) + idx * proofs_per, proofs_per);
+            });
+    });
 }
 
 // ------------------------------------------------------------------------------------------

@@ -10,6 +10,7 @@
 #include <unordered_map>
 
 #include "api_common.hpp"
+#include "combiner.hpp"
 
 namespace ckzg {
 namespace api {
@@ -206,6 +207,10 @@ static void destroy_settings(SettingsCtx *sc) {
     DeviceGuard guard;   // destroy_slot selects each slot's device; the caller's comes back afterwards
     sc->cancel_widening.store(true);   // a background table build stops at its next launch
     if (sc->widener.joinable()) sc->widener.join();
+    for (auto &c : sc->comb) {
+        delete c;   // (page-locked batch buffers)
+        c = nullptr;
+    }
     for (auto *p : sc->pools) destroy_pool(p);
     delete sc;
 }
@@ -615,6 +620,21 @@ C_KZG_RET create_settings_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affin
     if (ret != C_KZG_OK) {
         destroy_settings(sc);
         return ret;
+    }
+    if (opts.coalesce != 0) {
+        // Coalescing of concurrent one-unit callers (combiner.hpp).  Units per launch: commitments and blob proofs
+        // 256 (one staging chunk of their batch paths), cells / proofs / recovery 64 (the batch paths' latency form:
+        // page-locked both ways on one stream; 17 MB of results per launch).  Buffers are allocated by the first
+        // batch, never by a caller that finds the device idle.
+        int act = opts.coalesce_active;
+        act = (act < 1 ? 1 : (act > 8 ? 8 : act)) * (int)sc->pools.size();
+        const size_t blob = (size_t)dev::N_BLOB * 32, cells = (size_t)dev::N_CELLS_EXT * 2048, proofs = (size_t)dev::N_CELLS_EXT * 48;
+        struct Shape {
+            size_t units, in_per, out_per;
+        } shape[CB_COUNT] = {{256, blob, 48}, {64, blob, cells + 1}, {64, blob, proofs + 1}, {64, blob, cells + proofs + 1},
+                             {256, blob + 48, 48}, {64, cells, cells + proofs}};
+        for (int i = 0; i < CB_COUNT; i++)
+            sc->comb[i] = new Combiner(shape[i].units, shape[i].units * shape[i].in_per, shape[i].units * shape[i].out_per, act);
     }
     sc->load.ms[LP_SLOTS] += slots_clk.lap();
     {

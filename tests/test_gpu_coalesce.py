@@ -1,0 +1,211 @@
+"""GPU tests of the combiner (csrc/combiner.hpp): concurrent one-unit callers of the UNCHANGED ckzg.h entry points
+-- the reference's only parallel shape, bindings/go/main_test.go:953-971 -- are served by shared batch launches.
+What must hold: every caller gets exactly the bytes and the return code the one-blob call gives (expected values
+from the CPU oracle), a unit the batch path rejects fails its own caller only, and launches really are shared
+(ckzg_hip_coalesce_stats)."""
+import ctypes as C
+import struct
+import threading
+
+import pytest
+
+from conftest import HIP_SO
+from kzg_ctypes import Kzg, KzgError
+from test_gpu_commitment import rand_blob
+
+pytestmark = pytest.mark.gpu
+
+
+def _fanout():
+    import sys
+    return sys.modules["ckzg_4844_amd"].fanout
+
+
+def _spoil(blob, element=2111):
+    b = bytearray(blob)
+    b[32 * element:32 * element + 32] = b"\xff" * 32   # >= r: non-canonical (tests/*/invalid_blob_1 of the reference)
+    return bytes(b)
+
+
+@pytest.fixture(scope="module")
+def material(oracle):
+    blobs = [rand_blob(4004, i) for i in range(16)]
+    cm = [oracle.blob_to_kzg_commitment(b) for b in blobs]
+    return blobs, cm
+
+
+@pytest.fixture(scope="module")
+def cells_material(oracle, material):
+    blobs, _ = material
+    return [oracle.compute_cells_and_kzg_proofs(b) for b in blobs[:6]]
+
+
+def test_64_native_threads_of_mixed_commitments(hip, material):
+    """64 threads, every fourth one holding a blob with a non-canonical element: return codes and bytes per caller."""
+    fo = _fanout()
+    blobs, cm = material
+    ins, exp = [], []
+    for t in range(64):
+        if t % 4 == 3:
+            ins.append(_spoil(blobs[t % 16], 17 * t))
+            exp.append(None)
+        else:
+            ins.append(blobs[t % 16])
+            exp.append(cm[t % 16])
+    before = fo.coalesce_stats(hip, 0)
+    st, rets, outs = fo.run(hip, HIP_SO, fo.OP_COMMIT, ins, max_calls=40)
+    after = fo.coalesce_stats(hip, 0)
+    assert st["calls"] == 64 * 40
+    for t in range(64):
+        if exp[t] is None:
+            assert rets[t] == 1, "thread %d: a bad blob must give C_KZG_BADARGS" % t
+        else:
+            assert rets[t] == 0 and outs[t] == exp[t], "thread %d" % t
+    assert st["not_ok"] == 16 * 40      # the bad blobs' callers, nobody else
+    assert after["calls"] - before["calls"] == 64 * 40
+    assert after["batches"] > before["batches"] and after["largest"] >= 8, after   # launches were shared
+
+
+def test_python_threads_of_mixed_calls(hip, oracle, material, cells_material):
+    """Commitments, cells+proofs, cells only, blob proofs from Python threads at once (ctypes drops the GIL)."""
+    blobs, cm = material
+    proofs = [oracle.compute_blob_kzg_proof(blobs[i], cm[i]) for i in range(4)]
+    errors = []
+
+    def commit(t):
+        for k in range(6):
+            i = (t + k) % 16
+            if hip.blob_to_kzg_commitment(blobs[i]) != cm[i]:
+                errors.append(("commit", t, i))
+            try:
+                hip.blob_to_kzg_commitment(_spoil(blobs[i], t))
+                errors.append(("commit accepted a bad blob", t, i))
+            except KzgError:
+                pass
+
+    def cells(t):
+        for k in range(3):
+            i = (t + k) % 6
+            c, p = hip.compute_cells_and_kzg_proofs(blobs[i])
+            if (c, p) != cells_material[i]:
+                errors.append(("cells+proofs", t, i))
+            if t % 2 and hip.compute_cells(blobs[i]) != cells_material[i][0]:
+                errors.append(("cells", t, i))
+            try:
+                hip.compute_cells_and_kzg_proofs(_spoil(blobs[i], 4095))
+                errors.append(("cells accepted a bad blob", t, i))
+            except KzgError:
+                pass
+
+    def blob_proof(t):
+        for k in range(4):
+            i = (t + k) % 4
+            if hip.compute_blob_kzg_proof(blobs[i], cm[i]) != proofs[i]:
+                errors.append(("blob proof", t, i))
+            try:
+                hip.compute_blob_kzg_proof(blobs[i], b"\x8f" + cm[i][1:])   # not a point of the curve / subgroup
+                errors.append(("blob proof accepted a bad commitment", t, i))
+            except KzgError:
+                pass
+
+    th = [threading.Thread(target=f, args=(t,)) for t in range(12) for f in (commit, cells, blob_proof)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors[:5]
+
+
+def test_cells_and_proofs_shared_launches_match_oracle(hip, material, cells_material):
+    fo = _fanout()
+    blobs, _ = material
+    ins = [blobs[t % 6] for t in range(24)]
+    ins[5] = _spoil(ins[5])
+    before = fo.coalesce_stats(hip, 3)
+    st, rets, outs = fo.run(hip, HIP_SO, fo.OP_CELLS_PROOFS, ins, max_calls=4)
+    after = fo.coalesce_stats(hip, 3)
+    for t in range(24):
+        if t == 5:
+            assert rets[t] == 1
+            continue
+        c, p = cells_material[t % 6]
+        assert rets[t] == 0 and outs[t] == b"".join(c) + b"".join(p), "thread %d" % t
+    assert after["batches"] > before["batches"] and after["largest"] >= 4, after
+    # proofs only / cells only are operations of their own
+    st, rets, outs = fo.run(hip, HIP_SO, fo.OP_PROOFS, ins[:5] * 3, max_calls=2)
+    for t in range(15):
+        assert rets[t] == 0 and outs[t][fo.CELLS_BYTES:] == b"".join(cells_material[t % 5][1])
+    st, rets, outs = fo.run(hip, HIP_SO, fo.OP_CELLS, ins[:5] * 3, max_calls=2)
+    for t in range(15):
+        assert rets[t] == 0 and outs[t][:fo.CELLS_BYTES] == b"".join(cells_material[t % 5][0])
+
+
+def test_recover_callers_share_a_launch_per_index_set(hip, cells_material):
+    """Two groups of callers with different column sets run at once: a launch never mixes index sets."""
+    fo = _fanout()
+    sets = [list(range(0, 128, 2)), list(range(64)) + [100, 127]]
+    results = {}
+
+    def group(g):
+        idx = sets[g]
+        ins = [b"".join(cells_material[t % 4][0][i] for i in idx) for t in range(10)]
+        if g == 1:
+            ins[3] = ins[3][:40] + b"\xff" * 32 + ins[3][72:]     # a non-canonical element in one caller's cells
+        results[g] = fo.run(hip, HIP_SO, fo.OP_RECOVER, ins, max_calls=3, aux=struct.pack("<%dQ" % len(idx), *idx),
+                            aux_n=len(idx))
+
+    # (two libckzg_callers runs side by side: each has its own threads and buffers)
+    th = [threading.Thread(target=group, args=(g,)) for g in (0, 1)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    for g in (0, 1):
+        st, rets, outs = results[g]
+        for t in range(10):
+            if g == 1 and t == 3:
+                assert rets[t] == 1
+                continue
+            c, p = cells_material[t % 4]
+            assert rets[t] == 0 and outs[t] == b"".join(c) + b"".join(p), (g, t)
+    assert fo.coalesce_stats(hip, 5)["batches"] > 0
+
+
+def test_blob_proof_callers_with_one_bad_commitment(hip, oracle, material):
+    fo = _fanout()
+    blobs, cm = material
+    exp = [oracle.compute_blob_kzg_proof(blobs[i], cm[i]) for i in range(4)]
+    ins = [blobs[t % 4] for t in range(20)]
+    aux = [cm[t % 4] for t in range(20)]
+    aux[7] = b"\x8f" + aux[7][1:]
+    st, rets, outs = fo.run(hip, HIP_SO, fo.OP_BLOB_PROOF, ins, max_calls=5, aux=aux)
+    for t in range(20):
+        if t == 7:
+            assert rets[t] == 1
+        else:
+            assert rets[t] == 0 and outs[t] == exp[t % 4], t
+    assert fo.coalesce_stats(hip, 4)["batches"] > 0
+
+
+def test_coalescing_can_be_switched_off(oracle, material):
+    blobs, cm = material
+    k = Kzg(HIP_SO, "", precompute=0, options={"coalesce": 0, "commit_wbits": 8})
+    k.lib.ckzg_hip_set_option(b"coalesce", 1)
+    k.lib.ckzg_hip_set_option(b"commit_wbits", 10)
+    try:
+        fo = _fanout()
+        assert fo.coalesce_stats(k, 0) is None
+        st, rets, outs = fo.run(k, HIP_SO, fo.OP_COMMIT, [blobs[t % 16] for t in range(16)], max_calls=5)
+        assert rets == [0] * 16 and outs == [cm[t % 16] for t in range(16)]
+    finally:
+        k.close()
+
+
+def test_a_lone_caller_never_queues(hip, material):
+    fo = _fanout()
+    blobs, cm = material
+    before = fo.coalesce_stats(hip, 0)
+    for i in range(5):
+        assert hip.blob_to_kzg_commitment(blobs[i]) == cm[i]
+    after = fo.coalesce_stats(hip, 0)
+    assert after["solo"] - before["solo"] == 5 and after["batches"] == before["batches"]
