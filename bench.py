@@ -508,27 +508,34 @@ def sharded_rows(L, hip, mod, torch, dist, rank, world, red_dev, base):
                                                               "collective": "all-gather of 6,144 B of proofs per row"}}
 
 
-def concurrency_row(hip, ub):
-    """Re-entrancy: single-blob blob_to_kzg_commitment calls from 1 and from 8 threads sharing the settings."""
-    import threading
-    per_thread = 100
-
-    def run(nt):
-        def work():
-            for _ in range(per_thread):
-                hip.blob_to_kzg_commitment(ub)
-        th = [threading.Thread(target=work) for _ in range(nt)]
-        t0 = time.perf_counter()
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        return nt * per_thread / (time.perf_counter() - t0)
-
-    run(8)
-    r1, r8 = run(1), run(8)
-    return {"single_blob_commit_calls_per_s_1_thread": round(r1, 1), "8_threads": round(r8, 1),
-            "speedup": round(r8 / r1, 2)}
+def concurrency_rows(mod, hip, blobs_u8, seconds=0.4, threads=(1, 8, 32, 128, 256)):
+    """The reference API is one blob per call; its parallel shape is N threads each calling it on a shared
+    KZGSettings (bindings/go/main_test.go:953-971).  N native threads (fanout.py -> libckzg_callers.so: plain C
+    against ckzg.h) call the UNCHANGED blob_to_kzg_commitment / compute_cells_and_kzg_proofs for a fixed time;
+    the library coalesces them into batch launches (csrc/combiner.hpp).  Per thread count: calls/s, mean and worst
+    call latency, launches and mean units per batch launch (ckzg_hip_coalesce_stats)."""
+    fo = mod.fanout
+    ub = [blobs_u8[i].tobytes() for i in range(32)]
+    out = {"driver": "libckzg_callers.so: pthreads, one blob and one output buffer per thread, %.1f s per row" % seconds,
+           "coalescing": "on (csrc/combiner.hpp; 2 launches in flight per operation)"}
+    for name, op, idx in (("blob_to_kzg_commitment", fo.OP_COMMIT, 0), ("compute_cells_and_kzg_proofs", fo.OP_CELLS_PROOFS, 3)):
+        rows = {}
+        for nt in threads:
+            ins = [ub[t % 32] for t in range(nt)]
+            fo.run(hip, mod.HIP_SO, op, ins, seconds=0.1)   # warm-up: arenas, page-locked batch buffers
+            before = fo.coalesce_stats(hip, idx)
+            st, rets, _ = fo.run(hip, mod.HIP_SO, op, ins, seconds=seconds)
+            after = fo.coalesce_stats(hip, idx)
+            row = {"calls_per_s": round(st["calls_per_s"], 1), "mean_call_ms": round(st["mean_call_ms"], 3),
+                   "worst_call_ms": round(st["worst_call_ms"], 3), "failed_calls": st["not_ok"] + sum(1 for r in rets if r != 0)}
+            if before and after:
+                d = {k: after[k] - before[k] for k in ("solo", "batches", "batched", "run_us")}
+                row["launches"] = d["solo"] + d["batches"]
+                row["mean_units_per_batch_launch"] = round(d["batched"] / d["batches"], 1) if d["batches"] else None
+                row["mean_batch_launch_ms"] = round(d["run_us"] / d["batches"] / 1e3, 3) if d["batches"] else None
+            rows[str(nt)] = row
+        out[name] = rows
+    return out
 
 
 def main():
@@ -723,7 +730,7 @@ def main():
         except Exception as e:  # reported, never fatal for the headline
             sec["verify_recover_error"] = str(e)
         try:
-            sec["concurrent_callers"] = concurrency_row(hip, blobs[0].cpu().numpy().tobytes())
+            sec["concurrent_callers"] = concurrency_rows(mod, hip, blobs[:32].cpu().numpy())
         except Exception as e:
             sec["concurrent_callers"] = {"error": str(e)}
         # default footprint: what a caller gets from load_trusted_setup(precompute=0) without any option
@@ -746,6 +753,10 @@ def main():
                  "commit_blobs_per_s": round(BLOBS_PER_STEP / median(ts), 1),
                  "commit_roofline": roofline(ALGO_BYTES_PER_BLOB * BLOBS_PER_STEP, median(ks), "k_msm_accumulate")}
             d["cells_and_proofs"] = cells_rows(L, small, torch, dev, blobs, "default tables")
+            try:
+                d["concurrent_callers"] = concurrency_rows(mod, small, blobs[:32].cpu().numpy())
+            except Exception as e:
+                d["concurrent_callers"] = {"error": str(e)}
             sec["default_footprint"] = d
         finally:
             small.close()

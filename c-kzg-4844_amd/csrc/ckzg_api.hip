@@ -544,7 +544,7 @@ static bool ensure_stage_events(dev::DeviceCtx *ctx) {
 static size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 
 // One device's share of a host-pointer compute_cells_and_kzg_proofs batch.
-// pinned_io (n <= 64 only): the caller vouches that blobs and the outputs are page-locked and that the outputs
+// pinned_io (any n the caller's buffers hold; the combiner: <= 128): the caller vouches that blobs and the outputs are page-locked and that the outputs
 // are laid out [cells of n blobs][proofs of n blobs][n spare bytes] (the forms wanted only): the combiner's batch
 // buffers, DMA'd from and into in place.
 static C_KZG_RET cells_and_proofs_batch_on(dev::DeviceCtx *ctx, Cell *cells, KZGProof *proofs, uint8_t *status,
@@ -554,7 +554,7 @@ static C_KZG_RET cells_and_proofs_batch_on(dev::DeviceCtx *ctx, Cell *cells, KZG
     Arena &ar = ctx->api_arena;
     ArenaTrim trim(ar);
     C_KZG_RET ret = C_KZG_OK;
-    if (n <= 64) {
+    if (n <= 64 || pinned_io) {
         // latency path (the reference-shaped one-blob call among them): pinned staging both ways, one stream
         const size_t out_per = (cells ? cells_per : 0) + (proofs ? proofs_per : 0) + 1;
         if (!ar.begin(n * (BYTES_PER_BLOB + out_per) + 1024)) return C_KZG_MALLOC;

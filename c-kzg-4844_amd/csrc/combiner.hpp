@@ -5,21 +5,31 @@
 // bindings/rust/src/bindings/mod.rs:910-913).  A GPU serves N such callers best with ONE launch over N blobs, so a
 // Combiner sits between the unchanged C-ABI functions and the batch paths that back the additive *_batch symbols:
 //
-//   * While fewer than `max_active` launches of this operation are in flight, a caller runs its own one-unit call
-//     at once, exactly as without a combiner: no queue, no timer, no staging -- the idle path keeps its latency.
-//   * Otherwise the caller JOINS the open batch for its key (or opens one and becomes its owner): it copies its
-//     own inputs into the batch's page-locked buffer -- every caller moves its own bytes, in parallel -- and
-//     sleeps.  When a launch finishes, the oldest open batch is closed and its owner promoted: it leases a slot,
-//     runs the batch path once over everything that was queued behind it (inputs DMA'd from the page-locked
-//     buffer in place, results DMA'd into the batch's page-locked output buffer), and wakes the members, who
-//     copy their own results out and leave.  Whoever leaves a batch last returns its buffers to the free list.
+//   * A caller that finds no launch of its operation in flight runs its own one-unit call at once, exactly as
+//     without a combiner: no queue, no timer, no staging -- the idle path keeps its latency.
+//   * Otherwise the caller JOINS the open batch for its key (or opens one): it copies its own inputs into the
+//     batch's page-locked buffer -- every caller moves its own bytes, in parallel -- and sleeps.  When a launch
+//     finishes, the oldest open batch is closed and ONE of its members woken to run it (any member will do: the
+//     first that sees the batch released claims it; while fewer than `max_active` launches are in flight a batch
+//     does not wait for a launch to finish but goes as soon as it is about as large as the previous one): it leases a slot, runs the batch path once over everything
+//     that queued up (inputs DMA'd from the page-locked buffer in place, results DMA'd into the batch's
+//     page-locked output buffer), hands its launch place on, and wakes the members, who copy their own results
+//     out and leave.  Whoever leaves a batch last returns its buffers to the free list.
+//   * Members sleep on the batch's state word (futex), not on the combiner's mutex: a call takes that mutex once,
+//     to join; 127 members woken at once do not queue up behind each other on their way out.
 //   * A unit the batch path flags in its per-unit status (a non-canonical field element, an invalid commitment)
 //     fails ITS caller only; a failure of the launch itself (HIP error, out of memory) fails every member.
 //
 // Batches are per key: requests may only share a launch when the batch path treats them alike (same operation,
 // same outputs wanted; for recover_cells_and_kzg_proofs the same set of cell indices).
 #pragma once
+#include <linux/futex.h>
+#include <pthread.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include <atomic>
+#include <climits>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -31,11 +41,46 @@
 namespace ckzg {
 namespace api {
 
+namespace detail {
+static_assert(sizeof(std::atomic<uint32_t>) == sizeof(uint32_t), "futex word");
+// sleep while *w == expected (returns on a wake, a changed value or a signal: callers re-check in a loop)
+inline void futex_wait(std::atomic<uint32_t> *w, uint32_t expected) {
+    (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAIT_PRIVATE, expected, nullptr, nullptr, 0);
+}
+inline void futex_wake(std::atomic<uint32_t> *w, int count) {
+    (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAKE_PRIVATE, count, nullptr, nullptr, 0);
+}
+// Hundreds of callers take the combiner's mutex for a few dozen nanoseconds each, in bursts (a batch's members
+// return to their callers together and come back together): spin briefly before sleeping.
+class AdaptiveMutex {
+   public:
+    AdaptiveMutex() {
+        pthread_mutexattr_t a;
+        pthread_mutexattr_init(&a);
+        pthread_mutexattr_settype(&a, PTHREAD_MUTEX_ADAPTIVE_NP);
+        pthread_mutex_init(&m, &a);
+        pthread_mutexattr_destroy(&a);
+    }
+    ~AdaptiveMutex() { pthread_mutex_destroy(&m); }
+    AdaptiveMutex(const AdaptiveMutex &) = delete;
+    AdaptiveMutex &operator=(const AdaptiveMutex &) = delete;
+    void lock() { pthread_mutex_lock(&m); }
+    void unlock() { pthread_mutex_unlock(&m); }
+    bool try_lock() { return pthread_mutex_trylock(&m) == 0; }
+
+   private:
+    pthread_mutex_t m;
+};
+}  // namespace detail
+
 class Combiner {
    public:
     // in_bytes / out_bytes: page-locked bytes a batch of max_batch units needs; layout is the call site's business
     Combiner(size_t max_batch_, size_t in_bytes_, size_t out_bytes_, int max_active_)
-        : max_batch(max_batch_), in_bytes(in_bytes_), out_bytes(out_bytes_), max_active(max_active_ < 1 ? 1 : max_active_) {}
+        : max_batch(max_batch_), in_bytes(in_bytes_), out_bytes(out_bytes_), max_active(max_active_ < 1 ? 1 : max_active_) {
+        all.reserve((size_t)max_active + 2);        // so that the bookkeeping of a call cannot throw
+        free_list.reserve((size_t)max_active + 2);
+    }
     Combiner(const Combiner &) = delete;
     Combiner &operator=(const Combiner &) = delete;
     ~Combiner() {
@@ -56,28 +101,32 @@ class Combiner {
         uint64_t run_us = 0;       // wall time the batch launches took (lease + copies + kernels), microseconds
     };
     Stats stats() {
-        std::lock_guard<std::mutex> lock(mu);
+        std::lock_guard<detail::AdaptiveMutex> lock(mu);
         return st;
     }
 
     // solo():                               the caller's own one-unit call -> C_KZG_RET
     // copy_in(h_in, idx):                   place this caller's inputs as unit idx of the batch buffer
-    // run(h_in, h_out, status, n):          the batch path over units 0..n-1; status[i] != 0 flags unit i
+    // run(h_in, h_out, status, n):          the batch path over units 0..n-1; status[i] != 0 flags unit i.  Runs on the
+    //                                       thread of ANY member of the batch: it may only depend on the key
     // copy_out(h_out, idx, n):              fetch unit idx's results (called only if the unit succeeded)
     template <class Solo, class CopyIn, class Run, class CopyOut>
     C_KZG_RET submit(const void *key, size_t key_len, Solo &&solo, CopyIn &&copy_in, Run &&run, CopyOut &&copy_out) {
-        std::unique_lock<std::mutex> lock(mu);
+        std::unique_lock<detail::AdaptiveMutex> lock(mu);
         st.calls++;
         Batch *b = nullptr;
+        bool release_now = false;
         for (;;) {
-            if (active < max_active) {
-                // invariant: pending is empty here (a finishing launch promotes before it gives its place up)
+            if (active == 0) {
+                // the idle path: nothing of this operation is in flight, so nothing is queued either
                 active++;
                 st.solo++;
                 lock.unlock();
                 C_KZG_RET r = guarded([&]() -> C_KZG_RET { return solo(); });
                 lock.lock();
-                leader_done();
+                Batch *next = launch_done();
+                lock.unlock();
+                release(next);
                 return r;
             }
             for (Batch *p : pending) {
@@ -86,87 +135,141 @@ class Combiner {
                     break;
                 }
             }
-            if (b) break;
-            b = fresh_batch();
+            if (!b) {
+                b = fresh_batch();
+                if (b) {
+                    bool queued = false;
+                    try {
+                        b->key.assign((const uint8_t *)key, (const uint8_t *)key + key_len);
+                        pending.push_back(b);
+                        queued = true;
+                    } catch (...) {
+                    }
+                    if (!queued) {
+                        free_list.push_back(b);   // (capacity reserved)
+                        b = nullptr;
+                        alloc_failed_now = true;
+                    }
+                }
+            }
             if (b) {
-                b->key.assign((const uint8_t *)key, (const uint8_t *)key + key_len);
-                pending.push_back(b);
+                // A launch place is free while others are in flight: the callers of the launch that has just ended are
+                // on their way back, so the batch goes when about as many have joined as that launch served -- or when
+                // another launch ends (launch_done), whichever comes first.  No timer: the wait is bounded by launches
+                // that are in flight.
+                if (active < max_active && b == pending.front() && b->n + 1 >= go_threshold()) {
+                    pending.pop_front();
+                    active++;
+                    release_now = true;
+                }
                 break;
             }
-            if (all.empty()) {
-                // no page-locked memory to be had at all: this call goes alone, unqueued
+            if (all.empty() || alloc_failed_now) {
+                // no page-locked memory / no memory for the bookkeeping: this call goes alone, unqueued
+                alloc_failed_now = false;
                 lock.unlock();
                 return guarded([&]() -> C_KZG_RET { return solo(); });
             }
             cv_pool.wait(lock);   // every batch buffer is in use: wait for one, or for a launch place
         }
         const size_t idx = b->n++;
-        b->refs++;
+        b->refs.fetch_add(1, std::memory_order_relaxed);
         lock.unlock();
+        if (release_now) release(b);
         copy_in(b->h_in, idx);
         b->copied.fetch_add(1, std::memory_order_release);
-        lock.lock();
-        if (idx == 0) {
-            b->cv_owner.wait(lock, [&]() { return b->promoted; });
-            const size_t n = b->n;   // final: a promoted batch is no longer in `pending`
-            st.batches++;
-            st.batched += n;
-            if (n > st.largest) st.largest = n;
-            lock.unlock();
-            while (b->copied.load(std::memory_order_acquire) != n) std::this_thread::yield();   // members still copying in: microseconds
-            memset(b->status.data(), 0, n);
-            const auto t_run = std::chrono::steady_clock::now();
-            C_KZG_RET r = guarded([&]() -> C_KZG_RET { return run((const uint8_t *)b->h_in, b->h_out, b->status.data(), n); });
-            const uint64_t run_us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_run).count();
-            if (r == C_KZG_BADARGS) {
-                // flagged units answer for themselves; without a flag the verdict concerns the whole batch
-                for (size_t i = 0; i < n; i++) {
-                    if (b->status[i]) {
-                        r = C_KZG_OK;
-                        break;
-                    }
+        for (;;) {
+            uint32_t s = b->state.load(std::memory_order_acquire);
+            if (s == DONE) break;
+            if (s == RELEASED) {
+                if (b->state.compare_exchange_strong(s, RUNNING, std::memory_order_acq_rel)) {
+                    run_batch(b, run);
+                    break;
                 }
+                continue;
             }
-            lock.lock();
-            st.run_us += run_us;
-            b->ret = r;
-            b->done = true;
-            b->cv_done.notify_all();
-            leader_done();
-        } else {
-            b->cv_done.wait(lock, [&]() { return b->done; });
+            detail::futex_wait(&b->state, s);
         }
         const size_t n = b->n;
         const C_KZG_RET mine = b->status[idx] ? (C_KZG_RET)b->status[idx] : b->ret;
-        lock.unlock();
         if (mine == C_KZG_OK) copy_out((const uint8_t *)b->h_out, idx, n);
-        lock.lock();
-        if (--b->refs == 0) recycle(b);
+        if (b->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+            lock.lock();
+            free_list.push_back(b);   // (capacity reserved)
+            cv_pool.notify_all();
+        }
         return mine;
     }
 
    private:
+    enum : uint32_t { OPEN = 0, RELEASED = 1, RUNNING = 2, DONE = 3 };
     struct Batch {
         uint8_t *h_in = nullptr, *h_out = nullptr;   // page-locked
         std::vector<uint8_t> status, key;
-        size_t n = 0, refs = 0;
-        std::atomic<size_t> copied{0};
-        bool promoted = false, done = false;
+        size_t n = 0;                                // members; grows under mu while the batch is in `pending`
+        std::atomic<uint32_t> state{OPEN};           // OPEN -> RELEASED (it may run) -> RUNNING (claimed) -> DONE
+        std::atomic<uint32_t> refs{0};               // members that have not left yet
+        std::atomic<size_t> copied{0};               // members whose inputs are in h_in
         C_KZG_RET ret = C_KZG_OK;
-        std::condition_variable cv_owner, cv_done;
     };
 
-    // mu held.  A launch has ended: hand its place to the oldest open batch, or give it up.
-    void leader_done() {
+    // The calling member has claimed the batch (RELEASED -> RUNNING): n is final, the batch is out of `pending`.
+    template <class Run>
+    void run_batch(Batch *b, Run &run) {
+        const size_t n = b->n;
+        while (b->copied.load(std::memory_order_acquire) != n) std::this_thread::yield();   // members still copying in: microseconds
+        memset(b->status.data(), 0, n);
+        const auto t_run = std::chrono::steady_clock::now();
+        C_KZG_RET r = guarded([&]() -> C_KZG_RET { return run((const uint8_t *)b->h_in, b->h_out, b->status.data(), n); });
+        const uint64_t run_us =
+            (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_run).count();
+        if (r == C_KZG_BADARGS) {
+            // flagged units answer for themselves; without a flag the verdict concerns the whole batch
+            for (size_t i = 0; i < n; i++) {
+                if (b->status[i]) {
+                    r = C_KZG_OK;
+                    break;
+                }
+            }
+        }
+        b->ret = r;
+        Batch *next;
+        {
+            std::lock_guard<detail::AdaptiveMutex> lock(mu);
+            st.batches++;
+            st.batched += n;
+            if (n > st.largest) st.largest = n;
+            st.run_us += run_us;
+            expect = n;
+            next = launch_done();
+        }
+        release(next);   // the next launch starts while this one's members are being woken
+        b->state.store(DONE, std::memory_order_release);
+        detail::futex_wake(&b->state, INT_MAX);
+    }
+
+    // mu held.  A launch has ended: its place goes to the oldest open batch (returned, to be release()d once mu is
+    // dropped), or is given up.
+    Batch *launch_done() {
         if (!pending.empty()) {
             Batch *nb = pending.front();
             pending.pop_front();
-            nb->promoted = true;
-            nb->cv_owner.notify_one();
-        } else {
-            active--;
-            cv_pool.notify_all();
+            return nb;
         }
+        active--;
+        cv_pool.notify_all();
+        return nullptr;
+    }
+    // members an open batch waits for while a launch place is free: three quarters of the last launch
+    size_t go_threshold() const {
+        size_t t = (3 * expect + 3) / 4;
+        return t < 1 ? 1 : (t > max_batch ? max_batch : t);
+    }
+    // the batch may run: whichever member sees this first claims it; one sleeper is woken in case all of them sleep
+    static void release(Batch *nb) {
+        if (!nb) return;
+        nb->state.store(RELEASED, std::memory_order_release);
+        detail::futex_wake(&nb->state, 1);
     }
 
     // mu held.  A batch with buffers, from the free list or newly allocated; nullptr if neither is possible now.
@@ -177,60 +280,50 @@ class Combiner {
             free_list.pop_back();
         } else if ((int)all.size() < max_active + 2 && !alloc_failed) {
             b = new (std::nothrow) Batch();
-            if (b) {
-                // Portable: any device of a multi-device load may DMA from / into it
-                bool ok = hipHostMalloc((void **)&b->h_in, in_bytes ? in_bytes : 1, hipHostMallocPortable) == hipSuccess;
-                ok = ok && hipHostMalloc((void **)&b->h_out, out_bytes ? out_bytes : 1, hipHostMallocPortable) == hipSuccess;
-                if (ok) {
-                    try {
-                        b->status.resize(max_batch);
-                    } catch (...) {
-                        ok = false;
-                    }
+            bool ok = b != nullptr;
+            // Portable: any device of a multi-device load may DMA from / into it
+            ok = ok && hipHostMalloc((void **)&b->h_in, in_bytes ? in_bytes : 1, hipHostMallocPortable) == hipSuccess;
+            ok = ok && hipHostMalloc((void **)&b->h_out, out_bytes ? out_bytes : 1, hipHostMallocPortable) == hipSuccess;
+            if (ok) {
+                try {
+                    b->status.resize(max_batch);
+                } catch (...) {
+                    ok = false;
                 }
-                if (!ok) {
-                    (void)hipGetLastError();
-                    if (b->h_in) (void)hipHostFree(b->h_in);
-                    if (b->h_out) (void)hipHostFree(b->h_out);
-                    delete b;
-                    b = nullptr;
-                    alloc_failed = true;   // do not try again on every call
-                } else {
-                    CKZG_TSAN_NEW_MEMORY(b->h_in, in_bytes);
-                    CKZG_TSAN_NEW_MEMORY(b->h_out, out_bytes);
-                    try {
-                        all.push_back(b);
-                    } catch (...) {
-                        (void)hipHostFree(b->h_in);
-                        (void)hipHostFree(b->h_out);
-                        delete b;
-                        b = nullptr;
-                    }
-                }
+            }
+            if (!ok) {
+                (void)hipGetLastError();
+                if (b && b->h_in) (void)hipHostFree(b->h_in);
+                if (b && b->h_out) (void)hipHostFree(b->h_out);
+                delete b;
+                b = nullptr;
+                alloc_failed = true;       // do not try again on every call
+                alloc_failed_now = true;
+            } else {
+                CKZG_TSAN_NEW_MEMORY(b->h_in, in_bytes);
+                CKZG_TSAN_NEW_MEMORY(b->h_out, out_bytes);
+                all.push_back(b);   // (capacity reserved)
             }
         }
         if (b) {
-            b->n = b->refs = 0;
+            b->n = 0;
+            b->refs.store(0, std::memory_order_relaxed);
             b->copied.store(0, std::memory_order_relaxed);
-            b->promoted = b->done = false;
+            b->state.store(OPEN, std::memory_order_relaxed);
             b->ret = C_KZG_OK;
         }
         return b;
     }
 
-    void recycle(Batch *b) {
-        free_list.push_back(b);
-        cv_pool.notify_all();
-    }
-
     const size_t max_batch, in_bytes, out_bytes;
     const int max_active;
-    std::mutex mu;
-    std::condition_variable cv_pool;
+    detail::AdaptiveMutex mu;
+    std::condition_variable_any cv_pool;
     std::deque<Batch *> pending;       // open batches, oldest first
     std::vector<Batch *> all, free_list;
     int active = 0;                    // launches in flight (solo calls and batches)
-    bool alloc_failed = false;
+    size_t expect = 0;                 // units of the batch launch that ended last
+    bool alloc_failed = false, alloc_failed_now = false;
     Stats st;
 };
 

@@ -623,15 +623,15 @@ C_KZG_RET create_settings_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affin
     }
     if (opts.coalesce != 0) {
         // Coalescing of concurrent one-unit callers (combiner.hpp).  Units per launch: commitments and blob proofs
-        // 256 (one staging chunk of their batch paths), cells / proofs / recovery 64 (the batch paths' latency form:
-        // page-locked both ways on one stream; 17 MB of results per launch).  Buffers are allocated by the first
+        // 256 (one staging chunk of their batch paths), cells / proofs 128 and recovery 64 (the batch paths' latency form:
+        // page-locked both ways on one stream; 34 / 17 MB of results per launch).  Buffers are allocated by the first
         // batch, never by a caller that finds the device idle.
         int act = opts.coalesce_active;
         act = (act < 1 ? 1 : (act > 8 ? 8 : act)) * (int)sc->pools.size();
         const size_t blob = (size_t)dev::N_BLOB * 32, cells = (size_t)dev::N_CELLS_EXT * 2048, proofs = (size_t)dev::N_CELLS_EXT * 48;
         struct Shape {
             size_t units, in_per, out_per;
-        } shape[CB_COUNT] = {{256, blob, 48}, {64, blob, cells + 1}, {64, blob, proofs + 1}, {64, blob, cells + proofs + 1},
+        } shape[CB_COUNT] = {{256, blob, 48}, {128, blob, cells + 1}, {128, blob, proofs + 1}, {128, blob, cells + proofs + 1},
                              {256, blob + 48, 48}, {64, cells, cells + proofs}};
         for (int i = 0; i < CB_COUNT; i++)
             sc->comb[i] = new Combiner(shape[i].units, shape[i].units * shape[i].in_per, shape[i].units * shape[i].out_per, act);
