@@ -114,6 +114,12 @@ class Combiner {
     C_KZG_RET submit(const void *key, size_t key_len, Solo &&solo, CopyIn &&copy_in, Run &&run, CopyOut &&copy_out) {
         std::unique_lock<detail::AdaptiveMutex> lock(mu);
         st.calls++;
+        const int in = inside.fetch_add(1, std::memory_order_relaxed) + 1;
+        if (in > peak) peak = in;
+        struct Leave {
+            std::atomic<int> &c;
+            ~Leave() { c.fetch_sub(1, std::memory_order_relaxed); }
+        } leave{inside};
         Batch *b = nullptr;
         bool release_now = false;
         for (;;) {
@@ -130,7 +136,7 @@ class Combiner {
                 return r;
             }
             for (Batch *p : pending) {
-                if (p->n < max_batch && p->key.size() == key_len && (key_len == 0 || !memcmp(p->key.data(), key, key_len))) {
+                if (p->n < batch_cap() && p->key.size() == key_len && (key_len == 0 || !memcmp(p->key.data(), key, key_len))) {
                     b = p;
                     break;
                 }
@@ -153,10 +159,10 @@ class Combiner {
                 }
             }
             if (b) {
-                // A launch place is free while others are in flight: the callers of the launch that has just ended are
-                // on their way back, so the batch goes when about as many have joined as that launch served -- or when
-                // another launch ends (launch_done), whichever comes first.  No timer: the wait is bounded by launches
-                // that are in flight.
+                // A launch place is free while others are in flight: callers of the launch that has just ended are on
+                // their way back, so the batch goes when it holds most of its share of the callers seen lately -- or
+                // when another launch ends (launch_done), whichever comes first.  No timer: the wait is bounded by
+                // launches that are in flight.
                 if (active < max_active && b == pending.front() && b->n + 1 >= go_threshold()) {
                     pending.pop_front();
                     active++;
@@ -240,7 +246,8 @@ class Combiner {
             st.batched += n;
             if (n > st.largest) st.largest = n;
             st.run_us += run_us;
-            expect = n;
+            const int now = inside.load(std::memory_order_relaxed);
+            peak = peak - peak / 8 > now ? peak - peak / 8 : now;   // forget callers that have stopped calling
             next = launch_done();
         }
         release(next);   // the next launch starts while this one's members are being woken
@@ -260,10 +267,18 @@ class Combiner {
         cv_pool.notify_all();
         return nullptr;
     }
-    // members an open batch waits for while a launch place is free: three quarters of the last launch
+    // `peak` estimates how many threads are calling this operation concurrently.  Their fair division over the
+    // launch places keeps `max_active` batches of similar size rotating; one batch that swallows every caller
+    // would leave the device idle while they all copy out, come back and copy in.
+    // members an open batch waits for while a launch place is free: three quarters of a place's share
     size_t go_threshold() const {
-        size_t t = (3 * expect + 3) / 4;
+        const size_t t = (size_t)(3 * peak / 4) / (size_t)max_active;
         return t < 1 ? 1 : (t > max_batch ? max_batch : t);
+    }
+    // members a batch takes before later callers open the next one: a place's share and a quarter
+    size_t batch_cap() const {
+        const size_t c = ((size_t)peak * 5 / 4 + (size_t)max_active - 1) / (size_t)max_active;
+        return c < 1 ? 1 : (c > max_batch ? max_batch : c);
     }
     // the batch may run: whichever member sees this first claims it; one sleeper is woken in case all of them sleep
     static void release(Batch *nb) {
@@ -322,7 +337,8 @@ class Combiner {
     std::deque<Batch *> pending;       // open batches, oldest first
     std::vector<Batch *> all, free_list;
     int active = 0;                    // launches in flight (solo calls and batches)
-    size_t expect = 0;                 // units of the batch launch that ended last
+    std::atomic<int> inside{0};        // threads inside submit()
+    int peak = 0;                      // recent maximum of `inside` (decays by an eighth per batch launch)
     bool alloc_failed = false, alloc_failed_now = false;
     Stats st;
 };
