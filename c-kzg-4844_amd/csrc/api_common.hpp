@@ -194,8 +194,9 @@ struct Lease {
    private:
     void take(DevicePool *p);
 };
-// the pool whose device owns this device pointer (0 if unknown), for the *_device entry points
-int pool_of_pointer(const SettingsCtx *sc, const void *dptr);
+// the pool whose device owns ALL of these device pointers (null entries skipped), for the *_device entry points;
+// -1 if one of them is not device memory, they live on different devices, or that device holds no tables of `sc`
+int pool_of_pointers(const SettingsCtx *sc, const void *const *ptrs, int count);
 
 // implemented in device_ctx.hip
 C_KZG_RET create_settings_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affine,
@@ -266,6 +267,13 @@ inline void pin_thread_to_device_numa(int device) {
     snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
     f = fopen(path, "r");
     if (!f) return;
+    // never leave the CPUs the process was given (taskset, cgroup cpusets, a launcher's per-rank binding)
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) {
+        fclose(f);
+        return;
+    }
     cpu_set_t set;
     CPU_ZERO(&set);
     int lo, hi, count = 0;
@@ -277,6 +285,7 @@ inline void pin_thread_to_device_numa(int device) {
             ch = fgetc(f);
         }
         for (int c = lo; c <= hi && c < CPU_SETSIZE; c++) {
+            if (!CPU_ISSET(c, &allowed)) continue;
             CPU_SET(c, &set);
             count++;
         }
@@ -339,11 +348,16 @@ class CopyHelpers {
         size_t len;
         std::atomic<int> *pending;
     };
-    // false: no helper available, the caller does this part itself
-    bool submit(const Job &j) {
-        std::lock_guard<std::mutex> lock(mu);
-        if (!ensure_started()) return false;
-        q.push_back(j);
+    // false: no helper available (or no memory for the queue entry), the caller does this part itself.  Never throws:
+    // staged_copy has counted the part as pending and has parts in flight that point at its stack.
+    bool submit(const Job &j) noexcept {
+        try {
+            std::lock_guard<std::mutex> lock(mu);
+            if (!ensure_started()) return false;
+            q.push_back(j);
+        } catch (...) {
+            return false;
+        }
         cv.notify_one();
         return true;
     }

@@ -304,11 +304,6 @@ extern "C" C_KZG_RET bytes_to_kzg_proof(g1_t *out, const Bytes48 *b) {
 // blob_to_kzg_commitment (src/eip4844/eip4844.c:264-280) and its batch forms
 // ------------------------------------------------------------------------------------------
 
-// the slot a *_device entry point runs on: a slot of the pool whose GPU holds the caller's buffers
-struct DeviceLease {
-    Lease lease;
-    DeviceLease(const KZGSettings *s, SettingsCtx *sc, const void *dptr) : lease(s, sc ? pool_of_pointer(sc, dptr) : 0) {}
-};
 
 extern "C" C_KZG_RET ckzg_hip_blob_to_kzg_commitment_batch_device(void *d_out48, void *d_status,
                                                                   const void *d_blobs, uint64_t n,
@@ -316,8 +311,12 @@ extern "C" C_KZG_RET ckzg_hip_blob_to_kzg_commitment_batch_device(void *d_out48,
     return guarded([&]() -> C_KZG_RET {
         SettingsCtx *sc = settings_of(s);
         if (!sc) return C_KZG_ERROR;
-        DeviceLease dl(s, sc, d_blobs);
-        dev::DeviceCtx *ctx = dl.lease.ctx;
+        if (n == 0) return C_KZG_OK;
+        const void *ptrs[3] = {d_out48, d_status, d_blobs};
+        const int pool = pool_of_pointers(sc, ptrs, 3);
+        if (pool < 0 || !d_out48 || !d_blobs) return C_KZG_BADARGS;
+        Lease lease(s, pool);
+        dev::DeviceCtx *ctx = lease.ctx;
         if (!ctx) return C_KZG_ERROR;
         return (C_KZG_RET)dev::commit_blobs_device(ctx, (uint8_t *)d_out48, (uint8_t *)d_status,
                                                    (const uint8_t *)d_blobs, n);
@@ -523,8 +522,12 @@ extern "C" C_KZG_RET ckzg_hip_compute_cells_and_kzg_proofs_batch_device(void *d_
         if (d_cells == NULL && d_proofs == NULL) return C_KZG_BADARGS;
         SettingsCtx *sc = settings_of(s);
         if (!sc) return C_KZG_ERROR;
-        DeviceLease dl(s, sc, d_blobs);
-        dev::DeviceCtx *ctx = dl.lease.ctx;
+        if (n == 0) return C_KZG_OK;
+        const void *ptrs[4] = {d_cells, d_proofs, d_status, d_blobs};
+        const int pool = pool_of_pointers(sc, ptrs, 4);
+        if (pool < 0 || !d_blobs) return C_KZG_BADARGS;
+        Lease lease(s, pool);
+        dev::DeviceCtx *ctx = lease.ctx;
         if (!ctx) return C_KZG_ERROR;
         return (C_KZG_RET)dev::cells_and_proofs_device(ctx, (uint8_t *)d_cells, (uint8_t *)d_proofs,
                                                        (uint8_t *)d_status, (const uint8_t *)d_blobs, n);

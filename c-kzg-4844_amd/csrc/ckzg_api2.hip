@@ -1199,7 +1199,10 @@ extern "C" C_KZG_RET ckzg_hip_verify_blob_kzg_proof_batch_device(bool *ok, const
         *ok = false;
         SettingsCtx *sc = settings_of(s);
         if (!sc) return C_KZG_ERROR;
-        Lease lease(s, pool_of_pointer(sc, d_blobs));
+        const void *ptrs[3] = {d_blobs, d_commitments, d_proofs};
+        const int pool = pool_of_pointers(sc, ptrs, 3);
+        if (pool < 0 || !d_blobs || !d_commitments || !d_proofs) return C_KZG_BADARGS;
+        Lease lease(s, pool);
         if (!lease.ctx) return C_KZG_ERROR;
         return verify_blobs_core(ok, static_cast<const Blob *>(d_blobs), static_cast<const Bytes48 *>(d_commitments),
                                  static_cast<const Bytes48 *>(d_proofs), n, s, lease.ctx, /*resident=*/true);

@@ -64,7 +64,14 @@ struct Arena {
         // gives the block back after every call (a hipMalloc + a synchronising hipFree per call: ~0.5-0.8 ms)
         const size_t slack = (bytes >> 1) < ((size_t)256 << 20) ? (bytes >> 1) : ((size_t)256 << 20);
         size_t want = bytes + slack;
-        if (hipMalloc(&base, want) != hipSuccess) return false;
+        if (hipMalloc(&base, want) != hipSuccess) {
+            // Callers may treat this as "does not fit, do without" (the call-time table of a verification): the
+            // runtime keeps the failure as the thread's last error until somebody reads it, and the next
+            // hipGetLastError() after a kernel launch must not mistake it for a launch failure.
+            (void)hipGetLastError();
+            base = nullptr;
+            return false;
+        }
         cap = want;
         return true;
     }

@@ -106,17 +106,28 @@ Lease::~Lease() {
     pool->cv.notify_one();
 }
 
-int pool_of_pointer(const SettingsCtx *sc, const void *dptr) {
-    if (sc->pools.size() <= 1 || !dptr) return 0;
-    hipPointerAttribute_t at;
-    if (hipPointerGetAttributes(&at, dptr) != hipSuccess) {
-        (void)hipGetLastError();
-        return 0;
+// The pool that serves a *_device call: every non-null pointer must be device (or managed) memory of ONE device, and
+// that device must hold tables of this KZGSettings.  -1 otherwise: a host pointer, a pointer the runtime does not
+// know, buffers on different GPUs or on a GPU this KZGSettings was not loaded on would otherwise be dereferenced by
+// kernels of some other device -- a fault, or silent peer access.
+int pool_of_pointers(const SettingsCtx *sc, const void *const *ptrs, int count) {
+    int device = -1;
+    for (int i = 0; i < count; i++) {
+        if (!ptrs[i]) continue;
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, ptrs[i]) != hipSuccess) {
+            (void)hipGetLastError();   // an ordinary malloc'd pointer is "invalid value" to the runtime
+            return -1;
+        }
+        if (at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged) return -1;
+        if (device >= 0 && at.device != device) return -1;
+        device = at.device;
     }
+    if (device < 0) return -1;
     for (size_t i = 0; i < sc->pools.size(); i++) {
-        if (sc->pools[i]->device == at.device) return (int)i;
+        if (sc->pools[i]->device == device) return (int)i;
     }
-    return 0;
+    return -1;
 }
 
 // ------------------------------------------------------------------------------------------

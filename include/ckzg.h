@@ -80,7 +80,13 @@ typedef struct {
     size_t scratch_size;                /* unused by this build */
 } KZGSettings;
 
-/* ---- trusted setup: src/setup/setup.h:31-44 ---- */
+/* ---- trusted setup: src/setup/setup.h:31-44 ----
+ * One check is STRICTER than the reference's: the reference accepts any setup point that lies on the curve
+ * (src/setup/setup.c:447-477: blst_p1_uncompress, no subgroup check -- "the file is trusted"); this library also
+ * requires every G1 point of the file to lie in the prime-order subgroup (or be the identity) and answers
+ * C_KZG_BADARGS otherwise.  Its fixed-base tables and G1-FFT twiddles use the endomorphism (x, y) -> (beta x, y),
+ * which equals [lambda]P only on that subgroup: a sum over other points would silently differ from the reference's.
+ * The mainnet setup and every setup that is a real KZG ceremony output pass. */
 C_KZG_RET load_trusted_setup(KZGSettings *out, const uint8_t *g1_monomial_bytes,
                              uint64_t num_g1_monomial_bytes, const uint8_t *g1_lagrange_bytes,
                              uint64_t num_g1_lagrange_bytes, const uint8_t *g2_monomial_bytes,

@@ -8,7 +8,9 @@
  * symbols sit next to the unchanged ckzg.h ones; every one of them is plain C: pointers + sizes.
  *
  * "_device" variants take/return HIP device pointers on the GPU the settings were loaded on and
- * enqueue on the context's stream, returning after the work has completed.
+ * enqueue on the context's stream, returning after the work has completed.  Every pointer of such a call must be
+ * device (or managed) memory of ONE GPU that holds tables of the KZGSettings: a host pointer, a pointer the HIP
+ * runtime does not know, or buffers on different GPUs give C_KZG_BADARGS, nothing is launched.
  */
 #ifndef CKZG_HIP_H
 #define CKZG_HIP_H
