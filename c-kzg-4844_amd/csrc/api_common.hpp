@@ -74,6 +74,38 @@ struct Options {
 Options options_snapshot();
 // read at call time (ckzg_hip_set_option("gpu_sha_min", n)); 0 = decide by host CPU
 extern std::atomic<int> g_gpu_sha_min;
+// read at call time (ckzg_hip_set_option("host_threads", n)); 0 = automatic (host_thread_budget)
+extern std::atomic<int> g_host_threads;
+
+// How many host threads ONE process of this library may keep busy for a call (challenge hashing, staging copies,
+// point decompression at load): the CPUs the process may run on divided by the processes that share the host.
+// Under a one-process-per-GPU launcher every rank runs the same code at the same time on the same cores -- eight
+// ranks that each size their pools by the machine would run 8 x 32 hashing threads on whatever the container
+// grants -- so the share is cpus / LOCAL_WORLD_SIZE (torchrun exports it; WORLD_SIZE otherwise, single node).  A
+// one-process fan-out over several GPUs ("devices") shares ONE process-wide pool between its shards already.
+inline int host_thread_budget() {
+    const int forced = g_host_threads.load(std::memory_order_relaxed);
+    if (forced > 0) return forced;
+    static const int automatic = []() {
+        int cpus = 0;
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = CPU_COUNT(&set);
+        if (cpus <= 0) cpus = (int)std::thread::hardware_concurrency();
+        if (cpus <= 0) cpus = 4;
+        int ranks = 1;
+        for (const char *name : {"LOCAL_WORLD_SIZE", "WORLD_SIZE"}) {
+            const char *v = getenv(name);
+            if (v && *v && atoi(v) > 0) {
+                ranks = atoi(v);
+                break;
+            }
+        }
+        const int share = cpus / ranks;
+        return share < 1 ? 1 : share;
+    }();
+    return automatic;
+}
 
 // line tables of the three G2 constants that appear in verification equations
 struct PreparedG2 {
@@ -367,7 +399,8 @@ class CopyHelpers {
     bool ensure_started() {
         if (started) return nworkers > 0;
         started = true;
-        for (int i = 0; i < NHELP; i++) {
+        const int budget = host_thread_budget() - 1;   // (the caller copies a part itself)
+        for (int i = 0; i < NHELP && i < budget; i++) {
             try {
                 std::thread([this]() { run(); }).detach();
                 nworkers++;
@@ -430,9 +463,8 @@ class WorkerPool {
     bool ensure_started() {
         if (started) return nworkers > 0;
         started = true;
-        unsigned hw = std::thread::hardware_concurrency();
-        int want = hw ? (int)hw : 4;
-        if (want > 256) want = 256;   // eight concurrent verifications at full width (a fan-out over 8 GPUs in one process)
+        int want = host_thread_budget();   // this process's share of the host, not the machine
+        if (want > 256) want = 256;        // eight concurrent verifications at full width (a fan-out over 8 GPUs in one process)
         for (int i = 0; i < want; i++) {
             try {
                 std::thread([this]() { run(); }).detach();
@@ -467,9 +499,11 @@ inline void staged_copy(void *dst, const void *src, size_t bytes) {
         const char *e = getenv("CKZG_HIP_COPY_THREADS");   // ways a staging copy is split (the caller is one of them)
         long v = e && *e ? atol(e) : 8;   // measured (profiles/r03_copy_threads_ab.txt): 4 ways make the pageable source of a
                                            // 4096-blob verification memcpy-bound (median 15.8 ms), 8 ways DMA-bound (12.5 ms)
+        const long budget = host_thread_budget();
+        if (v > budget) v = budget;
         return (size_t)(v < 1 ? 1 : (v > 8 ? 8 : v));
     }();
-    if (nt == 1 || bytes < ((size_t)4 << 20) || std::thread::hardware_concurrency() < 8) {
+    if (nt == 1 || bytes < ((size_t)4 << 20)) {
         memcpy(dst, src, bytes);
         return;
     }

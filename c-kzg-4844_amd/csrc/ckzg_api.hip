@@ -23,6 +23,7 @@ namespace api {
 static std::mutex g_opts_mu;
 static Options g_opts;
 std::atomic<int> g_gpu_sha_min{0};
+std::atomic<int> g_host_threads{0};
 Options options_snapshot() {
     std::lock_guard<std::mutex> lock(g_opts_mu);
     return g_opts;
@@ -64,6 +65,9 @@ extern "C" C_KZG_RET ckzg_hip_set_option(const char *key, int64_t value) {
     } else if (!strcmp(key, "gpu_sha_min")) {
         if (value < 0 || value > (1 << 30)) return C_KZG_BADARGS;
         g_gpu_sha_min.store((int)value);  // read at call time, unlike the load-time options
+    } else if (!strcmp(key, "host_threads")) {
+        if (value < 0 || value > 1024) return C_KZG_BADARGS;
+        g_host_threads.store((int)value);  // read when the helper pools start and at call time
     } else if (!strcmp(key, "async_tables")) {
         if (value != 0 && value != 1) return C_KZG_BADARGS;
         g_opts.async_tables = (int)value;
@@ -81,6 +85,8 @@ extern "C" C_KZG_RET ckzg_hip_set_option(const char *key, int64_t value) {
     }
     return C_KZG_OK;
 }
+
+extern "C" int ckzg_hip_host_thread_budget(void) { return host_thread_budget(); }
 
 extern "C" int ckzg_hip_device_count(void) {
     int n = 0;
@@ -165,8 +171,8 @@ static C_KZG_RET load_trusted_setup_impl(KZGSettings *out, const uint8_t *g1_mon
     // The file is trusted: curve membership only, no subgroup check (setup.c:447-477)
     // (8192 square roots: ~0.25 s on one core, spread over up to 16 threads)
     {
-        unsigned hw = std::thread::hardware_concurrency();
-        const size_t nt = hw >= 16 ? 16 : (hw ? hw : 1);
+        const int budget = host_thread_budget();
+        const size_t nt = budget >= 16 ? 16 : (size_t)budget;
         std::atomic<int> bad(0);
         JoinThreads th;
         for (size_t t = 0; t < nt; t++) {

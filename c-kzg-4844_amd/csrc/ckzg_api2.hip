@@ -45,22 +45,28 @@ struct DBuf {
         if (!(expr)) return C_KZG_MALLOC; \
     } while (0)
 
-// Batches at least this large hash their Fiat-Shamir challenges on the GPU (k_sha256_challenges): the
-// GPU takes ~6 ms whatever the batch.  32 host threads take ~2 us per blob with the x86 SHA extensions,
-// less than the blob copy they run under, so such hosts never switch; without the extensions the host
-// needs ~10 us per blob and the GPU takes over at 512 blobs.
-static size_t gpu_sha_min_n() {
+// Where the Fiat-Shamir challenges of an n-blob batch are hashed (compute_challenge, eip4844.c:147-178: one SHA-256
+// over 131,152 bytes per blob).  The host hashes them on T threads underneath the blob copy: 66 us per blob and
+// thread with the x86 SHA extensions (2 us per blob on 32 threads), 320 us without; the copy takes 2.4 us per blob
+// (55 GB/s), so with T >= 28 SHA-NI threads the hash is free.  The GPU hash (k_sha256_challenges) needs the blobs
+// in HBM first and then GPU_SHA_US whatever n <= 65,536 (2,050 dependent compressions per blob).  T is this
+// process's share of the host (host_thread_budget: cpus / ranks on the host): a rank of an 8-GPU job in a 15-core
+// container has 1-2 threads and hashes a 512-blob shard in 17-34 ms on the host, in GPU_SHA_US + 1.2 ms on the GPU.
+static constexpr double GPU_SHA_US = 6000.0;
+static bool challenges_on_gpu(size_t n) {
     const int opt = g_gpu_sha_min.load();
-    if (opt > 0) return (size_t)opt;  // ckzg_hip_set_option("gpu_sha_min", n)
-    static const size_t dflt = []() {
-        const char *v = getenv("CKZG_HIP_GPU_SHA_MIN");
-        if (v && *v && atol(v) > 0) return (size_t)atol(v);  // 0 = automatic, like the option
+    if (opt > 0) return n >= (size_t)opt;  // ckzg_hip_set_option("gpu_sha_min", n)
+    if (n < 64) return false;              // a few waves: the GPU hash is pure latency
+    size_t t = (size_t)host_thread_budget();
+    if (t > 32) t = 32;
+    bool shani = false;
 #ifdef CKZG_HAVE_SHANI
-        if (host::cpu_has_sha_ni()) return (size_t)1 << 30;  // the host hash hides under the blob copy
+    shani = host::cpu_has_sha_ni();
 #endif
-        return (size_t)512;
-    }();
-    return dflt;
+    const double host_us = (double)n * (shani ? 66.0 : 320.0) / (double)t;
+    const double copy_us = (double)n * 2.4;
+    const double gpu_us = GPU_SHA_US * (double)((n + 65535) / 65536);
+    return host_us > copy_us + gpu_us;
 }
 
 struct RawScalar {
@@ -230,8 +236,7 @@ C_KZG_RET compute_kzg_proof_impl(KZGProof *proof_out, Fr &y_out, const Fr *poly,
 // (no thread is created or joined per call).  fn must not throw and must not itself wait for pool jobs -- a pool
 // worker never blocks on another pool job; the callers of this function are never pool workers.
 void parallel_for(size_t n, const std::function<void(size_t)> &fn) {
-    unsigned hw = std::thread::hardware_concurrency();
-    size_t nt = hw ? hw : 4;
+    size_t nt = (size_t)host_thread_budget();
     if (nt > 32) nt = 32;
     if (nt > n) nt = n;
     if (nt <= 1) {
@@ -470,14 +475,8 @@ struct OrderedHasher {
         while (active.load(std::memory_order_acquire) != 0) std::this_thread::yield();
     }
     void start(Fr *z, const Blob *blobs, const Bytes48 *cb) {
-        unsigned hw = std::thread::hardware_concurrency();
-        size_t nt = hw ? hw : 4;
+        size_t nt = (size_t)host_thread_budget();
         if (nt > 32) nt = 32;
-        static const size_t forced = []() {
-            const char *e = getenv("CKZG_HIP_HASH_THREADS");   // A/B knob
-            return e && *e ? (size_t)atol(e) : (size_t)0;
-        }();
-        if (forced) nt = forced;
         auto loop = [this, z, blobs, cb]() {
             for (;;) {
                 const size_t i = next.fetch_add(1, std::memory_order_relaxed);
@@ -534,7 +533,7 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     }
     tr.mark("host point validation");
     // (never for the small path: its commitments are validated on the host and are not in d_ptb)
-    const bool gpu_sha = resident || (!small && n >= gpu_sha_min_n());
+    const bool gpu_sha = resident || (!small && challenges_on_gpu(n));
     static const size_t pipe_min = []() {
         const char *e = getenv("CKZG_HIP_VERIFY_PIPE_MIN");
         return e && *e ? (size_t)atol(e) : (size_t)1024;

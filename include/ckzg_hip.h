@@ -66,12 +66,22 @@ extern "C" {
  *   "coalesce_active"  launches of one operation in flight per device before callers start to queue (1..8, default 2:
  *                   one batch computes while the next is copied in and the previous is copied out)
  *   "gpu_sha_min"   smallest verify_blob_kzg_proof_batch size whose Fiat-Shamir challenges are hashed on
- *                   the GPU; 0 (default): never on hosts with the x86 SHA extensions (the host hash runs under the
- *                   blob copy), from 512 blobs otherwise.  Batches of at most 3 blobs always hash on the host.
- *                   Takes effect immediately (every other option is read by load_trusted_setup).
+ *                   the GPU; 0 (default): automatic -- the host hashes (underneath the blob copy) unless this process's
+ *                   share of the host cores ("host_threads") is too small for it: the estimated host time
+ *                   n * 66 us / threads (320 us without the x86 SHA extensions) is compared with the blob copy plus the
+ *                   GPU hash's ~6 ms.  Batches of at most 3 blobs always hash on the host.
+ *                   Takes effect immediately (as does "host_threads"; every other option is read by load_trusted_setup).
+ *   "host_threads"  host threads one process of this library may keep busy per call (challenge hashing, staging copies,
+ *                   point decompression at load).  0 (default): the CPUs of the process's affinity mask divided by the
+ *                   processes that share the host (LOCAL_WORLD_SIZE, else WORLD_SIZE, of a one-process-per-GPU
+ *                   launcher; 1 otherwise).  The helper pools are sized by it when they start (first use).
  * A width that does not fit the free HBM is narrowed at load time (ckzg_hip_table_wbits reports the result).
  * Returns C_KZG_BADARGS for an unknown key or out-of-range value. */
 C_KZG_RET ckzg_hip_set_option(const char *key, int64_t value);
+
+/* Host threads this process's helper pools are sized for (the "host_threads" option; automatic: CPUs of the affinity
+ * mask / processes sharing the host, see ckzg_hip_set_option).  Needs no GPU. */
+int ckzg_hip_host_thread_budget(void);
 
 /* Number of visible HIP devices (0 if none / runtime missing). */
 int ckzg_hip_device_count(void);

@@ -1,0 +1,80 @@
+"""GPU tests for round-4 fixes: the verification's ladder fallback when HBM is REALLY too full for its call-time
+table (the allocation-failure interposer of tests/failalloc never enters the runtime, so it cannot see an error the
+runtime keeps), and the pointer checks of the *_device entry points."""
+import ctypes as C
+
+import pytest
+
+from conftest import HIP_SO
+from kzg_ctypes import Kzg
+from test_gpu_commitment import rand_blob
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def material(oracle):
+    blobs = [rand_blob(404, i) for i in range(4)]
+    cm = [oracle.blob_to_kzg_commitment(b) for b in blobs]
+    pr = [oracle.compute_blob_kzg_proof(b, c) for b, c in zip(blobs, cm)]
+    return blobs, cm, pr
+
+
+def test_batch_verification_when_hbm_is_too_full_for_the_call_time_table():
+    """verify_blob_kzg_proof_batch builds a fixed-base table over the batch's points when its arena can hold it
+    (434 MB of arena at n = 512) and falls back to ladder sums when it cannot (ckzg_api2.hip: verify_blobs_core).
+    tools/oom_fallback_probe.py fills the HBM for real and calls it on a fresh KZGSettings with 900 MB left (the
+    table fits) and with 330 MB left (it cannot): both calls must succeed with the right verdict for a valid batch
+    and for one with a wrong proof.  The failed arena allocation of the second level leaves an out-of-memory error
+    in the runtime's per-thread state; round 3 did not clear it and the next hipGetLastError() after a kernel launch
+    would have reported it.  The probe runs in a process of its own: a device with no memory left at
+    all makes the HSA runtime abort its process."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "oom_fallback_probe.py"), "900", "330"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    rows = [json.loads(line) for line in r.stdout.splitlines() if line.startswith("{") and '"rc"' in line]
+    assert r.returncode == 0 and len(rows) == 2, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+    for row in rows:
+        assert row["rc"] == 0 and row["ok"] is True, rows
+        assert row["rc_bad"] == 0 and row["ok_bad"] is False, rows
+    assert rows[0]["free_mb"] >= 800 and rows[1]["free_mb"] <= 340, rows   # the second level cannot have held the table
+
+
+def test_device_entry_points_reject_pointers_that_are_not_on_their_gpu(hip, material):
+    import torch
+    blobs, cm, pr = material
+    lib = hip.lib
+    p, u64 = C.c_void_p, C.c_uint64
+    d_blob = torch.frombuffer(bytearray(blobs[0]), dtype=torch.uint8).cuda()
+    d_out = torch.zeros(48, dtype=torch.uint8, device="cuda")
+    d_st = torch.zeros(1, dtype=torch.uint8, device="cuda")
+    h_out = C.create_string_buffer(48)
+    f = lib.ckzg_hip_blob_to_kzg_commitment_batch_device
+    f.restype = C.c_int
+    f.argtypes = [p, p, p, u64, p]
+    sp = C.addressof(hip.s)
+    assert f(d_out.data_ptr(), d_st.data_ptr(), d_blob.data_ptr(), 1, sp) == 0
+    assert bytes(d_out.cpu().numpy().tobytes()) == cm[0]
+    assert f(d_out.data_ptr(), None, d_blob.data_ptr(), 1, sp) == 0                       # the status array is optional
+    assert f(C.cast(h_out, p), d_st.data_ptr(), d_blob.data_ptr(), 1, sp) == 1            # host output buffer
+    assert f(d_out.data_ptr(), d_st.data_ptr(), C.cast(C.c_char_p(blobs[0]), p), 1, sp) == 1   # host blobs
+    assert f(None, d_st.data_ptr(), d_blob.data_ptr(), 1, sp) == 1
+    g = lib.ckzg_hip_compute_cells_and_kzg_proofs_batch_device
+    g.restype = C.c_int
+    g.argtypes = [p, p, p, p, u64, p]
+    d_proofs = torch.zeros(128 * 48, dtype=torch.uint8, device="cuda")
+    h_cells = C.create_string_buffer(128 * 2048)
+    assert g(None, d_proofs.data_ptr(), d_st.data_ptr(), d_blob.data_ptr(), 1, sp) == 0
+    assert g(C.cast(h_cells, p), d_proofs.data_ptr(), d_st.data_ptr(), d_blob.data_ptr(), 1, sp) == 1
+    v = lib.ckzg_hip_verify_blob_kzg_proof_batch_device
+    v.restype = C.c_int
+    v.argtypes = [p, p, p, p, u64, p]
+    ok = C.c_bool(False)
+    d_c = torch.frombuffer(bytearray(cm[0]), dtype=torch.uint8).cuda()
+    d_p = torch.frombuffer(bytearray(pr[0]), dtype=torch.uint8).cuda()
+    assert v(C.byref(ok), d_blob.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), 1, sp) == 0 and ok.value
+    assert v(C.byref(ok), d_blob.data_ptr(), C.cast(C.c_char_p(cm[0]), p), d_p.data_ptr(), 1, sp) == 1

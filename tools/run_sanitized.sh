@@ -33,6 +33,10 @@ if [ "$mode" = tsan ]; then
   LD_PRELOAD=$TSAN_RT CKZG_HIP_SO=c-kzg-4844_amd/libckzg_hip_tsan.so CKZG_TESTS_NO_AUTOBUILD=1 \
     timeout 1200 $NOASLR python -m pytest tests/test_gpu_round3.py -m gpu -q -x -p no:cacheprovider -k "async or fan_out or pipelined" >> $LOG 2>&1
   echo "rc=$?" >> $LOG
+  echo "== ThreadSanitizer: the combiner (concurrent one-blob callers sharing batch launches; native + Python threads)" >> $LOG
+  LD_PRELOAD=$TSAN_RT CKZG_HIP_SO=c-kzg-4844_amd/libckzg_hip_tsan.so CKZG_TESTS_NO_AUTOBUILD=1 \
+    timeout 1500 $NOASLR python -m pytest tests/test_gpu_coalesce.py -m gpu -q -x -p no:cacheprovider >> $LOG 2>&1
+  echo "rc=$?" >> $LOG
   tail -15 $LOG
   if grep -q "FATAL: ThreadSanitizer" $LOG; then echo "TSAN DID NOT START"; exit 3; fi
   if grep -q "WARNING: ThreadSanitizer" $LOG; then echo "TSAN REPORTS FOUND"; grep -A12 "WARNING: ThreadSanitizer" $LOG | head -120; exit 1; fi
