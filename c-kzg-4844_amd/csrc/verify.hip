@@ -667,10 +667,16 @@ int fr_mul_inplace_device(DeviceCtx *ctx, Fr *d_a, const Fr *d_b, size_t n, size
 // ------------------------------------------------------------------------------------------
 // Fiat-Shamir challenges on the GPU: z_i = SHA-256("FSBLOBVERIFY_V1_" | u64be 0 | u64be 4096 |
 // blob_i | commitment_i) mod r  (compute_challenge, src/eip4844/eip4844.c:147-178).
-// SHA-256 is sequential per message, so a lane owns a blob: 2050 compressions of 64 bytes each,
-// the same for every lane (no divergence).  The 32-byte header shifts the blob by half a block, so
-// block b (1 <= b <= 2047) is the 64 contiguous, 32-byte aligned bytes blob[64b-32, 64b+32); the
-// next block's four 16-byte loads are issued before the current block is compressed.
+// SHA-256 is sequential per message -- 2050 dependent compressions per blob -- and a wave on its own already issues
+// one VALU instruction per four cycles, which is all a SIMD has: the kernel's run time IS the instruction count of
+// the wave that carries the chaining state.  Of the 1,405 instructions a compression took in round 3, a third (the
+// message schedule W[16..63], the byte swaps, the + K[t]) do not depend on that state.  So a workgroup is TWO waves
+// over the same 64 blobs: the producer wave loads block i of its lane's blob, expands the schedule and stores
+// W[t] + K[t] to LDS (64 words per lane, double-buffered: 32 KB) while the consumer wave runs the 64 rounds of
+// block i - 1 from LDS -- 14 instructions a round, ~920 per block -- one barrier per block.  The two waves sit on
+// different SIMDs of the CU.  The 32-byte header shifts the blob by half a block, so block b (1 <= b <= 2047) is
+// the 64 contiguous, 32-byte aligned bytes blob[64b-32, 64b+32); the producer requests the next block's four
+// 16-byte loads before it expands the current one.
 // ------------------------------------------------------------------------------------------
 
 __device__ __constant__ uint32_t SHA256_K[64] = {
@@ -686,31 +692,10 @@ __device__ __constant__ uint32_t SHA256_K[64] = {
 __device__ __forceinline__ uint32_t rotr32(uint32_t x, int n) { return __builtin_rotateright32(x, n); }
 // gfx950's v_bitop3_b32 evaluates any three-input boolean function in one instruction (truth table = the function
 // applied to A = 0xF0, B = 0xCC, C = 0xAA): the three-way XORs of the sigma functions, Ch and Maj are one
-// instruction each instead of two or three -- 1,400 instead of 1,710 instructions per 64-byte block, and the kernel
-// is one wave per SIMD executing its instructions back to back, so that is its run time.
+// instruction each instead of two or three.
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 __device__ __forceinline__ uint32_t sha_ch(uint32_t e, uint32_t f, uint32_t g) { return __builtin_amdgcn_bitop3_b32(e, f, g, 0xCA); }
 __device__ __forceinline__ uint32_t sha_maj(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8); }
-
-// one compression; w[16] holds the block as big-endian words and is clobbered
-__device__ __forceinline__ void sha256_compress(uint32_t (&h)[8], uint32_t (&w)[16]) {
-    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
-#pragma unroll
-    for (int t = 0; t < 64; t++) {
-        if (t >= 16) {
-            uint32_t w15 = w[(t + 1) & 15], w2 = w[(t + 14) & 15];
-            uint32_t s0 = xor3(rotr32(w15, 7), rotr32(w15, 18), w15 >> 3);
-            uint32_t s1 = xor3(rotr32(w2, 17), rotr32(w2, 19), w2 >> 10);
-            w[t & 15] = w[t & 15] + s0 + w[(t + 9) & 15] + s1;
-        }
-        uint32_t S1 = xor3(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25));
-        uint32_t t1 = hh + S1 + sha_ch(e, f, g) + SHA256_K[t] + w[t & 15];
-        uint32_t S0 = xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22));
-        uint32_t t2 = S0 + sha_maj(a, b, c);
-        hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
-    }
-    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
-}
 
 __device__ __forceinline__ void be_words(uint32_t *w, const uint4 &v) {
     w[0] = __builtin_bswap32(v.x);
@@ -719,61 +704,120 @@ __device__ __forceinline__ void be_words(uint32_t *w, const uint4 &v) {
     w[3] = __builtin_bswap32(v.w);
 }
 
-__global__ __launch_bounds__(64) void k_sha256_challenges(Fr *z_out, const uint8_t *blobs, const uint8_t *commit48,
-                                                          size_t n) {
-    size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (g >= n) return;
+// producer: w[16] holds a block as big-endian words; writes W[t] + K[t], t = 0..63, as 16 uint4 to kw[.][lane]
+__device__ __forceinline__ void sha256_expand_to_lds(uint4 (*kw)[64], int lane, uint32_t (&w)[16]) {
+#pragma unroll
+    for (int t4 = 0; t4 < 16; t4++) {
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int t = 4 * t4 + k;
+            if (t >= 16) {
+                uint32_t w15 = w[(t + 1) & 15], w2 = w[(t + 14) & 15];
+                uint32_t s0 = xor3(rotr32(w15, 7), rotr32(w15, 18), w15 >> 3);
+                uint32_t s1 = xor3(rotr32(w2, 17), rotr32(w2, 19), w2 >> 10);
+                w[t & 15] = w[t & 15] + s0 + w[(t + 9) & 15] + s1;
+            }
+            o[k] = w[t & 15] + SHA256_K[t];
+        }
+        kw[t4][lane] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// consumer: the 64 rounds of one block from the W + K words the producer left in LDS
+__device__ __forceinline__ void sha256_rounds_from_lds(uint32_t (&h)[8], const uint4 (*kw)[64], int lane) {
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
+    for (int t4 = 0; t4 < 16; t4++) {
+        const uint4 q = kw[t4][lane];
+        const uint32_t x[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t S1 = xor3(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25));
+            uint32_t t1 = hh + S1 + sha_ch(e, f, g) + x[k];
+            uint32_t S0 = xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22));
+            uint32_t t2 = S0 + sha_maj(a, b, c);
+            hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+        }
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+
+constexpr int SHA_BLOCKS = 2050;   // 32-byte header + 131,072-byte blob + 48-byte commitment + padding
+
+__global__ __launch_bounds__(128) void k_sha256_challenges(Fr *z_out, const uint8_t *blobs, const uint8_t *commit48,
+                                                           size_t n) {
+    __shared__ uint4 kw[2][16][64];
+    const int lane = threadIdx.x & 63;
+    const bool producer = threadIdx.x >= 64;
+    const size_t g_real = blockIdx.x * (size_t)64 + lane;
+    const size_t g = g_real < n ? g_real : n - 1;   // lanes past the end repeat the last blob (no partly masked wave)
     const uint4 *bp = reinterpret_cast<const uint4 *>(blobs + g * (size_t)(N_BLOB * 32));
     const uint32_t *cp = reinterpret_cast<const uint32_t *>(commit48 + g * 48);
     uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
-    uint32_t w[16];
-    // block 0: "FSBLOBVERIFY_V1_" | 0^8 | u64be(4096) | blob[0,32)
-    w[0] = 0x4653424c; w[1] = 0x4f425645; w[2] = 0x52494659; w[3] = 0x5f56315f;
-    w[4] = 0; w[5] = 0; w[6] = 0; w[7] = N_BLOB;
-    uint4 n0 = bp[0], n1 = bp[1], n2, n3;
-    be_words(w + 8, n0);
-    be_words(w + 12, n1);
-    n0 = bp[2]; n1 = bp[3]; n2 = bp[4]; n3 = bp[5];
-    sha256_compress(h, w);
-    // blocks 1..2047: blob[64b-32, 64b+32) = uint4 index 4b-2 .. 4b+1
-    for (int b = 1; b < 2048; b++) {
-        be_words(w, n0);
-        be_words(w + 4, n1);
-        be_words(w + 8, n2);
-        be_words(w + 12, n3);
-        const int nb = 4 * (b + 1) - 2;  // next block; the last iteration prefetches the 32-byte tail
-        n0 = bp[nb];
-        n1 = bp[nb + 1];
-        if (b < 2047) {
-            n2 = bp[nb + 2];
-            n3 = bp[nb + 3];
-        }
-        sha256_compress(h, w);
+    uint4 n0, n1, n2, n3;   // producer: the next block's bytes, requested one block ahead
+    if (producer) {
+        n0 = bp[0];
+        n1 = bp[1];
     }
-    // block 2048: blob[131040, 131072) | commitment[0, 32)
-    be_words(w, n0);
-    be_words(w + 4, n1);
+    for (int i = 0; i <= SHA_BLOCKS; i++) {
+        if (producer) {
+            if (i < SHA_BLOCKS) {
+                uint32_t w[16];
+                if (i == 0) {
+                    // block 0: "FSBLOBVERIFY_V1_" | 0^8 | u64be(4096) | blob[0,32)
+                    w[0] = 0x4653424c; w[1] = 0x4f425645; w[2] = 0x52494659; w[3] = 0x5f56315f;
+                    w[4] = 0; w[5] = 0; w[6] = 0; w[7] = N_BLOB;
+                    be_words(w + 8, n0);
+                    be_words(w + 12, n1);
+                    n0 = bp[2]; n1 = bp[3]; n2 = bp[4]; n3 = bp[5];
+                } else if (i < 2048) {
+                    // blocks 1..2047: blob[64i-32, 64i+32) = uint4 index 4i-2 .. 4i+1
+                    be_words(w, n0);
+                    be_words(w + 4, n1);
+                    be_words(w + 8, n2);
+                    be_words(w + 12, n3);
+                    const int nb = 4 * (i + 1) - 2;  // next block; the last of these requests the 32-byte tail
+                    n0 = bp[nb];
+                    n1 = bp[nb + 1];
+                    if (i < 2047) {
+                        n2 = bp[nb + 2];
+                        n3 = bp[nb + 3];
+                    }
+                } else if (i == 2048) {
+                    // block 2048: blob[131040, 131072) | commitment[0, 32)
+                    be_words(w, n0);
+                    be_words(w + 4, n1);
 #pragma unroll
-    for (int k = 0; k < 8; k++) w[8 + k] = __builtin_bswap32(cp[k]);
-    sha256_compress(h, w);
-    // block 2049: commitment[32, 48) | 0x80 | zeros | bit length (131152 bytes)
+                    for (int k = 0; k < 8; k++) w[8 + k] = __builtin_bswap32(cp[k]);
+                } else {
+                    // block 2049: commitment[32, 48) | 0x80 | zeros | bit length (131152 bytes)
 #pragma unroll
-    for (int k = 0; k < 4; k++) w[k] = __builtin_bswap32(cp[8 + k]);
-    w[4] = 0x80000000u;
+                    for (int k = 0; k < 4; k++) w[k] = __builtin_bswap32(cp[8 + k]);
+                    w[4] = 0x80000000u;
 #pragma unroll
-    for (int k = 5; k < 15; k++) w[k] = 0;
-    w[15] = (uint32_t)((32 + N_BLOB * 32 + 48) * 8);
-    sha256_compress(h, w);
+                    for (int k = 5; k < 15; k++) w[k] = 0;
+                    w[15] = (uint32_t)((32 + N_BLOB * 32 + 48) * 8);
+                }
+                sha256_expand_to_lds(kw[i & 1], lane, w);
+            }
+        } else if (i >= 1) {
+            sha256_rounds_from_lds(h, kw[(i - 1) & 1], lane);
+        }
+        // block i is in LDS and block i - 1 has been consumed: the producer may overwrite the latter's buffer
+        __syncthreads();
+    }
+    if (producer || g_real >= n) return;
     // digest as a big-endian 256-bit integer, reduced mod r (hash_to_bls_field, eip4844.c:121-127)
     uint32_t raw[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) raw[k] = h[7 - k];
-    vst_fr(z_out + g, from_raw<FrParams>(raw));
+    vst_fr(z_out + g_real, from_raw<FrParams>(raw));
 }
 
 int sha256_challenges_device(DeviceCtx *ctx, Fr *d_z, const uint8_t *d_blobs, const uint8_t *d_commit48, size_t n) {
     if (!n) return 0;
-    hipLaunchKernelGGL(k_sha256_challenges, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, d_z,
+    hipLaunchKernelGGL(k_sha256_challenges, dim3((unsigned)((n + 63) / 64)), dim3(128), 0, ctx->stream, d_z,
                        d_blobs, d_commit48, n);
     HIP_TRY(hipGetLastError());
     return 0;
