@@ -89,6 +89,62 @@ def pmc_cross_check():
     return out or None
 
 
+VALU_PEAK_TMADS = 32.9   # measured v_mad_u64_u32 rate of the chip at 2.4 GHz, T lane-mad/s (tools/ubench/instr_rates.hip)
+LADDER_PRODUCTS = 1510   # field products of one twiddle multiplication of the G1 FFT, one-lane co-Z form
+MADS_PER_PRODUCT = 392
+
+
+def valu_roofline(lane_mads, kernel_ms, what):
+    """Achieved v_mad_u64_u32 rate of a kernel against the chip's measured rate: the honest bound of the curve work."""
+    if not kernel_ms or kernel_ms <= 0:
+        return None
+    ach = lane_mads / (kernel_ms * 1e-3) / 1e12
+    return {"bound": "v_mad_u64_u32 issue", "unit": "T lane-mad/s", "peak": VALU_PEAK_TMADS, "achieved": round(ach, 3),
+            "frac": round(ach / VALU_PEAK_TMADS, 4), "counted": what}
+
+
+_PMC_CACHE = {}
+
+
+def pmc_rows(row):
+    """Newest committed per-kernel counter summary of a secondary row (tools/pmc_rows.sh -> profiles/rNN_pmc_<row>.json):
+    separate rocprofv3 --pmc passes, per launch."""
+    import glob
+    if row not in _PMC_CACHE:
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s.json" % row)))
+        d = None
+        if files:
+            try:
+                d = json.load(open(files[-1]))
+                d["_file"] = os.path.relpath(files[-1], ROOT)
+            except Exception:  # noqa: BLE001
+                d = None
+        _PMC_CACHE[row] = d
+    return _PMC_CACHE[row]
+
+
+def pmc_kernel(row, name, pick="longest", streaming=False):
+    """Counters of kernel `name` in that summary (of its several launch shapes: the one with the longest mean duration,
+    or the largest grid).  streaming: the kernel reads with wide coalesced loads, for which gfx950's FETCH_SIZE tallies
+    64 B per 128-B request (MI355X_MICROARCH.md, HBM section) -- doubled here, and the entry says so."""
+    d = pmc_rows(row)
+    if not d:
+        return None
+    ks = [k for k in d["kernels"] if k["kernel"].startswith(name) and "counters_per_launch" in k]
+    if not ks:
+        return None
+    k = max(ks, key=(lambda x: x["mean_ms"]) if pick == "longest" else (lambda x: int(x["grid"] or 0)))
+    c = k["counters_per_launch"]
+    fetch = c.get("FETCH_SIZE", 0.0) * 1024 * (2 if streaming else 1)
+    out = {"kernel": k["kernel"], "grid": k["grid"], "launches_profiled": k["launches"], "mean_ms": k["mean_ms"],
+           "fetch_bytes": int(fetch), "write_bytes": int(c.get("WRITE_SIZE", 0.0) * 1024),
+           "traffic_bytes_per_launch": int(fetch + c.get("WRITE_SIZE", 0.0) * 1024),
+           "fetch_correction": "x2 (gfx950 FETCH_SIZE counts 64 B per 128-B streaming request)" if streaming else "none (96-byte gathers: matches the analytic count)",
+           "valu_wave_insts": c.get("SQ_INSTS_VALU"), "waves": c.get("SQ_WAVES"), "wave_quad_cycles": c.get("SQ_WAVE_CYCLES"),
+           "file": d["_file"], "tables_profiled": d.get("tables")}
+    return out
+
+
 def cpu_baseline(seconds_budget=12.0):
     """Oracle ('port' of the reference algorithm, oracle/okzg.c) timed on this host's cores."""
     import hashlib
@@ -235,11 +291,23 @@ def cells_rows(L, hip, torch, dev, blobs, label):
         th.append(time.perf_counter() - t1)
     if rc != 0 or hp1.raw != proofs_1.cpu().numpy().tobytes() or hc1.raw != cells_1.cpu().numpy().tobytes():
         raise SystemExit("bench: host-pointer compute_cells_and_kzg_proofs differs from the device-pointer call")
-    out = {"tables": tables_of(L, hip),
+    tb = tables_of(L, hip)
+    pw, fw = tb["proof_wbits"], tb["fk20_wbits"]
+    nwin_p = 2 * (127 // pw + 1) if pw else 0
+    nwin_f = 2 * (127 // fw + 1)
+    row = "cells_wide" if tb["commit_wbits"] >= 16 else "cells_default"
+    same = lambda k: k if (k and k["tables_profiled"] and k["tables_profiled"].get("proof_wbits") == pw   # noqa: E731
+                           and k["tables_profiled"].get("fk20_wbits") == fw) else None
+    out = {"tables": tb,
            "one_blob": {"ms_per_call": round(median(th) * 1e3, 3), "calls_per_s": round(1.0 / median(th), 1),
                         "ms_per_call_device_pointers": round(one_ms, 3),
                         "path": "low-latency (128 fixed-base MSMs over the monomial table, no G1 FFT)",
-                        "roofline": roofline(ALGO_BYTES_CELLS_PROOFS, one_k, "k_msm_accumulate")}}
+                        "roofline": dict(roofline(ALGO_BYTES_CELLS_PROOFS, one_k, "k_msm_accumulate",
+                                                  analytic_traffic(pw, 128) if pw else None),
+                                         traffic_source="analytic: 128 x nwin x 4096 table gathers of 96 B + int16 digits (bench.py: analytic_traffic)",
+                                         pmc_cross_check=same(pmc_kernel(row, "k_msm_accumulate<256>"))),
+                        "roofline_valu": valu_roofline(128 * nwin_p * 4096 * MADS_PER_ADDITION, one_k,
+                                                       "128 MSMs x %d windows x 4096 mixed additions x %d multiply-adds" % (nwin_p, MADS_PER_ADDITION))}}
     run(nb)
     tb, kb, fb = [], [], []
     for _ in range(3):
@@ -252,9 +320,20 @@ def cells_rows(L, hip, torch, dev, blobs, label):
         raise SystemExit("bench: low-latency and FK20 proof paths disagree")
     t_b, k_b, f_b = median(tb), median(kb), median(fb)
     dom, dom_name = (k_b, "k_msm_small") if k_b >= f_b else (f_b, "k_g1_fft_twiddle+k_g1_fft_addsub (2 G1 FFTs)")
+    small_traffic = int(nb * (128 * 64 * nwin_f * (96 * (1.0 - 2.0 ** -fw) + 2) + 128 * 192))
+    fft_pmc = same(pmc_kernel(row, "k_g1_fft_twiddle", pick="grid"))
+    mads_small = nb * 128 * 64 * nwin_f * MADS_PER_ADDITION
+    mads_fft = nb * 642 * LADDER_PRODUCTS * MADS_PER_PRODUCT
     out["batch_2048"] = {"blobs_per_s": round(nb / t_b, 1), "ms_per_blob": round(t_b / nb * 1e3, 4),
                          "path": "FK20", "k_msm_small_ms": round(k_b, 3), "g1_fft_ms": round(f_b, 3),
-                         "roofline": roofline(ALGO_BYTES_CELLS_PROOFS * nb, dom, dom_name)}
+                         "roofline": dict(roofline(ALGO_BYTES_CELLS_PROOFS * nb, dom, dom_name,
+                                                   small_traffic if k_b >= f_b else (fft_pmc["traffic_bytes_per_launch"] * 12 if fft_pmc else None)),
+                                          traffic_source="analytic: 128 x 64 x nwin gathers of 96 B + digits per blob (k_msm_small)" if k_b >= f_b
+                                          else "PMC: 12 launches of k_g1_fft_twiddle per batch, FETCH_SIZE + WRITE_SIZE per launch",
+                                          pmc_cross_check={"k_msm_small": same(pmc_kernel(row, "k_msm_small")), "k_g1_fft_twiddle": fft_pmc}),
+                         "roofline_valu": {"k_msm_small": valu_roofline(mads_small, k_b, "128 x 64 x %d mixed additions x %d multiply-adds per blob" % (nwin_f, MADS_PER_ADDITION)),
+                                           "g1_fft": valu_roofline(mads_fft, f_b, "642 twiddle ladders x %d products x %d multiply-adds per blob" % (LADDER_PRODUCTS, MADS_PER_PRODUCT)),
+                                           "both_kernels": valu_roofline(mads_small + mads_fft, k_b + f_b, "k_msm_small + the two G1 FFTs: the curve work of compute_fk20_cell_proofs (src/eip7594/fk20.c:139-286)")}}
     # host pointers: pageable input, pageable outputs (268 KB per blob back over PCIe)
     hb = blobs2.cpu().numpy().tobytes()
     hc = C.create_string_buffer(nb * 128 * 2048)
@@ -347,8 +426,9 @@ def verify_and_recover_rows(L, hip, base):
     # configs[3] in its three forms: pageable host pointers (above), page-locked host pointers (DMA'd in place,
     # chunk by chunk under the evaluation kernels), inputs resident in HBM (kernel-only time)
     row = out["verify_blob_kzg_proof_batch_n%d" % n]
-    row["roofline"] = roofline(ALGO_BYTES_VERIFY_BLOB * n, row["ms"], "whole call, pageable host pointers (PCIe H2D of the blobs)",
-                               bound="pcie", peak=PCIE_PEAK_GBS)
+    row["roofline"] = dict(roofline(ALGO_BYTES_VERIFY_BLOB * n, row["ms"], "whole call, pageable host pointers (PCIe H2D of the blobs)",
+                                    ALGO_BYTES_VERIFY_BLOB * n, bound="pcie", peak=PCIE_PEAK_GBS),
+                           traffic_source="by construction: every input byte crosses the link exactly once (bytes over PCIe, not HBM)")
     try:
         import torch
         hb = HipBuffers(torch, torch.device("cuda", torch.cuda.current_device()))
@@ -367,8 +447,10 @@ def verify_and_recover_rows(L, hip, base):
         if rc != 0 or not ok.value:
             raise RuntimeError("pinned verify rc=%d ok=%s" % (rc, ok.value))
         row["pinned_caller_memory"] = {"ms": round(median(ts) * 1e3, 3), "blobs_per_s": round(n / median(ts), 1),
-                                       "roofline": roofline(ALGO_BYTES_VERIFY_BLOB * n, median(ts) * 1e3,
-                                                            "whole call, page-locked host pointers", bound="pcie", peak=PCIE_PEAK_GBS)}
+                                       "roofline": dict(roofline(ALGO_BYTES_VERIFY_BLOB * n, median(ts) * 1e3,
+                                                                 "whole call, page-locked host pointers", ALGO_BYTES_VERIFY_BLOB * n,
+                                                                 bound="pcie", peak=PCIE_PEAK_GBS),
+                                                        traffic_source="by construction: every input byte crosses the link exactly once")}
         L.verify_blobs_dev(C.byref(ok), dptr[0], dptr[1], dptr[2], n, sp)
         ts, ks, k0, k2 = [], [], [], []
         for _ in range(5):
@@ -378,11 +460,30 @@ def verify_and_recover_rows(L, hip, base):
             ks.append(L.kms(sp, 3)); k0.append(L.kms(sp, 0)); k2.append(L.kms(sp, 2))
         if rc != 0 or not ok.value:
             raise RuntimeError("resident verify rc=%d ok=%s" % (rc, ok.value))
+        prow = "verify_wide" if tables_of(L, hip)["commit_wbits"] >= 16 else "verify_default"
+        parts = {"k_sha256_challenges": pmc_kernel(prow, "k_sha256_challenges", streaming=True),
+                 "k_bytes_to_fr": pmc_kernel(prow, "k_bytes_to_fr", pick="grid", streaming=True),
+                 "k_eval_barycentric": pmc_kernel(prow, "k_eval_barycentric<false>", streaming=True),
+                 "k_table_chain_x28": pmc_kernel(prow, "k_table_chain_x28"),
+                 "k_msm_accumulate_x28": pmc_kernel(prow, "k_msm_accumulate_x28")}
+        have = [v for v in parts.values() if v]
+        sha = parts["k_sha256_challenges"]
         row["resident_inputs"] = {"ms": round(median(ts) * 1e3, 3), "blobs_per_s": round(n / median(ts), 1),
                                   "kernel_ms": {"total": round(median(ks), 3), "validate_convert_hash_evaluate": round(median(k0), 3),
                                                 "sums": round(median(k2), 3)},
-                                  "roofline": roofline(ALGO_BYTES_VERIFY_BLOB * n, median(ks),
-                                                       "k_sha256_challenges + k_eval_barycentric + k_validate_g1 + k_msm_accumulate_x28 over the call-time table (device time of the call)")}
+                                  "roofline": dict(roofline(ALGO_BYTES_VERIFY_BLOB * n, median(ks),
+                                                            "k_sha256_challenges + k_eval_barycentric + k_validate_g1 + k_msm_accumulate_x28 over the call-time table (device time of the call)",
+                                                            sum(v["traffic_bytes_per_launch"] for v in have) if have else None),
+                                                   traffic_source="PMC: FETCH_SIZE (x2 for the streaming kernels) + WRITE_SIZE of the five kernels that move the call's bytes, one launch each" if have else None,
+                                                   pmc_per_kernel=parts),
+                                  # the call's longest kernel is a dependent chain of 2,050 SHA-256 compressions per blob on ONE wave
+                                  # per 64 blobs: its bound is the issue rate of a lone wave (one VALU instruction per 4 cycles)
+                                  "roofline_valu": None if not (sha and sha["valu_wave_insts"] and sha["waves"]) else {
+                                      "bound": "VALU issue of one wave per SIMD (sequential chain)", "unit": "G wave-instructions/s per wave",
+                                      "peak": 0.6, "kernel": "k_sha256_challenges", "kernel_ms": sha["mean_ms"],
+                                      "achieved": round(sha["valu_wave_insts"] / sha["waves"] / (sha["mean_ms"] * 1e-3) / 1e9, 4),
+                                      "frac": round(sha["valu_wave_insts"] / sha["waves"] / (sha["mean_ms"] * 1e-3) / 0.6e9, 4),
+                                      "note": "mean over the producer (message schedule) and consumer (rounds) wave of each workgroup; peak = 2.4 GHz / 4 cycles; from " + sha["file"]}}
         del hb, pin_t, dev_t
     except Exception as e:  # noqa: BLE001 -- reported, the pageable row stands
         row["forms_error"] = str(e)
@@ -422,14 +523,148 @@ def verify_and_recover_rows(L, hip, base):
         raise RuntimeError("recover batch rc=%d or wrong proofs" % rc)
     k_small, k_fft, k_dev = L.kms(sp, 1), L.kms(sp, 4), L.kms(sp, 3)
     dom, dom_name = (k_small, "k_msm_small") if k_small >= k_fft else (k_fft, "k_g1_fft_twiddle* + k_g1_fft_addsub (2 G1 FFTs)")
+    tb = tables_of(L, hip)
+    fw = tb["fk20_wbits"]
+    nwin_f = 2 * (127 // fw + 1)
+    prow = "verify_wide" if tb["commit_wbits"] >= 16 else "verify_default"
+    small_traffic = int(nb * (128 * 64 * nwin_f * (96 * (1.0 - 2.0 ** -fw) + 2) + 128 * 192))
+    fftq = pmc_kernel(prow, "k_g1_fft_twiddle_quad", pick="grid")
     out["recover_cells_and_kzg_proofs_batch256"] = {
         "rows_per_s": round(nb / median(ts), 1), "ms": round(median(ts) * 1e3, 3), "runs": 3,
         "kernel_ms": {"device_section": round(k_dev, 3), "k_msm_small": round(k_small, 3), "g1_fft": round(k_fft, 3)},
-        "roofline": roofline(ALGO_BYTES_RECOVER_ROW * nb, dom, dom_name),
-        "roofline_whole_call": roofline(ALGO_BYTES_RECOVER_ROW * nb, median(ts) * 1e3, "whole call, pageable host pointers",
-                                        bound="pcie", peak=PCIE_PEAK_GBS),
+        "roofline": dict(roofline(ALGO_BYTES_RECOVER_ROW * nb, dom, dom_name,
+                                  small_traffic if k_small >= k_fft else (fftq["traffic_bytes_per_launch"] * 12 if fftq else None)),
+                         traffic_source="analytic: 128 x 64 x nwin gathers of 96 B + digits per row (k_msm_small)" if k_small >= k_fft
+                         else "PMC: 12 ladder launches of the two G1 FFTs, FETCH_SIZE + WRITE_SIZE per launch",
+                         pmc_cross_check={"k_msm_small": pmc_kernel(prow, "k_msm_small"), "k_g1_fft_twiddle_quad": fftq}),
+        "roofline_valu": valu_roofline(nb * 128 * 64 * nwin_f * MADS_PER_ADDITION, k_small,
+                                       "k_msm_small: 128 x 64 x %d mixed additions x %d multiply-adds per row (the G1 FFT of a 256-row batch "
+                                       "runs its ladders four lanes per point: latency-bound, see DESIGN)" % (nwin_f, MADS_PER_ADDITION)),
+        "roofline_whole_call": dict(roofline(ALGO_BYTES_RECOVER_ROW * nb, median(ts) * 1e3, "whole call, pageable host pointers",
+                                             ALGO_BYTES_RECOVER_ROW * nb, bound="pcie", peak=PCIE_PEAK_GBS),
+                                    traffic_source="by construction: inputs and outputs cross the link exactly once"),
         "note": "64 of 128 cells per row (every other cell), same columns in every row; cells and proofs out"}
     return out
+
+
+def footprint_curve(mod, L, torch, dev, blobs, local_rank):
+    """What table memory buys: commitments/s (1024 resident blobs), one-blob compute_cells_and_kzg_proofs latency
+    (host pointers) and the FK20 batch rate (1024 resident blobs) at increasing window widths, each point its own
+    load_trusted_setup after the previous point's tables were freed.  The 16/16/13-bit point is the main
+    KZGSettings of this run (appended by the caller)."""
+    pts = []
+    nb = 1024
+    sub = blobs[:nb]
+    status = torch.empty((nb,), dtype=torch.uint8, device=dev)
+    out48 = torch.empty((nb, 48), dtype=torch.uint8, device=dev)
+    cells = torch.empty((nb, 128, 2048), dtype=torch.uint8, device=dev)
+    proofs = torch.empty((nb, 128, 48), dtype=torch.uint8, device=dev)
+    hb1 = blobs[0].cpu().numpy().tobytes()
+    hc1 = C.create_string_buffer(128 * 2048)
+    hp1 = C.create_string_buffer(128 * 48)
+    for cw, pw, fw in ((10, 8, 8), (12, 12, 10), (13, 13, 11), (14, 14, 12)):
+        t0 = time.perf_counter()
+        k = mod.Kzg(mod.HIP_SO, options={"device": local_rank, "commit_wbits": cw, "proof_wbits": pw, "fk20_wbits": fw})
+        load_s = time.perf_counter() - t0
+        try:
+            sp = C.addressof(k.s)
+            fn1 = L._fn("compute_cells_and_kzg_proofs", [C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p])
+            L.commit_dev(out48.data_ptr(), status.data_ptr(), sub.data_ptr(), nb, sp)
+            ts = []
+            for _ in range(3):
+                t = time.perf_counter()
+                rc = L.commit_dev(out48.data_ptr(), status.data_ptr(), sub.data_ptr(), nb, sp)
+                ts.append(time.perf_counter() - t)
+            fn1(hc1, hp1, hb1, sp)
+            t1 = []
+            for _ in range(10):
+                t = time.perf_counter()
+                rc |= fn1(hc1, hp1, hb1, sp)
+                t1.append(time.perf_counter() - t)
+            L.cells_dev(cells.data_ptr(), proofs.data_ptr(), status.data_ptr(), sub.data_ptr(), nb, sp)
+            t = time.perf_counter()
+            rc |= L.cells_dev(cells.data_ptr(), proofs.data_ptr(), status.data_ptr(), sub.data_ptr(), nb, sp)
+            tb = time.perf_counter() - t
+            if rc != 0:
+                raise RuntimeError("footprint point %d/%d/%d failed rc=%d" % (cw, pw, fw, rc))
+            pts.append({"tables": tables_of(L, k), "load_s": round(load_s, 2),
+                        "commit_blobs_per_s": round(nb / median(ts), 1),
+                        "cells_and_proofs_one_blob_ms": round(median(t1) * 1e3, 3),
+                        "cells_and_proofs_batch_blobs_per_s": round(nb / tb, 1)})
+        finally:
+            k.close()
+    return pts
+
+
+def predicted_scaling(value_n1, host_ptr_n1, sec):
+    """What the 1/2/4/8-GPU curve of each BASELINE config should be on THIS host, from numbers measured in this run at
+    N = 1 and the resource that bounds each (DESIGN.md section 6).  Ranks are independent (no data-path collective);
+    what they share is the host: its cores (hash threads, staging copies) and its memory bandwidth."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    MEMCPY_GBPS_PER_CORE, SHA_US_PER_BLOB_THREAD, COPY_US_PER_BLOB, GPU_SHA_US, EVAL_US, TAIL_US = 8.0, 66.0, 2.4, 4900.0, 1900.0, 2000.0
+    out = {"host_cpus_usable": cores,
+           "model": {"memcpy_GBps_per_core": MEMCPY_GBPS_PER_CORE, "sha256_us_per_blob_per_thread": SHA_US_PER_BLOB_THREAD,
+                     "pcie_us_per_blob": COPY_US_PER_BLOB, "gpu_sha_us": GPU_SHA_US, "threads_per_rank": "cpus // N (ckzg_hip_host_thread_budget)"},
+           "by_config": {}}
+    ns = (1, 2, 4, 8)
+    thr = {n: max(1, cores // n) for n in ns}
+    out["by_config"]["configs[1] commitments, inputs resident (value)"] = {
+        "bound": "GPU integer VALU (k_msm_accumulate); nothing is shared between ranks", "unit": "blobs/s",
+        "predicted": {str(n): round(n * value_n1, 0) for n in ns}}
+    if host_ptr_n1:
+        out["by_config"]["configs[1] commitments, pageable host pointers"] = {
+            "bound": "per rank min(GPU + PCIe pipeline, staging memcpy on min(8, threads) cores)", "unit": "blobs/s",
+            "predicted": {str(n): round(n * min(host_ptr_n1, min(8, thr[n]) * MEMCPY_GBPS_PER_CORE * 1e9 / 131072.0), 0) for n in ns}}
+    try:
+        one = sec["cells_and_proofs"]["one_blob"]["calls_per_s"]
+        out["by_config"]["configs[2] compute_cells_and_kzg_proofs, one blob per call"] = {
+            "bound": "latency of one call (replicas only: one caller per GPU)", "unit": "calls/s",
+            "predicted": {str(n): round(n * one, 1) for n in ns}}
+    except (KeyError, TypeError):
+        pass
+    try:
+        m1 = sec["verify_blob_kzg_proof_batch_n4096"]["ms"]
+        pred = {}
+        for n in ns:
+            if n == 1:
+                pred["1"] = round(4096 / (m1 * 1e-3), 0)
+                continue
+            per = 4096 // n
+            t = min(32, thr[n])
+            host_us, copy_us = per * SHA_US_PER_BLOB_THREAD / t, per * COPY_US_PER_BLOB
+            us = (max(copy_us, host_us) if host_us <= copy_us + GPU_SHA_US else copy_us + GPU_SHA_US + EVAL_US) + TAIL_US
+            pred[str(n)] = round(4096 / (us * 1e-6), 0)
+        out["by_config"]["configs[3] verify_blob_kzg_proof_batch, 4096 blobs sharded"] = {
+            "bound": "per shard: host SHA-256 on cpus//N threads or (automatic below ~1 thread per 30 blobs) the GPU hash's fixed 4.9 ms, "
+                     "+ ~2 ms of sums and pairing per shard; N = 1 is this run's measurement", "unit": "blobs/s", "predicted": pred}
+    except (KeyError, TypeError):
+        pass
+    try:
+        m1 = sec["recover_cells_and_kzg_proofs_batch256"]["ms"]
+        floor = 9.0
+        out["by_config"]["configs[4] recover_cells_and_kzg_proofs, 256 rows sharded"] = {
+            "bound": "latency floor of a small shard (~9 ms: six dependent ladder launches of FK20 + the recovery transforms)", "unit": "rows/s",
+            "predicted": {str(n): round(256 / ((floor + max(0.0, m1 - floor) / n) * 1e-3), 0) for n in ns}}
+    except (KeyError, TypeError):
+        pass
+    return out
+
+
+def committed_single_gpu_value():
+    """The newest committed N = 1 line (profiles/rNN_final_bench_line.json): what an N-rank run is predicted from."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_final_bench_line*.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            d = d[0] if isinstance(d, list) else d
+            if d.get("n_gpus") == 1 and d.get("value"):
+                return float(d["value"]), os.path.relpath(f, ROOT)
+        except Exception:  # noqa: BLE001
+            continue
+    return None, None
 
 
 def pin_to_gpu_numa_node(torch, local_rank):
@@ -574,8 +809,7 @@ def main():
         # RCCL comes up BEFORE the tables are allocated: its buffers and hardware queues are claimed while the HBM
         # is still empty, and the line records what was free on every rank before and after the load.
         # The ranks only meet at barriers and at one MAX over their timings (the path has no data-path collective,
-        # SURVEY 8e).  RCCL carries them; if it cannot come up on this node (every rank then fails alike) the same
-        # two calls go over gloo on a second rendezvous port, and the line says so in "barrier_backend".
+        # SURVEY 8e).  RCCL carries them; if it cannot come up on this node the run FAILS (value null, exit code 3).
         backend = os.environ.get("CKZG_BENCH_BACKEND", "nccl")
         try:
             dist.init_process_group(backend, rank=rank, world_size=world)
@@ -583,16 +817,14 @@ def main():
             dist.all_reduce(t)
             if backend == "nccl":
                 torch.cuda.synchronize()
-        except Exception as e:  # noqa: BLE001 -- whatever RCCL raised, the control plane can still run
-            if backend != "nccl":
-                raise
-            sys.stderr.write("bench: rank %d: RCCL did not come up (%s); barriers over gloo\n" % (rank, str(e)[:200]))
-            try:
-                dist.destroy_process_group()
-            except Exception:  # noqa: BLE001
-                pass
-            os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        except Exception as e:  # noqa: BLE001
+            # An N-GPU number timed over anything but RCCL would not be the number asked for: no silent fallback.
+            # Rank 0 prints a line whose value is null, every rank exits non-zero.
+            sys.stderr.write("bench: rank %d: %s did not come up: %s\n" % (rank, backend, str(e)[:300]))
+            if rank == 0:
+                print(json.dumps({"metric": "blob_to_kzg_commitment throughput", "value": None, "unit": "blobs/s", "n_gpus": world,
+                                  "error": "%s (RCCL) initialisation failed: %s" % (backend, str(e)[:300])}))
+            sys.exit(3)
     red_dev = dev if (world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")
 
     import __graft_entry__ as ge
@@ -751,7 +983,11 @@ def main():
                 raise RuntimeError("default-table commit rc=%d" % rc)
             d = {"tables": tables_of(L, small),
                  "commit_blobs_per_s": round(BLOBS_PER_STEP / median(ts), 1),
-                 "commit_roofline": roofline(ALGO_BYTES_PER_BLOB * BLOBS_PER_STEP, median(ks), "k_msm_accumulate")}
+                 "commit_roofline": dict(roofline(ALGO_BYTES_PER_BLOB * BLOBS_PER_STEP, median(ks), "k_msm_accumulate",
+                                                  analytic_traffic(int(L.table_wbits(sps, 0)), BLOBS_PER_STEP)),
+                                         traffic_source="analytic (bench.py: analytic_traffic)"),
+                 "commit_roofline_valu": valu_roofline(BLOBS_PER_STEP * 2 * (127 // int(L.table_wbits(sps, 0)) + 1) * 4096 * MADS_PER_ADDITION,
+                                                       median(ks), "nwin x 4096 mixed additions per blob")}
             d["cells_and_proofs"] = cells_rows(L, small, torch, dev, blobs, "default tables")
             try:
                 d["concurrent_callers"] = concurrency_rows(mod, small, blobs[:32].cpu().numpy())
@@ -865,8 +1101,41 @@ def main():
                 line["cpu_baseline"] = cpu_baseline()
             except Exception as e:  # the oracle is only a reported baseline
                 line["cpu_baseline"] = {"error": str(e)}
-        print(json.dumps(line))
+        # the 1/2/4/8-GPU curve this host should give, per BASELINE config, and what bounds it
+        if world == 1:
+            line["predicted_scaling"] = predicted_scaling(value, None if host_ptr is None else host_ptr["value"], secondary or {})
+        else:
+            v1, src = committed_single_gpu_value()
+            line["predicted"] = {"value": None if v1 is None else round(world * v1, 0), "unit": "blobs/s",
+                                 "from": "N x the committed one-GPU value (%s): ranks share nothing on this path" % src,
+                                 "bound": "GPU integer VALU per rank"}
+        if isinstance(secondary, dict) and "cells_and_proofs" in secondary:
+            # BASELINE configs by name, so that a reader does not have to know which row is which
+            dflt = secondary.get("default_footprint", {}).get("cells_and_proofs", {}).get("one_blob", {})
+            line["baseline_configs"] = {
+                "configs[1]": {"blobs_per_s_resident": line["value"], "blobs_per_s_host_pointers": line["value_host_pointer"]},
+                "configs[2]": {"precompute": 0,
+                               "library_default_tables_ms_per_call": dflt.get("ms_per_call"),
+                               "wide_tables_ms_per_call": secondary["cells_and_proofs"]["one_blob"]["ms_per_call"],
+                               "note": "load_trusted_setup(..., precompute = 0) with no option set gives the default-table "
+                                       "figure (5 GB of tables); the wide figure needs commit/proof/FK20 widths 16/16/13 (238 GB)"},
+                "configs[3]": secondary.get("verify_blob_kzg_proof_batch_n4096", {}).get("ms"),
+                "configs[4]": secondary.get("recover_cells_and_kzg_proofs_batch256", {}).get("ms")}
+    tables_main = tables_of(L, hip) if rank == 0 else None
     hip.close()
+    if rank == 0 and world == 1 and not args.no_secondary and isinstance(secondary, dict) and "error" not in secondary:
+        # after the 238 GB are released: what narrower tables give (each point is its own load)
+        try:
+            curve = footprint_curve(mod, L, torch, dev, blobs, local_rank)
+            curve.append({"tables": tables_main, "commit_blobs_per_s": line["value"],
+                          "cells_and_proofs_one_blob_ms": secondary["cells_and_proofs"]["one_blob"]["ms_per_call"],
+                          "cells_and_proofs_batch_blobs_per_s": secondary["cells_and_proofs"]["batch_2048"]["blobs_per_s"],
+                          "note": "the main KZGSettings of this run (batch of 2048)"})
+            secondary["footprint_curve"] = curve
+        except BaseException as e:  # noqa: BLE001
+            secondary["footprint_curve"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    if rank == 0:
+        print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
 

@@ -1,13 +1,13 @@
 #!/bin/bash
 # rocprofv3 evidence for the dominant kernels of the SECONDARY rows (compute_cells_and_kzg_proofs one blob and batch,
 # resident batch verification, recovery), run on the GPU box via gpurun from the repo root:
-#   bash tools/pmc_rows.sh [rows...]      default rows: cells_wide cells_default verify
+#   bash tools/pmc_rows.sh [rows...]      default rows: cells_wide verify_wide
 # Per row: one --kernel-trace --stats pass, then SEPARATE --pmc passes (FETCH_SIZE, WRITE_SIZE, an SQ set), never
 # combined with --stats or other trace domains.  tools/summarize_pmc_rows.py turns the directories into
 # profiles/<prefix>_pmc_<row>.json.
 export TMPDIR=/tmp
 O=gpurun_out/pmc_rows
-ROWS=${@:-cells_wide cells_default verify}
+ROWS=${@:-cells_wide verify_wide}
 mkdir -p $O
 for row in $ROWS; do
   rm -rf $O/$row && mkdir -p $O/$row

@@ -3,8 +3,9 @@
   cells_wide    compute_cells_and_kzg_proofs: 1 blob x 5 (low-latency path: k_msm_accumulate over the 16-bit monomial
                 table) and a 2048-blob batch x 2 (FK20: k_msm_small<8>, the G1-FFT ladders, k_ntt_tile), 16/16/13-bit tables
   cells_default the same on the library's default tables
-  verify        ckzg_hip_verify_blob_kzg_proof_batch_device, 4096 blobs x 3 (k_sha256_challenges, k_eval_barycentric,
-                validation, call-time table) + recover_cells_and_kzg_proofs batch of 256 rows x 2, default tables
+  verify_wide   ckzg_hip_verify_blob_kzg_proof_batch_device, 4096 blobs x 3 (k_sha256_challenges, k_eval_barycentric,
+                validation, call-time table) + recover_cells_and_kzg_proofs batch of 256 rows x 2, 16/16/13-bit tables
+  verify_default the same on the library's default tables
 Prints one JSON line with the wall-clock of what it ran."""
 import ctypes as C
 import json
@@ -22,7 +23,7 @@ def main():
     import torch
     import __graft_entry__ as ge
     mod = ge.load_package()
-    opts = dict(bench.WIDE) if row == "cells_wide" else {}
+    opts = dict(bench.WIDE) if row.endswith("_wide") else {}
     hip = mod.Kzg(mod.HIP_SO, options=opts)
     L = bench.Lib(hip.lib)
     sp = C.addressof(hip.s)
