@@ -596,7 +596,7 @@ def footprint_curve(mod, L, torch, dev, blobs, local_rank):
     return pts
 
 
-def predicted_scaling(value_n1, host_ptr_n1, sec):
+def predicted_scaling(value_n1, host_ptr_n1, sec, lib_budget=None, effective_cores=None):
     """What the 1/2/4/8-GPU curve of each BASELINE config should be on THIS host, from numbers measured in this run at
     N = 1 and the resource that bounds each (DESIGN.md section 6).  Ranks are independent (no data-path collective);
     what they share is the host: its cores (hash threads, staging copies) and its memory bandwidth."""
@@ -604,8 +604,14 @@ def predicted_scaling(value_n1, host_ptr_n1, sec):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    visible = cores
+    if lib_budget:
+        cores = min(cores, lib_budget)      # what the library itself sizes its pools by (affinity mask, cgroup quota)
+    if effective_cores:
+        cores = min(cores, effective_cores)  # what the host really delivered to the CPU baseline of this run
     MEMCPY_GBPS_PER_CORE, SHA_US_PER_BLOB_THREAD, COPY_US_PER_BLOB, GPU_SHA_US, EVAL_US, TAIL_US = 8.0, 66.0, 2.4, 4900.0, 1900.0, 2000.0
-    out = {"host_cpus_usable": cores,
+    out = {"host_cpus_visible": visible, "host_cores_assumed": cores,
+           "host_cores_source": "min(affinity mask, the library's ckzg_hip_host_thread_budget, parallel speed-up the CPU baseline of this run reached)",
            "model": {"memcpy_GBps_per_core": MEMCPY_GBPS_PER_CORE, "sha256_us_per_blob_per_thread": SHA_US_PER_BLOB_THREAD,
                      "pcie_us_per_blob": COPY_US_PER_BLOB, "gpu_sha_us": GPU_SHA_US, "threads_per_rank": "cpus // N (ckzg_hip_host_thread_budget)"},
            "by_config": {}}
@@ -1103,7 +1109,15 @@ def main():
                 line["cpu_baseline"] = {"error": str(e)}
         # the 1/2/4/8-GPU curve this host should give, per BASELINE config, and what bounds it
         if world == 1:
-            line["predicted_scaling"] = predicted_scaling(value, None if host_ptr is None else host_ptr["value"], secondary or {})
+            eff = None
+            try:
+                cb = line["cpu_baseline"]
+                eff = max(1, int(round(cb["all_cores"]["value"] / cb["value"])))
+            except (KeyError, TypeError, ZeroDivisionError):
+                pass
+            budget = L._fn("ckzg_hip_host_thread_budget", [])()
+            line["predicted_scaling"] = predicted_scaling(value, None if host_ptr is None else host_ptr["value"], secondary or {},
+                                                          lib_budget=int(budget), effective_cores=eff)
         else:
             v1, src = committed_single_gpu_value()
             line["predicted"] = {"value": None if v1 is None else round(world * v1, 0), "unit": "blobs/s",

@@ -93,6 +93,25 @@ inline int host_thread_budget() {
         if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = CPU_COUNT(&set);
         if (cpus <= 0) cpus = (int)std::thread::hardware_concurrency();
         if (cpus <= 0) cpus = 4;
+        // a container's CPU quota (cgroup v2 cpu.max, v1 cfs quota / period): 256 visible CPUs with 15 cores' worth
+        // of time are 15 cores
+        {
+            long quota = -1, period = 0;
+            if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+                char q[32] = {0};
+                if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atol(q);
+                fclose(f);
+            } else {
+                FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"), *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+                if (fq && fp && (fscanf(fq, "%ld", &quota) != 1 || fscanf(fp, "%ld", &period) != 1)) quota = -1;
+                if (fq) fclose(fq);
+                if (fp) fclose(fp);
+            }
+            if (quota > 0 && period > 0) {
+                const int q = (int)((quota + period - 1) / period);
+                if (q >= 1 && q < cpus) cpus = q;
+            }
+        }
         int ranks = 1;
         for (const char *name : {"LOCAL_WORLD_SIZE", "WORLD_SIZE"}) {
             const char *v = getenv(name);

@@ -1,0 +1,55 @@
+"""The library sizes its helper pools (challenge hashers, staging-copy helpers, point decompression at load) by this
+process's SHARE of the host: CPUs of the affinity mask (and of the cgroup quota) divided by the ranks of a
+one-process-per-GPU launcher.  Eight ranks that each sized their pools by the machine would put 8 x 32 hashing threads
+on the same cores.  No GPU needed: ckzg_hip_host_thread_budget is a host-only query."""
+import os
+import subprocess
+import sys
+
+from conftest import HIP_SO
+
+CODE = ("import ctypes as C, os\n"
+        "l = C.CDLL(%r)\n"
+        "print(len(os.sched_getaffinity(0)), l.ckzg_hip_host_thread_budget())\n"
+        "assert l.ckzg_hip_set_option(b'host_threads', 3) == 0\n"
+        "print(l.ckzg_hip_host_thread_budget())\n"
+        "assert l.ckzg_hip_set_option(b'host_threads', 0) == 0\n"
+        "print(l.ckzg_hip_host_thread_budget())\n" % HIP_SO)
+
+
+def _run(env_extra, affinity=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "LOCAL_WORLD_SIZE")}
+    env.update(env_extra)
+    cmd = [sys.executable, "-c", CODE]
+    if affinity is not None:
+        cmd = ["taskset", "-c", affinity] + cmd
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-1000:]
+    lines = r.stdout.split("\n")
+    cpus, auto = (int(x) for x in lines[0].split())
+    return cpus, auto, int(lines[1]), int(lines[2])
+
+
+def test_budget_is_the_affinity_mask_without_a_launcher():
+    cpus, auto, forced, back = _run({})
+    assert 1 <= auto <= cpus      # (a cgroup quota may lower it)
+    assert forced == 3 and back == auto
+
+
+def test_budget_divides_by_the_ranks_on_the_host():
+    cpus, one, _, _ = _run({})
+    for world in (2, 8, 64):
+        _, auto, forced, back = _run({"WORLD_SIZE": str(world)})
+        assert auto == max(1, one // world), (world, one, auto)
+        assert forced == 3 and back == auto      # the option overrides, 0 gives the automatic value back
+    # torchrun's LOCAL_WORLD_SIZE (ranks on THIS node) wins over WORLD_SIZE (ranks of the job)
+    _, auto, _, _ = _run({"WORLD_SIZE": "64", "LOCAL_WORLD_SIZE": "2"})
+    assert auto == max(1, one // 2)
+
+
+def test_budget_follows_a_restricted_affinity_mask():
+    if len(os.sched_getaffinity(0)) < 2:
+        return
+    first = sorted(os.sched_getaffinity(0))[:2]
+    cpus, auto, _, _ = _run({}, affinity=",".join(str(c) for c in first))
+    assert cpus == 2 and auto <= 2

@@ -42,6 +42,12 @@ def main():
                 if k_src in r:
                     c.setdefault("_" + k_dst, r[k_src])
     out = {"row": os.path.basename(os.path.normpath(d)), "total_kernel_ms_in_trace": round(total, 3), "kernels": []}
+    try:   # what the workload printed in its --stats pass: the tables it ran on and its wall-clock numbers
+        w = json.load(open(os.path.join(d, "stats.json")))
+        out["tables"] = w.get("tables")
+        out["workload"] = {k: v for k, v in w.items() if k not in ("tables", "row")}
+    except Exception:  # noqa: BLE001
+        pass
     for (name, grid, wg), v in sorted(kern.items(), key=lambda kv: -sum(kv[1]["ms"])):
         share = sum(v["ms"]) / total
         if share < 0.005:
