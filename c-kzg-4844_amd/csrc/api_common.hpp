@@ -76,6 +76,9 @@ Options options_snapshot();
 extern std::atomic<int> g_gpu_sha_min;
 // read at call time (ckzg_hip_set_option("host_threads", n)); 0 = automatic (host_thread_budget)
 extern std::atomic<int> g_host_threads;
+// read at call time: smallest verify_blob_kzg_proof_batch that takes the pipelined (chunked copy) form; whether the
+// verifications may build their call-time table (0: ladder sums, the path a device too full for the table takes)
+extern std::atomic<int> g_verify_pipe_min, g_verify_call_table;
 
 // How many host threads ONE process of this library may keep busy for a call (challenge hashing, staging copies,
 // point decompression at load): the CPUs the process may run on divided by the processes that share the host.
@@ -515,9 +518,9 @@ class WorkerPool {
 
 inline void staged_copy(void *dst, const void *src, size_t bytes) {
     static const size_t nt = []() {
-        const char *e = getenv("CKZG_HIP_COPY_THREADS");   // ways a staging copy is split (the caller is one of them)
-        long v = e && *e ? atol(e) : 8;   // measured (profiles/r03_copy_threads_ab.txt): 4 ways make the pageable source of a
-                                           // 4096-blob verification memcpy-bound (median 15.8 ms), 8 ways DMA-bound (12.5 ms)
+        // ways a staging copy is split (the caller is one of them).  Measured (profiles/r03_copy_threads_ab.txt): 4 ways make
+        // the pageable source of a 4096-blob verification memcpy-bound (median 15.8 ms), 8 ways DMA-bound (12.5 ms)
+        long v = dev::ab_knob("CKZG_HIP_COPY_THREADS", 8);
         const long budget = host_thread_budget();
         if (v > budget) v = budget;
         return (size_t)(v < 1 ? 1 : (v > 8 ? 8 : v));

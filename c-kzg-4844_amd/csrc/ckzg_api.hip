@@ -24,6 +24,7 @@ static std::mutex g_opts_mu;
 static Options g_opts;
 std::atomic<int> g_gpu_sha_min{0};
 std::atomic<int> g_host_threads{0};
+std::atomic<int> g_verify_pipe_min{1024}, g_verify_call_table{1};
 Options options_snapshot() {
     std::lock_guard<std::mutex> lock(g_opts_mu);
     return g_opts;
@@ -65,6 +66,12 @@ extern "C" C_KZG_RET ckzg_hip_set_option(const char *key, int64_t value) {
     } else if (!strcmp(key, "gpu_sha_min")) {
         if (value < 0 || value > (1 << 30)) return C_KZG_BADARGS;
         g_gpu_sha_min.store((int)value);  // read at call time, unlike the load-time options
+    } else if (!strcmp(key, "verify_pipe_min")) {
+        if (value < 2 || value > (1 << 30)) return C_KZG_BADARGS;
+        g_verify_pipe_min.store((int)value);
+    } else if (!strcmp(key, "verify_call_table")) {
+        if (value != 0 && value != 1) return C_KZG_BADARGS;
+        g_verify_call_table.store((int)value);
     } else if (!strcmp(key, "host_threads")) {
         if (value < 0 || value > 1024) return C_KZG_BADARGS;
         g_host_threads.store((int)value);  // read when the helper pools start and at call time
@@ -342,11 +349,8 @@ extern "C" C_KZG_RET ckzg_hip_blob_to_kzg_commitment_batch_device(void *d_out48,
 static C_KZG_RET commit_batch_on(dev::DeviceCtx *ctx, KZGCommitment *out, uint8_t *status, const Blob *blobs,
                                  uint64_t n, bool pinned_io = false) {
     if (n == 0) return C_KZG_OK;
-    static const uint64_t CH = []() {
-        const char *v = getenv("CKZG_HIP_COMMIT_CHUNK");
-        long c = v && *v ? atol(v) : 256;   // measured: profiles/r03_commit_chunk_ab.txt (512: -11 % from pageable memory)
-        return (uint64_t)(c < 16 ? 16 : (c > 1024 ? 1024 : c));
-    }();
+    // measured: profiles/r03_commit_chunk_ab.txt (512: -11 % from pageable memory)
+    static const uint64_t CH = (uint64_t)(dev::ab_knob("CKZG_HIP_COMMIT_CHUNK", 256) < 16 ? 16 : (dev::ab_knob("CKZG_HIP_COMMIT_CHUNK", 256) > 1024 ? 1024 : dev::ab_knob("CKZG_HIP_COMMIT_CHUNK", 256)));
     const uint64_t FIRST = CH < 64 ? CH : 64;
     const uint64_t m = n < CH ? n : CH;
     Trace tr("commit_batch");

@@ -285,11 +285,8 @@ struct LincombJob {
 // every n up to 65,536.  The default is therefore the ladders; CKZG_HIP_BUCKET_MIN=n (or algo = 2 at the
 // ckzg_hip_g1_lincomb boundary) routes sums of at least n terms to the buckets.
 static size_t bucket_min_terms() {
-    static const size_t v = []() {
-        const char *e = getenv("CKZG_HIP_BUCKET_MIN");
-        return e && *e ? (size_t)atol(e) : ~(size_t)0;
-    }();
-    return v;
+    static const long v = dev::ab_knob("CKZG_HIP_BUCKET_MIN", -1);   // never, unless an A/B build says otherwise
+    return v < 0 ? ~(size_t)0 : (size_t)v;
 }
 
 C_KZG_RET gpu_lincomb_multi(dev::DeviceCtx *ctx, G1Jac *outs, const LincombJob *jobs, int njobs, int algo = 0) {
@@ -303,10 +300,7 @@ C_KZG_RET gpu_lincomb_multi(dev::DeviceCtx *ctx, G1Jac *outs, const LincombJob *
         if (jobs[j].size() > max_job) max_job = jobs[j].size();
     }
     if (algo == 0) {
-        static const int forced = []() {
-            const char *e = getenv("CKZG_HIP_LINCOMB");
-            return e && *e ? atoi(e) : 0;
-        }();
+        static const int forced = (int)dev::ab_knob("CKZG_HIP_LINCOMB", 0);
         algo = forced ? forced : (max_job >= bucket_min_terms() ? 2 : 1);
         if (algo == 2 && !dev::bucket_msm_available()) algo = 1;   // the product build has no bucket kernels
     }
@@ -316,11 +310,8 @@ C_KZG_RET gpu_lincomb_multi(dev::DeviceCtx *ctx, G1Jac *outs, const LincombJob *
     }
     // ladders: four lanes per half-term (k_lincomb_partial_quad) while 8 lanes per term still fit the chip in
     // about two waves per SIMD; beyond that the one-lane-per-half form does fewer lane-products in total
-    // (algo 3 / 4 force the one-lane / four-lane ladders; CKZG_HIP_QUAD_MAX moves the hand-over)
-    static const size_t quad_max = []() {
-        const char *e = getenv("CKZG_HIP_QUAD_MAX");
-        return e && *e ? (size_t)atol(e) : (size_t)8192;
-    }();
+    // (algo 3 / 4 force the one-lane / four-lane ladders)
+    static const size_t quad_max = (size_t)dev::ab_knob("CKZG_HIP_QUAD_MAX", 8192);
     const bool quad = algo == 4 || (algo == 1 && total <= quad_max);
     if (algo == 3 || algo == 4) algo = 1;
     const int wbits = dev::bucket_msm_wbits(max_job);
@@ -534,10 +525,7 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     tr.mark("host point validation");
     // (never for the small path: its commitments are validated on the host and are not in d_ptb)
     const bool gpu_sha = resident || (!small && challenges_on_gpu(n));
-    static const size_t pipe_min = []() {
-        const char *e = getenv("CKZG_HIP_VERIFY_PIPE_MIN");
-        return e && *e ? (size_t)atol(e) : (size_t)1024;
-    }();
+    const size_t pipe_min = (size_t)g_verify_pipe_min.load(std::memory_order_relaxed);   // option "verify_pipe_min"
     const bool piped = !resident && !small && !gpu_sha && n >= pipe_min;
     // Call-time table (msm.hip): while the blobs of a batch cross PCIe (or, in the resident form, while one lane per
     // blob hashes them) the GPU is mostly idle and the batch challenge does not exist yet, so the 128 doublings per
@@ -549,15 +537,11 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     // 4096 13.8 -> 11.9, and in the one-copy form of smaller batches n = 8 2.48 -> 2.25, 64 3.00 -> 2.33,
     // 512 3.81 -> 3.29, 768 4.76 -> 3.70; resident: 1024 9.4 -> 8.4, 4096 12.6 -> 11.4.  From 8 blobs upwards (below
     // that: the host path of SMALL_VERIFY_N, or ladders).
-    static const int call_table_wbits = []() {
-        const char *e = getenv("CKZG_HIP_VERIFY_TABLE_WBITS");   // 0 switches the call-time table off (A/B)
-        return e && *e ? atoi(e) : 6;
-    }();
-    static const size_t call_table_min = []() {
-        const char *e = getenv("CKZG_HIP_VERIFY_TABLE_MIN");
-        return e && *e ? (size_t)atol(e) : (size_t)8;
-    }();
-    bool use_table = call_table_wbits >= 4 && call_table_wbits <= 10 && n >= call_table_min && !small;
+    // (option "verify_call_table" = 0 keeps the ladder sums: the path a device too full for the table takes)
+    static const int call_table_wbits = (int)dev::ab_knob("CKZG_HIP_VERIFY_TABLE_WBITS", 6);
+    static const size_t call_table_min = (size_t)dev::ab_knob("CKZG_HIP_VERIFY_TABLE_MIN", 8);
+    bool use_table = g_verify_call_table.load(std::memory_order_relaxed) != 0 && call_table_wbits >= 4 && call_table_wbits <= 10 &&
+                     n >= call_table_min && !small;
     dev::FixedBaseTable tbl;
     size_t tbl_bytes = 0, tbl_tmp = 0, sums_scratch = 0;
     Arena &ar = ctx->api_arena;
@@ -648,11 +632,8 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     bool have_digest = false;   // the pipelined form hashes the batch transcript while the batch is in flight
     if (piped) {
         // ---- pipelined host-pointer form ----
-        static const size_t CH = []() {   // 256 blobs = 32 MB per chunk: ~0.6 ms of PCIe, 16 chunks at n = 4096
-            const char *e = getenv("CKZG_HIP_VERIFY_CHUNK");   // A/B knob
-            size_t v = e && *e ? (size_t)atol(e) : (size_t)256;
-            return v < 16 ? (size_t)16 : v;
-        }();
+        // 256 blobs = 32 MB per chunk: ~0.6 ms of PCIe, 16 chunks at n = 4096 (profiles/r03_verify_pipeline_sweep.txt)
+        static const size_t CH = (size_t)(dev::ab_knob("CKZG_HIP_VERIFY_CHUNK", 256) < 16 ? 16 : dev::ab_knob("CKZG_HIP_VERIFY_CHUNK", 256));
         const size_t nch = (n + CH - 1) / CH;
         const bool src_pinned = host_pointer_is_pinned(blobs);
         if (!src_pinned) OKM(ensure_pinned(ctx->h_stage, ctx->h_stage_bytes, CH * (size_t)BYTES_PER_BLOB));
@@ -1491,15 +1472,10 @@ static C_KZG_RET verify_cells_on(dev::DeviceCtx *ctx, bool *ok, const Bytes48 *c
     // profiles/r03_verify_x28_sweep.txt): n = 1024 3.20 -> 2.88 ms, 2048 4.56 -> 3.20, 4096 7.54 -> 5.50,
     // 6144 9.81 -> 7.67, and n = 128 2.38 -> 2.31, 256 2.42 -> 2.32, 384 2.55 -> 2.36, 768 2.91 -> 2.49; below a
     // blob's worth of cells the two forms tie at the 2.3 ms latency floor of the call: from 128 cells upwards.
-    static const int call_table_wbits = []() {
-        const char *e = getenv("CKZG_HIP_VERIFY_TABLE_WBITS");   // 0 switches the call-time table off (A/B)
-        return e && *e ? atoi(e) : 6;
-    }();
-    static const size_t cell_table_min = []() {
-        const char *e = getenv("CKZG_HIP_VERIFY_CELL_TABLE_MIN");
-        return e && *e ? (size_t)atol(e) : (size_t)128;
-    }();
-    bool use_table = call_table_wbits >= 4 && call_table_wbits <= 10 && n >= cell_table_min;
+    static const int call_table_wbits = (int)dev::ab_knob("CKZG_HIP_VERIFY_TABLE_WBITS", 6);
+    static const size_t cell_table_min = (size_t)dev::ab_knob("CKZG_HIP_VERIFY_CELL_TABLE_MIN", 128);
+    bool use_table = g_verify_call_table.load(std::memory_order_relaxed) != 0 && call_table_wbits >= 4 && call_table_wbits <= 10 &&
+                     n >= cell_table_min;
     size_t npts = n + nc + (use_table ? l : 0);   // proofs, distinct commitments [, g1_values_monomial[0..63]]
     dev::FixedBaseTable tbl;
     size_t tbl_bytes = 0, tbl_tmp = 0, sums_scratch = 0;

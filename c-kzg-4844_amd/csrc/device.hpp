@@ -10,6 +10,7 @@
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include "g1.hpp"
 
 namespace ckzg {
@@ -29,6 +30,18 @@ constexpr int N_CELLS_EXT = 128;   // CELLS_PER_EXT_BLOB
 // and each scalar yields nwin = 2*twin signed digits in [-half, half]: windows 0..twin-1 are the k2
 // (phi) half, twin..nwin-1 the k1 half.  The MSM is a plain sum of npoints*nwin table entries -- no
 // buckets, no doublings, no data-dependent scatter -- at half the memory of a 255-bit table.
+// The tuning constants of the product are constants.  The A/B build (-DCKZG_AB: tools/build_variant.sh) reads them
+// from the environment instead, once per process, so that tools/ab_*.sh can sweep one constant on one box; the
+// measured sweeps that chose the defaults are under profiles/.  No losing variant lives in the product.
+#ifdef CKZG_AB
+inline long ab_knob(const char *env, long dflt) {
+    const char *e = getenv(env);
+    return e && *e ? atol(e) : dflt;
+}
+#else
+constexpr long ab_knob(const char *, long dflt) { return dflt; }
+#endif
+
 struct FixedBaseTable {
     G1Affine *d_table = nullptr;
     int npoints = 0;

@@ -240,12 +240,7 @@ __device__ __forceinline__ void r4_group(int grp, int s, int dif, int &t, int &p
 
 // the additions around the radix-4 ladders: latency work, four lanes per addition (A/B: CKZG_R4_ONE_LANE_ADDS)
 __device__ __forceinline__ void r4_add(XYZZ28 &a, bool &ainf, const XYZZ28 &b, bool binf, int ql) {
-#ifndef CKZG_R4_ONE_LANE_ADDS
     quad::xyzz28_add_quad(a, ainf, b, binf, ql);
-#else
-    (void)ql;
-    xyzz28_add(a, ainf, b, binf);
-#endif
 }
 
 __device__ __forceinline__ int r4_exponent(int k, int t, int s, int dif) {
@@ -278,14 +273,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const uint32_t ell = (uint32_t)(q / pad);
     uint32_t f = (uint32_t)(q - (size_t)ell * pad);
     if (ell >= (uint32_t)R4_LADDERS) return;
-#ifndef CKZG_R4_PARTIAL_WAVES
     // quads of the padding repeat the last transform instead of leaving the wave partly masked
     const bool live = f < nfft;
     if (!live) f = nfft - 1;
-#else
-    const bool live = true;
-    if (f >= nfft) return;
-#endif
     const int grp = (int)ell / 5, k = (int)ell % 5;
     int t, p0, p1, p2, p3;
     r4_group(grp, s, dif, t, p0, p1, p2, p3);
@@ -405,12 +395,9 @@ static int g1_fft_r4_pairs(DeviceCtx *ctx, G1XYZZ *d_data, G1XYZZ *d_tmp, G1XYZZ
 }
 
 static size_t r4_max_transforms() {
-    static const size_t v = []() {
-        // measured hand-over (tools/bench_fk20_sizes.py, profiles/r02_quad_ab.txt): radix-4 pairs win up to ~100
-        // transforms, tie with the radix-2 four-lane form up to ~200, lose beyond
-        const char *e = getenv("CKZG_HIP_R4_FFT_MAX");
-        return e && *e ? (size_t)atol(e) : (size_t)128;
-    }();
+    // measured hand-over (tools/bench_fk20_sizes.py, profiles/r02_quad_ab.txt): radix-4 pairs win up to ~100
+    // transforms, tie with the radix-2 four-lane form up to ~200, lose beyond
+    static const size_t v = (size_t)ab_knob("CKZG_HIP_R4_FFT_MAX", 128);
     return v;
 }
 
@@ -421,10 +408,7 @@ static int g1_fft_stages(DeviceCtx *ctx, G1XYZZ *d_data, const uint32_t *d_glv, 
     // four lanes per butterfly while that is at most ~two waves per SIMD (64 butterflies x nfft x 4 lanes): up
     // to there the one-lane form is latency-bound (a lone wave issues a mad every 9.4 cycles) and the quad
     // form's 12 lane-products per doubling instead of 7 cost nothing
-    static const size_t quad_max = []() {
-        const char *e = getenv("CKZG_HIP_QUAD_FFT_MAX");
-        return e && *e ? (size_t)atol(e) : (size_t)512;
-    }();
+    static const size_t quad_max = (size_t)ab_knob("CKZG_HIP_QUAD_FFT_MAX", 512);
     const bool use_quad = nfft <= quad_max;
     const dim3 qgrid((unsigned)((nfft + 15) / 16 * 16 * 4));        // 64 butterflies x padded transforms x 4 / 64 lanes
     for (int s = s_from; dif ? s >= s_to : s <= s_to; s += dif ? -1 : 1) {

@@ -62,8 +62,7 @@ constexpr int pow2_above(int v) {  // smallest power of two > v
 // Measured on gfx950 (tools/ubench/mad_latency.hip): 64-bit shifts and adds cost as much issue time as a
 // v_mad_u64_u32 (4.6 vs 4.85 cycles at two waves per SIMD) and a dependent chain of mads runs at the same
 // rate as 16 independent ones, so the single accumulator costs nothing and needs 28 fewer live registers
-// than the row-wise form's 15 accumulators.  CKZG_F28_ROWWISE selects the row-wise form for A/B runs.
-#ifndef CKZG_F28_ROWWISE
+// than the row-wise form's 15 accumulators (rounds 1-2; profiles/r02_fp28_ab.txt).
 // acc += a * b: one v_mad_u64_u32.  (LLVM re-associates a column's long sum into two chains -- the a*b terms
 // and the q*p terms -- and joins them with a 64-bit add, so the instruction counts of this form and of the
 // row-wise one come out equal: 3548 mads + 236 v_lshl_add_u64 + 234 v_lshrrev_b64 per mixed addition.  Forcing a
@@ -72,16 +71,6 @@ constexpr int pow2_above(int v) {  // smallest power of two > v
 // row-wise and 10.22 ms for this plain form, which wins through its smaller register footprint --
 // 191 instead of 209 VGPRs.  tools/ab_fp28.sh, profiles/r02_fp28_ab.txt.)
 HD void mad64(uint64_t &acc, uint32_t a, uint32_t b) { acc += (uint64_t)a * b; }
-// A zero-instruction fence on the accumulator (device only, opt-in with CKZG_F28_FENCE): the value must exist in
-// a register pair here, so the a*b terms before it and the q*p terms after it cannot be re-associated into two
-// chains that a 64-bit add then joins.
-HD void acc_fence(uint64_t &acc) {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(CKZG_F28_FENCE)
-    asm("" : "+v"(acc));
-#else
-    (void)acc;
-#endif
-}
 HD void mad64c(uint64_t &acc, uint32_t a, uint32_t c) { acc += (uint64_t)a * c; }
 
 // CKZG_F28_ASM_BLOCKS (device code of the translation units that define it -- msm.hip): the same three
@@ -111,7 +100,6 @@ HD F28<1, 2> mul(const F28<LA, VA> &a, const F28<LB, VB> &b) {
     for (int k = 0; k < 14; k++) {
 #pragma unroll
         for (int i = 0; i <= k; i++) mad64(acc, a.l[i], b.l[k - i]);
-        acc_fence(acc);
 #pragma unroll
         for (int i = 0; i < k; i++) mad64c(acc, q[i], FP28_P[k - i]);
         q[k] = ((uint32_t)acc * (uint32_t)FP28_NINV) & M28;
@@ -123,7 +111,6 @@ HD F28<1, 2> mul(const F28<LA, VA> &a, const F28<LB, VB> &b) {
     for (int k = 14; k < 27; k++) {
 #pragma unroll
         for (int i = k - 13; i < 14; i++) mad64(acc, a.l[i], b.l[k - i]);
-        acc_fence(acc);
 #pragma unroll
         for (int i = k - 13; i < 14; i++) mad64c(acc, q[i], FP28_P[k - i]);
         r.l[k - 14] = (uint32_t)acc & M28;
@@ -154,7 +141,6 @@ HD F28<1, 2> mul_add2(const F28<LA, VA> &a, const F28<LB, VB> &b, const F28<LC, 
         for (int i = 0; i <= k; i++) mad64(acc, a.l[i], b.l[k - i]);
 #pragma unroll
         for (int i = 0; i <= k; i++) mad64(acc, c.l[i], d.l[k - i]);
-        acc_fence(acc);
 #pragma unroll
         for (int i = 0; i < k; i++) mad64c(acc, q[i], FP28_P[k - i]);
         q[k] = ((uint32_t)acc * (uint32_t)FP28_NINV) & M28;
@@ -168,7 +154,6 @@ HD F28<1, 2> mul_add2(const F28<LA, VA> &a, const F28<LB, VB> &b, const F28<LC, 
         for (int i = k - 13; i < 14; i++) mad64(acc, a.l[i], b.l[k - i]);
 #pragma unroll
         for (int i = k - 13; i < 14; i++) mad64(acc, c.l[i], d.l[k - i]);
-        acc_fence(acc);
 #pragma unroll
         for (int i = k - 13; i < 14; i++) mad64c(acc, q[i], FP28_P[k - i]);
         r.l[k - 14] = (uint32_t)acc & M28;
@@ -202,7 +187,6 @@ HD F28<1, 2> sqr(const F28<LA, VA> &a) {
 #pragma unroll
         for (int i = 0; 2 * i < k; i++) mad64(acc, a.l[i], d[k - i]);
         if ((k & 1) == 0) mad64(acc, a.l[k / 2], a.l[k / 2]);
-        acc_fence(acc);
 #pragma unroll
         for (int i = 0; i < k; i++) mad64c(acc, q[i], FP28_P[k - i]);
         q[k] = ((uint32_t)acc * (uint32_t)FP28_NINV) & M28;
@@ -215,7 +199,6 @@ HD F28<1, 2> sqr(const F28<LA, VA> &a) {
 #pragma unroll
         for (int i = k - 13; 2 * i < k; i++) mad64(acc, a.l[i], d[k - i]);
         if ((k & 1) == 0) mad64(acc, a.l[k / 2], a.l[k / 2]);
-        acc_fence(acc);
 #pragma unroll
         for (int i = k - 13; i < 14; i++) mad64c(acc, q[i], FP28_P[k - i]);
         r.l[k - 14] = (uint32_t)acc & M28;
@@ -224,113 +207,6 @@ HD F28<1, 2> sqr(const F28<LA, VA> &a) {
     r.l[13] = (uint32_t)acc;
     return r;
 }
-#else
-// row-wise form (15 column accumulators, one row per limb of b)
-template <int LA, int VA, int LB, int VB>
-HD F28<1, 2> mul(const F28<LA, VA> &a, const F28<LB, VB> &b) {
-    // column accumulators: 14 products a_j*b_i (< LA*LB*2^56) + 14 products q*p_j (< 2^56) + carry
-    static_assert(14 * LA * LB + 14 + 1 <= 255, "64-bit column accumulator would overflow");
-    // result < a*b/2^392 + p; 2^392/p > 2520
-    static_assert(VA * VB <= 2500, "Montgomery product would not be < 2p");
-    uint64_t t[15];
-#pragma unroll
-    for (int j = 0; j < 15; j++) t[j] = 0;
-#pragma unroll
-    for (int i = 0; i < 14; i++) {
-        const uint32_t bi = b.l[i];
-#pragma unroll
-        for (int j = 0; j < 14; j++) t[j] += (uint64_t)a.l[j] * bi;
-        const uint32_t q = ((uint32_t)t[0] * (uint32_t)FP28_NINV) & M28;
-#pragma unroll
-        for (int j = 0; j < 14; j++) t[j] += (uint64_t)q * FP28_P[j];
-        t[1] += t[0] >> 28;
-#pragma unroll
-        for (int j = 0; j < 14; j++) t[j] = t[j + 1];
-        t[14] = 0;
-    }
-    F28<1, 2> r;
-#pragma unroll
-    for (int j = 0; j < 13; j++) {
-        t[j + 1] += t[j] >> 28;
-        r.l[j] = (uint32_t)t[j] & M28;
-    }
-    r.l[13] = (uint32_t)t[13];
-    return r;
-}
-
-// (a*b + c*d)/2^392 mod p with ONE Montgomery reduction: 588 multiply-adds instead of 784 for two
-// products.  Same row structure as mul(): both partial products of a row land in the column
-// accumulators before the row's q*p is added.
-template <int LA, int VA, int LB, int VB, int LC, int VC, int LD, int VD>
-HD F28<1, 2> mul_add2(const F28<LA, VA> &a, const F28<LB, VB> &b, const F28<LC, VC> &c, const F28<LD, VD> &d) {
-    static_assert(14 * (LA * LB + LC * LD) + 14 + 1 <= 255, "64-bit column accumulator would overflow");
-    static_assert(VA * VB + VC * VD <= 2500, "Montgomery result would not be < 2p");
-    uint64_t t[15];
-#pragma unroll
-    for (int j = 0; j < 15; j++) t[j] = 0;
-#pragma unroll
-    for (int i = 0; i < 14; i++) {
-        const uint32_t bi = b.l[i], di = d.l[i];
-#pragma unroll
-        for (int j = 0; j < 14; j++) t[j] += (uint64_t)a.l[j] * bi;
-#pragma unroll
-        for (int j = 0; j < 14; j++) t[j] += (uint64_t)c.l[j] * di;
-        const uint32_t q = ((uint32_t)t[0] * (uint32_t)FP28_NINV) & M28;
-#pragma unroll
-        for (int j = 0; j < 14; j++) t[j] += (uint64_t)q * FP28_P[j];
-        t[1] += t[0] >> 28;
-#pragma unroll
-        for (int j = 0; j < 14; j++) t[j] = t[j + 1];
-        t[14] = 0;
-    }
-    F28<1, 2> r;
-#pragma unroll
-    for (int j = 0; j < 13; j++) {
-        t[j + 1] += t[j] >> 28;
-        r.l[j] = (uint32_t)t[j] & M28;
-    }
-    r.l[13] = (uint32_t)t[13];
-    return r;
-}
-
-// Montgomery square: the 91 cross products are taken once against a doubled operand (105
-// multiply-adds for the product instead of 196), then the same 14-row reduction: 301 vs 392 mads.
-template <int LA, int VA>
-HD F28<1, 2> sqr(const F28<LA, VA> &a) {
-    // product column k holds <= 7 doubled cross terms (< 2*LA^2*2^56) + one square + 14 q*p terms
-    static_assert(15 * LA * LA + 14 + 1 <= 255, "64-bit column accumulator would overflow");
-    static_assert(2 * LA <= 15, "doubled limb would overflow 32 bits");
-    static_assert(VA * VA <= 2500, "Montgomery product would not be < 2p");
-    uint64_t t[29];
-#pragma unroll
-    for (int k = 0; k < 29; k++) t[k] = 0;
-    uint32_t d[14];
-#pragma unroll
-    for (int j = 0; j < 14; j++) d[j] = a.l[j] << 1;
-#pragma unroll
-    for (int i = 0; i < 14; i++) {
-        t[2 * i] += (uint64_t)a.l[i] * a.l[i];
-#pragma unroll
-        for (int j = i + 1; j < 14; j++) t[i + j] += (uint64_t)a.l[i] * d[j];
-    }
-#pragma unroll
-    for (int i = 0; i < 14; i++) {
-        const uint32_t q = ((uint32_t)t[i] * (uint32_t)FP28_NINV) & M28;
-#pragma unroll
-        for (int j = 0; j < 14; j++) t[i + j] += (uint64_t)q * FP28_P[j];
-        t[i + 1] += t[i] >> 28;
-    }
-    F28<1, 2> r;
-#pragma unroll
-    for (int j = 0; j < 13; j++) {
-        t[14 + j + 1] += t[14 + j] >> 28;
-        r.l[j] = (uint32_t)t[14 + j] & M28;
-    }
-    r.l[13] = (uint32_t)t[27];
-    return r;
-}
-
-#endif  // CKZG_F28_ROWWISE
 
 template <int LA, int VA, int LB, int VB>
 HD F28<LA + LB, VA + VB> add(const F28<LA, VA> &a, const F28<LB, VB> &b) {

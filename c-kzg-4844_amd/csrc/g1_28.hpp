@@ -798,7 +798,6 @@ HDNI inline void eat28_build(EAT28 (&tbl)[4], F28<1, 2> &zc, const XYZZ28 &p) {
 // The schedule depends on the digits, so it is meant for callers whose lanes share the
 // scalar: the G1 FFT stage kernels, where a wave works on one twiddle.  Only for points of the
 // prime-order subgroup.
-#ifndef CKZG_NAF_JACOBIAN_TABLE
 HDNI inline void xyzz28_mul_glv_naf(XYZZ28 &out, bool &out_inf, const XYZZ28 &p, bool p_inf, const int8_t *naf1,
                                     const int8_t *naf2) {
     bool inf = true;
@@ -829,41 +828,6 @@ HDNI inline void xyzz28_mul_glv_naf(XYZZ28 &out, bool &out_inf, const XYZZ28 &p,
     }
     out_inf = inf;
 }
-#else
-// (A/B builds: the table in Jacobian form, additions with cached Z^2, Z^3, phi applied per addition)
-HDNI inline void xyzz28_mul_glv_naf(XYZZ28 &out, bool &out_inf, const XYZZ28 &p, bool p_inf, const int8_t *naf1,
-                                    const int8_t *naf2) {
-    JACT28 tbl[8];  // [2m] = (2m+1)P, [2m+1] = -(2m+1)P
-    JAC28 acc;
-    bool inf = true;
-    if (!p_inf) {
-        const F28<1, 1> beta = f28_const<1, 1>(FP28_BETA_LAMBDA);
-        JAC28 cur = jac28_from_xyzz(p), p2 = cur;
-        jac28_dbl(p2);
-        const JACT28 p2t = jac28_table_entry(p2);
-        tbl[0] = jac28_table_entry(cur);
-        for (int m = 1; m < 4; m++) {
-            bool ci = false;
-            jac28_add(cur, ci, p2t);                // a subgroup point: (2m+1)P is finite
-            tbl[2 * m] = jac28_table_entry(cur);
-        }
-        for (int m = 0; m < 4; m++) tbl[2 * m + 1] = jact28_neg(tbl[2 * m]);
-        for (int i = GLV_NAF_LEN - 1; i >= 0; i--) {
-            if (!inf) jac28_dbl(acc);
-            const int d1 = naf1[i], d2 = naf2[i];
-            if (d1) jac28_add(acc, inf, tbl[(d1 > 0 ? d1 - 1 : -d1)]);
-            if (d2) {
-                JACT28 e = tbl[(d2 > 0 ? d2 - 1 : -d2)];
-                e.x = widen<1, 34>(mul(e.x, beta));
-                jac28_add(acc, inf, e);
-            }
-        }
-    }
-    if (!inf) out = jac28_to_xyzz(acc);
-    out_inf = inf;
-}
-
-#endif
 
 // [k]P = [k1]P + [k2]phi(P), phi(X, Y, Z) = (beta*X, Y, Z) = [lambda]P for P in G1, for lanes with
 // DIFFERENT scalars: a uniform 4-bit window schedule (4 doublings, then one table addition per half) so

@@ -125,35 +125,6 @@ __device__ __forceinline__ void jac28_add_quad(JAC28 &a, bool &ainf, const JACT2
 // Only for points of the prime-order subgroup (every multiple 1..15 is finite).  All four lanes of the quad
 // pass the same arguments and receive the same result.  (The first form of the round, kept for A/B builds with
 // CKZG_QUAD_W4_UNSIGNED: 15-entry table, five-step additions; the signed-window form below replaces it.)
-#ifdef CKZG_QUAD_W4_UNSIGNED
-__device__ __noinline__ void xyzz28_mul_w4_128_quad(XYZZ28 &out, bool &out_inf, const XYZZ28 &p, bool p_inf,
-                                                    const uint32_t *k, int ql) {
-    JACT28 tbl[15];
-    JAC28 acc;
-    bool inf = true;
-    if (!p_inf) {
-        JAC28 cur = jac28_from_xyzz(p);
-        tbl[0] = jac28_table_entry(cur);
-        for (int i = 1; i < 15; i++) {
-            bool ci = false;
-            jac28_add_quad(cur, ci, tbl[0], ql);
-            tbl[i] = jac28_table_entry(cur);
-        }
-        for (int w = 31; w >= 0; w--) {
-            if (!inf) {
-                jac28_dbl_quad(acc, ql);
-                jac28_dbl_quad(acc, ql);
-                jac28_dbl_quad(acc, ql);
-                jac28_dbl_quad(acc, ql);
-            }
-            uint32_t d = (k[w >> 3] >> ((w & 7) * 4)) & 15u;
-            if (d) jac28_add_quad(acc, inf, tbl[d - 1], ql);
-        }
-    }
-    if (!inf) out = jac28_to_xyzz(acc);
-    out_inf = inf;
-}
-#endif
 
 // a <- a + b in XYZZ coordinates (add-2008-s), both operands general: four product steps instead of fourteen
 // products.  Quad form of xyzz28_add; ainf / binf are the (replicated) infinity flags.
@@ -489,7 +460,6 @@ __device__ __forceinline__ void jac28_add_quad_zz(JAC28 &a, F28<1, 2> &zz, bool 
     zz = qread<2>(p4);
 }
 
-#ifndef CKZG_QUAD_W4_UNSIGNED
 // [k]P for a 128-bit k (one GLV half): uniform SIGNED 4-bit windows (digits -8..8, 33 of them), so the table is
 // P..8P (7 additions instead of 14) and every addition is the four-step form above.  ~560 dependent product steps
 // instead of ~650.  Only for points of the prime-order subgroup (every multiple 1..8 is finite).  All four lanes
@@ -552,9 +522,7 @@ __device__ __noinline__ void xyzz28_mul_w4_128_quad(XYZZ28 &out, bool &out_inf, 
     if (!inf) out = jac28_to_xyzz(acc);
     out_inf = inf;
 }
-#endif
 
-#ifndef CKZG_QUAD_JACOBIAN_TABLE
 // [k]P = [k1]P + [k2]phi(P) with both halves in width-4 NAF: quad form of xyzz28_mul_glv_naf (the G1 FFT's
 // twiddle multiplication; the digit strings are shared by the whole wave).  Co-Z table, mixed additions.
 __device__ __noinline__ void xyzz28_mul_glv_naf_quad(XYZZ28 &out, bool &out_inf, const XYZZ28 &p, bool p_inf,
@@ -584,40 +552,6 @@ __device__ __noinline__ void xyzz28_mul_glv_naf_quad(XYZZ28 &out, bool &out_inf,
     }
     out_inf = inf;
 }
-#else
-// (A/B builds: Jacobian table with cached Z^2, Z^3, five-step additions, phi applied per addition)
-__device__ __noinline__ void xyzz28_mul_glv_naf_quad(XYZZ28 &out, bool &out_inf, const XYZZ28 &p, bool p_inf,
-                                                     const int8_t *naf1, const int8_t *naf2, int ql) {
-    JACT28 tbl[8];  // [2m] = (2m+1)P, [2m+1] = -(2m+1)P
-    JAC28 acc;
-    bool inf = true;
-    if (!p_inf) {
-        const F28<1, 1> beta = f28_const<1, 1>(FP28_BETA_LAMBDA);
-        JAC28 cur = jac28_from_xyzz(p), p2 = cur;
-        jac28_dbl_quad(p2, ql);
-        const JACT28 p2t = jac28_table_entry(p2);
-        tbl[0] = jac28_table_entry(cur);
-        for (int m = 1; m < 4; m++) {
-            bool ci = false;
-            jac28_add_quad(cur, ci, p2t, ql);
-            tbl[2 * m] = jac28_table_entry(cur);
-        }
-        for (int m = 0; m < 4; m++) tbl[2 * m + 1] = jact28_neg(tbl[2 * m]);
-        for (int i = GLV_NAF_LEN - 1; i >= 0; i--) {
-            if (!inf) jac28_dbl_quad(acc, ql);
-            const int d1 = naf1[i], d2 = naf2[i];
-            if (d1) jac28_add_quad(acc, inf, tbl[(d1 > 0 ? d1 - 1 : -d1)], ql);
-            if (d2) {
-                JACT28 e = tbl[(d2 > 0 ? d2 - 1 : -d2)];
-                e.x = widen<1, 34>(mul(e.x, beta));
-                jac28_add_quad(acc, inf, e, ql);
-            }
-        }
-    }
-    if (!inf) out = jac28_to_xyzz(acc);
-    out_inf = inf;
-}
-#endif
 
 }  // namespace quad
 }  // namespace ckzg

@@ -49,20 +49,9 @@ int scratch_reserve(DeviceCtx *ctx, size_t bytes) {
 // table construction (setup time)
 // ------------------------------------------------------------------------------------------
 
-// wb[w][i] = 2^(wbits*w) * P_i
-__global__ void k_window_bases(G1XYZZ *wb, const G1Affine *bases, int npoints, int wbits, int nwin) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= npoints) return;
-    G1Jac acc = jac_from_affine(bases[i]);
-    for (int w = 0; w < nwin; w++) {
-        wb[(size_t)w * npoints + i] = xyzz_from_jac(acc);
-        for (int k = 0; k < wbits; k++) acc = jac_dbl(acc);
-    }
-}
-
-// The same on the four lanes of a DPP quad per point (g1_quad.hpp), in the 28-bit field: the (nwin - 1) * wbits
-// sequential doublings are the latency floor of every call-time table build (126 of them for a 6-bit table: 2.4 ms in
-// the one-lane form above whatever the number of points).  A doubling is three product steps on four lanes instead of
+// wb[w][i] = 2^(wbits*w) * P_i on the four lanes of a DPP quad per point (g1_quad.hpp), in the 28-bit field: the
+// (nwin - 1) * wbits sequential doublings are the latency floor of every call-time table build (126 of them for a 6-bit
+// table: 2.4 ms with one lane per point whatever the number of points, 0.75-1.0 ms here).  A doubling is three product steps on four lanes instead of
 // seven products on one; the conversion of a window base to the XYZZ form the chain builder reads is three more steps,
 // each lane finishing one coordinate: zz = z^2 | x | y | zzz = z^3, all multiplied into the 2^384 domain on the way.
 __global__ __launch_bounds__(64) void k_window_bases_quad(G1XYZZ *wb, const G1Affine *bases, int npoints, int wbits, int nwin) {
@@ -99,38 +88,8 @@ __global__ __launch_bounds__(64) void k_window_bases_quad(G1XYZZ *wb, const G1Af
 }
 
 static void enqueue_window_bases(hipStream_t stream, G1XYZZ *d_wb, const G1Affine *d_bases, int npoints, int wbits, int nwin) {
-    static const bool one_lane = []() {
-        const char *e = getenv("CKZG_HIP_WINDOW_BASES");   // "old": the one-lane kernel (A/B)
-        return e && !strcmp(e, "old");
-    }();
-    if (one_lane)
-        hipLaunchKernelGGL(k_window_bases, dim3((npoints + 63) / 64), dim3(64), 0, stream, d_wb, d_bases, npoints, wbits, nwin);
-    else
-        hipLaunchKernelGGL(k_window_bases_quad, dim3((unsigned)(((size_t)npoints * 4 + 63) / 64)), dim3(64), 0, stream, d_wb,
-                           d_bases, npoints, wbits, nwin);
-}
-
-constexpr int CHAIN_SEG = 64;
-
-// tmp[i*half + e] = (e+1) * B_i for one window; each thread owns a run of CHAIN_SEG multiples
-__global__ void k_table_chain(G1XYZZ *tmp, const G1XYZZ *wb, int npoints, size_t half) {
-    size_t gid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    size_t segs = (half + CHAIN_SEG - 1) / CHAIN_SEG;
-    if (gid >= (size_t)npoints * segs) return;
-    size_t i = gid / segs, s = gid % segs;
-    G1XYZZ b = wb[i];
-    uint32_t m = (uint32_t)(s * CHAIN_SEG + 1);
-    G1XYZZ acc = G1XYZZ::inf();
-    for (int bit = 31 - __builtin_clz(m); bit >= 0; bit--) {
-        acc = xyzz_dbl(acc);
-        if ((m >> bit) & 1u) acc = xyzz_add(acc, b);
-    }
-    size_t e0 = s * CHAIN_SEG;
-    size_t e1 = e0 + CHAIN_SEG < half ? e0 + CHAIN_SEG : half;
-    for (size_t e = e0; e < e1; e++) {
-        tmp[i * half + e] = acc;
-        acc = xyzz_add(acc, b);
-    }
+    hipLaunchKernelGGL(k_window_bases_quad, dim3((unsigned)(((size_t)npoints * 4 + 63) / 64)), dim3(64), 0, stream, d_wb, d_bases,
+                       npoints, wbits, nwin);
 }
 
 // Montgomery simultaneous inversion: each thread normalises a run of L points
@@ -406,11 +365,7 @@ int build_fixed_base_table(DeviceCtx *ctx, FixedBaseTable *t, const G1Affine *d_
     t->twin = FixedBaseTable::twin_for(wbits);
     t->nwin = 2 * t->twin;
     t->half = (size_t)1 << (wbits - 1);
-    static const bool old_builder = []() {
-        const char *e = getenv("CKZG_HIP_TABLE_BUILDER");
-        return e && !strcmp(e, "old");
-    }();
-    DevTmp wb, tmp, prefix, table, wba;   // `table` is handed to *t only when the build has completed
+    DevTmp wb, prefix, table, wba;   // `table` is handed to *t only when the build has completed
     t->d_table = nullptr;
     HIP_TRY(hipMalloc(&table.p, t->bytes()));
     G1Affine *d_table = static_cast<G1Affine *>(table.p);
@@ -418,44 +373,15 @@ int build_fixed_base_table(DeviceCtx *ctx, FixedBaseTable *t, const G1Affine *d_
     G1XYZZ *d_wb = static_cast<G1XYZZ *>(wb.p);
     const auto t_alloc = std::chrono::steady_clock::now();
     enqueue_window_bases(ctx->stream, d_wb, d_bases, npoints, wbits, t->twin);
-    if (!old_builder) {
+    {
+        // affine chains with a shared inversion (k_table_seeds / k_table_steps): entries are written once, in their
+        // final form; 13x faster than the round-1/2 builder (XYZZ chains + a normalisation pass, profiles/r03_load_ab.jsonl)
         const size_t nchains = (size_t)t->twin * npoints;
         HIP_TRY(hipMalloc(&wba.p, nchains * sizeof(G1Affine)));
         HIP_TRY(hipMalloc(&prefix.p, nchains * sizeof(Fp)));
         int rc = enqueue_affine_chain_table(ctx->stream, *t, d_table, d_wb, static_cast<G1Affine *>(wba.p),
                                             static_cast<Fp *>(prefix.p), cancel);
         if (rc) return rc;
-    } else {
-    // one window of a chunk of points at a time, so that the construction scratch (240 B per entry) stays
-    // below ~2 GiB whatever the table width
-    size_t per_point = t->half * (sizeof(G1XYZZ) + sizeof(Fp));
-    int chunk = (int)(((size_t)2 << 30) / per_point);
-    if (chunk < 1) chunk = 1;
-    if (chunk > npoints) chunk = npoints;
-    const size_t slab = (size_t)chunk * t->half;
-    HIP_TRY(hipMalloc(&tmp.p, slab * sizeof(G1XYZZ)));
-    HIP_TRY(hipMalloc(&prefix.p, slab * sizeof(Fp)));
-    G1XYZZ *d_tmp = static_cast<G1XYZZ *>(tmp.p);
-    Fp *d_prefix = static_cast<Fp *>(prefix.p);
-    const int L = 128;
-    const size_t segs = (t->half + CHAIN_SEG - 1) / CHAIN_SEG;
-    for (int w = 0; w < t->twin; w++) {
-        for (int i0 = 0; i0 < npoints; i0 += chunk) {
-            if (cancel && cancel->load(std::memory_order_relaxed)) {
-                (void)hipStreamSynchronize(ctx->stream);
-                return 5;
-            }
-            if (cancel && (w || i0)) HIP_TRY(hipStreamSynchronize(ctx->stream));   // a background build yields between slabs
-            const int cnt = npoints - i0 < chunk ? npoints - i0 : chunk;
-            const size_t entries = (size_t)cnt * t->half;
-            const size_t chain_threads = (size_t)cnt * segs, aff_threads = (entries + L - 1) / L;
-            hipLaunchKernelGGL(k_table_chain, dim3((unsigned)((chain_threads + 63) / 64)), dim3(64), 0,
-                               ctx->stream, d_tmp, d_wb + (size_t)w * npoints + i0, cnt, t->half);
-            hipLaunchKernelGGL(k_batch_to_affine, dim3((unsigned)((aff_threads + 63) / 64)), dim3(64), 0,
-                               ctx->stream, d_table + ((size_t)w * npoints + i0) * t->half, d_tmp, d_prefix,
-                               entries, L, 1);
-        }
-    }
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -514,23 +440,6 @@ __global__ void k_raw_digits(int16_t *digits, const uint32_t *scalars, size_t to
 // accumulate: the dominant kernel
 // ------------------------------------------------------------------------------------------
 
-// One term of a fixed-base sum: gather table entry (tw, pt, |d|) and add its +-multiple to the accumulator.
-__device__ __forceinline__ void msm_term(XYZZ28 &acc28, bool &inf, bool &yneg, const G1Affine *table, size_t p,
-                                         int half_shift, int d) {
-    uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-    const uint4 *src = reinterpret_cast<const uint4 *>(table + ((p << half_shift) + (mag - 1)));
-    uint32_t wd[24];
-    uint32_t any = 0;
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        uint4 v = src[k];
-        wd[4 * k] = v.x; wd[4 * k + 1] = v.y; wd[4 * k + 2] = v.z; wd[4 * k + 3] = v.w;
-        any |= v.x | v.y | v.z | v.w;
-    }
-    if (any != 0) {  // (0,0) encodes a table entry at infinity
-        xyzz28_madd_alt(acc28, inf, yneg, f28_unpack<1>(wd), f28_unpack<1>(wd + 12), d < 0);
-    }
-}
 
 // phi(X, Y, ZZ, ZZZ) = (beta X, Y, ZZ, ZZZ) = [lambda](X, Y, ZZ, ZZZ) on G1: turns the sum of the k2-half
 // terms, which were gathered from the plain table, into the sum over the phi-mapped bases.
@@ -581,7 +490,6 @@ __device__ __forceinline__ void msm_sum_pairs(XYZZ28 &acc28, bool &inf, bool &yn
                                               int half_shift, uint32_t prio_bit = 0) {
     bool phi_pending = first < phi_pairs;
     const uint32_t slot_parity = prio_bit ? msm_wave_slot_parity() : 0u;
-#ifndef CKZG_MSM_NO_PREFETCH
     uint32_t qn = first;
     int d = 0, d1 = qn < q1 ? dg[qn] : 0;
     uint4 e[6];
@@ -622,20 +530,6 @@ __device__ __forceinline__ void msm_sum_pairs(XYZZ28 &acc28, bool &inf, bool &yn
         d = d1;
         d1 = d2;
     }
-#else
-    for (uint32_t q = first; q < q1; q += STRIDE) {
-        if (phi_pending && q >= phi_pairs) {
-            if (!inf) msm_apply_phi(acc28);
-            phi_pending = false;
-        }
-        int d = dg[q];
-        if (d != 0) {
-            uint32_t w = q / ppv, i = q - w * ppv;
-            uint32_t tw = w >= twin ? w - twin : w;
-            msm_term(acc28, inf, yneg, table, (size_t)tw * npoints + voff + i, half_shift, d);
-        }
-    }
-#endif
     if (phi_pending && !inf) msm_apply_phi(acc28);
 }
 
@@ -669,11 +563,7 @@ __global__ __launch_bounds__(THREADS) void k_msm_accumulate(
     G1XYZZ *partials, const G1Affine *table, const int16_t *digits, uint32_t pairs_per_vec,
     uint32_t pairs_per_block, int half_shift, uint32_t blocks_per_vec, uint32_t ppv,
     uint32_t npoints, uint32_t vecs_per_group, uint32_t part_stride, uint32_t prio_bit) {
-#ifndef CKZG_NO_QUAD_TREE
     __shared__ uint32_t sh[57][THREADS];
-#else
-    __shared__ uint32_t sh[57][THREADS / 2];   // A/B builds: the one-lane fold
-#endif
 #ifdef CKZG_MSM_TRACE
     msm_trace_mark(blockIdx.x * (THREADS / 64) + threadIdx.x / 64, 0);
 #endif
@@ -692,11 +582,7 @@ __global__ __launch_bounds__(THREADS) void k_msm_accumulate(
                            half_shift, prio_bit);
     if (prio_bit) __builtin_amdgcn_s_setprio(0);
     xyzz28_fix_sign(acc28, inf, yneg);
-#ifndef CKZG_NO_QUAD_TREE
     quad::block_reduce_xyzz28_quad<THREADS>(acc28, inf, sh);   // four lanes per pair: the fold is ~3x shorter
-#else
-    block_reduce_xyzz28<THREADS>(acc28, inf, sh);
-#endif
     if (threadIdx.x == 0) partials[(size_t)vec * part_stride + chunk] = xyzz28_to_xyzz(acc28, inf);
 #ifdef CKZG_MSM_TRACE
     msm_trace_mark(blockIdx.x * (THREADS / 64) + threadIdx.x / 64, 1);
@@ -843,17 +729,11 @@ __global__ __launch_bounds__(64) void k_msm_finalize_tree(uint8_t *out48, uint8_
 // workgroups, each costing its threads' additions plus the 8-level LDS tree, so the choice trades
 // tail effect against tree overhead:  cost = rounds * (pairs_per_thread * ADD + TREE).
 static uint32_t pick_pairs_per_block(size_t nvec, uint32_t pairs_per_vec) {
-    static const long forced = []() {
-        const char *v = getenv("CKZG_HIP_PPB");
-        return v && *v ? atol(v) : 0L;
-    }();
+    static const long forced = ab_knob("CKZG_HIP_PPB", 0);
     if (forced >= 256) return (uint32_t)forced;
     // the fold: 9 passes of a four-step quad addition (g1_quad.hpp), ~400 multiply-adds a step; it overlaps with
-    // the CU's other workgroup.  CKZG_HIP_TREE_COST overrides it for A/B runs (the one-lane tree was 20440).
-    static const double TREE = []() {
-        const char *v = getenv("CKZG_HIP_TREE_COST");
-        return v && *v ? atof(v) : 9 * 4 * 400.0 * 0.5;
-    }();
+    // the CU's other workgroup (the one-lane tree of round 1 cost 20440)
+    static const double TREE = (double)ab_knob("CKZG_HIP_TREE_COST", 9 * 4 * 400 / 2);
     const double ADD = 3542.0;
     const size_t resident = 512;
     uint32_t best_ppb = pairs_per_vec;
@@ -873,22 +753,15 @@ static uint32_t pick_pairs_per_block(size_t nvec, uint32_t pairs_per_vec) {
 }
 
 // slice width (log2 ticks of 100 MHz) of the fair-priority scheme of msm_fair_prio; 0 = off.
-// CKZG_HIP_MSM_PRIO_BIT / CKZG_HIP_SMALL_PRIO_BIT override the defaults for A/B runs.
 // Measured on the headline launch (1024 blobs, same box, interleaved runs, profiles/r03_prio_ab.txt): off 10.03 ms,
 // 2^9..2^13 ticks no change, 2^15 9.72-9.75 ms, 2^17 9.68 ms, 2^19 10.07 ms -> 2^16 ticks = 0.66 ms per slice.
 // (k_msm_small showed no gain at any slice width and keeps the scheme off.)
 static uint32_t msm_prio_bit() {
-    static const uint32_t v = []() {
-        const char *e = getenv("CKZG_HIP_MSM_PRIO_BIT");
-        return e && *e ? (uint32_t)atoi(e) : 16u;
-    }();
+    static const uint32_t v = (uint32_t)ab_knob("CKZG_HIP_MSM_PRIO_BIT", 16);
     return v;
 }
 static uint32_t small_prio_bit() {
-    static const uint32_t v = []() {
-        const char *e = getenv("CKZG_HIP_SMALL_PRIO_BIT");
-        return e && *e ? (uint32_t)atoi(e) : 0u;
-    }();
+    static const uint32_t v = (uint32_t)ab_knob("CKZG_HIP_SMALL_PRIO_BIT", 0);
     return v;
 }
 
@@ -949,11 +822,8 @@ int msm_small_vectors_device(DeviceCtx *ctx, const FixedBaseTable &t, G1XYZZ *d_
     uint32_t pairs_per_vec = (uint32_t)t.nwin * ppv;
     HIP_TRY(hipEventRecord(ctx->ev[5], ctx->stream));
     // few vectors: one wave each (latency); many vectors: 16 lanes each (throughput); a chip full several times
-    // over: 8 lanes each, whose fold is one level shorter (CKZG_HIP_SMALL_LPV = 4 | 8 | 16 forces a form for A/B)
-    static const long forced_lpv = []() {
-        const char *v = getenv("CKZG_HIP_SMALL_LPV");
-        return v && *v ? atol(v) : 0L;
-    }();
+    // over: 8 lanes each, whose fold is one level shorter
+    static const long forced_lpv = ab_knob("CKZG_HIP_SMALL_LPV", 0);
     const long lpv = forced_lpv ? forced_lpv : (nvec >= 65536 ? 8 : 16);
     if (nvec >= 4096 && lpv == 4) {
         hipLaunchKernelGGL(k_msm_small<4>, dim3((unsigned)((nvec + 15) / 16)), dim3(64), 0, ctx->stream, d_out,

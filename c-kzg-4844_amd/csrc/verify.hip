@@ -339,11 +339,8 @@ int decompress_g1_batch_device(DeviceCtx *ctx, G1Affine *d_out, uint8_t *d_statu
 
 int subgroup_g1_batch_device(DeviceCtx *ctx, uint8_t *d_status, const G1Affine *d_pts, size_t n, hipStream_t stream) {
     if (!n) return 0;
-    // four lanes per point while that is at most ~2 waves per SIMD (CKZG_HIP_QUAD_MAX moves the hand-over)
-    static const size_t quad_max = []() {
-        const char *e = getenv("CKZG_HIP_QUAD_MAX");
-        return e && *e ? (size_t)atol(e) : (size_t)8192;
-    }();
+    // four lanes per point while that is at most ~2 waves per SIMD
+    static const size_t quad_max = (size_t)ab_knob("CKZG_HIP_QUAD_MAX", 8192);
     if (n <= 4 * quad_max) {
         hipLaunchKernelGGL(k_subgroup_g1_quad, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, stream ? stream : ctx->stream,
                            d_status, d_pts, n);

@@ -71,6 +71,11 @@ extern "C" {
  *                   n * 66 us / threads (320 us without the x86 SHA extensions) is compared with the blob copy plus the
  *                   GPU hash's ~6 ms.  Batches of at most 3 blobs always hash on the host.
  *                   Takes effect immediately (as does "host_threads"; every other option is read by load_trusted_setup).
+ *   "verify_pipe_min"  smallest verify_blob_kzg_proof_batch (host pointers) that crosses PCIe in 256-blob chunks while
+ *                   earlier chunks are already evaluated; default 1024.  Takes effect immediately.
+ *   "verify_call_table"  1 (default): verifications of >= 8 blobs / >= 128 cells build a fixed-base table over the
+ *                   points of the call and take their sums from it; 0: ladder sums (also what a call does by itself when
+ *                   the device is too full for the table).  Takes effect immediately.
  *   "host_threads"  host threads one process of this library may keep busy per call (challenge hashing, staging copies,
  *                   point decompression at load).  0 (default): the CPUs of the process's affinity mask divided by the
  *                   processes that share the host (LOCAL_WORLD_SIZE, else WORLD_SIZE, of a one-process-per-GPU

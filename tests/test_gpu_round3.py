@@ -116,8 +116,8 @@ def test_resident_verification_small_batches(hip, rt, material, n):
 
 
 def test_pipe_threshold_can_be_lowered_for_every_chunk_shape(material):
-    """CKZG_HIP_VERIFY_PIPE_MIN is read once per process: a child process runs 300 / 513 blobs through the
-    pipelined form (two chunks, the second of 44 / a third chunk of one blob)."""
+    """ckzg_hip_set_option("verify_pipe_min", 2): a child process (the option is process-wide) runs 300 / 513 blobs
+    through the pipelined form (two chunks, the second of 44 / a third chunk of one blob)."""
     import json
     import os
     import subprocess
@@ -127,7 +127,7 @@ import ctypes as C, json, sys
 sys.path.insert(0, "tests")
 from kzg_ctypes import HIP_SO, Kzg
 from test_gpu_commitment import rand_blob
-hip = Kzg(HIP_SO, "", precompute=0, options={"commit_wbits": 8, "proof_wbits": 0})
+hip = Kzg(HIP_SO, "", precompute=0, options={"commit_wbits": 8, "proof_wbits": 0, "verify_pipe_min": 2})
 blobs = [rand_blob(171, i) for i in range(4)]
 cm = [hip.blob_to_kzg_commitment(b) for b in blobs]
 pr = [hip.compute_blob_kzg_proof(b, c) for b, c in zip(blobs, cm)]
@@ -141,7 +141,7 @@ for n in (300, 513):
 print(json.dumps(out))
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CKZG_HIP_VERIFY_PIPE_MIN="2")
+    env = dict(os.environ)
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     res = json.loads(r.stdout.strip().splitlines()[-1])
@@ -372,8 +372,8 @@ def test_call_time_table_sums_in_cell_batch_verification(hip, oracle, material):
 
 
 # ---------------------------------------------------------------------------------------------
-# the ladder sums stay a supported path (CKZG_HIP_VERIFY_TABLE_WBITS=0, and the fallback of a device too full for
-# the call-time table): the same batches, table off, in a child process (the knob is read once per process)
+# the ladder sums stay a supported path (option "verify_call_table" = 0, and the fallback of a device too full for
+# the call-time table): the same batches, table off, in a child process (the option is process-wide)
 # ---------------------------------------------------------------------------------------------
 
 @pytest.mark.gpu
@@ -387,7 +387,7 @@ import ctypes as C, json, sys
 sys.path.insert(0, "tests")
 from kzg_ctypes import HIP_SO, Kzg
 from test_gpu_commitment import rand_blob
-hip = Kzg(HIP_SO, "", precompute=0, options={"commit_wbits": 8})
+hip = Kzg(HIP_SO, "", precompute=0, options={"commit_wbits": 8, "verify_call_table": 0})
 blobs = [rand_blob(173, i) for i in range(3)] + [bytes(131072)]     # the zero blob: commitment and proofs at infinity
 cm = [hip.blob_to_kzg_commitment(b) for b in blobs]
 pr = [hip.compute_blob_kzg_proof(b, c) for b, c in zip(blobs, cm)]
@@ -409,7 +409,7 @@ for n in (130, 700):
 print(json.dumps(out))
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CKZG_HIP_VERIFY_TABLE_WBITS="0")
+    env = dict(os.environ)
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     res = json.loads(r.stdout.strip().splitlines()[-1])

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (sweeps tuning constants: needs the A/B build -- bash tools/build_variant.sh ab -DCKZG_AB; export CKZG_HIP_SO=c-kzg-4844_amd/libckzg_hip_ab.so)
 # A/B of the one-lane and the four-lane (DPP quad, g1_quad.hpp) forms of the latency-bound G1 work:
 # verify_cell_kzg_proof_batch (ladders + subgroup test; CKZG_HIP_QUAD_MAX=0 disables the quad forms) and the
 # small-batch FK20 path (G1 FFT twiddles; CKZG_HIP_QUAD_FFT_MAX=0 disables).  Bounded steps.

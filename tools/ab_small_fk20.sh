@@ -1,4 +1,5 @@
 #!/bin/bash
+# (sweeps tuning constants: needs the A/B build -- bash tools/build_variant.sh ab -DCKZG_AB; export CKZG_HIP_SO=c-kzg-4844_amd/libckzg_hip_ab.so)
 # Small-batch FK20 latency (compute_cells_and_kzg_proofs through FK20, 1..64 blobs, default 8-bit table) for the
 # default build and variants named on the command line, inside one gpurun call.
 export TMPDIR=/tmp

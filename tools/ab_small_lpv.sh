@@ -1,4 +1,5 @@
 #!/bin/bash
+# (sweeps tuning constants: needs the A/B build -- bash tools/build_variant.sh ab -DCKZG_AB; export CKZG_HIP_SO=c-kzg-4844_amd/libckzg_hip_ab.so)
 # A/B of the lanes-per-vector forms of k_msm_small (CKZG_HIP_SMALL_LPV = 4 | 8 | 16) inside one gpurun call:
 # correctness of the forced forms on the cells tests, then the 2048-blob batch row from the wide tables.
 export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (sweeps tuning constants: needs the A/B build -- bash tools/build_variant.sh ab -DCKZG_AB; export CKZG_HIP_SO=c-kzg-4844_amd/libckzg_hip_ab.so)
 # verify_cell_kzg_proof_batch / verify_blob_kzg_proof_batch latencies for the default build and variants named on
 # the command line, inside one gpurun call (default tables).
 export TMPDIR=/tmp

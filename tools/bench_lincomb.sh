@@ -1,4 +1,5 @@
 #!/bin/bash
+# (sweeps tuning constants: needs the A/B build -- bash tools/build_variant.sh ab -DCKZG_AB; export CKZG_HIP_SO=c-kzg-4844_amd/libckzg_hip_ab.so)
 # A/B of the two variable-base sum paths inside verify_cell_kzg_proof_batch, one process each (the choice is
 # read once per process): CKZG_HIP_LINCOMB=1 per-term GLV ladders (verify.hip), =2 bucket kernels
 # (pippenger.hip).  PROFILE=1 adds a rocprofv3 kernel trace of the n=8192 and n=65536 cases.

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """load_trusted_setup wall clock and its phases (ckzg_hip_load_times) for a given set of table widths.
 usage: python tools/bench_load.py [commit_wbits proof_wbits fk20_wbits] [async]     (default 16 16 13, synchronous)
-CKZG_HIP_TABLE_BUILDER=old selects the round-1/2 table builder (XYZZ chains + batch normalisation) for A/B runs."""
+(The round-1/2 table builder this was A/B'd against is gone; profiles/r03_load_ab.jsonl keeps the comparison.)"""
 import ctypes as C
 import json
 import os
@@ -29,7 +29,7 @@ def main():
     L.wait_tables(sp)
     t_all = time.perf_counter() - t0
     assert c == b"\xc0" + bytes(47)
-    print(json.dumps({"builder": os.environ.get("CKZG_HIP_TABLE_BUILDER", "affine-chains"), "async": use_async, "tables": bench.tables_of(L, hip),
+    print(json.dumps({"builder": "affine-chains", "async": use_async, "tables": bench.tables_of(L, hip),
                       "load_call_returned_after_s": round(t_ret, 3), "time_to_first_commitment_s": round(t_first, 3),
                       "all_tables_ready_s": round(t_all, 3), "phases_s": bench.load_phases(L, hip)}))
     hip.close()

@@ -1,7 +1,11 @@
 #!/bin/bash
-# Build a second copy of the product with extra compiler flags, for A/B runs inside one gpurun call:
-#   bash tools/build_variant.sh rowwise -DCKZG_F28_ROWWISE   ->  c-kzg-4844_amd/libckzg_hip_rowwise.so
-# then   CKZG_HIP_SO=c-kzg-4844_amd/libckzg_hip_rowwise.so python bench.py ...
+# Build a second copy of the library with extra compiler flags, for A/B runs inside one gpurun call:
+#   bash tools/build_variant.sh ab -DCKZG_AB      ->  c-kzg-4844_amd/libckzg_hip_ab.so: the tuning constants of the
+#                                                     product (device.hpp: ab_knob) are read from CKZG_HIP_* variables
+#   bash tools/build_variant.sh trace -DCKZG_MSM_TRACE   per-wave trace of k_msm_accumulate (tools/msm_trace.py)
+# then   CKZG_HIP_SO=c-kzg-4844_amd/libckzg_hip_ab.so CKZG_HIP_SMALL_LPV=8 python tools/row_driver.py cells wide ...
+# The product itself reads no tuning variable (tools/ab_*.sh, tools/bench_lincomb.sh, tools/bench_fk20_sizes.py need
+# the ab build).
 set -e
 name=$1; shift
 cd "$(dirname "$0")/../c-kzg-4844_amd"
