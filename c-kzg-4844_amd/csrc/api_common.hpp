@@ -544,6 +544,21 @@ inline void staged_copy(void *dst, const void *src, size_t bytes) {
     while (pending.load(std::memory_order_acquire) != 0) std::this_thread::yield();
 }
 
+// The wait that ends a ONE-unit call.  hipStreamSynchronize parks the thread on an interrupt, and being woken costs
+// 15-30 us of a 250 us call; polling the stream for the few hundred microseconds such a call lasts costs a fraction
+// of one core (the combiner lets at most `coalesce_active` callers per operation get here at a time).  After 2 ms the
+// call is not a latency call any more and the thread blocks as usual.
+inline hipError_t wait_stream_low_latency(hipStream_t stream) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int spins = 0;; spins++) {
+        const hipError_t e = hipStreamQuery(stream);
+        if (e != hipErrorNotReady) return e;
+        if ((spins & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+    (void)hipGetLastError();   // hipErrorNotReady is not an error
+    return hipStreamSynchronize(stream);
+}
+
 // true if the caller's host buffer is page-locked (hipHostMalloc / hipHostRegister): such a buffer is DMA'd
 // from directly, chunk by chunk, without the staging copy a pageable one needs
 inline bool host_pointer_is_pinned(const void *p) {

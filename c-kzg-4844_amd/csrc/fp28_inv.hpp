@@ -21,35 +21,67 @@ struct DivstepMatrix {
     int32_t u, v, q, r;
 };
 
-// 30 divsteps on the low 30 bits of f and g; returns the new eta
+// A limb stored as (int32_t)(c & M) is, to the compiler, still the 64-bit value it was cut from, and its next product
+// with a matrix entry becomes a 64 x 64-bit multiplication (v_mad_u64_u32 + two v_mul_lo_u32 + a v_add3_u32 of sign
+// corrections).  Passing the limb through an empty asm makes it a plain 32-bit register again, and
+// (int64_t)a * b is ONE v_mad_i64_i32: 661 -> ~230 instructions per update of (f, g) and (d, e).
+HD int32_t limb32(int32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(x));
+#endif
+    return x;
+}
+
+// 30 divsteps on the low 30 bits of f and g; returns the new eta.
+// Variable-time form (nothing here is secret): a run of zero bits of g is ONE step (count trailing zeros, shift g and
+// the matrix column by the run), and an odd g has its bottom min(eta + 1, bits left, 6) bits cancelled at once by the
+// multiple w = -g/f mod 2^6 of f -- for odd f, f (f^2 - 2) = -1/f mod 64 -- which is what that many consecutive
+// divsteps would add up to.  A batch of 30 divsteps is ~6 trips round this loop instead of 30 round the bit-by-bit
+// one: the inversion that closes every commitment, every proof batch and every step of the table builder drops from
+// ~31,000 to ~13,000 instructions of one lane.
 HD int32_t divsteps30(int32_t eta, uint32_t f, uint32_t g, DivstepMatrix &t) {
-    int32_t u = 1, v = 0, q = 0, r = 1;
-    for (int i = 0; i < 30; i++) {
-        if (g & 1u) {
-            if (eta < 0) {
-                eta = -eta;
-                uint32_t tf = f;
-                f = g;
-                g = 0u - tf;
-                int32_t tu = u, tv = v;
-                u = q;
-                v = r;
-                q = -tu;
-                r = -tv;
-            }
-            g += f;
-            q += u;
-            r += v;
+    uint32_t u = 1, v = 0, q = 0, r = 1;
+    int left = 30;
+    for (;;) {
+        // zeros of g, counted only up to the bits that are left (sentinel above them)
+        const uint32_t sentinel = g | (0xffffffffu << left);
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int zeros = (int)__builtin_ctz(sentinel);
+#else
+        const int zeros = __builtin_ctz(sentinel);
+#endif
+        g >>= zeros;
+        u <<= zeros;
+        v <<= zeros;
+        eta -= zeros;
+        left -= zeros;
+        if (left == 0) break;
+        // g is odd
+        if (eta < 0) {
+            eta = -eta;
+            uint32_t tmp = f;
+            f = g;
+            g = 0u - tmp;
+            tmp = u;
+            u = q;
+            q = 0u - tmp;
+            tmp = v;
+            v = r;
+            r = 0u - tmp;
         }
-        eta--;
-        g >>= 1;
-        u <<= 1;
-        v <<= 1;
+        // no more bits than are left, and no more than eta + 1 (after that many the sign of eta flips)
+        int limit = eta + 1 > left ? left : eta + 1;
+        if (limit > 6) limit = 6;
+        const uint32_t m = (1u << limit) - 1u;
+        const uint32_t w = (g * f * (f * f - 2u)) & m;   // -g/f mod 2^limit
+        g += f * w;
+        q += u * w;
+        r += v * w;
     }
-    t.u = u;
-    t.v = v;
-    t.q = q;
-    t.r = r;
+    t.u = limb32((int32_t)u);
+    t.v = limb32((int32_t)v);
+    t.q = limb32((int32_t)q);
+    t.r = limb32((int32_t)r);
     return eta;
 }
 
@@ -64,13 +96,13 @@ HD void update_fg30(int32_t *f, int32_t *g, const DivstepMatrix &t) {
     for (int i = 1; i < 13; i++) {
         cf += (int64_t)t.u * f[i] + (int64_t)t.v * g[i];
         cg += (int64_t)t.q * f[i] + (int64_t)t.r * g[i];
-        f[i - 1] = (int32_t)(cf & M);
-        g[i - 1] = (int32_t)(cg & M);
+        f[i - 1] = limb32((int32_t)(cf & M));
+        g[i - 1] = limb32((int32_t)(cg & M));
         cf >>= 30;
         cg >>= 30;
     }
-    f[12] = (int32_t)cf;
-    g[12] = (int32_t)cg;
+    f[12] = limb32((int32_t)cf);
+    g[12] = limb32((int32_t)cg);
 }
 
 // (d, e) <- t * (d, e) / 2^30 mod p: a multiple of p makes the low 30 bits vanish first
@@ -88,13 +120,13 @@ HD void update_de30(int32_t *d, int32_t *e, const DivstepMatrix &t) {
     for (int i = 1; i < 13; i++) {
         cd += (int64_t)t.u * d[i] + (int64_t)t.v * e[i] + (int64_t)FP30_P[i] * md;
         ce += (int64_t)t.q * d[i] + (int64_t)t.r * e[i] + (int64_t)FP30_P[i] * me;
-        d[i - 1] = (int32_t)(cd & M);
-        e[i - 1] = (int32_t)(ce & M);
+        d[i - 1] = limb32((int32_t)(cd & M));
+        e[i - 1] = limb32((int32_t)(ce & M));
         cd >>= 30;
         ce >>= 30;
     }
-    d[12] = (int32_t)cd;
-    e[12] = (int32_t)ce;
+    d[12] = limb32((int32_t)cd);
+    e[12] = limb32((int32_t)ce);
 }
 
 // 1/a in the 2^392 Montgomery domain; 0 for a == 0 (mod p), like the Fermat ladder

@@ -18,13 +18,13 @@ HD void fr_update_fg30(int32_t *f, int32_t *g, const DivstepMatrix &t) {
     for (int i = 1; i < 9; i++) {
         cf += (int64_t)t.u * f[i] + (int64_t)t.v * g[i];
         cg += (int64_t)t.q * f[i] + (int64_t)t.r * g[i];
-        f[i - 1] = (int32_t)(cf & M);
-        g[i - 1] = (int32_t)(cg & M);
+        f[i - 1] = limb32((int32_t)(cf & M));
+        g[i - 1] = limb32((int32_t)(cg & M));
         cf >>= 30;
         cg >>= 30;
     }
-    f[8] = (int32_t)cf;
-    g[8] = (int32_t)cg;
+    f[8] = limb32((int32_t)cf);
+    g[8] = limb32((int32_t)cg);
 }
 
 HD void fr_update_de30(int32_t *d, int32_t *e, const DivstepMatrix &t) {
@@ -41,13 +41,13 @@ HD void fr_update_de30(int32_t *d, int32_t *e, const DivstepMatrix &t) {
     for (int i = 1; i < 9; i++) {
         cd += (int64_t)t.u * d[i] + (int64_t)t.v * e[i] + (int64_t)FR30_R[i] * md;
         ce += (int64_t)t.q * d[i] + (int64_t)t.r * e[i] + (int64_t)FR30_R[i] * me;
-        d[i - 1] = (int32_t)(cd & M);
-        e[i - 1] = (int32_t)(ce & M);
+        d[i - 1] = limb32((int32_t)(cd & M));
+        e[i - 1] = limb32((int32_t)(ce & M));
         cd >>= 30;
         ce >>= 30;
     }
-    d[8] = (int32_t)cd;
-    e[8] = (int32_t)ce;
+    d[8] = limb32((int32_t)cd);
+    e[8] = limb32((int32_t)ce);
 }
 
 // 1/a for a in Montgomery form (radix 2^256), result in Montgomery form; 0 for a == 0

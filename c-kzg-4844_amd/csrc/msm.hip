@@ -562,7 +562,7 @@ template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_msm_accumulate(
     G1XYZZ *partials, const G1Affine *table, const int16_t *digits, uint32_t pairs_per_vec,
     uint32_t pairs_per_block, int half_shift, uint32_t blocks_per_vec, uint32_t ppv,
-    uint32_t npoints, uint32_t vecs_per_group, uint32_t part_stride, uint32_t prio_bit) {
+    uint32_t npoints, uint32_t vecs_per_group, uint32_t part_stride, uint32_t prio_bit, uint32_t *raw_out) {
     __shared__ uint32_t sh[57][THREADS];
 #ifdef CKZG_MSM_TRACE
     msm_trace_mark(blockIdx.x * (THREADS / 64) + threadIdx.x / 64, 0);
@@ -583,7 +583,13 @@ __global__ __launch_bounds__(THREADS) void k_msm_accumulate(
     if (prio_bit) __builtin_amdgcn_s_setprio(0);
     xyzz28_fix_sign(acc28, inf, yneg);
     quad::block_reduce_xyzz28_quad<THREADS>(acc28, inf, sh);   // four lanes per pair: the fold is ~3x shorter
-    if (threadIdx.x == 0) partials[(size_t)vec * part_stride + chunk] = xyzz28_to_xyzz(acc28, inf);
+    if (raw_out) {
+        // latency form (k_msm_fold_finalize reads it): the sum as it stands in LDS -- 56 limbs of the 28-bit domain and
+        // the infinity flag -- with no conversion to the reduced 12-limb form and back
+        if (threadIdx.x < 57) raw_out[((size_t)vec * part_stride + chunk) * 57 + threadIdx.x] = sh[threadIdx.x][0];
+    } else if (threadIdx.x == 0) {
+        partials[(size_t)vec * part_stride + chunk] = xyzz28_to_xyzz(acc28, inf);
+    }
 #ifdef CKZG_MSM_TRACE
     msm_trace_mark(blockIdx.x * (THREADS / 64) + threadIdx.x / 64, 1);
 #endif
@@ -724,6 +730,92 @@ __global__ __launch_bounds__(64) void k_msm_finalize_tree(uint8_t *out48, uint8_
     }
 }
 
+// Latency form of the two kernels above, for the few vectors of a one-blob call whose sums were cut into hundreds of
+// partial sums to fill the chip: ONE 1024-thread workgroup per vector folds its bpv <= 512 raw partial sums
+// (k_msm_accumulate's raw_out) on 256 DPP quads -- every level of the tree is a four-step quad addition, ~4 us,
+// where k_msm_reduce_partials opened with two one-lane additions of 15 us each -- and its first lane normalises and
+// compresses.  One launch instead of two, no conversion of the partial sums out of the 28-bit domain and back.
+#ifdef CKZG_FOLD_TRACE
+__device__ uint64_t g_fold_trace[16];
+#define FOLD_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_fold_trace[i] = wall_clock64(); } while (0)
+#else
+#define FOLD_STAMP(i) ((void)0)
+#endif
+__global__ __launch_bounds__(1024) void k_msm_fold_finalize(uint8_t *out48, uint8_t *status, const uint32_t *raw,
+                                                           const uint32_t *bad, uint32_t bpv) {
+    __shared__ uint32_t sh[57][256];
+    FOLD_STAMP(0);
+    const int tid = threadIdx.x, ql = tid & 3, quad_id = tid >> 2;
+    const size_t v = blockIdx.x;
+    const uint32_t *rv = raw + v * (size_t)bpv * 57;
+    uint32_t cnt = bpv, h = (cnt + 1) / 2;
+    if ((uint32_t)quad_id < h) {
+        XYZZ28 x, y;
+        uint32_t *dx = reinterpret_cast<uint32_t *>(&x), *dy = reinterpret_cast<uint32_t *>(&y);
+        const uint32_t *px = rv + (size_t)quad_id * 57;
+        const bool has_y = (uint32_t)quad_id + h < cnt;
+        const uint32_t *py = rv + (size_t)(has_y ? quad_id + h : quad_id) * 57;
+#pragma unroll
+        for (int k = 0; k < 56; k++) {
+            dx[k] = px[k];
+            dy[k] = py[k];
+        }
+        bool xi = px[56] != 0;
+        const bool yi = !has_y || py[56] != 0;
+        quad::xyzz28_add_quad(x, xi, y, yi, ql);
+        if (ql == 0) {
+#pragma unroll
+            for (int k = 0; k < 56; k++) sh[k][quad_id] = dx[k];
+            sh[56][quad_id] = xi ? 1u : 0u;
+        }
+    }
+    __syncthreads();
+    FOLD_STAMP(1);
+    cnt = h;
+    while (cnt > 1) {
+        h = (cnt + 1) / 2;
+        if ((uint32_t)quad_id < cnt / 2) {
+            XYZZ28 x, y;
+            uint32_t *dx = reinterpret_cast<uint32_t *>(&x), *dy = reinterpret_cast<uint32_t *>(&y);
+#pragma unroll
+            for (int k = 0; k < 56; k++) {
+                dx[k] = sh[k][quad_id];
+                dy[k] = sh[k][quad_id + h];
+            }
+            bool xi = sh[56][quad_id] != 0;
+            const bool yi = sh[56][quad_id + h] != 0;
+            quad::xyzz28_add_quad(x, xi, y, yi, ql);
+            if (ql == 0) {
+#pragma unroll
+                for (int k = 0; k < 56; k++) sh[k][quad_id] = dx[k];
+                sh[56][quad_id] = xi ? 1u : 0u;
+            }
+        }
+        __syncthreads();
+        cnt = h;
+    }
+    FOLD_STAMP(2);
+    if (tid == 0) {
+        XYZZ28 acc;
+        uint32_t *dst = reinterpret_cast<uint32_t *>(&acc);
+#pragma unroll
+        for (int k = 0; k < 56; k++) dst[k] = sh[k][0];
+#ifdef CKZG_FOLD_TRACE
+        auto tinv = f28_inv(acc.zzz);
+        FOLD_STAMP(3);
+        if (tinv.l[0] == 0xdeadbeef) out48[0] = 1;   // keep it alive
+#endif
+        G1Affine a = xyzz28_to_affine(acc, sh[56][0] != 0);
+        FOLD_STAMP(4);
+        uint8_t buf[48];
+        g1_compress_affine(buf, a);
+        FOLD_STAMP(5);
+        for (int k = 0; k < 48; k++) out48[v * 48 + k] = buf[k];
+        if (status) status[v] = (bad && bad[v]) ? 1 : 0;
+        FOLD_STAMP(6);
+    }
+}
+
 // How many (window, point) pairs one 256-thread workgroup of k_msm_accumulate sums.  The chip holds
 // 512 such workgroups at once (2 per CU at ~200 VGPRs); a launch is `rounds` waves of resident
 // workgroups, each costing its threads' additions plus the 8-level LDS tree, so the choice trades
@@ -752,6 +844,24 @@ static uint32_t pick_pairs_per_block(size_t nvec, uint32_t pairs_per_vec) {
     return best_ppb;
 }
 
+// The fixed-base sums of a call with a handful of vectors (the reference-shaped one-blob calls: blob_to_kzg_commitment,
+// compute_kzg_proof, compute_blob_kzg_proof) are latency: nothing else is on the device, so the cut is the FINEST
+// that keeps every workgroup resident at once (512 of them) -- with one pair per thread a lane's "addition" is a copy
+// and the workgroup is its nine-round quad fold; the partial sums then go through k_msm_fold_finalize.  Larger
+// batches are throughput and take the cost model above.
+static uint32_t pick_pairs_per_block_fixed(size_t nvec, uint32_t pairs_per_vec) {
+    for (uint32_t ppb = 256; ppb <= 1024; ppb *= 2) {
+        const size_t bpv = (pairs_per_vec + ppb - 1) / ppb;
+        if (nvec * bpv <= 512 && bpv > 8) return ppb;
+    }
+    return pick_pairs_per_block(nvec, pairs_per_vec);
+}
+// bytes of partial sums of nvec vectors cut into bpv blocks each, plus one reduced sum per vector: raw 57-word records
+// when k_msm_fold_finalize folds them (bpv > 8), reduced XYZZ points otherwise
+static size_t partials_bytes(size_t nvec, uint32_t bpv) {
+    return bpv > 8 ? nvec * ((size_t)bpv * 57 * sizeof(uint32_t) + sizeof(G1XYZZ)) : nvec * ((size_t)bpv + 1) * sizeof(G1XYZZ);
+}
+
 // slice width (log2 ticks of 100 MHz) of the fair-priority scheme of msm_fair_prio; 0 = off.
 // Measured on the headline launch (1024 blobs, same box, interleaved runs, profiles/r03_prio_ab.txt): off 10.03 ms,
 // 2^9..2^13 ticks no change, 2^15 9.72-9.75 ms, 2^17 9.68 ms, 2^19 10.07 ms -> 2^16 ticks = 0.66 ms per slice.
@@ -772,18 +882,25 @@ static int run_msm(DeviceCtx *ctx, const FixedBaseTable &t, uint8_t *d_out48, ui
     uint32_t pairs_per_vec = (uint32_t)t.nwin * t.npoints;
     uint32_t bpv = (pairs_per_vec + ppb - 1) / ppb;
     HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+    if (bpv > 8) {
+        // few vectors cut finely (pick_pairs_per_block_fixed): raw partial sums, one fold + finalize launch
+        if (bpv > 512) return 2;
+        uint32_t *d_raw = reinterpret_cast<uint32_t *>(d_partials);
+        hipLaunchKernelGGL(k_msm_accumulate<256>, dim3((unsigned)(nvec * bpv)), dim3(256), 0, ctx->stream,
+                           d_partials, t.d_table, d_digits, pairs_per_vec, ppb, t.wbits - 1, bpv,
+                           (uint32_t)t.npoints, (uint32_t)t.npoints, 1u, bpv, msm_prio_bit(), d_raw);
+        HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
+        hipLaunchKernelGGL(k_msm_fold_finalize, dim3((unsigned)nvec), dim3(1024), 0, ctx->stream, d_out48, d_status, d_raw,
+                           d_bad, bpv);
+        HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(k_msm_accumulate<256>, dim3((unsigned)(nvec * bpv)), dim3(256), 0, ctx->stream,
                        d_partials, t.d_table, d_digits, pairs_per_vec, ppb, t.wbits - 1, bpv,
-                       (uint32_t)t.npoints, (uint32_t)t.npoints, 1u, bpv, msm_prio_bit());
+                       (uint32_t)t.npoints, (uint32_t)t.npoints, 1u, bpv, msm_prio_bit(), (uint32_t *)nullptr);
     HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
-    if (bpv > 8) {
-        // partials[nvec*bpv ..] is free: run_msm callers size d_partials for nvec*bpv + nvec
-        G1XYZZ *d_sums = d_partials + nvec * (size_t)bpv;
-        hipLaunchKernelGGL(k_msm_reduce_partials, dim3((unsigned)nvec), dim3(64), 0, ctx->stream, d_sums,
-                           d_partials, bpv);
-        hipLaunchKernelGGL(k_msm_finalize, dim3((unsigned)((nvec + 63) / 64)), dim3(64), 0, ctx->stream,
-                           d_out48, d_status, d_sums, d_bad, 1u, nvec);
-    } else if (bpv >= 2 && nvec <= 4096) {
+    if (bpv >= 2 && nvec <= 4096) {
         // few vectors: fold the partials in a tree (latency); many: one lane per vector (dense inversions)
         if (bpv <= 2)
             hipLaunchKernelGGL(k_msm_finalize_tree<2>, dim3((unsigned)((nvec + 31) / 32)), dim3(64), 0, ctx->stream, d_out48,
@@ -807,6 +924,15 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 void commit_collect_times(DeviceCtx *ctx) {
     float ms;
+#ifdef CKZG_FOLD_TRACE
+    {
+        uint64_t h[16] = {};
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fold_trace), sizeof h) == hipSuccess && getenv("CKZG_FOLD_TRACE_PRINT"))
+            fprintf(stderr, "[fold trace, 10 ns ticks] level0 %llu  tree %llu  inv(extra) %llu  to_affine %llu  compress %llu  store %llu\n",
+                    (unsigned long long)(h[1] - h[0]), (unsigned long long)(h[2] - h[1]), (unsigned long long)(h[3] - h[2]),
+                    (unsigned long long)(h[4] - h[3]), (unsigned long long)(h[5] - h[4]), (unsigned long long)(h[6] - h[5]));
+    }
+#endif
     if (hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]) == hipSuccess) ctx->last_ms[0] = ms;
     if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_ms[1] = ms;
     if (hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]) == hipSuccess) ctx->last_ms[2] = ms;
@@ -851,8 +977,8 @@ int msm_small_vectors_device(DeviceCtx *ctx, const FixedBaseTable &t, G1XYZZ *d_
 // points.  d_partials must hold msm_partials_needed() XYZZ points.
 size_t msm_partials_needed(const FixedBaseTable &t, size_t nvec) {
     uint32_t pairs_per_vec = (uint32_t)t.nwin * t.npoints;
-    uint32_t ppb = pick_pairs_per_block(nvec, pairs_per_vec);
-    return nvec * ((pairs_per_vec + ppb - 1) / ppb) + nvec;
+    uint32_t ppb = pick_pairs_per_block_fixed(nvec, pairs_per_vec);
+    return (partials_bytes(nvec, (pairs_per_vec + ppb - 1) / ppb) + sizeof(G1XYZZ) - 1) / sizeof(G1XYZZ);
 }
 
 int msm_from_digits_device(DeviceCtx *ctx, const FixedBaseTable &t, uint8_t *d_out48,
@@ -860,7 +986,7 @@ int msm_from_digits_device(DeviceCtx *ctx, const FixedBaseTable &t, uint8_t *d_o
     if (nvec == 0) return 0;
     if (!t.d_table) return 2;
     uint32_t pairs_per_vec = (uint32_t)t.nwin * t.npoints;
-    uint32_t ppb = pick_pairs_per_block(nvec, pairs_per_vec);
+    uint32_t ppb = pick_pairs_per_block_fixed(nvec, pairs_per_vec);
     return run_msm(ctx, t, d_out48, nullptr, d_digits, nullptr, d_partials, nvec, ppb);
 }
 
@@ -870,10 +996,10 @@ int msm_from_digits_device(DeviceCtx *ctx, const FixedBaseTable &t, uint8_t *d_o
 size_t commit_scratch_bytes(const DeviceCtx *ctx, size_t n) {
     const FixedBaseTable &t = ctx->commit;
     uint32_t pairs_per_vec = (uint32_t)t.nwin * t.npoints;
-    uint32_t ppb = pick_pairs_per_block(n, pairs_per_vec);
+    uint32_t ppb = pick_pairs_per_block_fixed(n, pairs_per_vec);
     uint32_t bpv = (pairs_per_vec + ppb - 1) / ppb;
     return align_up(n * (size_t)pairs_per_vec * sizeof(int16_t), 256) + align_up(n * sizeof(uint32_t), 256) +
-           align_up(n * ((size_t)bpv + 1) * sizeof(G1XYZZ), 256);
+           align_up(partials_bytes(n, bpv), 256);
 }
 
 int commit_blobs_enqueue(DeviceCtx *ctx, uint8_t *d_out48, uint8_t *d_status, const uint8_t *d_blobs,
@@ -882,11 +1008,11 @@ int commit_blobs_enqueue(DeviceCtx *ctx, uint8_t *d_out48, uint8_t *d_status, co
     const FixedBaseTable &t = ctx->commit;
     if (!t.d_table) return 2;
     uint32_t pairs_per_vec = (uint32_t)t.nwin * t.npoints;
-    uint32_t ppb = pick_pairs_per_block(n, pairs_per_vec);
+    uint32_t ppb = pick_pairs_per_block_fixed(n, pairs_per_vec);
     uint32_t bpv = (pairs_per_vec + ppb - 1) / ppb;
     size_t dig_bytes = align_up(n * (size_t)pairs_per_vec * sizeof(int16_t), 256);
     size_t bad_bytes = align_up(n * sizeof(uint32_t), 256);
-    if (ctx->scratch.cap < dig_bytes + bad_bytes + align_up(n * ((size_t)bpv + 1) * sizeof(G1XYZZ), 256)) return 2;
+    if (ctx->scratch.cap < dig_bytes + bad_bytes + align_up(partials_bytes(n, bpv), 256)) return 2;
     uint8_t *base = static_cast<uint8_t *>(ctx->scratch.ptr);
     int16_t *d_digits = reinterpret_cast<int16_t *>(base);
     uint32_t *d_bad = reinterpret_cast<uint32_t *>(base + dig_bytes);
@@ -920,7 +1046,7 @@ int commit_accumulate8_enqueue(DeviceCtx *ctx, G1XYZZ *d_part8, uint32_t *d_bad,
                        d_digits, d_bad, d_blobs, total, t.wbits, t.twin);
     hipLaunchKernelGGL(k_msm_accumulate<256>, dim3((unsigned)(k * bpv)), dim3(256), 0, ctx->stream,
                        d_part8, t.d_table, d_digits, pairs_per_vec, ppb, t.wbits - 1, bpv,
-                       (uint32_t)t.npoints, (uint32_t)t.npoints, 1u, 8u, msm_prio_bit());
+                       (uint32_t)t.npoints, (uint32_t)t.npoints, 1u, 8u, msm_prio_bit(), (uint32_t *)nullptr);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -956,7 +1082,7 @@ int commit_blobs_device(DeviceCtx *ctx, uint8_t *d_out48, uint8_t *d_status, con
     size_t trace_waves = 0;
     if (trace_file && *trace_file) {
         const FixedBaseTable &t = ctx->commit;
-        uint32_t ppv = (uint32_t)t.nwin * t.npoints, ppb = pick_pairs_per_block(n, ppv);
+        uint32_t ppv = (uint32_t)t.nwin * t.npoints, ppb = pick_pairs_per_block_fixed(n, ppv);
         trace_waves = n * ((ppv + ppb - 1) / ppb) * 4;
         HIP_TRY(hipMalloc(&d_trace, trace_waves * 32));
         HIP_TRY(hipMemset(d_trace, 0, trace_waves * 32));
@@ -988,10 +1114,10 @@ int msm_commit_table_raw_device(DeviceCtx *ctx, uint8_t *d_out48, const uint32_t
     const FixedBaseTable &t = ctx->commit;
     if (!t.d_table) return 2;
     uint32_t pairs_per_vec = (uint32_t)t.nwin * t.npoints;
-    uint32_t ppb = pick_pairs_per_block(n, pairs_per_vec);
+    uint32_t ppb = pick_pairs_per_block_fixed(n, pairs_per_vec);
     uint32_t bpv = (pairs_per_vec + ppb - 1) / ppb;
     size_t dig_bytes = align_up(n * (size_t)pairs_per_vec * sizeof(int16_t), 256);
-    size_t part_bytes = align_up(n * ((size_t)bpv + 1) * sizeof(G1XYZZ), 256);
+    size_t part_bytes = align_up(partials_bytes(n, bpv), 256);
     int rc = scratch_reserve(ctx, dig_bytes + part_bytes);
     if (rc) return rc;
     uint8_t *base = static_cast<uint8_t *>(ctx->scratch.ptr);
