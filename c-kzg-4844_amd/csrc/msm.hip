@@ -731,8 +731,8 @@ __global__ __launch_bounds__(64) void k_msm_finalize_tree(uint8_t *out48, uint8_
 }
 
 // Latency form of the two kernels above, for the few vectors of a one-blob call whose sums were cut into hundreds of
-// partial sums to fill the chip: ONE 1024-thread workgroup per vector folds its bpv <= 512 raw partial sums
-// (k_msm_accumulate's raw_out) on 256 DPP quads -- every level of the tree is a four-step quad addition, ~4 us,
+// partial sums to fill the chip: ONE 512-thread workgroup per vector folds its bpv <= 512 raw partial sums
+// (k_msm_accumulate's raw_out) on 128 DPP quads -- every level of the tree is a four-step quad addition, ~4 us,
 // where k_msm_reduce_partials opened with two one-lane additions of 15 us each -- and its first lane normalises and
 // compresses.  One launch instead of two, no conversion of the partial sums out of the 28-bit domain and back.
 #ifdef CKZG_FOLD_TRACE
@@ -741,20 +741,21 @@ __device__ uint64_t g_fold_trace[16];
 #else
 #define FOLD_STAMP(i) ((void)0)
 #endif
-__global__ __launch_bounds__(1024) void k_msm_fold_finalize(uint8_t *out48, uint8_t *status, const uint32_t *raw,
-                                                           const uint32_t *bad, uint32_t bpv) {
+constexpr int FOLD_THREADS = 512;   // 128 quads, two waves per SIMD: the full register file per lane (no spills in the inversion)
+__global__ __launch_bounds__(FOLD_THREADS) void k_msm_fold_finalize(uint8_t *out48, uint8_t *status, const uint32_t *raw,
+                                                                   const uint32_t *bad, uint32_t bpv) {
     __shared__ uint32_t sh[57][256];
     FOLD_STAMP(0);
     const int tid = threadIdx.x, ql = tid & 3, quad_id = tid >> 2;
     const size_t v = blockIdx.x;
     const uint32_t *rv = raw + v * (size_t)bpv * 57;
     uint32_t cnt = bpv, h = (cnt + 1) / 2;
-    if ((uint32_t)quad_id < h) {
+    for (uint32_t pr = (uint32_t)quad_id; pr < h; pr += FOLD_THREADS / 4) {
         XYZZ28 x, y;
         uint32_t *dx = reinterpret_cast<uint32_t *>(&x), *dy = reinterpret_cast<uint32_t *>(&y);
-        const uint32_t *px = rv + (size_t)quad_id * 57;
-        const bool has_y = (uint32_t)quad_id + h < cnt;
-        const uint32_t *py = rv + (size_t)(has_y ? quad_id + h : quad_id) * 57;
+        const uint32_t *px = rv + (size_t)pr * 57;
+        const bool has_y = pr + h < cnt;
+        const uint32_t *py = rv + (size_t)(has_y ? pr + h : pr) * 57;
 #pragma unroll
         for (int k = 0; k < 56; k++) {
             dx[k] = px[k];
@@ -765,8 +766,8 @@ __global__ __launch_bounds__(1024) void k_msm_fold_finalize(uint8_t *out48, uint
         quad::xyzz28_add_quad(x, xi, y, yi, ql);
         if (ql == 0) {
 #pragma unroll
-            for (int k = 0; k < 56; k++) sh[k][quad_id] = dx[k];
-            sh[56][quad_id] = xi ? 1u : 0u;
+            for (int k = 0; k < 56; k++) sh[k][pr] = dx[k];
+            sh[56][pr] = xi ? 1u : 0u;
         }
     }
     __syncthreads();
@@ -774,21 +775,21 @@ __global__ __launch_bounds__(1024) void k_msm_fold_finalize(uint8_t *out48, uint
     cnt = h;
     while (cnt > 1) {
         h = (cnt + 1) / 2;
-        if ((uint32_t)quad_id < cnt / 2) {
+        for (uint32_t pr = (uint32_t)quad_id; pr < cnt / 2; pr += FOLD_THREADS / 4) {
             XYZZ28 x, y;
             uint32_t *dx = reinterpret_cast<uint32_t *>(&x), *dy = reinterpret_cast<uint32_t *>(&y);
 #pragma unroll
             for (int k = 0; k < 56; k++) {
-                dx[k] = sh[k][quad_id];
-                dy[k] = sh[k][quad_id + h];
+                dx[k] = sh[k][pr];
+                dy[k] = sh[k][pr + h];
             }
-            bool xi = sh[56][quad_id] != 0;
-            const bool yi = sh[56][quad_id + h] != 0;
+            bool xi = sh[56][pr] != 0;
+            const bool yi = sh[56][pr + h] != 0;
             quad::xyzz28_add_quad(x, xi, y, yi, ql);
             if (ql == 0) {
 #pragma unroll
-                for (int k = 0; k < 56; k++) sh[k][quad_id] = dx[k];
-                sh[56][quad_id] = xi ? 1u : 0u;
+                for (int k = 0; k < 56; k++) sh[k][pr] = dx[k];
+                sh[56][pr] = xi ? 1u : 0u;
             }
         }
         __syncthreads();
@@ -882,15 +883,18 @@ static int run_msm(DeviceCtx *ctx, const FixedBaseTable &t, uint8_t *d_out48, ui
     uint32_t pairs_per_vec = (uint32_t)t.nwin * t.npoints;
     uint32_t bpv = (pairs_per_vec + ppb - 1) / ppb;
     HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
-    if (bpv > 8) {
-        // few vectors cut finely (pick_pairs_per_block_fixed): raw partial sums, one fold + finalize launch
-        if (bpv > 512) return 2;
+    // A handful of vectors cut finely by pick_pairs_per_block_fixed (a one-blob call, the smallest coalesced batches):
+    // raw partial sums, one fold + finalize launch.  Only there: a 1024-thread fold workgroup needs a compute unit to
+    // itself (16 waves of 128 registers, 58 KB of LDS), and in a mid-size batch of the throughput regime -- where two
+    // launches of concurrent callers overlap -- it would wait for the OTHER launch's accumulate workgroups to drain
+    // (measured: 128 callers 80.6 -> 64.6 k commitments/s when every bpv > 8 launch took this form).
+    if (bpv > 8 && bpv <= 512 && ppb <= 1024 && nvec * bpv <= 512) {
         uint32_t *d_raw = reinterpret_cast<uint32_t *>(d_partials);
         hipLaunchKernelGGL(k_msm_accumulate<256>, dim3((unsigned)(nvec * bpv)), dim3(256), 0, ctx->stream,
                            d_partials, t.d_table, d_digits, pairs_per_vec, ppb, t.wbits - 1, bpv,
                            (uint32_t)t.npoints, (uint32_t)t.npoints, 1u, bpv, msm_prio_bit(), d_raw);
         HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
-        hipLaunchKernelGGL(k_msm_fold_finalize, dim3((unsigned)nvec), dim3(1024), 0, ctx->stream, d_out48, d_status, d_raw,
+        hipLaunchKernelGGL(k_msm_fold_finalize, dim3((unsigned)nvec), dim3(FOLD_THREADS), 0, ctx->stream, d_out48, d_status, d_raw,
                            d_bad, bpv);
         HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
         HIP_TRY(hipGetLastError());
@@ -900,7 +904,15 @@ static int run_msm(DeviceCtx *ctx, const FixedBaseTable &t, uint8_t *d_out48, ui
                        d_partials, t.d_table, d_digits, pairs_per_vec, ppb, t.wbits - 1, bpv,
                        (uint32_t)t.npoints, (uint32_t)t.npoints, 1u, bpv, msm_prio_bit(), (uint32_t *)nullptr);
     HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
-    if (bpv >= 2 && nvec <= 4096) {
+    if (bpv > 8) {
+        // mid-size batches split finely by the cost model: fold per vector on one wave, then dense one-lane finalize
+        // (partials[nvec*bpv ..] is free: the callers size d_partials with partials_bytes())
+        G1XYZZ *d_sums = d_partials + nvec * (size_t)bpv;
+        hipLaunchKernelGGL(k_msm_reduce_partials, dim3((unsigned)nvec), dim3(64), 0, ctx->stream, d_sums,
+                           d_partials, bpv);
+        hipLaunchKernelGGL(k_msm_finalize, dim3((unsigned)((nvec + 63) / 64)), dim3(64), 0, ctx->stream,
+                           d_out48, d_status, d_sums, d_bad, 1u, nvec);
+    } else if (bpv >= 2 && nvec <= 4096) {
         // few vectors: fold the partials in a tree (latency); many: one lane per vector (dense inversions)
         if (bpv <= 2)
             hipLaunchKernelGGL(k_msm_finalize_tree<2>, dim3((unsigned)((nvec + 31) / 32)), dim3(64), 0, ctx->stream, d_out48,

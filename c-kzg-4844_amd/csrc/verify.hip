@@ -59,15 +59,19 @@ __global__ __launch_bounds__(EV_THREADS) void k_eval_barycentric(Fr *y_out, uint
     const Fr z = vld_fr(zs + blockIdx.x);
     if (tid == 0) hit = -1;
     __syncthreads();
-    Fr den[EV_PER], pre[EV_PER];
+    // Montgomery's trick over the thread's EV_PER denominators.  Only the prefix products are kept: a denominator
+    // is one subtraction from a root the way back loads anyway, and keeping all EV_PER of them as well put 2 x 16 field
+    // elements per thread into scratch memory -- 1.4 GB of spill writes per 4096-blob launch against 0.5 GB of
+    // polynomial (profiles/r04_pmc_verify_wide.json).
+    Fr pre[EV_PER];
     Fr acc = Fr::one();
 #pragma unroll
     for (int k = 0; k < EV_PER; k++) {
         int i = tid + k * EV_THREADS;
-        den[k] = sub(z, vld_fr(brp_roots + i));
-        if (den[k].is_zero()) hit = i;  // at most one domain point equals z
+        const Fr den = sub(z, vld_fr(brp_roots + i));
+        if (den.is_zero()) hit = i;  // at most one domain point equals z
         pre[k] = acc;
-        acc = mul(acc, den[k]);
+        acc = mul(acc, den);
     }
     __syncthreads();
     if (hit >= 0) {
@@ -83,10 +87,11 @@ __global__ __launch_bounds__(EV_THREADS) void k_eval_barycentric(Fr *y_out, uint
 #pragma unroll
     for (int k = EV_PER - 1; k >= 0; k--) {
         int i = tid + k * EV_THREADS;
+        const Fr root = vld_fr(brp_roots + i);
         Fr di = mul(inv, pre[k]);  // 1/(z - w_i)
-        inv = mul(inv, den[k]);
+        inv = mul(inv, sub(z, root));
         if (QUOT) vst_fr(qinv + i, di);
-        sum = add(sum, mul(mul(di, vld_fr(brp_roots + i)), vld_fr(p + i)));
+        sum = add(sum, mul(mul(di, root), vld_fr(p + i)));
     }
     // workgroup sum
     for (int s = EV_THREADS / 2; s >= 1; s >>= 1) {

@@ -22,5 +22,5 @@ for f in csrc/ckzg_api.hip csrc/device_ctx.hip csrc/msm.hip csrc/ntt.hip csrc/fk
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-pass-failed "${extra[@]}" -c $f -o $o &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--version-script=exports.map -o libckzg_hip_$name.so build_$name/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic -Wl,--version-script=exports.map -o libckzg_hip_$name.so build_$name/*.o
 ls -la libckzg_hip_$name.so
