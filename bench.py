@@ -660,12 +660,13 @@ def predicted_scaling(value_n1, host_ptr_n1, sec, lib_budget=None, effective_cor
 
 
 def committed_single_gpu_value():
-    """The newest committed N = 1 line (profiles/rNN_final_bench_line.json): what an N-rank run is predicted from."""
+    """The newest committed N = 1 line (profiles/rNN_final_bench_lines.json): what an N-rank run is predicted from."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_final_bench_line*.json")), reverse=True):
         try:
             d = json.load(open(f))
             d = d[0] if isinstance(d, list) else d
+            d = d.get("default_command_python_bench_py", d)   # (tools/collect_profiles.py keeps two lines per file)
             if d.get("n_gpus") == 1 and d.get("value"):
                 return float(d["value"]), os.path.relpath(f, ROOT)
         except Exception:  # noqa: BLE001

@@ -52,7 +52,7 @@ struct DBuf {
 // in HBM first and then GPU_SHA_US whatever n <= 65,536 (2,050 dependent compressions per blob).  T is this
 // process's share of the host (host_thread_budget: cpus / ranks on the host): a rank of an 8-GPU job in a 15-core
 // container has 1-2 threads and hashes a 512-blob shard in 17-34 ms on the host, in GPU_SHA_US + 1.2 ms on the GPU.
-static constexpr double GPU_SHA_US = 6000.0;
+static constexpr double GPU_SHA_US = 4900.0;   // k_sha256_challenges at n <= 4096 (profiles/r04_pmc_verify_wide.json: 4.84 ms)
 static bool challenges_on_gpu(size_t n) {
     const int opt = g_gpu_sha_min.load();
     if (opt > 0) return n >= (size_t)opt;  // ckzg_hip_set_option("gpu_sha_min", n)

@@ -69,7 +69,7 @@ extern "C" {
  *                   the GPU; 0 (default): automatic -- the host hashes (underneath the blob copy) unless this process's
  *                   share of the host cores ("host_threads") is too small for it: the estimated host time
  *                   n * 66 us / threads (320 us without the x86 SHA extensions) is compared with the blob copy plus the
- *                   GPU hash's ~6 ms.  Batches of at most 3 blobs always hash on the host.
+ *                   GPU hash's ~4.9 ms.  Batches of at most 3 blobs always hash on the host.
  *                   Takes effect immediately (as does "host_threads"; every other option is read by load_trusted_setup).
  *   "verify_pipe_min"  smallest verify_blob_kzg_proof_batch (host pointers) that crosses PCIe in 256-blob chunks while
  *                   earlier chunks are already evaluated; default 1024.  Takes effect immediately.
