@@ -606,7 +606,7 @@ def predicted_scaling(value_n1, host_ptr_n1, sec, lib_budget=None, effective_cor
         cores = os.cpu_count() or 1
     visible = cores
     if lib_budget:
-        cores = min(cores, lib_budget)      # what the library itself sizes its pools by (affinity mask, cgroup quota)
+        cores = min(cores, lib_budget)      # what the library itself sizes its pools by (affinity mask)
     if effective_cores:
         cores = min(cores, effective_cores)  # what the host really delivered to the CPU baseline of this run
     MEMCPY_GBPS_PER_CORE, SHA_US_PER_BLOB_THREAD, COPY_US_PER_BLOB, GPU_SHA_US, EVAL_US, TAIL_US = 8.0, 66.0, 2.4, 4900.0, 1900.0, 2000.0

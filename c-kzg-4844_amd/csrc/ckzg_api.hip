@@ -359,7 +359,8 @@ static C_KZG_RET commit_batch_on(dev::DeviceCtx *ctx, KZGCommitment *out, uint8_
     Arena &ar = ctx->api_arena;
     // One finalize for the whole batch (partial sums of every chunk parked in d_part8) when every chunk of the
     // schedule splits a blob into at most 8 partial sums; otherwise each chunk finalizes itself.
-    bool deferred = n > FIRST;
+    const bool one_chunk = n <= FIRST || (pinned_io && n <= CH);   // (a coalesced batch: nothing to stage, one copy + one launch)
+    bool deferred = !one_chunk;
     {
         uint64_t want = FIRST;
         for (uint64_t off = 0, k = 0; off < n && deferred; off += k) {
@@ -370,7 +371,7 @@ static C_KZG_RET commit_batch_on(dev::DeviceCtx *ctx, KZGCommitment *out, uint8_
     }
     if (!ar.begin(2 * m * BYTES_PER_BLOB + n * 49 + (deferred ? n * (8 * sizeof(G1XYZZ) + 4) : 0) + 2048)) return C_KZG_MALLOC;
     ArenaTrim trim(ar);
-    ABuf<uint8_t> d_blobs[2] = {ABuf<uint8_t>(ar, m * BYTES_PER_BLOB), ABuf<uint8_t>(ar, n > FIRST ? m * BYTES_PER_BLOB : 1)};
+    ABuf<uint8_t> d_blobs[2] = {ABuf<uint8_t>(ar, m * BYTES_PER_BLOB), ABuf<uint8_t>(ar, one_chunk ? 1 : m * BYTES_PER_BLOB)};
     ABuf<uint8_t> d_out(ar, n * 49);  // commitments, then the status bytes
     ABuf<G1XYZZ> d_part8(ar, deferred ? n * 8 : 1);
     ABuf<uint32_t> d_bad_all(ar, deferred ? n : 1);
@@ -395,7 +396,7 @@ static C_KZG_RET commit_batch_on(dev::DeviceCtx *ctx, KZGCommitment *out, uint8_
         }
     }
     tr.mark("buffers + events");
-    if (n <= FIRST && ret == C_KZG_OK) {
+    if (one_chunk && ret == C_KZG_OK) {
         // one small chunk (the reference-shaped single-blob call among them): nothing to overlap, so the
         // copy in, the kernels and the copy out run on the one compute stream with a single wait
         const uint8_t *h_in = reinterpret_cast<const uint8_t *>(blobs);
