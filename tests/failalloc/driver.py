@@ -278,6 +278,41 @@ for nth in range(0, 96):
 k0.lib.ckzg_hip_set_option(b"replicas", 1)
 report["fan_out"] = {"failures_injected": injected}
 
+# ---- concurrent one-blob callers (csrc/combiner.hpp): 24 native threads share batch launches while the n-th allocation
+# ---- from now on fails (sticky: the page-locked batch buffers, the arenas and staging of the slots the launches lease,
+# ---- whatever comes n-th).  Every call must come back with the right commitment or with C_KZG_MALLOC -- no hang, no
+# ---- crash, no wrong bytes -- and once allocations work again so must every caller.
+import importlib.util  # noqa: E402
+_pkg = os.path.join(os.path.dirname(os.path.dirname(HERE)), "c-kzg-4844_amd")
+_spec = importlib.util.spec_from_file_location("ckzg_fanout", os.path.join(_pkg, "fanout.py"))
+fo = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(fo)
+watch = LeakWatch()
+threads = 24
+ins = [many[t % 40] for t in range(threads)]
+want_cm = [many_c[t % 40] for t in range(threads)]
+coalesce_injected, coalesce_batches = 0, 0
+for nth in list(range(0, 12)) + [16, 24, 40]:
+    k = load()
+    fa.failalloc_arm(nth, 1)
+    st, rets, outs = fo.run(k, LIB, fo.OP_COMMIT, ins, max_calls=6)
+    fired = fa.failalloc_fired()
+    fa.failalloc_disarm()
+    for t in range(threads):
+        if rets[t] == 0 and outs[t] != want_cm[t]:
+            problems.append("coalesced callers, allocations failing from the %d-th: thread %d got OK with WRONG bytes" % (nth, t))
+        elif rets[t] not in (0, C_KZG_MALLOC):
+            problems.append("coalesced callers, allocations failing from the %d-th: thread %d -> C_KZG_RET %d" % (nth, t, rets[t]))
+    st2, rets2, outs2 = fo.run(k, LIB, fo.OP_COMMIT, ins, max_calls=4)
+    if rets2 != [0] * threads or outs2 != want_cm:
+        problems.append("coalesced callers: wrong results after allocations work again (failed from the %d-th)" % nth)
+    cs = fo.coalesce_stats(k, 0)
+    coalesce_batches += cs["batches"] if cs else 0
+    k.close()
+    coalesce_injected += 1 if fired else 0
+    watch.check("coalesced callers, allocations failing from the %d-th" % nth)
+report["coalesced_callers"] = {"levels_with_failures": coalesce_injected, "batch_launches": coalesce_batches}
+
 # ---- background widening under an exhausted device: the tables stay at whatever width was reached, calls go on
 k = load(options={"async_tables": 1, "commit_wbits": 13, "proof_wbits": 11, "fk20_wbits": 10})
 fa.failalloc_arm(0, 1)

@@ -28,6 +28,7 @@ def test_every_allocation_of_every_entry_point_may_fail(tmp_path):
     assert rep["load"]["ops"]["single"]["failures_injected"] >= 20
     assert rep["load"]["ops_streams_events"]["single"]["failures_injected"] >= 40
     assert rep["fan_out"]["failures_injected"] >= 40
+    assert rep["coalesced_callers"]["levels_with_failures"] >= 10 and rep["coalesced_callers"]["batch_launches"] >= 10
     host_only = {"verify_kzg_proof"}   # one pairing check on the host: allocates nothing on the device
     assert all(v["single"]["failures_injected"] >= 1 for n, v in rep["ops"].items() if n not in host_only), rep["ops"]
     assert sum(v["single"]["failures_injected"] for v in rep["ops_streams_events"].values()) >= 10
