@@ -187,6 +187,7 @@ static void destroy_slot(dev::DeviceCtx *ctx) {
     }
     for (auto e : ctx->chunk_ev) (void)hipEventDestroy(e);
     if (ctx->table_ev) (void)hipEventDestroy(ctx->table_ev);
+    if (ctx->one_commit.exec) (void)hipGraphExecDestroy(ctx->one_commit.exec);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->out_stream) (void)hipStreamDestroy(ctx->out_stream);

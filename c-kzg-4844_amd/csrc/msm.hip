@@ -949,6 +949,7 @@ void commit_collect_times(DeviceCtx *ctx) {
     if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_ms[1] = ms;
     if (hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]) == hipSuccess) ctx->last_ms[2] = ms;
     if (hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[4]) == hipSuccess) ctx->last_ms[3] = ms;
+    (void)hipGetLastError();   // an event that cannot be read is no error of the call: do not leave it for the next hipGetLastError()
 }
 
 // Many small MSMs against sub-ranges of one table (FK20: 128 vectors of 64 points per blob).
