@@ -14,8 +14,12 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <linux/futex.h>
 #include <pthread.h>
 #include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+#include <climits>
 #include <thread>
 #include <vector>
 
@@ -370,6 +374,21 @@ C_KZG_RET for_each_device_shard(const KZGSettings *s, uint64_t n, uint64_t min_s
     return ret;
 }
 
+// Sleeping on a 32-bit word instead of spinning on it (the combiner's batches, the transcript hasher of a pipelined
+// verification, the waits for pool jobs): futex_wait returns on a wake, a changed value or a signal -- callers
+// re-check in a loop; the happens-before edge is the acquire load / release store of the word itself.
+static_assert(sizeof(std::atomic<uint32_t>) == sizeof(uint32_t), "futex word");
+inline void futex_wait(std::atomic<uint32_t> *w, uint32_t expected) {
+    (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAIT_PRIVATE, expected, nullptr, nullptr, 0);
+}
+inline void futex_wake(std::atomic<uint32_t> *w, int count) {
+    (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAKE_PRIVATE, count, nullptr, nullptr, 0);
+}
+// block until *w == 0 (the countdown of outstanding pool jobs of a call); the job that takes it to 0 calls futex_wake
+inline void wait_until_zero(std::atomic<uint32_t> *w) {
+    for (uint32_t v; (v = w->load(std::memory_order_acquire)) != 0;) futex_wait(w, v);
+}
+
 // pageable <-> pinned staging copy.  One core moves ~10 GB/s, which would make a copy (13 ms per
 // 1024 blobs) longer than the kernels it is supposed to hide behind: large chunks are split eight ways, seven
 // parts going to a small process-wide set of persistent helper threads (started on first use, never per chunk;
@@ -384,7 +403,7 @@ class CopyHelpers {
         void *dst;
         const void *src;
         size_t len;
-        std::atomic<int> *pending;
+        std::atomic<uint32_t> *pending;
     };
     // false: no helper available (or no memory for the queue entry), the caller does this part itself.  Never throws:
     // staged_copy has counted the part as pending and has parts in flight that point at its stack.
@@ -426,7 +445,8 @@ class CopyHelpers {
                 q.pop_front();
             }
             if (j.len) memcpy(j.dst, j.src, j.len);
-            j.pending->fetch_sub(1, std::memory_order_release);
+            std::atomic<uint32_t> *p = j.pending;   // (the submitter's stack: not touched after the count reaches zero)
+            if (p->fetch_sub(1, std::memory_order_acq_rel) == 1) futex_wake(p, INT_MAX);
         }
     }
     std::mutex mu;
@@ -514,7 +534,7 @@ inline void staged_copy(void *dst, const void *src, size_t bytes) {
         return;
     }
     const size_t part = (bytes / nt + 4095) & ~(size_t)4095;
-    std::atomic<int> pending{0};
+    std::atomic<uint32_t> pending{0};
     for (size_t t = 1; t < nt; t++) {
         size_t o = t * part, len = o >= bytes ? 0 : (bytes - o < part ? bytes - o : part);
         if (!len) continue;
@@ -525,7 +545,7 @@ inline void staged_copy(void *dst, const void *src, size_t bytes) {
         }
     }
     memcpy(dst, src, part < bytes ? part : bytes);
-    while (pending.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+    wait_until_zero(&pending);
 }
 
 // The wait that ends a ONE-unit call.  hipStreamSynchronize parks the thread on an interrupt, and being woken costs

@@ -260,7 +260,7 @@ void parallel_for(size_t n, const std::function<void(size_t)> &fn) {
     }
     struct Shared {
         std::atomic<size_t> next{0};
-        std::atomic<int> active{0};
+        std::atomic<uint32_t> active{0};   // pool jobs of this call that have not returned yet (futex word)
     } sh;
     auto loop = [&sh, &fn, n]() {
         for (;;) {
@@ -273,12 +273,12 @@ void parallel_for(size_t n, const std::function<void(size_t)> &fn) {
         sh.active.fetch_add(1, std::memory_order_relaxed);
         if (!WorkerPool::get().submit([&sh, loop]() {
                 loop();
-                sh.active.fetch_sub(1, std::memory_order_release);
+                if (sh.active.fetch_sub(1, std::memory_order_acq_rel) == 1) futex_wake(&sh.active, INT_MAX);
             }))
             sh.active.fetch_sub(1, std::memory_order_relaxed);
     }
     loop();
-    while (sh.active.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+    wait_until_zero(&sh.active);   // (asleep, not spinning: the stragglers may need this core)
 }
 
 // Several variable-base lincombs sum_i k_i P_i in ONE launch.  Job j takes n points starting at
@@ -392,10 +392,10 @@ constexpr uint64_t SMALL_VERIFY_N = 3;
 // (0.49 ms at n = 4096, after the last byte and before everything that needs r).
 struct TranscriptHasher {
     Sha256 h;
-    std::atomic<size_t> published{0};   // chunks whose download has been enqueued (its event recorded)
+    std::atomic<uint32_t> published{0};   // chunks whose download has been enqueued (its event recorded); futex word
     std::atomic<bool> abort{false};
     bool failed = false;
-    std::atomic<bool> done{false};      // the pool job has returned
+    std::atomic<uint32_t> running{0};     // 1 while the pool job has not returned; futex word
     bool on_pool = false;
     std::thread t;                      // only when the worker pool did not take the job
     TranscriptHasher() = default;
@@ -403,13 +403,14 @@ struct TranscriptHasher {
     TranscriptHasher &operator=(const TranscriptHasher &) = delete;
     void wait() {
         if (on_pool) {
-            while (!done.load(std::memory_order_acquire)) std::this_thread::yield();
+            wait_until_zero(&running);
         } else if (t.joinable()) {
             t.join();
         }
     }
     ~TranscriptHasher() {
         abort.store(true);
+        futex_wake(&published, INT_MAX);   // the job may be asleep waiting for the next chunk
         wait();
     }
     void start(int device, size_t n, size_t chunk, const hipEvent_t *landed, const Bytes48 *cb, const Bytes48 *pb,
@@ -427,9 +428,11 @@ struct TranscriptHasher {
             const size_t nch = (n + chunk - 1) / chunk;
             uint8_t zb[64];
             for (size_t c = 0; c < nch; c++) {
-                while (published.load(std::memory_order_acquire) <= c) {
+                // asleep until the caller publishes the next chunk (12 ms of a spinning pool worker per pipelined
+                // verification otherwise)
+                for (uint32_t seen; (seen = published.load(std::memory_order_acquire)) <= c;) {
                     if (abort.load()) return;
-                    std::this_thread::yield();
+                    futex_wait(&published, seen);
                 }
                 if (hipEventSynchronize(landed[c]) != hipSuccess) {
                     failed = true;
@@ -446,13 +449,21 @@ struct TranscriptHasher {
             }
         };
         // (a pool job may wait for the GPU and for the publishing caller, never for another pool job)
+        running.store(1, std::memory_order_relaxed);
         on_pool = WorkerPool::get().submit([this, body]() {
             body();
-            done.store(true, std::memory_order_release);
+            running.store(0, std::memory_order_release);
+            futex_wake(&running, INT_MAX);
         });
-        if (!on_pool) t = std::thread(body);
+        if (!on_pool) {
+            running.store(0, std::memory_order_relaxed);
+            t = std::thread(body);
+        }
     }
-    void publish(size_t chunks) { published.store(chunks, std::memory_order_release); }
+    void publish(size_t chunks) {
+        published.store((uint32_t)chunks, std::memory_order_release);
+        futex_wake(&published, INT_MAX);
+    }
     bool finish(uint8_t digest[32]) {
         wait();
         if (failed) return false;
@@ -467,7 +478,7 @@ struct TranscriptHasher {
 struct OrderedHasher {
     std::atomic<size_t> next{0};
     std::vector<std::atomic<uint32_t>> done;   // per chunk: blobs hashed
-    std::atomic<int> active{0};                // pool jobs of this call that have not returned yet
+    std::atomic<uint32_t> active{0};           // pool jobs of this call that have not returned yet (futex word)
     size_t n, chunk;
     JoinThreads th;                            // only when the process-wide pool could not be used
     OrderedHasher(size_t n_, size_t chunk_) : done((n_ + chunk_ - 1) / chunk_), n(n_), chunk(chunk_) {
@@ -478,7 +489,7 @@ struct OrderedHasher {
     // nothing of this object (or of z / blobs / cb) may be touched by a worker once the call has returned
     ~OrderedHasher() {
         next.store(n, std::memory_order_relaxed);   // an abandoned call: the workers stop at their next blob
-        while (active.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+        wait_until_zero(&active);
     }
     void start(Fr *z, const Blob *blobs, const Bytes48 *cb) {
         size_t nt = (size_t)host_thread_budget();
@@ -488,14 +499,15 @@ struct OrderedHasher {
                 const size_t i = next.fetch_add(1, std::memory_order_relaxed);
                 if (i >= n) return;
                 z[i] = challenge_from_bytes(blobs[i].bytes, cb[i].bytes);
-                done[i / chunk].fetch_add(1, std::memory_order_release);
+                const size_t c = i / chunk, want = n - c * chunk < chunk ? n - c * chunk : chunk;
+                if (done[c].fetch_add(1, std::memory_order_acq_rel) + 1 == want) futex_wake(&done[c], INT_MAX);   // chunk complete
             }
         };
         for (size_t t = 0; t < nt; t++) {
             active.fetch_add(1, std::memory_order_relaxed);
             if (!WorkerPool::get().submit([this, loop]() {
                     loop();
-                    active.fetch_sub(1, std::memory_order_release);
+                    if (active.fetch_sub(1, std::memory_order_acq_rel) == 1) futex_wake(&active, INT_MAX);
                 })) {
                 active.fetch_sub(1, std::memory_order_relaxed);
                 try {
@@ -508,7 +520,8 @@ struct OrderedHasher {
     }
     void wait_chunk(size_t c) const {
         const size_t lo = c * chunk, want = (n - lo < chunk ? n - lo : chunk);
-        while (done[c].load(std::memory_order_acquire) < want) std::this_thread::yield();
+        auto *w = const_cast<std::atomic<uint32_t> *>(&done[c]);
+        for (uint32_t v; (v = w->load(std::memory_order_acquire)) < want;) futex_wait(w, v);
     }
 };
 
@@ -1529,10 +1542,10 @@ static C_KZG_RET verify_cells_on(dev::DeviceCtx *ctx, bool *ok, const Bytes48 *c
     // the check of the validation flags -- happens underneath it.
     Fr r;
     struct HashJob {
-        std::atomic<bool> done{false};
+        std::atomic<uint32_t> running{0};   // futex word
         bool submitted = false;
         void wait() {
-            while (submitted && !done.load(std::memory_order_acquire)) std::this_thread::yield();
+            if (submitted) wait_until_zero(&running);
         }
         ~HashJob() { wait(); }   // nothing the worker reads or writes may die before it is through
     } hash_job;
@@ -1543,9 +1556,11 @@ static C_KZG_RET verify_cells_on(dev::DeviceCtx *ctx, bool *ok, const Bytes48 *c
     };
     if (n >= 256) {
         HashJob *hj = &hash_job;
+        hash_job.running.store(1, std::memory_order_relaxed);
         hash_job.submitted = WorkerPool::get().submit([hash_all, hj]() {
             hash_all();
-            hj->done.store(true, std::memory_order_release);
+            hj->running.store(0, std::memory_order_release);
+            futex_wake(&hj->running, INT_MAX);
         });
     }
     OKM(ensure_pinned(ctx->h_out, ctx->h_out_bytes, 2 * (n + nc) + n * 4));

@@ -23,10 +23,7 @@
 // Batches are per key: requests may only share a launch when the batch path treats them alike (same operation,
 // same outputs wanted; for recover_cells_and_kzg_proofs the same set of cell indices).
 #pragma once
-#include <linux/futex.h>
 #include <pthread.h>
-#include <sys/syscall.h>
-#include <unistd.h>
 
 #include <atomic>
 #include <climits>
@@ -42,14 +39,6 @@ namespace ckzg {
 namespace api {
 
 namespace detail {
-static_assert(sizeof(std::atomic<uint32_t>) == sizeof(uint32_t), "futex word");
-// sleep while *w == expected (returns on a wake, a changed value or a signal: callers re-check in a loop)
-inline void futex_wait(std::atomic<uint32_t> *w, uint32_t expected) {
-    (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAIT_PRIVATE, expected, nullptr, nullptr, 0);
-}
-inline void futex_wake(std::atomic<uint32_t> *w, int count) {
-    (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAKE_PRIVATE, count, nullptr, nullptr, 0);
-}
 // Hundreds of callers take the combiner's mutex for a few dozen nanoseconds each, in bursts (a batch's members
 // return to their callers together and come back together): spin briefly before sleeping.
 class AdaptiveMutex {
@@ -194,7 +183,7 @@ class Combiner {
                 }
                 continue;
             }
-            detail::futex_wait(&b->state, s);
+            futex_wait(&b->state, s);
         }
         const size_t n = b->n;
         const C_KZG_RET mine = b->status[idx] ? (C_KZG_RET)b->status[idx] : b->ret;
@@ -252,7 +241,7 @@ class Combiner {
         }
         release(next);   // the next launch starts while this one's members are being woken
         b->state.store(DONE, std::memory_order_release);
-        detail::futex_wake(&b->state, INT_MAX);
+        futex_wake(&b->state, INT_MAX);
     }
 
     // mu held.  A launch has ended: its place goes to the oldest open batch (returned, to be release()d once mu is
@@ -284,7 +273,7 @@ class Combiner {
     static void release(Batch *nb) {
         if (!nb) return;
         nb->state.store(RELEASED, std::memory_order_release);
-        detail::futex_wake(&nb->state, 1);
+        futex_wake(&nb->state, 1);
     }
 
     // mu held.  A batch with buffers, from the free list or newly allocated; nullptr if neither is possible now.
