@@ -261,12 +261,14 @@ class Combiner {
     // would leave the device idle while they all copy out, come back and copy in.
     // members an open batch waits for while a launch place is free: three quarters of a place's share
     size_t go_threshold() const {
-        const size_t t = (size_t)(3 * peak / 4) / (size_t)max_active;
+        static const long pct = dev::ab_knob("CKZG_HIP_COALESCE_GO_PCT", 75);
+        const size_t t = (size_t)((long)peak * pct / 100) / (size_t)max_active;
         return t < 1 ? 1 : (t > max_batch ? max_batch : t);
     }
     // members a batch takes before later callers open the next one: a place's share and a quarter
     size_t batch_cap() const {
-        const size_t c = ((size_t)peak * 5 / 4 + (size_t)max_active - 1) / (size_t)max_active;
+        static const long cap_pct = dev::ab_knob("CKZG_HIP_COALESCE_CAP_PCT", 125);
+        const size_t c = ((size_t)((long)peak * cap_pct / 100) + (size_t)max_active - 1) / (size_t)max_active;
         return c < 1 ? 1 : (c > max_batch ? max_batch : c);
     }
     // the batch may run: whichever member sees this first claims it; one sleeper is woken in case all of them sleep
