@@ -179,7 +179,7 @@ LoadTimes &pending_load_times();
 
 // the ckzg.h entry points whose concurrent callers are coalesced (combiner.hpp); the three output forms of
 // compute_cells_and_kzg_proofs are separate operations because they run different batch paths
-enum CombinedOp { CB_COMMIT = 0, CB_CELLS, CB_PROOFS, CB_CELLS_PROOFS, CB_BLOB_PROOF, CB_RECOVER, CB_COUNT };
+enum CombinedOp { CB_COMMIT = 0, CB_CELLS, CB_PROOFS, CB_CELLS_PROOFS, CB_BLOB_PROOF, CB_RECOVER, CB_VERIFY_BLOB, CB_COUNT };
 class Combiner;
 
 struct SettingsCtx {

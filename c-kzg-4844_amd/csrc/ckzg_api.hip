@@ -859,8 +859,8 @@ extern "C" int ckzg_hip_coalesce_stats(const KZGSettings *s, int op, uint64_t *o
     SettingsCtx *sc = settings_of(s, false);
     if (!sc || !out || op < 0 || op >= (int)CB_COUNT || !sc->comb[op]) return 0;
     const Combiner::Stats st = sc->comb[op]->stats();
-    const uint64_t v[6] = {st.calls, st.solo, st.batches, st.batched, st.largest, st.run_us};
-    int k = n < 6 ? n : 6;
+    const uint64_t v[7] = {st.calls, st.solo, st.batches, st.batched, st.largest, st.run_us, st.retried};
+    int k = n < 7 ? n : 7;
     for (int i = 0; i < k; i++) out[i] = v[i];
     return k;
 }

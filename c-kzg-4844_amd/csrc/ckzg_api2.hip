@@ -1156,13 +1156,53 @@ extern "C" C_KZG_RET verify_kzg_proof(bool *ok, const Bytes48 *commitment_bytes,
     });
 }
 
+// eip4844.c:537-595.  Threads that verify single blobs concurrently on one KZGSettings (what a consensus client does
+// with the blobs of a block) are served by ONE verify_blob_kzg_proof_batch launch over all of them (combiner.hpp): if
+// that batch comes out true every member is valid (the batch equation's soundness error is 2^-255); if it does not --
+// a wrong proof, a malformed point, a non-canonical field element somewhere in it -- nothing is known about any single
+// member and each one runs its own verification afterwards (RETRY_SOLO), so an invalid blob costs its batch one wasted
+// launch and never changes another caller's answer.  A lone caller takes the single-blob path at once, as before.
 extern "C" C_KZG_RET verify_blob_kzg_proof(bool *ok, const Blob *blob, const Bytes48 *commitment_bytes,
                                            const Bytes48 *proof_bytes, const KZGSettings *s) {
     return guarded([&]() -> C_KZG_RET {
         *ok = false;
-        Lease lease(s);
-        if (!lease.ctx) return C_KZG_ERROR;
-        return verify_blobs_core(ok, blob, commitment_bytes, proof_bytes, 1, s, lease.ctx);
+        SettingsCtx *sc = settings_of(s);
+        if (!sc) return C_KZG_ERROR;
+        auto solo = [&]() -> C_KZG_RET {
+            *ok = false;
+            Lease lease(s);
+            if (!lease.ctx) return C_KZG_ERROR;
+            return verify_blobs_core(ok, blob, commitment_bytes, proof_bytes, 1, s, lease.ctx);
+        };
+        Combiner *cb = sc->comb[CB_VERIFY_BLOB];
+        if (!cb) return solo();
+        const size_t UNITS = 128;   // device_ctx.hip: create_settings_ctx
+        return cb->submit(
+            nullptr, 0, solo,
+            [&](uint8_t *h_in, size_t idx) {
+                memcpy(h_in + idx * BYTES_PER_BLOB, blob, BYTES_PER_BLOB);
+                memcpy(h_in + UNITS * BYTES_PER_BLOB + idx * 48, commitment_bytes, 48);
+                memcpy(h_in + UNITS * (BYTES_PER_BLOB + 48) + idx * 48, proof_bytes, 48);
+            },
+            [&](const uint8_t *h_in, uint8_t *h_out, uint8_t *st, size_t n) -> C_KZG_RET {
+                bool all = false;
+                C_KZG_RET r;
+                {
+                    Lease lease(s);
+                    if (!lease.ctx) return C_KZG_ERROR;
+                    r = verify_blobs_core(&all, reinterpret_cast<const Blob *>(h_in),
+                                          reinterpret_cast<const Bytes48 *>(h_in + UNITS * BYTES_PER_BLOB),
+                                          reinterpret_cast<const Bytes48 *>(h_in + UNITS * (BYTES_PER_BLOB + 48)), n, s, lease.ctx);
+                }
+                if (r != C_KZG_OK && r != C_KZG_BADARGS) return r;   // the launch itself failed: every member hears it
+                const bool good = r == C_KZG_OK && all;
+                for (size_t i = 0; i < n; i++) {
+                    h_out[i] = good ? 1 : 0;
+                    st[i] = good ? 0 : Combiner::RETRY_SOLO;
+                }
+                return C_KZG_OK;
+            },
+            [&](const uint8_t *h_out, size_t idx, size_t) { *ok = h_out[idx] != 0; });
     });
 }
 

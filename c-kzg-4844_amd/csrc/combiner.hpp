@@ -65,8 +65,13 @@ class AdaptiveMutex {
 class Combiner {
    public:
     // in_bytes / out_bytes: page-locked bytes a batch of max_batch units needs; layout is the call site's business
-    Combiner(size_t max_batch_, size_t in_bytes_, size_t out_bytes_, int max_active_)
-        : max_batch(max_batch_), in_bytes(in_bytes_), out_bytes(out_bytes_), max_active(max_active_ < 1 ? 1 : max_active_) {
+    // solo_below: while no more than this many threads have been calling concurrently of late, every caller runs its own
+    // one-unit call (as many at a time as there are callers): right for operations whose single call is mostly HOST
+    // work that scales over the callers' own cores (a verification: transcript hash + pairing), wrong for the ones a
+    // single launch already fills the device with (0: only a caller that finds nothing in flight goes alone).
+    Combiner(size_t max_batch_, size_t in_bytes_, size_t out_bytes_, int max_active_, int solo_below_ = 0)
+        : max_batch(max_batch_), in_bytes(in_bytes_), out_bytes(out_bytes_), max_active(max_active_ < 1 ? 1 : max_active_),
+          solo_below(solo_below_) {
         all.reserve((size_t)max_active + 2);        // so that the bookkeeping of a call cannot throw
         free_list.reserve((size_t)max_active + 2);
     }
@@ -88,11 +93,16 @@ class Combiner {
         uint64_t batched = 0;      // calls served by those launches
         uint64_t largest = 0;      // units in the largest launch
         uint64_t run_us = 0;       // wall time the batch launches took (lease + copies + kernels), microseconds
+        uint64_t retried = 0;      // calls a batch launch could not answer and that ran alone afterwards
     };
     Stats stats() {
         std::lock_guard<detail::AdaptiveMutex> lock(mu);
         return st;
     }
+
+    // status value a batch path gives a unit it cannot answer for inside the batch (a verification batch that did not
+    // come out true says nothing about its single members): that caller runs its own one-unit call afterwards
+    static constexpr uint8_t RETRY_SOLO = 0xff;
 
     // solo():                               the caller's own one-unit call -> C_KZG_RET
     // copy_in(h_in, idx):                   place this caller's inputs as unit idx of the batch buffer
@@ -112,8 +122,9 @@ class Combiner {
         Batch *b = nullptr;
         bool release_now = false;
         for (;;) {
-            if (active == 0) {
-                // the idle path: nothing of this operation is in flight, so nothing is queued either
+            if (active == 0 || (peak <= solo_below && pending.empty())) {
+                // the idle path: nothing of this operation is in flight (so nothing is queued either), or so few callers
+                // are about that each is better off with a launch of its own
                 active++;
                 st.solo++;
                 lock.unlock();
@@ -186,12 +197,21 @@ class Combiner {
             futex_wait(&b->state, s);
         }
         const size_t n = b->n;
+        const bool retry = b->status[idx] == RETRY_SOLO;
         const C_KZG_RET mine = b->status[idx] ? (C_KZG_RET)b->status[idx] : b->ret;
         if (mine == C_KZG_OK) copy_out((const uint8_t *)b->h_out, idx, n);
         if (b->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) {
             lock.lock();
             free_list.push_back(b);   // (capacity reserved)
             cv_pool.notify_all();
+            lock.unlock();
+        }
+        if (retry) {
+            {
+                std::lock_guard<detail::AdaptiveMutex> relock(mu);
+                st.retried++;
+            }
+            return guarded([&]() -> C_KZG_RET { return solo(); });   // (unqueued: it leases a slot of its own)
         }
         return mine;
     }
@@ -247,7 +267,9 @@ class Combiner {
     // mu held.  A launch has ended: its place goes to the oldest open batch (returned, to be release()d once mu is
     // dropped), or is given up.
     Batch *launch_done() {
-        if (!pending.empty()) {
+        // (solo launches of a `solo_below` operation may exceed the places batches rotate through: a batch only takes
+        // the place of a launch that leaves fewer than max_active behind)
+        if (!pending.empty() && active <= max_active) {
             Batch *nb = pending.front();
             pending.pop_front();
             return nb;
@@ -322,7 +344,7 @@ class Combiner {
     }
 
     const size_t max_batch, in_bytes, out_bytes;
-    const int max_active;
+    const int max_active, solo_below;
     detail::AdaptiveMutex mu;
     std::condition_variable_any cv_pool;
     std::deque<Batch *> pending;       // open batches, oldest first

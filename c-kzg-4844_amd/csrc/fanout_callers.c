@@ -15,7 +15,7 @@
 
 #include "ckzg.h"
 
-enum { OP_COMMIT = 0, OP_CELLS_PROOFS = 1, OP_BLOB_PROOF = 2, OP_RECOVER = 3, OP_CELLS = 4, OP_PROOFS = 5 };
+enum { OP_COMMIT = 0, OP_CELLS_PROOFS = 1, OP_BLOB_PROOF = 2, OP_RECOVER = 3, OP_CELLS = 4, OP_PROOFS = 5, OP_VERIFY_BLOB = 6 };
 
 typedef struct {
     int op, id;
@@ -49,6 +49,12 @@ static int one_call(Worker *w) {
         case OP_RECOVER:
             return recover_cells_and_kzg_proofs((Cell *)w->out, (KZGProof *)(w->out + cells_b), (const uint64_t *)w->aux,
                                                 (const Cell *)w->in, w->aux_n, w->s);
+        case OP_VERIFY_BLOB: {   /* aux = commitment | proof; the verdict goes to out[0] */
+            bool ok = false;
+            const int r = verify_blob_kzg_proof(&ok, (const Blob *)w->in, (const Bytes48 *)w->aux, (const Bytes48 *)(w->aux + 48), w->s);
+            w->out[0] = ok ? 1 : 0;
+            return r;
+        }
         default: return C_KZG_BADARGS;
     }
 }

@@ -9,12 +9,12 @@ import os
 PKG = os.path.dirname(os.path.abspath(__file__))
 CALLERS_SO = os.path.join(PKG, "libckzg_callers.so")
 
-OP_COMMIT, OP_CELLS_PROOFS, OP_BLOB_PROOF, OP_RECOVER, OP_CELLS, OP_PROOFS = range(6)
+OP_COMMIT, OP_CELLS_PROOFS, OP_BLOB_PROOF, OP_RECOVER, OP_CELLS, OP_PROOFS, OP_VERIFY_BLOB = range(7)
 CELLS_BYTES = 128 * 2048
 PROOFS_BYTES = 128 * 48
 OUT_STRIDE = {OP_COMMIT: 48, OP_BLOB_PROOF: 48, OP_CELLS_PROOFS: CELLS_BYTES + PROOFS_BYTES,
               OP_RECOVER: CELLS_BYTES + PROOFS_BYTES, OP_CELLS: CELLS_BYTES + PROOFS_BYTES,
-              OP_PROOFS: CELLS_BYTES + PROOFS_BYTES}
+              OP_PROOFS: CELLS_BYTES + PROOFS_BYTES, OP_VERIFY_BLOB: 1}
 
 _lib = None
 
@@ -35,7 +35,8 @@ def _callers(libpath):
 def run(kzg, libpath, op, inputs, threads=None, seconds=1.0, max_calls=0, aux=None, aux_n=0):
     """inputs: one bytes object per thread (blob, or the concatenated cells of a recover call).
     aux: None | one bytes object shared by every thread (recover: little-endian u64 cell indices, aux_n of them)
-    | a list with one 48-byte commitment per thread (blob proofs).
+    | a list with one 48-byte commitment per thread (blob proofs) | a list with commitment + proof (96 bytes) per thread
+    (OP_VERIFY_BLOB: the output byte is the verdict).
     Returns (stats dict, last return code per thread, last output bytes per thread)."""
     lib = _callers(libpath)
     threads = threads or len(inputs)
@@ -67,11 +68,11 @@ def run(kzg, libpath, op, inputs, threads=None, seconds=1.0, max_calls=0, aux=No
 
 
 def coalesce_stats(kzg, op_index):
-    """ckzg_hip_coalesce_stats: op_index 0 commitment, 1/2/3 cells / proofs / both, 4 blob proof, 5 recover."""
+    """ckzg_hip_coalesce_stats: op_index 0 commitment, 1/2/3 cells / proofs / both, 4 blob proof, 5 recover, 6 blob verification."""
     f = kzg.lib.ckzg_hip_coalesce_stats
     f.restype = C.c_int
     f.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.c_int]
-    v = (C.c_uint64 * 6)()
-    k = f(C.addressof(kzg.s), op_index, v, 6)
-    names = ("calls", "solo", "batches", "batched", "largest", "run_us")
-    return {n: int(v[i]) for i, n in enumerate(names)} if k == 6 else None
+    v = (C.c_uint64 * 7)()
+    k = f(C.addressof(kzg.s), op_index, v, 7)
+    names = ("calls", "solo", "batches", "batched", "largest", "run_us", "retried")
+    return {n: int(v[i]) for i, n in enumerate(names)} if k == 7 else None

@@ -55,13 +55,15 @@ extern "C" {
  *                   widening has finished, ckzg_hip_tables_ready polls it; free_trusted_setup cancels it.  0 (default):
  *                   the load builds the requested widths itself before it returns.  env CKZG_HIP_ASYNC_TABLES.
  *   "coalesce"      1 (default): threads that call blob_to_kzg_commitment, compute_cells_and_kzg_proofs,
- *                   compute_blob_kzg_proof or recover_cells_and_kzg_proofs (same cell indices) concurrently on one
+ *                   compute_blob_kzg_proof, verify_blob_kzg_proof or recover_cells_and_kzg_proofs (same cell indices) concurrently on one
  *                   KZGSettings -- the reference API's only parallel shape, bindings/go/main_test.go:953-971 -- share
  *                   batch launches: a caller that finds fewer than "coalesce_active" launches of its operation in
  *                   flight runs its own one-unit call at once (a lone caller's latency is unchanged: no queue, no
  *                   timer); later arrivals copy their inputs into a page-locked batch buffer and are served together by
  *                   ONE launch of the batch path when a launch place frees up.  A unit the batch path rejects (a
- *                   non-canonical field element, an invalid commitment) fails its own caller only.  0: every call
+ *                   non-canonical field element, an invalid commitment) fails its own caller only; single-blob
+ *                   verifications share ONE batch verification, and when that does not come out true every member
+ *                   runs its own afterwards (a bad proof never changes another caller's answer).  0: every call
  *                   leases a stream of its own, as in rounds 2-3.
  *   "coalesce_active"  launches of one operation in flight per device before callers start to queue (1..8, default 2:
  *                   one batch computes while the next is copied in and the previous is copied out)
@@ -185,8 +187,9 @@ int ckzg_hip_tables_ready(const KZGSettings *s);
 
 /* Coalescing counters of one operation of `s` since it was loaded.  op: 0 blob_to_kzg_commitment, 1 / 2 / 3
  * compute_cells_and_kzg_proofs with cells only / proofs only / both, 4 compute_blob_kzg_proof,
- * 5 recover_cells_and_kzg_proofs.  Fills at most n of: calls, calls that ran alone (idle path), batch launches,
- * calls served by batch launches, units in the largest launch, microseconds spent inside batch launches.  Returns the number filled (0: coalescing off). */
+ * 5 recover_cells_and_kzg_proofs, 6 verify_blob_kzg_proof.  Fills at most n of: calls, calls that ran alone (idle
+ * path), batch launches, calls served by batch launches, units in the largest launch, microseconds spent inside batch
+ * launches, calls a batch could not answer and that ran alone afterwards (verifications only).  Returns the number filled (0: coalescing off). */
 int ckzg_hip_coalesce_stats(const KZGSettings *s, int op, uint64_t *out, int n);
 
 /* Bytes of HBM held by the context's tables. */

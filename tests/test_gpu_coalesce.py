@@ -209,3 +209,36 @@ def test_a_lone_caller_never_queues(hip, material):
         assert hip.blob_to_kzg_commitment(blobs[i]) == cm[i]
     after = fo.coalesce_stats(hip, 0)
     assert after["solo"] - before["solo"] == 5 and after["batches"] == before["batches"]
+
+
+def test_single_blob_verifications_share_a_batch_and_bad_ones_answer_for_themselves(hip, oracle, material):
+    """verify_blob_kzg_proof from 48 native threads: valid triples, a wrong proof (valid point, other blob's), a commitment
+    that is no curve point, a non-canonical blob.  Every caller gets exactly what the single call gives: true / false /
+    C_KZG_BADARGS -- whatever batch it happened to share."""
+    fo = _fanout()
+    blobs, cm = material
+    pr = [oracle.compute_blob_kzg_proof(blobs[i], cm[i]) for i in range(8)]
+    ins, aux, exp = [], [], []
+    for t in range(48):
+        i = t % 8
+        if t in (5, 29):
+            ins.append(blobs[i]); aux.append(cm[i] + pr[(i + 1) % 8]); exp.append((0, 0))          # wrong proof -> false
+        elif t == 11:
+            ins.append(blobs[i]); aux.append(b"\x8f" + cm[i][1:] + pr[i]); exp.append((1, 0))       # malformed commitment -> BADARGS
+        elif t == 40:
+            ins.append(_spoil(blobs[i], 99)); aux.append(cm[i] + pr[i]); exp.append((1, 0))         # non-canonical element -> BADARGS
+        else:
+            ins.append(blobs[i]); aux.append(cm[i] + pr[i]); exp.append((0, 1))
+    before = fo.coalesce_stats(hip, 6)
+    st, rets, outs = fo.run(hip, HIP_SO, fo.OP_VERIFY_BLOB, ins, max_calls=6, aux=aux)
+    after = fo.coalesce_stats(hip, 6)
+    for t in range(48):
+        assert (rets[t], outs[t][0]) == exp[t], (t, rets[t], outs[t][0], exp[t])
+    assert after["batches"] > before["batches"] and after["retried"] > before["retried"], after
+    # all-valid callers: batches come out true, nobody is sent back
+    good = [t for t in range(48) if exp[t] == (0, 1)]
+    before = fo.coalesce_stats(hip, 6)
+    st, rets, outs = fo.run(hip, HIP_SO, fo.OP_VERIFY_BLOB, [ins[t] for t in good], max_calls=6, aux=[aux[t] for t in good])
+    after = fo.coalesce_stats(hip, 6)
+    assert rets == [0] * len(good) and all(o[0] == 1 for o in outs)
+    assert after["retried"] == before["retried"] and after["largest"] >= 4, after

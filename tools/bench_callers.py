@@ -42,13 +42,17 @@ def main():
         k = mod.Kzg(mod.HIP_SO, options=opts)
         try:
             for op_name in args.ops.split(","):
-                op, idx = {"commit": (fo.OP_COMMIT, 0), "cells": (fo.OP_CELLS_PROOFS, 3), "proof": (fo.OP_BLOB_PROOF, 4)}[op_name]
+                op, idx = {"commit": (fo.OP_COMMIT, 0), "cells": (fo.OP_CELLS_PROOFS, 3), "proof": (fo.OP_BLOB_PROOF, 4),
+                           "verify": (fo.OP_VERIFY_BLOB, 6)}[op_name]
                 aux = None
                 for nt in [int(x) for x in args.threads.split(",")]:
                     ins = [blobs[t % 32] for t in range(nt)]
-                    if op == fo.OP_BLOB_PROOF:
+                    if op in (fo.OP_BLOB_PROOF, fo.OP_VERIFY_BLOB):
                         cm = [k.blob_to_kzg_commitment(b) for b in blobs]
                         aux = [cm[t % 32] for t in range(nt)]
+                    if op == fo.OP_VERIFY_BLOB:
+                        pr = [k.compute_blob_kzg_proof(b, c) for b, c in zip(blobs, cm)]
+                        aux = [cm[t % 32] + pr[t % 32] for t in range(nt)]
                     fo.run(k, mod.HIP_SO, op, ins, seconds=0.15, aux=aux)   # warm-up: arenas, batch buffers
                     before = fo.coalesce_stats(k, idx)
                     st, rets, _ = fo.run(k, mod.HIP_SO, op, ins, seconds=args.seconds, aux=aux)
@@ -57,7 +61,8 @@ def main():
                            "calls_per_s": round(st["calls_per_s"], 1), "mean_call_ms": round(st["mean_call_ms"], 3),
                            "worst_call_ms": round(st["worst_call_ms"], 3), "not_ok": st["not_ok"]}
                     if after:
-                        d = {n: after[n] - before[n] for n in ("calls", "solo", "batches", "batched", "run_us")}
+                        d = {n: after[n] - before[n] for n in ("calls", "solo", "batches", "batched", "run_us", "retried")}
+                        row["retried"] = d["retried"]
                         row["mean_launch_ms"] = round(d["run_us"] / d["batches"] / 1e3, 3) if d["batches"] else None
                         row["launches"] = d["solo"] + d["batches"]
                         row["mean_batch"] = round(d["batched"] / d["batches"], 1) if d["batches"] else None
