@@ -753,20 +753,24 @@ def sharded_rows(L, hip, mod, torch, dist, rank, world, red_dev, base):
 def concurrency_rows(mod, hip, blobs_u8, seconds=0.4, threads=(1, 8, 32, 128, 256)):
     """The reference API is one blob per call; its parallel shape is N threads each calling it on a shared
     KZGSettings (bindings/go/main_test.go:953-971).  N native threads (fanout.py -> libckzg_callers.so: plain C
-    against ckzg.h) call the UNCHANGED blob_to_kzg_commitment / compute_cells_and_kzg_proofs for a fixed time;
+    against ckzg.h) call the UNCHANGED blob_to_kzg_commitment / compute_cells_and_kzg_proofs / verify_blob_kzg_proof for a fixed time;
     the library coalesces them into batch launches (csrc/combiner.hpp).  Per thread count: calls/s, mean and worst
     call latency, launches and mean units per batch launch (ckzg_hip_coalesce_stats)."""
     fo = mod.fanout
     ub = [blobs_u8[i].tobytes() for i in range(32)]
     out = {"driver": "libckzg_callers.so: pthreads, one blob and one output buffer per thread, %.1f s per row" % seconds,
            "coalescing": "on (csrc/combiner.hpp; 2 launches in flight per operation)"}
-    for name, op, idx in (("blob_to_kzg_commitment", fo.OP_COMMIT, 0), ("compute_cells_and_kzg_proofs", fo.OP_CELLS_PROOFS, 3)):
+    cm = [hip.blob_to_kzg_commitment(b) for b in ub]
+    pr = [hip.compute_blob_kzg_proof(b, c) for b, c in zip(ub, cm)]
+    for name, op, idx in (("blob_to_kzg_commitment", fo.OP_COMMIT, 0), ("compute_cells_and_kzg_proofs", fo.OP_CELLS_PROOFS, 3),
+                          ("verify_blob_kzg_proof", fo.OP_VERIFY_BLOB, 6)):
         rows = {}
         for nt in threads:
             ins = [ub[t % 32] for t in range(nt)]
-            fo.run(hip, mod.HIP_SO, op, ins, seconds=0.1)   # warm-up: arenas, page-locked batch buffers
+            aux = [cm[t % 32] + pr[t % 32] for t in range(nt)] if op == fo.OP_VERIFY_BLOB else None
+            fo.run(hip, mod.HIP_SO, op, ins, seconds=0.1, aux=aux)   # warm-up: arenas, page-locked batch buffers
             before = fo.coalesce_stats(hip, idx)
-            st, rets, _ = fo.run(hip, mod.HIP_SO, op, ins, seconds=seconds)
+            st, rets, _ = fo.run(hip, mod.HIP_SO, op, ins, seconds=seconds, aux=aux)
             after = fo.coalesce_stats(hip, idx)
             row = {"calls_per_s": round(st["calls_per_s"], 1), "mean_call_ms": round(st["mean_call_ms"], 3),
                    "worst_call_ms": round(st["worst_call_ms"], 3), "failed_calls": st["not_ok"] + sum(1 for r in rets if r != 0)}
