@@ -649,9 +649,12 @@ C_KZG_RET create_settings_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affin
             // a single verification is mostly host work (transcript, pairing) that scales over the callers' own cores:
             // up to one caller per stream slot they stay on their own, beyond that four batches rotate (measured:
             // 8 threads 6.4 k calls/s alone vs 2.6 k coalesced; 128 threads 6.2 k alone vs 35 k coalesced)
-            const bool verify = i == CB_VERIFY_BLOB;
+            // Up to three concurrent commitment / blob-proof callers also stay on their own: a one-blob launch leaves most
+            // of the device idle, and three of them overlap better than batches of one or two taking turns (measured,
+            // default tables: 3 threads 8.9 k commitments/s alone vs 5.7 k coalesced; from 6 threads the batches win).
+            const bool verify = i == CB_VERIFY_BLOB, light = i == CB_COMMIT || i == CB_BLOB_PROOF;
             sc->comb[i] = new Combiner(shape[i].units, shape[i].units * shape[i].in_per, shape[i].units * shape[i].out_per,
-                                       verify ? 2 * act : act, verify ? nslots : 0);
+                                       verify ? 2 * act : act, verify ? nslots : (light ? 3 : 0));
         }
     }
     sc->load.ms[LP_SLOTS] += slots_clk.lap();
