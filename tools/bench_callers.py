@@ -43,19 +43,24 @@ def main():
         try:
             for op_name in args.ops.split(","):
                 op, idx = {"commit": (fo.OP_COMMIT, 0), "cells": (fo.OP_CELLS_PROOFS, 3), "proof": (fo.OP_BLOB_PROOF, 4),
-                           "verify": (fo.OP_VERIFY_BLOB, 6)}[op_name]
-                aux = None
+                           "verify": (fo.OP_VERIFY_BLOB, 6), "recover": (fo.OP_RECOVER, 5)}[op_name]
+                aux, aux_n, rec_in = None, 0, None
+                if op == fo.OP_RECOVER:   # every caller holds the even columns of its blob (the same index set: one key)
+                    import struct
+                    keep = list(range(0, 128, 2))
+                    rec_in = [b"".join(k.compute_cells(b)[i] for i in keep) for b in blobs[:8]]
+                    aux, aux_n = struct.pack("<64Q", *keep), 64
                 for nt in [int(x) for x in args.threads.split(",")]:
-                    ins = [blobs[t % 32] for t in range(nt)]
+                    ins = [blobs[t % 32] for t in range(nt)] if rec_in is None else [rec_in[t % 8] for t in range(nt)]
                     if op in (fo.OP_BLOB_PROOF, fo.OP_VERIFY_BLOB):
                         cm = [k.blob_to_kzg_commitment(b) for b in blobs]
                         aux = [cm[t % 32] for t in range(nt)]
                     if op == fo.OP_VERIFY_BLOB:
                         pr = [k.compute_blob_kzg_proof(b, c) for b, c in zip(blobs, cm)]
                         aux = [cm[t % 32] + pr[t % 32] for t in range(nt)]
-                    fo.run(k, mod.HIP_SO, op, ins, seconds=0.15, aux=aux)   # warm-up: arenas, batch buffers
+                    fo.run(k, mod.HIP_SO, op, ins, seconds=0.15, aux=aux, aux_n=aux_n)   # warm-up: arenas, batch buffers
                     before = fo.coalesce_stats(k, idx)
-                    st, rets, _ = fo.run(k, mod.HIP_SO, op, ins, seconds=args.seconds, aux=aux)
+                    st, rets, _ = fo.run(k, mod.HIP_SO, op, ins, seconds=args.seconds, aux=aux, aux_n=aux_n)
                     after = fo.coalesce_stats(k, idx)
                     row = {"op": op_name, "wide": args.wide, "coalesce_active": act, "threads": nt,
                            "calls_per_s": round(st["calls_per_s"], 1), "mean_call_ms": round(st["mean_call_ms"], 3),
