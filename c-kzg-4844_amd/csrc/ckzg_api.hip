@@ -420,15 +420,29 @@ static C_KZG_RET commit_batch_on(dev::DeviceCtx *ctx, KZGCommitment *out, uint8_
             const void *key[7] = {ctx->commit.d_table, d_blobs[0].p, d_out.p, ctx->scratch.ptr, h_in, h_res,
                                   reinterpret_cast<const void *>((uintptr_t)ctx->commit.wbits)};
             if (!g.exec || memcmp(g.key, key, sizeof key) != 0) {
+                // ONE capture at a time in the process (they are rare: once per slot and table set)
+                static std::mutex capture_mu;
+                std::lock_guard<std::mutex> capture_lock(capture_mu);
                 if (g.exec) (void)hipGraphExecDestroy(g.exec);
                 g.exec = nullptr;
                 hipGraph_t graph = nullptr;
-                bool ok = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+                // Relaxed mode: the sequence itself holds nothing but asynchronous copies, a memset, kernels and event
+                // records, and OTHER threads must stay free to allocate and synchronise meanwhile -- under the thread-local
+                // mode this runtime still let another thread's hipMalloc / hipHostMalloc / synchronous copy (the first call
+                // on a fresh slot) invalidate the capture, and calls on both sides failed (found by the TSan pass)
+                bool ok = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed) == hipSuccess;
                 const C_KZG_RET rc = ok ? enqueue_all() : C_KZG_ERROR;
                 ok = ok && hipStreamEndCapture(ctx->stream, &graph) == hipSuccess && rc == C_KZG_OK && graph != nullptr;
                 ok = ok && hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) == hipSuccess;
                 if (graph) (void)hipGraphDestroy(graph);
                 if (!ok) {
+                    // the stream must not stay in capture mode whatever went wrong
+                    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                    if (hipStreamIsCapturing(ctx->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+                        hipGraph_t junk = nullptr;
+                        (void)hipStreamEndCapture(ctx->stream, &junk);
+                        if (junk) (void)hipGraphDestroy(junk);
+                    }
                     (void)hipGetLastError();
                     if (g.exec) (void)hipGraphExecDestroy(g.exec);
                     g.exec = nullptr;

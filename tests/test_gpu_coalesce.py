@@ -108,7 +108,15 @@ def test_python_threads_of_mixed_calls(hip, oracle, material, cells_material):
             except KzgError:
                 pass
 
-    th = [threading.Thread(target=f, args=(t,)) for t in range(12) for f in (commit, cells, blob_proof)]
+    def guard(f):   # an exception in a thread must fail the test, not vanish
+        def run(t):
+            try:
+                f(t)
+            except Exception as e:  # noqa: BLE001
+                errors.append((f.__name__, t, repr(e)))
+        return run
+
+    th = [threading.Thread(target=guard(f), args=(t,)) for t in range(12) for f in (commit, cells, blob_proof)]
     for x in th:
         x.start()
     for x in th:
@@ -242,3 +250,64 @@ def test_single_blob_verifications_share_a_batch_and_bad_ones_answer_for_themsel
     after = fo.coalesce_stats(hip, 6)
     assert rets == [0] * len(good) and all(o[0] == 1 for o in outs)
     assert after["retried"] == before["retried"] and after["largest"] >= 4, after
+
+
+def test_first_calls_of_concurrent_callers_on_fresh_settings(material):
+    """The one-blob commitment is a captured hipGraph per stream slot; three callers that arrive together on a fresh
+    KZGSettings each capture theirs.  Every later call on every slot must still work (two concurrent captures once left
+    a stream in an invalidated capture: found by the ThreadSanitizer pass, whose timing made it likely)."""
+    fo = _fanout()
+    blobs, cm = material
+    for rnd in range(6):
+        k = Kzg(HIP_SO, "", precompute=0, options={"commit_wbits": 8, "proof_wbits": 4, "fk20_wbits": 4})
+        try:
+            # first calls of everything at once: three callers capture their graphs while five others make the first
+            # allocations of their slots (arenas, page-locked staging) and copy synchronously
+            first_errors = []
+
+            def first(t):
+                try:
+                    if t < 3:
+                        for _ in range(3):
+                            if k.blob_to_kzg_commitment(blobs[t]) != cm[t]:
+                                first_errors.append(("commit", t))
+                    elif t < 6:
+                        k.compute_blob_kzg_proof(blobs[t], cm[t])
+                    else:
+                        k.compute_cells(blobs[t])
+                except Exception as e:  # noqa: BLE001
+                    first_errors.append((t, repr(e)))
+
+            th = [threading.Thread(target=first, args=(t,)) for t in range(8)]
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            assert not first_errors, (rnd, first_errors[:3])
+            for nt in (3, 3, 8):
+                st, rets, outs = fo.run(k, HIP_SO, fo.OP_COMMIT, [blobs[t % 16] for t in range(nt)], max_calls=3)
+                assert rets == [0] * nt and outs == [cm[t % 16] for t in range(nt)], (rnd, nt, rets)
+            # every slot serves other work afterwards
+            pr = k.compute_blob_kzg_proof(blobs[0], cm[0])
+            bad = []
+
+            def verify():
+                try:
+                    for _ in range(3):
+                        if not k.verify_blob_kzg_proof(blobs[0], cm[0], pr):
+                            bad.append("false")
+                except KzgError as e:
+                    bad.append(str(e))
+
+            th = [threading.Thread(target=verify) for _ in range(8)]
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            assert not bad, (rnd, bad[:3])
+            assert k.compute_cells(blobs[1]) is not None
+        finally:
+            k.close()
+    k.lib.ckzg_hip_set_option(b"commit_wbits", 10)
+    k.lib.ckzg_hip_set_option(b"proof_wbits", 8)
+    k.lib.ckzg_hip_set_option(b"fk20_wbits", 0)
