@@ -35,6 +35,13 @@
 
 #include "api_common.hpp"
 
+// page-locked batch buffers (tests/native/combiner_stress.cpp, which runs the state machine without a GPU, supplies
+// plain malloc / free instead)
+#ifndef CKZG_COMBINER_PINNED_ALLOC
+#define CKZG_COMBINER_PINNED_ALLOC(pp, bytes) (hipHostMalloc((void **)(pp), (bytes), hipHostMallocPortable) == hipSuccess)
+#define CKZG_COMBINER_PINNED_FREE(p) ((void)hipHostFree(p))
+#endif
+
 namespace ckzg {
 namespace api {
 
@@ -80,8 +87,8 @@ class Combiner {
     ~Combiner() {
         // free_trusted_setup must not race with calls (src/setup/setup.c:162-190): nobody is inside
         for (Batch *b : all) {
-            if (b->h_in) (void)hipHostFree(b->h_in);
-            if (b->h_out) (void)hipHostFree(b->h_out);
+            if (b->h_in) CKZG_COMBINER_PINNED_FREE(b->h_in);
+            if (b->h_out) CKZG_COMBINER_PINNED_FREE(b->h_out);
             delete b;
         }
     }
@@ -310,8 +317,8 @@ class Combiner {
             b = new (std::nothrow) Batch();
             bool ok = b != nullptr;
             // Portable: any device of a multi-device load may DMA from / into it
-            ok = ok && hipHostMalloc((void **)&b->h_in, in_bytes ? in_bytes : 1, hipHostMallocPortable) == hipSuccess;
-            ok = ok && hipHostMalloc((void **)&b->h_out, out_bytes ? out_bytes : 1, hipHostMallocPortable) == hipSuccess;
+            ok = ok && CKZG_COMBINER_PINNED_ALLOC(&b->h_in, in_bytes ? in_bytes : 1);
+            ok = ok && CKZG_COMBINER_PINNED_ALLOC(&b->h_out, out_bytes ? out_bytes : 1);
             if (ok) {
                 try {
                     b->status.resize(max_batch);
@@ -321,8 +328,8 @@ class Combiner {
             }
             if (!ok) {
                 (void)hipGetLastError();
-                if (b && b->h_in) (void)hipHostFree(b->h_in);
-                if (b && b->h_out) (void)hipHostFree(b->h_out);
+                if (b && b->h_in) CKZG_COMBINER_PINNED_FREE(b->h_in);
+                if (b && b->h_out) CKZG_COMBINER_PINNED_FREE(b->h_out);
                 delete b;
                 b = nullptr;
                 alloc_failed = true;       // do not try again on every call

@@ -1,0 +1,111 @@
+// combiner_stress.cpp -- the combiner's state machine (csrc/combiner.hpp) WITHOUT a GPU: N threads submit units whose
+// "batch path" is a host function, with plain malloc for the batch buffers.  What is checked is the protocol: every
+// caller gets the result of ITS OWN input, a flagged unit fails its own caller only, a RETRY_SOLO unit runs alone
+// afterwards, keys never mix in one launch, nothing hangs.  Built by tests/test_combiner_cpu.py with the host compiler
+// of hipcc, once plain and once under -fsanitize=thread (the lock-free parts: batch state words, reference counts,
+// the copied counter).  TEST INFRASTRUCTURE; exit code 0 = ok.
+#include <cstdlib>
+#include <atomic>
+#include <cstdint>
+static std::atomic<long> g_allocs_left{1L << 40};   // the scenario "the page-locked pool runs dry" counts this down
+static bool test_alloc(uint8_t **pp, size_t bytes) {
+    if (g_allocs_left.fetch_sub(1) <= 0) return false;
+    return (*pp = static_cast<uint8_t *>(malloc(bytes))) != nullptr;
+}
+#define CKZG_COMBINER_PINNED_ALLOC(pp, bytes) test_alloc((pp), (bytes))
+#define CKZG_COMBINER_PINNED_FREE(p) free(p)
+#include "../../c-kzg-4844_amd/csrc/combiner.hpp"
+
+#include <cstdio>
+#include <random>
+#include <unistd.h>
+
+using namespace ckzg::api;
+
+namespace ckzg {
+namespace api {
+std::atomic<int> g_gpu_sha_min{0}, g_host_threads{0}, g_verify_pipe_min{1024}, g_verify_call_table{1};
+}  // namespace api
+}  // namespace ckzg
+
+static uint64_t mix(uint64_t x, uint64_t key) {
+    x ^= key * 0x9e3779b97f4a7c15ull;
+    x ^= x >> 29;
+    x *= 0xbf58476d1ce4e5b9ull;
+    return x ^ (x >> 32);
+}
+
+int main(int argc, char **argv) {
+    const int threads = argc > 1 ? atoi(argv[1]) : 48, calls = argc > 2 ? atoi(argv[2]) : 400;
+    std::atomic<long> wrong{0}, solos{0};
+    // scenarios: plain; few-callers-go-alone threshold; only ONE batch buffer could be allocated (the others fail: callers
+    // wait for the buffer or go alone); every fifth launch fails as a whole (its members all see the error, later
+    // launches are unaffected)
+    for (int scenario = 0; scenario < 4; scenario++) {
+        const int solo_below = scenario == 1 ? 4 : 0;
+        g_allocs_left.store(scenario == 2 ? 3 : 1L << 40);    // 2 buffers of the first batch + h_in of the second
+        std::atomic<long> launches{0}, failed_calls{0};
+        Combiner cb(/*max_batch=*/32, /*in=*/32 * 8, /*out=*/32 * 8, /*max_active=*/2, solo_below);
+        std::vector<std::thread> th;
+        for (int t = 0; t < threads; t++) {
+            th.emplace_back([&, t]() {
+                std::mt19937_64 rng(1234 + t);
+                for (int c = 0; c < calls; c++) {
+                    const uint64_t key = rng() % 3;                 // three kinds of requests that must not share a launch
+                    const uint64_t in = rng();
+                    const int kind = (int)(mix(in, 77) % 16);       // 0: flagged (BADARGS), 1: RETRY_SOLO, else fine
+                    uint64_t out = 0;
+                    auto solo = [&]() -> C_KZG_RET {
+                        solos.fetch_add(1, std::memory_order_relaxed);
+                        usleep(120);                                // (a launch takes time: that is what lets callers queue)
+                        if (kind == 0) return C_KZG_BADARGS;
+                        out = mix(in, key);
+                        return C_KZG_OK;
+                    };
+                    C_KZG_RET r = cb.submit(
+                        &key, sizeof key, solo,
+                        [&](uint8_t *h_in, size_t idx) {
+                            memcpy(h_in + idx * 8, &in, 8);
+                        },
+                        [&, key](const uint8_t *h_in, uint8_t *h_out, uint8_t *st, size_t n) -> C_KZG_RET {
+                            for (size_t i = 0; i < n; i++) {
+                                uint64_t v;
+                                memcpy(&v, h_in + i * 8, 8);
+                                const int k2 = (int)(mix(v, 77) % 16);   // the unit's kind as the BATCH path sees it
+                                const uint64_t res = mix(v, key);
+                                memcpy(h_out + i * 8, &res, 8);
+                                st[i] = k2 == 0 ? (uint8_t)C_KZG_BADARGS : (k2 == 1 ? Combiner::RETRY_SOLO : 0);
+                            }
+                            usleep(150);
+                            if (scenario == 3 && launches.fetch_add(1) % 5 == 4) return C_KZG_ERROR;
+                            return C_KZG_OK;
+                        },
+                        [&](const uint8_t *h_out, size_t idx, size_t) { memcpy(&out, h_out + idx * 8, 8); });
+                    // what must have happened: a flagged input fails (its own call only), every other one holds
+                    // mix(in, key) -- a launch that mixed keys or a swapped slot would give another value; a RETRY_SOLO
+                    // unit got its value from the solo path afterwards
+                    if (scenario == 3 && r == C_KZG_ERROR) {
+                        failed_calls.fetch_add(1);   // (a member of a failed launch; flagged units keep their own code)
+                        continue;
+                    }
+                    if (kind == 0 ? r != C_KZG_BADARGS : (r != C_KZG_OK || out != mix(in, key))) wrong.fetch_add(1);
+                }
+            });
+        }
+        for (auto &x : th) x.join();
+        const Combiner::Stats st = cb.stats();
+        printf("scenario %d: failed-launch calls %ld; ", scenario, failed_calls.load());
+        if (scenario == 3 && failed_calls.load() == 0) return 3;
+        if (scenario != 3 && failed_calls.load() != 0) return 3;
+        printf("solo_below=%d: calls %llu solo %llu batches %llu batched %llu largest %llu retried %llu wrong %ld\n", solo_below,
+               (unsigned long long)st.calls, (unsigned long long)st.solo, (unsigned long long)st.batches,
+               (unsigned long long)st.batched, (unsigned long long)st.largest, (unsigned long long)st.retried, wrong.load());
+        if (st.calls != (uint64_t)threads * calls) return 2;
+        if (threads <= solo_below) {
+            if (st.batches != 0) return 2;   // so few callers that each goes alone
+        } else if (st.batches == 0 || (threads >= 16 && st.largest < 2) || st.retried == 0) {
+            return 2;
+        }
+    }
+    return wrong.load() ? 1 : 0;
+}
