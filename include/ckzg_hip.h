@@ -78,6 +78,12 @@ extern "C" {
  *   "verify_call_table"  1 (default): verifications of >= 8 blobs / >= 128 cells build a fixed-base table over the
  *                   points of the call and take their sums from it; 0: ladder sums (also what a call does by itself when
  *                   the device is too full for the table).  Takes effect immediately.
+ *   "commit_graph"  1 (default): a lone blob_to_kzg_commitment call submits its copies and kernels as one captured
+ *                   hipGraph (one submission instead of six; -20 us).  The capture itself (once per stream slot and table
+ *                   set) is only made while no other thread is inside the library -- this HIP runtime faults when other
+ *                   threads allocate or copy during a capture -- so a process that always calls from many threads at
+ *                   once stays on plain stream launches.  0: plain stream launches always.  2: diagnostic, capture
+ *                   anew on every call that finds the library to itself.  Takes effect immediately.
  *   "host_threads"  host threads one process of this library may keep busy per call (challenge hashing, staging copies,
  *                   point decompression at load).  0 (default): the CPUs of the process's affinity mask divided by the
  *                   processes that share the host (LOCAL_WORLD_SIZE, else WORLD_SIZE, of a one-process-per-GPU
@@ -89,6 +95,11 @@ C_KZG_RET ckzg_hip_set_option(const char *key, int64_t value);
 /* Host threads this process's helper pools are sized for (the "host_threads" option; automatic: CPUs of the affinity
  * mask / processes sharing the host, see ckzg_hip_set_option).  Needs no GPU. */
 int ckzg_hip_host_thread_budget(void);
+
+/* The captured graph of the lone one-blob blob_to_kzg_commitment call (option "commit_graph"), process-wide counts:
+ * out[0] captures made, out[1] captures put off because another thread was inside the library (the call went out as
+ * plain stream launches), out[2] calls launched as a graph.  Needs no GPU. */
+void ckzg_hip_commit_graph_stats(uint64_t out[3]);
 
 /* Number of visible HIP devices (0 if none / runtime missing). */
 int ckzg_hip_device_count(void);

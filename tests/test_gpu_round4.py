@@ -78,3 +78,76 @@ def test_device_entry_points_reject_pointers_that_are_not_on_their_gpu(hip, mate
     d_p = torch.frombuffer(bytearray(pr[0]), dtype=torch.uint8).cuda()
     assert v(C.byref(ok), d_blob.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), 1, sp) == 0 and ok.value
     assert v(C.byref(ok), d_blob.data_ptr(), C.cast(C.c_char_p(cm[0]), p), d_p.data_ptr(), 1, sp) == 1
+
+
+# ---------------------------------------------------------------------------------------------
+# the captured graph of the lone one-blob commitment: captures only while the library is otherwise idle
+# (a capture that overlaps other threads' HIP calls faults inside this runtime: found by the full suite, reproduced by
+# tools/debug/stress_mixed.py with "commit_graph" = 2 in two seconds before the quiet section existed)
+# ---------------------------------------------------------------------------------------------
+
+def _graph_stats(api):
+    st = (C.c_uint64 * 3)()
+    api.lib.ckzg_hip_commit_graph_stats(st)
+    return list(st)
+
+
+def test_lone_commitment_goes_out_as_a_graph(hip, oracle):
+    blob = rand_blob(401, 0)
+    want = oracle.blob_to_kzg_commitment(blob)
+    before = _graph_stats(hip)
+    for _ in range(20):
+        assert hip.blob_to_kzg_commitment(blob) == want
+    after = _graph_stats(hip)
+    assert after[2] - before[2] >= 19, (before, after)       # launched as a graph (the first call may capture)
+    assert after[1] == before[1], (before, after)            # nobody else inside: no capture was put off
+    hip.lib.ckzg_hip_set_option(b"commit_graph", 0)
+    try:
+        mid = _graph_stats(hip)
+        assert hip.blob_to_kzg_commitment(blob) == want
+        assert _graph_stats(hip)[2] == mid[2]
+    finally:
+        hip.lib.ckzg_hip_set_option(b"commit_graph", 1)
+
+
+def test_captures_are_never_made_while_other_threads_are_inside(hip, oracle):
+    import threading
+    blobs = [rand_blob(402, i) for i in range(4)]
+    cm = [hip.blob_to_kzg_commitment(b) for b in blobs]
+    pr = [hip.compute_blob_kzg_proof(b, c) for b, c in zip(blobs, cm)]
+    cp = [hip.compute_cells_and_kzg_proofs(b) for b in blobs]
+    assert cm[2] == oracle.blob_to_kzg_commitment(blobs[2])
+    errs = []
+
+    def work(t, rnd):
+        try:
+            for k in range(3):
+                i = (t + k + rnd) % 4
+                kind = (t + k + rnd) % 4
+                if kind == 0 or kind == 2:
+                    ok = hip.blob_to_kzg_commitment(blobs[i]) == cm[i]
+                elif kind == 1:
+                    ok = hip.compute_cells_and_kzg_proofs(blobs[i]) == cp[i]
+                else:
+                    ok = hip.verify_blob_kzg_proof_batch(blobs, cm, pr)
+                if not ok:
+                    errs.append((t, k, kind))
+        except Exception as e:  # noqa: BLE001
+            errs.append((t, repr(e)))
+
+    hip.lib.ckzg_hip_set_option(b"commit_graph", 2)   # every commitment call that is alone captures anew
+    try:
+        before = _graph_stats(hip)
+        for rnd in range(25):
+            th = [threading.Thread(target=work, args=(t, rnd)) for t in range(12)]
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            assert not errs, errs[:4]
+            assert hip.blob_to_kzg_commitment(blobs[rnd % 4]) == cm[rnd % 4]   # alone: this one does capture
+        after = _graph_stats(hip)
+        assert after[0] - before[0] >= 25, (before, after)
+    finally:
+        hip.lib.ckzg_hip_set_option(b"commit_graph", 1)
+    assert hip.blob_to_kzg_commitment(blobs[0]) == cm[0]
