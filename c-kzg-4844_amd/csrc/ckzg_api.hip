@@ -301,6 +301,7 @@ static C_KZG_RET load_trusted_setup_file_impl(KZGSettings *out, FILE *in, uint64
 
 extern "C" C_KZG_RET load_trusted_setup_file(KZGSettings *out, FILE *in, uint64_t precompute) {
     if (out) memset(out, 0, sizeof *out);
+    if (!out || !in) return C_KZG_BADARGS;   // (the reference dereferences both)
     return guarded([&]() { return load_trusted_setup_file_impl(out, in, precompute); });
 }
 

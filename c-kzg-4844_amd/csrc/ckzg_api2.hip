@@ -1427,6 +1427,7 @@ extern "C" C_KZG_RET ckzg_hip_recover_cells_and_kzg_proofs_batch(Cell *recovered
     return guarded([&]() -> C_KZG_RET {
         if (recovered_cells == NULL && recovered_proofs == NULL) return C_KZG_BADARGS;
         if (num_cells > CELLS_PER_EXT_BLOB || num_cells < CELLS_PER_BLOB) return C_KZG_BADARGS;
+        if (cell_indices == NULL || cells == NULL) return C_KZG_BADARGS;   // (the reference dereferences both)
         for (size_t i = 0; i < num_cells; i++) {
             if (cell_indices[i] >= CELLS_PER_EXT_BLOB) return C_KZG_BADARGS;
             if (i > 0 && cell_indices[i] <= cell_indices[i - 1]) return C_KZG_BADARGS;

@@ -68,14 +68,22 @@ int main(int argc, char **argv) {
                         {
                             // the quiet section a stream capture asks for (api_common.hpp): granted only if this thread is
                             // the only one inside the library, and then nobody enters until it ends
-                            HipQuietTry quiet;
-                            if (quiet.ok) {
-                                quiet_granted.fetch_add(1, std::memory_order_relaxed);
-                                for (int probe = 0; probe < 3; probe++) {
-                                    if (in_library.load(std::memory_order_acquire) != 1) quiet_violated.fetch_add(1);
-                                    usleep(20);
+                            // (a thread that is trading its hold -- inside the constructor or destructor of HipQuietTry --
+                            // holds nothing and makes no HIP call: it does not count as inside)
+                            in_library.fetch_sub(1, std::memory_order_acq_rel);
+                            {
+                                HipQuietTry quiet;
+                                in_library.fetch_add(1, std::memory_order_acq_rel);
+                                if (quiet.ok) {
+                                    quiet_granted.fetch_add(1, std::memory_order_relaxed);
+                                    for (int probe = 0; probe < 3; probe++) {
+                                        if (in_library.load(std::memory_order_acquire) != 1) quiet_violated.fetch_add(1);
+                                        usleep(20);
+                                    }
                                 }
+                                in_library.fetch_sub(1, std::memory_order_acq_rel);
                             }
+                            in_library.fetch_add(1, std::memory_order_acq_rel);
                         }
                         usleep(120);                                // (a launch takes time: that is what lets callers queue)
                         if (kind == 0) return C_KZG_BADARGS;

@@ -99,3 +99,30 @@ def test_load_rejects_bad_arguments_before_touching_the_gpu(lib):
     assert f(C.byref(s), g1, len(g1), g1, len(g1), g2, len(g2), 16) == 1   # precompute > 15
     assert f(C.byref(s), g1, len(g1) - 48, g1, len(g1), g2, len(g2), 0) == 1  # wrong sizes
     assert f(C.byref(s), g1, len(g1), g1, len(g1), g2, len(g2), 0) == 1   # not valid encodings
+
+
+def test_null_arguments_are_rejected_not_dereferenced(lib):
+    # (the reference dereferences these; found by clang --analyze over the host side)
+    s = KZGSettings()
+    f = lib.load_trusted_setup_file
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    assert f(None, None, 0) == 1
+    assert f(C.byref(s), None, 0) == 1
+    r = lib.ckzg_hip_recover_cells_and_kzg_proofs_batch
+    r.restype = C.c_int
+    r.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+    cells = C.create_string_buffer(128 * 2048)
+    assert r(cells, None, None, None, cells, 64, 1, C.byref(s)) == 1
+    idx = (C.c_uint64 * 64)(*range(64))
+    assert r(cells, None, None, idx, None, 64, 1, C.byref(s)) == 1
+    g = lib.ckzg_hip_commit_graph_stats
+    g.restype = None
+    st = (C.c_uint64 * 3)(7, 7, 7)
+    g(None)
+    g(st)
+    assert list(st) == [0, 0, 0]
+    o = lib.ckzg_hip_set_option
+    o.restype = C.c_int
+    o.argtypes = [C.c_char_p, C.c_int64]
+    assert o(b"commit_graph", 3) == 1 and o(b"commit_graph", -1) == 1 and o(b"commit_graph", 0) == 0 and o(b"commit_graph", 1) == 0
