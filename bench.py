@@ -855,6 +855,10 @@ def main():
     hip = mod.Kzg(mod.HIP_SO, options=opts)
     returned_s = time.perf_counter() - t_load
     hip.lib.ckzg_hip_set_option(b"async_tables", 0)   # later loads of this process are ordinary ones
+    if world > 1:
+        # RCCL's watchdog thread makes HIP calls of its own; the library can keep its graph captures away from its own
+        # threads only (include/ckzg_hip.h: "commit_graph"), so a multi-rank run takes plain stream launches
+        hip.lib.ckzg_hip_set_option(b"commit_graph", 0)
     first_commitment = hip.blob_to_kzg_commitment(first_blob)
     first_commit_s = time.perf_counter() - t_load
     L = Lib(hip.lib)

@@ -82,7 +82,9 @@ extern "C" {
  *                   hipGraph (one submission instead of six; -20 us).  The capture itself (once per stream slot and table
  *                   set) is only made while no other thread is inside the library -- this HIP runtime faults when other
  *                   threads allocate or copy during a capture -- so a process that always calls from many threads at
- *                   once stays on plain stream launches.  0: plain stream launches always.  2: diagnostic, capture
+ *                   once stays on plain stream launches.  The library can only vouch for its own threads: a host
+ *                   whose OTHER components call HIP from other threads while this one calls in should set 0.
+ *                   0: plain stream launches always.  2: diagnostic, capture
  *                   anew on every call that finds the library to itself.  Takes effect immediately.
  *   "host_threads"  host threads one process of this library may keep busy per call (challenge hashing, staging copies,
  *                   point decompression at load).  0 (default): the CPUs of the process's affinity mask divided by the
