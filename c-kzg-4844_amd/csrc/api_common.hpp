@@ -89,7 +89,7 @@ extern std::atomic<int> g_verify_pipe_min, g_verify_call_table;
 // point decompression at load): the CPUs of the process's affinity mask divided by the processes that share the host.
 // Under a one-process-per-GPU launcher every rank runs the same code at the same time on the same cores -- eight
 // ranks that each size their pools by the machine would run 8 x 32 hashing threads on whatever the container
-// grants -- so the share is cpus / LOCAL_WORLD_SIZE (torchrun exports it; WORLD_SIZE otherwise, single node).  A
+// grants -- so the share is cpus / (ranks on this node).  A
 // one-process fan-out over several GPUs ("devices") shares ONE process-wide pool between its shards already.
 inline int host_thread_budget() {
     const int forced = g_host_threads.load(std::memory_order_relaxed);
@@ -104,14 +104,31 @@ inline int host_thread_budget() {
         // (A cgroup CPU quota is deliberately NOT applied: it is a budget of CPU time per 100 ms period, and a call that
         // hashes 512 MB in a 12 ms burst on 32 threads stays inside a 16-core quota -- capping the pool at 16 threads
         // made the 4096-blob verification 18.1 instead of 12.5 ms on exactly such a box.)
-        int ranks = 1;
-        for (const char *name : {"LOCAL_WORLD_SIZE", "WORLD_SIZE"}) {
+        // ranks on THIS node: only node-local variables are trusted as they are (torchrun, Open MPI, MPICH / Intel MPI,
+        // MVAPICH, Slurm).  WORLD_SIZE counts the ranks of the whole job -- 64 on an 8-node launch by mpirun / srun, which
+        // export no LOCAL_WORLD_SIZE -- so it is clamped to the GPUs this process can see (one process per GPU; 8 when
+        // the count is unknown: no node of this platform holds more).
+        auto positive = [](const char *name) -> int {
             const char *v = getenv(name);
-            if (v && *v && atoi(v) > 0) {
-                ranks = atoi(v);
-                break;
-            }
+            if (!v || !*v) return 0;
+            char *end = nullptr;
+            const long x = strtol(v, &end, 10);
+            return (end == v || x < 1 || x > 1 << 20) ? 0 : (int)x;
+        };
+        int ranks = 0;
+        for (const char *name : {"LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS", "MV2_COMM_WORLD_LOCAL_SIZE",
+                                 "SLURM_NTASKS_PER_NODE"}) {
+            if ((ranks = positive(name)) > 0) break;
         }
+        if (ranks == 0 && (ranks = positive("WORLD_SIZE")) > 0) {
+            int gpus = 0;
+            if (hipGetDeviceCount(&gpus) != hipSuccess || gpus < 1) {
+                (void)hipGetLastError();
+                gpus = 8;
+            }
+            if (ranks > gpus) ranks = gpus;
+        }
+        if (ranks < 1) ranks = 1;
         const int share = cpus / ranks;
         return share < 1 ? 1 : share;
     }();

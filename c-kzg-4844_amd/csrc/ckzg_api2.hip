@@ -392,8 +392,11 @@ constexpr uint64_t SMALL_VERIFY_N = 3;
 // (0.49 ms at n = 4096, after the last byte and before everything that needs r).
 struct TranscriptHasher {
     Sha256 h;
-    std::atomic<uint32_t> published{0};   // chunks whose download has been enqueued (its event recorded); futex word
-    std::atomic<bool> abort{false};
+    // chunks whose download has been enqueued (its event recorded); futex word.  ABORT in the same word: a separate
+    // flag checked before futex_wait could be set (and the wake sent) between the check and the wait, and the job would
+    // sleep for good with `published` unchanged -- the destructor then hangs in wait() (round-4 advisor finding).
+    std::atomic<uint32_t> published{0};
+    static constexpr uint32_t ABORT = UINT32_MAX;
     bool failed = false;
     std::atomic<uint32_t> running{0};     // 1 while the pool job has not returned; futex word
     bool on_pool = false;
@@ -409,7 +412,7 @@ struct TranscriptHasher {
         }
     }
     ~TranscriptHasher() {
-        abort.store(true);
+        published.store(ABORT, std::memory_order_release);
         futex_wake(&published, INT_MAX);   // the job may be asleep waiting for the next chunk
         wait();
     }
@@ -430,10 +433,9 @@ struct TranscriptHasher {
             for (size_t c = 0; c < nch; c++) {
                 // asleep until the caller publishes the next chunk (12 ms of a spinning pool worker per pipelined
                 // verification otherwise)
-                for (uint32_t seen; (seen = published.load(std::memory_order_acquire)) <= c;) {
-                    if (abort.load()) return;
-                    futex_wait(&published, seen);
-                }
+                uint32_t seen;
+                while ((seen = published.load(std::memory_order_acquire)) <= c) futex_wait(&published, seen);
+                if (seen == ABORT) return;   // the owner is being destroyed: nobody will ask for the digest
                 if (hipEventSynchronize(landed[c]) != hipSuccess) {
                     failed = true;
                     return;
@@ -1131,8 +1133,15 @@ extern "C" C_KZG_RET compute_blob_kzg_proof(KZGProof *out, const Blob *blob, con
             [&](const uint8_t *h_in, uint8_t *h_out, uint8_t *st, size_t n) -> C_KZG_RET {
                 Lease lease(s);
                 if (!lease.ctx) return C_KZG_ERROR;
-                return blob_proof_batch_on(lease.ctx, reinterpret_cast<KZGProof *>(h_out), st, reinterpret_cast<const Blob *>(h_in),
-                                           reinterpret_cast<const Bytes48 *>(h_in + UNITS * BYTES_PER_BLOB), n, s);
+                C_KZG_RET r = blob_proof_batch_on(lease.ctx, reinterpret_cast<KZGProof *>(h_out), st, reinterpret_cast<const Blob *>(h_in),
+                                                  reinterpret_cast<const Bytes48 *>(h_in + UNITS * BYTES_PER_BLOB), n, s);
+                // blob_proof_batch_on writes flags only on its last path, where a non-OK return is the code of a flagged
+                // unit (BADARGS, or ERROR / MALLOC from one unit's host quotient): the verdict is per unit, and the
+                // combiner demotes exactly BADARGS-with-flags to that -- an unflagged member must not inherit it
+                if (r != C_KZG_OK)
+                    for (size_t i = 0; i < n; i++)
+                        if (st[i]) return C_KZG_BADARGS;
+                return r;
             },
             [&](const uint8_t *h_out, size_t idx, size_t) { memcpy(out, h_out + idx * 48, 48); });
     });

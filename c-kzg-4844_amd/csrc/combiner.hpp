@@ -137,6 +137,7 @@ class Combiner {
                 lock.unlock();
                 C_KZG_RET r = guarded([&]() -> C_KZG_RET { return solo(); });
                 lock.lock();
+                decay_peak();   // the go-alone regime has to forget a past burst too (it runs no batch that would)
                 Batch *next = launch_done();
                 lock.unlock();
                 release(next);
@@ -149,6 +150,30 @@ class Combiner {
                 }
             }
             if (!b) {
+                if (free_list.empty() && (int)all.size() < max_active + 2 && !alloc_failed) {
+                    // A new batch needs page-locked buffers: tens of milliseconds of hipHostMalloc for the large ones.
+                    // ONE caller allocates, with the mutex released (everybody else keeps joining, running and
+                    // leaving meanwhile); callers that would need the same buffer go alone for that while, as they
+                    // would without a combiner.
+                    if (allocating) {
+                        lock.unlock();
+                        return guarded([&]() -> C_KZG_RET { return solo(); });
+                    }
+                    allocating = true;
+                    lock.unlock();
+                    Batch *nb = allocate_batch();
+                    lock.lock();
+                    allocating = false;
+                    if (nb) {
+                        all.push_back(nb);         // (capacity reserved)
+                        free_list.push_back(nb);   // (capacity reserved)
+                    } else {
+                        alloc_failed = true;       // do not try again on every call
+                        alloc_failed_now = true;
+                    }
+                    cv_pool.notify_all();
+                    if (nb) continue;   // the world has moved on meanwhile: look again (idle path, a joinable batch, ...)
+                }
                 b = fresh_batch();
                 if (b) {
                     bool queued = false;
@@ -262,13 +287,22 @@ class Combiner {
             st.batched += n;
             if (n > st.largest) st.largest = n;
             st.run_us += run_us;
-            const int now = inside.load(std::memory_order_relaxed);
-            peak = peak - peak / 8 > now ? peak - peak / 8 : now;   // forget callers that have stopped calling
+            decay_peak();
             next = launch_done();
         }
         release(next);   // the next launch starts while this one's members are being woken
         b->state.store(DONE, std::memory_order_release);
         futex_wake(&b->state, INT_MAX);
+    }
+
+    // mu held.  Forget callers that have stopped calling: an eighth per finished launch, but always at least one (an
+    // integer eighth of a peak below 8 is zero: after one burst of 4..7 callers the estimate never came down again and
+    // the `solo_below` regime was lost for the lifetime of the KZGSettings -- round-4 advisor finding), never below the
+    // number of threads inside right now.
+    void decay_peak() {
+        const int now = inside.load(std::memory_order_relaxed);
+        const int dec = peak - (peak / 8 > 1 ? peak / 8 : 1);
+        peak = dec > now ? dec : now;
     }
 
     // mu held.  A launch has ended: its place goes to the oldest open batch (returned, to be release()d once mu is
@@ -307,46 +341,42 @@ class Combiner {
         futex_wake(&nb->state, 1);
     }
 
-    // mu held.  A batch with buffers, from the free list or newly allocated; nullptr if neither is possible now.
+    // NOT under mu.  A new batch with its page-locked buffers, or nullptr.
+    Batch *allocate_batch() {
+        Batch *b = new (std::nothrow) Batch();
+        bool ok = b != nullptr;
+        // Portable: any device of a multi-device load may DMA from / into it
+        ok = ok && CKZG_COMBINER_PINNED_ALLOC(&b->h_in, in_bytes ? in_bytes : 1);
+        ok = ok && CKZG_COMBINER_PINNED_ALLOC(&b->h_out, out_bytes ? out_bytes : 1);
+        if (ok) {
+            try {
+                b->status.resize(max_batch);
+            } catch (...) {
+                ok = false;
+            }
+        }
+        if (!ok) {
+            (void)hipGetLastError();
+            if (b && b->h_in) CKZG_COMBINER_PINNED_FREE(b->h_in);
+            if (b && b->h_out) CKZG_COMBINER_PINNED_FREE(b->h_out);
+            delete b;
+            return nullptr;
+        }
+        CKZG_TSAN_NEW_MEMORY(b->h_in, in_bytes);
+        CKZG_TSAN_NEW_MEMORY(b->h_out, out_bytes);
+        return b;
+    }
+
+    // mu held.  A batch with buffers from the free list, reset; nullptr if there is none now.
     Batch *fresh_batch() {
-        Batch *b = nullptr;
-        if (!free_list.empty()) {
-            b = free_list.back();
-            free_list.pop_back();
-        } else if ((int)all.size() < max_active + 2 && !alloc_failed) {
-            b = new (std::nothrow) Batch();
-            bool ok = b != nullptr;
-            // Portable: any device of a multi-device load may DMA from / into it
-            ok = ok && CKZG_COMBINER_PINNED_ALLOC(&b->h_in, in_bytes ? in_bytes : 1);
-            ok = ok && CKZG_COMBINER_PINNED_ALLOC(&b->h_out, out_bytes ? out_bytes : 1);
-            if (ok) {
-                try {
-                    b->status.resize(max_batch);
-                } catch (...) {
-                    ok = false;
-                }
-            }
-            if (!ok) {
-                (void)hipGetLastError();
-                if (b && b->h_in) CKZG_COMBINER_PINNED_FREE(b->h_in);
-                if (b && b->h_out) CKZG_COMBINER_PINNED_FREE(b->h_out);
-                delete b;
-                b = nullptr;
-                alloc_failed = true;       // do not try again on every call
-                alloc_failed_now = true;
-            } else {
-                CKZG_TSAN_NEW_MEMORY(b->h_in, in_bytes);
-                CKZG_TSAN_NEW_MEMORY(b->h_out, out_bytes);
-                all.push_back(b);   // (capacity reserved)
-            }
-        }
-        if (b) {
-            b->n = 0;
-            b->refs.store(0, std::memory_order_relaxed);
-            b->copied.store(0, std::memory_order_relaxed);
-            b->state.store(OPEN, std::memory_order_relaxed);
-            b->ret = C_KZG_OK;
-        }
+        if (free_list.empty()) return nullptr;
+        Batch *b = free_list.back();
+        free_list.pop_back();
+        b->n = 0;
+        b->refs.store(0, std::memory_order_relaxed);
+        b->copied.store(0, std::memory_order_relaxed);
+        b->state.store(OPEN, std::memory_order_relaxed);
+        b->ret = C_KZG_OK;
         return b;
     }
 
@@ -359,7 +389,7 @@ class Combiner {
     int active = 0;                    // launches in flight (solo calls and batches)
     std::atomic<int> inside{0};        // threads inside submit()
     int peak = 0;                      // recent maximum of `inside` (decays by an eighth per batch launch)
-    bool alloc_failed = false, alloc_failed_now = false;
+    bool alloc_failed = false, alloc_failed_now = false, allocating = false;
     Stats st;
 };
 

@@ -43,6 +43,57 @@ static uint64_t mix(uint64_t x, uint64_t key) {
     return x ^ (x >> 32);
 }
 
+// After a burst of callers has gone, few callers must get the go-alone regime back (`peak` has to decay all the way:
+// an integer eighth of a peak below 8 is zero, and the round-4 combiner stayed in the batching regime for good).
+static int burst_then_few() {
+    Combiner cb(/*max_batch=*/32, /*in=*/32 * 8, /*out=*/32 * 8, /*max_active=*/2, /*solo_below=*/3);
+    auto phase = [&](int threads, int calls) {
+        std::vector<std::thread> th;
+        for (int t = 0; t < threads; t++) {
+            th.emplace_back([&, t]() {
+                for (int c = 0; c < calls; c++) {
+                    uint64_t in = (uint64_t)t * 100000 + c, out = 0;
+                    (void)guarded([&]() -> C_KZG_RET {
+                        return cb.submit(
+                            nullptr, 0,
+                            [&]() -> C_KZG_RET {
+                                usleep(50);
+                                out = mix(in, 1);
+                                return C_KZG_OK;
+                            },
+                            [&](uint8_t *h_in, size_t idx) { memcpy(h_in + idx * 8, &in, 8); },
+                            [&](const uint8_t *h_in, uint8_t *h_out, uint8_t *, size_t n) -> C_KZG_RET {
+                                for (size_t i = 0; i < n; i++) {
+                                    uint64_t v;
+                                    memcpy(&v, h_in + i * 8, 8);
+                                    v = mix(v, 1);
+                                    memcpy(h_out + i * 8, &v, 8);
+                                }
+                                usleep(60);
+                                return C_KZG_OK;
+                            },
+                            [&](const uint8_t *h_out, size_t idx, size_t) { memcpy(&out, h_out + idx * 8, 8); });
+                    });
+                    if (out != mix(in, 1)) abort();
+                }
+            });
+        }
+        for (auto &x : th) x.join();
+    };
+    phase(3, 300);
+    const Combiner::Stats s0 = cb.stats();
+    phase(6, 300);    // the burst: more callers than solo_below -> batches
+    const Combiner::Stats s1 = cb.stats();
+    phase(3, 600);    // few callers again
+    const Combiner::Stats s2 = cb.stats();
+    const uint64_t solo_fresh = s0.solo, solo_after = s2.solo - s1.solo;
+    printf("burst_then_few: fresh 3 threads %llu/900 alone; burst of 6: %llu batches; 3 threads afterwards %llu/1800 alone\n",
+           (unsigned long long)solo_fresh, (unsigned long long)(s1.batches - s0.batches), (unsigned long long)solo_after);
+    if (solo_fresh != 900) return 5;
+    if (s1.batches == s0.batches) return 5;
+    return solo_after >= 1700 ? 0 : 5;   // (the first few calls after the burst may still join a batch)
+}
+
 int main(int argc, char **argv) {
     const int threads = argc > 1 ? atoi(argv[1]) : 48, calls = argc > 2 ? atoi(argv[2]) : 400;
     std::atomic<long> wrong{0}, solos{0};
@@ -141,5 +192,6 @@ int main(int argc, char **argv) {
     printf("quiet sections: granted %ld, violated %ld\n", quiet_granted.load(), quiet_violated.load());
     if (quiet_violated.load()) return 4;
     if (threads <= 2 && quiet_granted.load() == 0) return 4;   // (with a crowd inside it may never be granted: that is the point)
-    return wrong.load() ? 1 : 0;
+    if (wrong.load()) return 1;
+    return burst_then_few();
 }

@@ -582,7 +582,15 @@ def _run_bench(extra_env, args):
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    # stdout: ONE compact line (the driver's contract, < 4 KB); the full record is one stderr line
+    out = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(out) == 1 and len(out[0]) < 4000, (len(out), [len(x) for x in out])
+    compact = json.loads(out[0])
+    full = json.loads([ln for ln in r.stderr.splitlines() if ln.startswith('{"bench_full_record"')][-1])["bench_full_record"]
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "roofline"):
+        assert compact[k] == full[k] or k == "roofline", k
+    assert compact["roofline"]["frac"] == full["roofline"]["frac"]
+    return full
 
 
 def test_bench_two_ranks_control_flow_on_one_gpu():

@@ -38,13 +38,35 @@ def test_budget_is_the_affinity_mask_without_a_launcher():
 
 def test_budget_divides_by_the_ranks_on_the_host():
     cpus, one, _, _ = _run({})
-    for world in (2, 8, 64):
+    for world in (2, 8):
         _, auto, forced, back = _run({"WORLD_SIZE": str(world)})
         assert auto == max(1, one // world), (world, one, auto)
         assert forced == 3 and back == auto      # the option overrides, 0 gives the automatic value back
     # torchrun's LOCAL_WORLD_SIZE (ranks on THIS node) wins over WORLD_SIZE (ranks of the job)
     _, auto, _, _ = _run({"WORLD_SIZE": "64", "LOCAL_WORLD_SIZE": "2"})
     assert auto == max(1, one // 2)
+    # ... and so do the node-local variables of the MPI launchers and Slurm
+    for name in ("OMPI_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS", "SLURM_NTASKS_PER_NODE"):
+        _, auto, _, _ = _run({"WORLD_SIZE": "64", name: "4"})
+        assert auto == max(1, one // 4), name
+
+
+def test_job_wide_world_size_is_clamped_to_one_node():
+    """WORLD_SIZE = 64 from mpirun / srun on 8 nodes (no LOCAL_WORLD_SIZE) must not leave each rank cpus / 64 threads:
+    at most one rank per visible GPU shares this host (8 when no GPU can be counted, as on this CPU box)."""
+    import ctypes as C
+    cpus, one, _, _ = _run({})
+    try:
+        n = C.c_int(0)
+        gpus = n.value if C.CDLL("libamdhip64.so").hipGetDeviceCount(C.byref(n)) == 0 and n.value > 0 else 8
+    except OSError:
+        gpus = 8
+    _, auto, _, _ = _run({"WORLD_SIZE": "64"})
+    assert auto == max(1, one // min(64, gpus)), (one, auto, gpus)
+    # garbage is ignored, not atoi'ed
+    for junk in ("", "abc", "-3", "0", "99999999999999999999"):
+        _, auto, _, _ = _run({"WORLD_SIZE": junk})
+        assert auto == one, junk
 
 
 def test_budget_follows_a_restricted_affinity_mask():
