@@ -763,11 +763,12 @@ def concurrency_rows(mod, hip, blobs_u8, seconds=0.4, threads=(1, 8, 32, 128, 25
         for nt in threads:
             ins = [ub[t % 32] for t in range(nt)]
             aux = [cm[t % 32] + pr[t % 32] for t in range(nt)] if op == fo.OP_VERIFY_BLOB else None
-            fo.run(hip, mod.HIP_SO, op, ins, seconds=0.1, aux=aux)   # warm-up: arenas, page-locked batch buffers
+            fo.run(hip, mod.HIP_SO, op, ins, seconds=0.2, aux=aux)   # warm-up: arenas, page-locked batch buffers
             before = fo.coalesce_stats(hip, idx)
             st, rets, _ = fo.run(hip, mod.HIP_SO, op, ins, seconds=seconds, aux=aux)
             after = fo.coalesce_stats(hip, idx)
             row = {"calls_per_s": round(st["calls_per_s"], 1), "mean_call_ms": round(st["mean_call_ms"], 3),
+                   "p50_call_ms": round(st["p50_call_ms"], 3), "p99_call_ms": round(st["p99_call_ms"], 3),
                    "worst_call_ms": round(st["worst_call_ms"], 3), "failed_calls": st["not_ok"] + sum(1 for r in rets if r != 0)}
             if before and after:
                 d = {k: after[k] - before[k] for k in ("solo", "batches", "batched", "run_us")}
@@ -927,10 +928,8 @@ def main():
     hip = mod.Kzg(mod.HIP_SO, options=opts)
     returned_s = time.perf_counter() - t_load
     hip.lib.ckzg_hip_set_option(b"async_tables", 0)   # later loads of this process are ordinary ones
-    if world > 1:
-        # RCCL's watchdog thread makes HIP calls of its own; the library can keep its graph captures away from its own
-        # threads only (include/ckzg_hip.h: "commit_graph"), so a multi-rank run takes plain stream launches
-        hip.lib.ckzg_hip_set_option(b"commit_graph", 0)
+    # (round 4 switched "commit_graph" off here for multi-rank runs: RCCL's watchdog thread makes HIP calls of its own and
+    # a stream capture could not be kept away from it.  The graph is built node by node now -- nothing to switch off.)
     first_commitment = hip.blob_to_kzg_commitment(first_blob)
     first_commit_s = time.perf_counter() - t_load
     L = Lib(hip.lib)

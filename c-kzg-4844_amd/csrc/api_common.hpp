@@ -267,57 +267,13 @@ void start_widening(const KZGSettings *s);   // "async_tables": after the warm-u
 void wait_for_tables(const KZGSettings *s);
 bool tables_ready(const KZGSettings *s);
 
-// Quiet section for hipStreamBeginCapture .. hipGraphInstantiate.  In this runtime (ROCm 7.2) a stream capture is
-// invalidated by HIP calls OTHER threads make meanwhile -- allocations, synchronous copies, first launches -- in every
-// capture mode, and the capturing thread then faults inside libamdhip64 on the graph that is no longer there
-// (tools/debug/stress_mixed.py with "commit_graph" = 2 reproduces it within seconds; profiles/r04_capture_crash.txt).
-// So every entry into the library holds this lock SHARED for as long as it may make HIP calls (guarded(), the table
-// widener, free_trusted_setup), and a capture runs only if it gets it EXCLUSIVELY without waiting: i.e. when the
-// calling thread is the only one inside the library -- the lone caller the captured graph exists for.  Otherwise the
-// call goes out as plain stream launches and a later, lonelier call captures.  Nobody ever WAITS for exclusivity, so
-// the gate cannot deadlock with slot leases or batch members waiting for each other; a thread that enters during a
-// capture waits the ~0.3 ms it takes.
-namespace detail {
-inline std::shared_mutex &hip_quiet_mu() {
-    static std::shared_mutex m;
-    return m;
-}
-inline int &hip_call_depth() {
-    static thread_local int depth = 0;
-    return depth;
-}
-}  // namespace detail
-struct HipCallScope {   // outermost scope of a thread holds the shared lock
-    HipCallScope() {
-        if (detail::hip_call_depth()++ == 0) detail::hip_quiet_mu().lock_shared();
-    }
-    ~HipCallScope() {
-        if (--detail::hip_call_depth() == 0) detail::hip_quiet_mu().unlock_shared();
-    }
-    HipCallScope(const HipCallScope &) = delete;
-    HipCallScope &operator=(const HipCallScope &) = delete;
-};
-struct HipQuietTry {    // inside a HipCallScope: trade the shared hold for the exclusive one if nobody else is inside
-    bool ok;
-    HipQuietTry() {
-        detail::hip_quiet_mu().unlock_shared();
-        ok = detail::hip_quiet_mu().try_lock();
-        if (!ok) detail::hip_quiet_mu().lock_shared();
-    }
-    ~HipQuietTry() {
-        if (ok) {
-            detail::hip_quiet_mu().unlock();
-            detail::hip_quiet_mu().lock_shared();
-        }
-    }
-    HipQuietTry(const HipQuietTry &) = delete;
-    HipQuietTry &operator=(const HipQuietTry &) = delete;
-};
+// (Round 4 kept a process-wide shared lock here -- every entry held it, a stream capture needed it exclusively --
+// because a capture on this runtime is invalidated by other threads' HIP calls.  The one graph the library uses is now
+// built node by node (msm.hip: commit_one_graph_build), which involves no capture: the lock and its quiet section are gone.)
 
 // No C++ exception may cross the C ABI (the reference returns C_KZG_MALLOC where these would throw).
 template <class F>
 C_KZG_RET guarded(F &&f) noexcept {
-    HipCallScope in_library;
     try {
         return f();
     } catch (const std::bad_alloc &) {

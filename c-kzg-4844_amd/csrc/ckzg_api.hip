@@ -25,8 +25,8 @@ static Options g_opts;
 std::atomic<int> g_gpu_sha_min{0};
 std::atomic<int> g_host_threads{0};
 std::atomic<int> g_verify_pipe_min{1024}, g_verify_call_table{1};
-static std::atomic<int> g_commit_graph{1};   // option "commit_graph": a lone one-blob commitment goes out as one captured graph
-static std::atomic<uint64_t> g_graph_stats[3];   // captures, captures skipped (library busy), graph launches
+static std::atomic<int> g_commit_graph{1};   // option "commit_graph": a lone one-blob commitment goes out as one (explicitly built) graph
+static std::atomic<uint64_t> g_graph_stats[3];   // graphs built, builds that failed (plain launches instead), graph launches
 Options options_snapshot() {
     std::lock_guard<std::mutex> lock(g_opts_mu);
     return g_opts;
@@ -75,7 +75,7 @@ extern "C" C_KZG_RET ckzg_hip_set_option(const char *key, int64_t value) {
         if (value != 0 && value != 1) return C_KZG_BADARGS;
         g_verify_call_table.store((int)value);
     } else if (!strcmp(key, "commit_graph")) {
-        if (value < 0 || value > 2) return C_KZG_BADARGS;   // (2: diagnostic -- capture anew on every call)
+        if (value < 0 || value > 2) return C_KZG_BADARGS;   // (2: diagnostic -- build the graph anew on every call)
         g_commit_graph.store((int)value);  // read at call time
     } else if (!strcmp(key, "host_threads")) {
         if (value < 0 || value > 1024) return C_KZG_BADARGS;
@@ -142,7 +142,6 @@ static C_KZG_RET compute_roots_of_unity(KZGSettings *s) {  // setup.c:99-153
 extern "C" void free_trusted_setup(KZGSettings *s) {  // setup.c:162-190
     if (s == NULL) return;
     if (s->roots_of_unity) {
-        HipCallScope in_library;   // (hipFree, stream and graph destruction: not while another thread captures)
         destroy_settings_ctx(s);   // no-op for a struct this library did not finish loading
     }
     free(s->roots_of_unity);
@@ -429,45 +428,27 @@ static C_KZG_RET commit_batch_on(dev::DeviceCtx *ctx, KZGCommitment *out, uint8_
         };
         bool launched = false;
         if (n == 1 && !pinned_io && !ctx->one_commit.unusable && g_commit_graph.load(std::memory_order_relaxed) != 0) {
-            // the reference-shaped call: its six dependent nodes go to the device as ONE captured graph
+            // the reference-shaped call: its six dependent nodes go to the device as ONE graph
             auto &g = ctx->one_commit;
             const void *key[7] = {ctx->commit.d_table, d_blobs[0].p, d_out.p, ctx->scratch.ptr, h_in, h_res,
                                   reinterpret_cast<const void *>((uintptr_t)ctx->commit.wbits)};
             bool have = g.exec && memcmp(g.key, key, sizeof key) == 0 && g_commit_graph.load(std::memory_order_relaxed) != 2;
             if (!have) {
-                // A capture needs the library to itself (api_common.hpp: HipQuietTry says why); they are rare -- once per
-                // slot and table set, again when a slot's buffers moved.  Not alone: plain launches this time.
-                HipQuietTry quiet;
-                if (!quiet.ok) {
+                // built node by node (dev::commit_one_graph_build): no stream capture, so no quiet section and nothing a
+                // HIP call of another thread -- of this library or of anything else in the process -- can invalidate.
+                // Rare: once per slot and table set, again when a slot's buffers moved.
+                g_graph_stats[0].fetch_add(1, std::memory_order_relaxed);
+                if (g.exec) (void)hipGraphExecDestroy(g.exec);
+                g.exec = nullptr;
+                const int rc = dev::commit_one_graph_build(ctx, &g.exec, d_out.p, d_status, (const uint8_t *)d_blobs[0].p, h_in, h_res);
+                if (rc != 0) {
+                    (void)hipGetLastError();
+                    g.exec = nullptr;
+                    g.unusable = true;   // plain launches from now on (rc 4: this table geometry has no raw-partials form)
                     g_graph_stats[1].fetch_add(1, std::memory_order_relaxed);
                 } else {
-                    g_graph_stats[0].fetch_add(1, std::memory_order_relaxed);
-                    if (g.exec) (void)hipGraphExecDestroy(g.exec);
-                    g.exec = nullptr;
-                    hipGraph_t graph = nullptr;
-                    // (relaxed mode: nothing in the sequence is unsafe to capture -- asynchronous copies, a memset, kernels,
-                    // event records -- and HIP users outside this library are not to be failed by our capture)
-                    bool ok = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed) == hipSuccess;
-                    const C_KZG_RET rc = ok ? enqueue_all() : C_KZG_ERROR;
-                    ok = ok && hipStreamEndCapture(ctx->stream, &graph) == hipSuccess && rc == C_KZG_OK && graph != nullptr;
-                    ok = ok && hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) == hipSuccess;
-                    if (graph) (void)hipGraphDestroy(graph);
-                    if (!ok) {
-                        // the stream must not stay in capture mode whatever went wrong
-                        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-                        if (hipStreamIsCapturing(ctx->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
-                            hipGraph_t junk = nullptr;
-                            (void)hipStreamEndCapture(ctx->stream, &junk);
-                            if (junk) (void)hipGraphDestroy(junk);
-                        }
-                        (void)hipGetLastError();
-                        if (g.exec) (void)hipGraphExecDestroy(g.exec);
-                        g.exec = nullptr;
-                        g.unusable = true;
-                    } else {
-                        memcpy(g.key, key, sizeof key);
-                        have = true;
-                    }
+                    memcpy(g.key, key, sizeof key);
+                    have = true;
                 }
             }
             if (have) {

@@ -239,6 +239,10 @@ int bad_to_status_enqueue(DeviceCtx *ctx, uint8_t *d_status, const uint32_t *d_b
 // FK20 proofs from monomial coefficients already on the device ([n][4096] Fr, Montgomery)
 int fk20_proofs_device(DeviceCtx *ctx, uint8_t *d_proofs, const Fr *d_poly_monomial, size_t n);
 void fk20_collect_times(DeviceCtx *ctx);
+// the six nodes of commit_blobs_enqueue(n = 1) between a host input and a host result buffer as an explicitly built,
+// instantiated graph (msm.hip says why not a capture); 0 ok, 4 geometry does not apply, 2 HIP error
+int commit_one_graph_build(DeviceCtx *ctx, hipGraphExec_t *exec_out, uint8_t *d_out48, uint8_t *d_status,
+                           const uint8_t *d_blob, const void *h_in, void *h_res);
 // after a synchronised commit_blobs_enqueue: its event pairs -> ctx->last_ms[0..3] (digits, accumulate, finalize, all)
 void commit_collect_times(DeviceCtx *ctx);
 // verify.hip

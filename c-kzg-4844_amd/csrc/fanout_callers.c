@@ -6,6 +6,7 @@
  *
  * Every thread owns one input and one output buffer; results of the LAST call of each thread are left in `outs`
  * so that the caller can check them against the oracle.  Return codes are counted per thread. */
+#include <math.h>
 #include <pthread.h>
 #include <stdatomic.h>
 #include <stdint.h>
@@ -16,6 +17,15 @@
 #include "ckzg.h"
 
 enum { OP_COMMIT = 0, OP_CELLS_PROOFS = 1, OP_BLOB_PROOF = 2, OP_RECOVER = 3, OP_CELLS = 4, OP_PROOFS = 5, OP_VERIFY_BLOB = 6 };
+
+#define HIST_BINS 200       /* 8 bins per octave from 1 us: bin 199 starts at ~30 s */
+static int hist_bin(double ms) {
+    const double us = ms * 1e3;
+    if (us <= 1.0) return 0;
+    int b = (int)(8.0 * log2(us));
+    return b < 0 ? 0 : (b >= HIST_BINS ? HIST_BINS - 1 : b);
+}
+static double hist_bin_upper_ms(int b) { return exp2((b + 1) / 8.0) * 1e-3; }
 
 typedef struct {
     int op, id;
@@ -29,6 +39,7 @@ typedef struct {
     int last_ret;
     double worst_ms, total_ms;
     uint64_t max_calls;       /* 0: until *stop */
+    uint32_t hist[HIST_BINS]; /* call durations, 8 bins per octave from 1 us (percentiles over all threads) */
 } Worker;
 
 static double now_ms(void) {
@@ -69,6 +80,7 @@ static void *worker_main(void *arg) {
         w->calls++;
         w->total_ms += dt;
         if (dt > w->worst_ms) w->worst_ms = dt;
+        w->hist[hist_bin(dt)]++;
         if (r != C_KZG_OK) w->not_ok++;
         w->last_ret = r;
     }
@@ -79,7 +91,9 @@ static void *worker_main(void *arg) {
  * ins: threads buffers of in_stride bytes; auxs: threads buffers of aux_stride bytes (or NULL; aux_stride 0 = one
  * shared buffer); outs: threads buffers of out_stride bytes.
  * stats[0] = calls, [1] = calls with a non-OK return, [2] = wall seconds, [3] = worst single call in ms,
- * [4] = mean call in ms; last_rets[threads] = return code of every thread's last call (may be NULL).
+ * [4] = mean call in ms, [5] / [6] / [7] = p50 / p99 / p99.9 of the call durations in ms (upper edge of the histogram
+ * bin, 8 bins per octave: +9 % at most); last_rets[threads] = return code of every thread's last call (may be NULL).
+ * `stats` must hold 8 doubles.
  * Returns 0, or -1 if the threads could not be started. */
 int callers_run(const KZGSettings *s, int op, int threads, double seconds, uint64_t max_calls, const uint8_t *ins,
                 uint64_t in_stride, const uint8_t *auxs, uint64_t aux_stride, uint64_t aux_n, uint8_t *outs,
@@ -135,6 +149,19 @@ int callers_run(const KZGSettings *s, int op, int threads, double seconds, uint6
         stats[2] = wall;
         stats[3] = worst;
         stats[4] = calls > 0 ? total / calls : 0;
+        static const double pct[3] = {0.50, 0.99, 0.999};
+        for (int k = 0; k < 3; k++) {
+            const double want = pct[k] * calls;
+            double seen = 0;
+            stats[5 + k] = 0;
+            for (int b = 0; b < HIST_BINS && calls > 0; b++) {
+                for (int i = 0; i < started; i++) seen += (double)w[i].hist[b];
+                if (seen >= want) {
+                    stats[5 + k] = hist_bin_upper_ms(b) < worst ? hist_bin_upper_ms(b) : worst;
+                    break;
+                }
+            }
+        }
     }
     free(w);
     free(th);

@@ -1043,6 +1043,98 @@ int commit_blobs_enqueue(DeviceCtx *ctx, uint8_t *d_out48, uint8_t *d_status, co
     return run_msm(ctx, t, d_out48, d_status, d_digits, d_bad, d_partials, n, ppb);
 }
 
+// The lone one-blob commitment (blob_to_kzg_commitment, eip4844.c:264-280) as an EXPLICITLY built graph: copy in,
+// flag reset, recoding, accumulate (raw partial sums), fold + finalize, copy out -- the six dependent nodes of
+// commit_blobs_enqueue(n = 1) added one by one (hipGraphAddMemcpyNode1D / MemsetNode / KernelNode) with the same
+// launch geometry and arguments.  No stream capture: a capture is invalidated (and the capturing thread faults inside
+// libamdhip64 on this runtime) by HIP calls other threads make meanwhile -- round 4 therefore captured only while the
+// calling thread was alone in the library and could not protect against HIP users outside it (RCCL's watchdog,
+// PyTorch).  Node-by-node construction touches no stream and no global capture state, so it needs no quiet section
+// and serves busy processes too.  Returns 0 and the instantiated graph, 4 if this table geometry does not take the
+// raw-partials form (the caller then keeps plain launches), 2 on a HIP error.
+int commit_one_graph_build(DeviceCtx *ctx, hipGraphExec_t *exec_out, uint8_t *d_out48, uint8_t *d_status,
+                           const uint8_t *d_blob, const void *h_in, void *h_res) {
+    const FixedBaseTable &t = ctx->commit;
+    if (!t.d_table) return 2;
+    const size_t n = 1;
+    uint32_t pairs_per_vec = (uint32_t)t.nwin * t.npoints;
+    uint32_t ppb = pick_pairs_per_block_fixed(n, pairs_per_vec);
+    uint32_t bpv = (pairs_per_vec + ppb - 1) / ppb;
+    if (!(bpv > 8 && bpv <= 512 && ppb <= 1024 && n * bpv <= 512)) return 4;   // run_msm's raw-partials condition
+    size_t dig_bytes = align_up(n * (size_t)pairs_per_vec * sizeof(int16_t), 256);
+    size_t bad_bytes = align_up(n * sizeof(uint32_t), 256);
+    if (ctx->scratch.cap < dig_bytes + bad_bytes + align_up(partials_bytes(n, bpv), 256)) return 2;
+    uint8_t *base = static_cast<uint8_t *>(ctx->scratch.ptr);
+    int16_t *d_digits = reinterpret_cast<int16_t *>(base);
+    uint32_t *d_bad = reinterpret_cast<uint32_t *>(base + dig_bytes);
+    G1XYZZ *d_partials = reinterpret_cast<G1XYZZ *>(base + dig_bytes + bad_bytes);
+    const uint32_t *d_raw = reinterpret_cast<const uint32_t *>(d_partials);
+
+    struct GraphOwner {   // destroyed on every exit path; the instantiated executable is independent of it
+        hipGraph_t g = nullptr;
+        ~GraphOwner() {
+            if (g) (void)hipGraphDestroy(g);
+        }
+    } own;
+    HIP_TRY(hipGraphCreate(&own.g, 0));
+    hipGraphNode_t n_in, n_zero, n_digits, n_acc, n_fold, n_out;
+    HIP_TRY(hipGraphAddMemcpyNode1D(&n_in, own.g, nullptr, 0, const_cast<uint8_t *>(d_blob), h_in, (size_t)N_BLOB * 32,
+                                    hipMemcpyHostToDevice));
+    hipMemsetParams zp;
+    memset(&zp, 0, sizeof zp);
+    zp.dst = d_bad;
+    zp.elementSize = 4;
+    zp.width = n;
+    zp.height = 1;
+    zp.pitch = n * 4;
+    zp.value = 0;
+    HIP_TRY(hipGraphAddMemsetNode(&n_zero, own.g, nullptr, 0, &zp));
+
+    hipKernelNodeParams kp;
+    // k_blob_digits(digits, bad, blobs, total, wbits, twin)
+    size_t total = n * N_BLOB;
+    int wbits = t.wbits, twin = t.twin;
+    const uint8_t *blob_arg = d_blob;
+    void *a_digits[] = {&d_digits, &d_bad, &blob_arg, &total, &wbits, &twin};
+    memset(&kp, 0, sizeof kp);
+    kp.func = reinterpret_cast<void *>(k_blob_digits);
+    kp.gridDim = dim3((unsigned)((total + 255) / 256));
+    kp.blockDim = dim3(256);
+    kp.kernelParams = a_digits;
+    hipGraphNode_t dep_digits[] = {n_in, n_zero};
+    HIP_TRY(hipGraphAddKernelNode(&n_digits, own.g, dep_digits, 2, &kp));
+
+    // k_msm_accumulate<256, true>(partials, table, digits, pairs_per_vec, pairs_per_block, half_shift, blocks_per_vec,
+    //                             ppv, npoints, vecs_per_group, part_stride, prio_bit)
+    const G1Affine *table = t.d_table;
+    const int16_t *digits_arg = d_digits;
+    int half_shift = t.wbits - 1;
+    uint32_t npts = (uint32_t)t.npoints, one = 1u, prio = msm_prio_bit();
+    void *a_acc[] = {&d_partials, &table, &digits_arg, &pairs_per_vec, &ppb, &half_shift, &bpv, &npts, &npts, &one, &bpv, &prio};
+    memset(&kp, 0, sizeof kp);
+    kp.func = reinterpret_cast<void *>(k_msm_accumulate<256, true>);
+    kp.gridDim = dim3((unsigned)(n * bpv));
+    kp.blockDim = dim3(256);
+    kp.kernelParams = a_acc;
+    HIP_TRY(hipGraphAddKernelNode(&n_acc, own.g, &n_digits, 1, &kp));
+
+    // k_msm_fold_finalize(out48, status, raw, bad, bpv)
+    const uint32_t *bad_arg = d_bad;
+    void *a_fold[] = {&d_out48, &d_status, &d_raw, &bad_arg, &bpv};
+    memset(&kp, 0, sizeof kp);
+    kp.func = reinterpret_cast<void *>(k_msm_fold_finalize);
+    kp.gridDim = dim3((unsigned)n);
+    kp.blockDim = dim3(FOLD_THREADS);
+    kp.kernelParams = a_fold;
+    HIP_TRY(hipGraphAddKernelNode(&n_fold, own.g, &n_acc, 1, &kp));
+
+    HIP_TRY(hipGraphAddMemcpyNode1D(&n_out, own.g, &n_fold, 1, h_res, d_out48, n * 49, hipMemcpyDeviceToHost));
+    hipGraphExec_t exec = nullptr;
+    HIP_TRY(hipGraphInstantiate(&exec, own.g, nullptr, nullptr, 0));
+    *exec_out = exec;
+    return 0;
+}
+
 // The host-pointer pipeline's form: only recoding + accumulation for a chunk of k blobs, partial sums left in
 // d_part8[blob][8] (unused slots stay all-zero = infinity; the caller zeroed the array) and the per-blob flags in
 // d_bad; ONE commit_finalize8_enqueue over the whole batch follows the last chunk.  A finalize per chunk would put

@@ -54,7 +54,7 @@ def run(kzg, libpath, op, inputs, threads=None, seconds=1.0, max_calls=0, aux=No
         auxs = C.create_string_buffer(b"".join(aux), aux_stride * threads)
     out_stride = OUT_STRIDE[op]
     outs = C.create_string_buffer(out_stride * threads)
-    stats = (C.c_double * 5)()
+    stats = (C.c_double * 8)()
     rets = (C.c_int * threads)()
     rc = lib.callers_run(C.addressof(kzg.s), op, threads, float(seconds), int(max_calls), ins, in_stride,
                          auxs, aux_stride, aux_n, outs, out_stride, stats, rets)
@@ -63,7 +63,7 @@ def run(kzg, libpath, op, inputs, threads=None, seconds=1.0, max_calls=0, aux=No
     raw = outs.raw
     st = {"threads": threads, "calls": int(stats[0]), "not_ok": int(stats[1]), "seconds": stats[2],
           "calls_per_s": stats[0] / stats[2] if stats[2] > 0 else 0.0, "worst_call_ms": stats[3],
-          "mean_call_ms": stats[4]}
+          "mean_call_ms": stats[4], "p50_call_ms": stats[5], "p99_call_ms": stats[6], "p999_call_ms": stats[7]}
     return st, list(rets), [raw[i * out_stride:(i + 1) * out_stride] for i in range(threads)]
 
 

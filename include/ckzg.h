@@ -64,9 +64,10 @@ typedef struct { ckzg_fp2_t x, y, z; } g2_t;
 
 /* ---- KZGSettings: src/setup/settings.h:27-79.  80 bytes on LP64; bindings allocate or embed it
  *      themselves, so the size and field order are ABI.  Field contents are private to the
- *      library.  The GPU context hangs off a hidden header in front of the roots_of_unity
- *      allocation, so copies/moves of the struct (Go embeds it by value, Rust moves it) keep
- *      working and no field is added. ---- */
+ *      library.  The GPU context is found through a registry keyed by the roots_of_unity
+ *      pointer (device_ctx.hip), so copies/moves of the struct (Go embeds it by value, Rust moves
+ *      it) keep working, no field is added, and a struct this library did not load is simply
+ *      not found (C_KZG_ERROR). ---- */
 typedef struct {
     fr_t *roots_of_unity;               /* w^i, i = 0..8192 */
     fr_t *brp_roots_of_unity;           /* bit-reversed, 8192 */

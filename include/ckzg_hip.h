@@ -78,18 +78,16 @@ extern "C" {
  *   "verify_call_table"  1 (default): verifications of >= 8 blobs / >= 128 cells build a fixed-base table over the
  *                   points of the call and take their sums from it; 0: ladder sums (also what a call does by itself when
  *                   the device is too full for the table).  Takes effect immediately.
- *   "commit_graph"  1 (default): a lone blob_to_kzg_commitment call submits its copies and kernels as one captured
- *                   hipGraph (one submission instead of six; -20 us).  The capture itself (once per stream slot and table
- *                   set) is only made while no other thread is inside the library -- this HIP runtime faults when other
- *                   threads allocate or copy during a capture -- so a process that always calls from many threads at
- *                   once stays on plain stream launches.  The library can only vouch for its own threads: a host
- *                   whose OTHER components call HIP from other threads while this one calls in should set 0.
- *                   0: plain stream launches always.  2: diagnostic, capture
- *                   anew on every call that finds the library to itself.  Takes effect immediately.
+ *   "commit_graph"  1 (default): a lone blob_to_kzg_commitment call submits its copies and kernels as ONE hipGraph (one
+ *                   submission instead of six; -20 us).  The graph is built node by node (hipGraphAddMemcpyNode /
+ *                   KernelNode), once per stream slot and table set -- no stream capture is involved, so HIP calls
+ *                   made meanwhile by other threads of the process (this library's or anybody else's: RCCL, PyTorch)
+ *                   cannot disturb it.  0: plain stream launches always.  2: diagnostic, build the graph anew on every
+ *                   lone call.  Takes effect immediately.
  *   "host_threads"  host threads one process of this library may keep busy per call (challenge hashing, staging copies,
  *                   point decompression at load).  0 (default): the CPUs of the process's affinity mask divided by the
- *                   processes that share the host (LOCAL_WORLD_SIZE, else WORLD_SIZE, of a one-process-per-GPU
- *                   launcher; 1 otherwise).  The helper pools are sized by it when they start (first use).
+ *                   processes that share the host (LOCAL_WORLD_SIZE or the MPI / Slurm node-local rank counts; else
+ *                   WORLD_SIZE clamped to the visible GPUs; 1 otherwise).  The helper pools are sized by it when they start (first use).
  * A width that does not fit the free HBM is narrowed at load time (ckzg_hip_table_wbits reports the result).
  * Returns C_KZG_BADARGS for an unknown key or out-of-range value. */
 C_KZG_RET ckzg_hip_set_option(const char *key, int64_t value);
@@ -98,9 +96,9 @@ C_KZG_RET ckzg_hip_set_option(const char *key, int64_t value);
  * mask / processes sharing the host, see ckzg_hip_set_option).  Needs no GPU. */
 int ckzg_hip_host_thread_budget(void);
 
-/* The captured graph of the lone one-blob blob_to_kzg_commitment call (option "commit_graph"), process-wide counts:
- * out[0] captures made, out[1] captures put off because another thread was inside the library (the call went out as
- * plain stream launches), out[2] calls launched as a graph.  Needs no GPU. */
+/* The graph of the lone one-blob blob_to_kzg_commitment call (option "commit_graph"), process-wide counts:
+ * out[0] graphs built, out[1] builds that failed (the slot stays on plain stream launches), out[2] calls launched as a
+ * graph.  Needs no GPU. */
 void ckzg_hip_commit_graph_stats(uint64_t out[3]);
 
 /* Number of visible HIP devices (0 if none / runtime missing). */

@@ -29,7 +29,6 @@ std::atomic<int> g_gpu_sha_min{0}, g_host_threads{0}, g_verify_pipe_min{1024}, g
 }  // namespace ckzg
 
 static std::atomic<int> in_library{0};
-static std::atomic<long> quiet_granted{0}, quiet_violated{0};
 struct InLibrary {   // counted strictly inside the shared hold of guarded()
     std::atomic<int> &c;
     explicit InLibrary(std::atomic<int> &c_) : c(c_) { c.fetch_add(1, std::memory_order_acq_rel); }
@@ -116,26 +115,6 @@ int main(int argc, char **argv) {
                     uint64_t out = 0;
                     auto solo = [&]() -> C_KZG_RET {
                         solos.fetch_add(1, std::memory_order_relaxed);
-                        {
-                            // the quiet section a stream capture asks for (api_common.hpp): granted only if this thread is
-                            // the only one inside the library, and then nobody enters until it ends
-                            // (a thread that is trading its hold -- inside the constructor or destructor of HipQuietTry --
-                            // holds nothing and makes no HIP call: it does not count as inside)
-                            in_library.fetch_sub(1, std::memory_order_acq_rel);
-                            {
-                                HipQuietTry quiet;
-                                in_library.fetch_add(1, std::memory_order_acq_rel);
-                                if (quiet.ok) {
-                                    quiet_granted.fetch_add(1, std::memory_order_relaxed);
-                                    for (int probe = 0; probe < 3; probe++) {
-                                        if (in_library.load(std::memory_order_acquire) != 1) quiet_violated.fetch_add(1);
-                                        usleep(20);
-                                    }
-                                }
-                                in_library.fetch_sub(1, std::memory_order_acq_rel);
-                            }
-                            in_library.fetch_add(1, std::memory_order_acq_rel);
-                        }
                         usleep(120);                                // (a launch takes time: that is what lets callers queue)
                         if (kind == 0) return C_KZG_BADARGS;
                         out = mix(in, key);
@@ -189,9 +168,6 @@ int main(int argc, char **argv) {
             return 2;
         }
     }
-    printf("quiet sections: granted %ld, violated %ld\n", quiet_granted.load(), quiet_violated.load());
-    if (quiet_violated.load()) return 4;
-    if (threads <= 2 && quiet_granted.load() == 0) return 4;   // (with a crowd inside it may never be granted: that is the point)
     if (wrong.load()) return 1;
     return burst_then_few();
 }

@@ -81,9 +81,9 @@ def test_device_entry_points_reject_pointers_that_are_not_on_their_gpu(hip, mate
 
 
 # ---------------------------------------------------------------------------------------------
-# the captured graph of the lone one-blob commitment: captures only while the library is otherwise idle
-# (a capture that overlaps other threads' HIP calls faults inside this runtime: found by the full suite, reproduced by
-# tools/debug/stress_mixed.py with "commit_graph" = 2 in two seconds before the quiet section existed)
+# the graph of the lone one-blob commitment.  Round 4 CAPTURED it, and a capture that overlaps other threads' HIP calls
+# faults inside this runtime (profiles/r04_capture_crash.txt); round 5 builds it node by node (msm.hip:
+# commit_one_graph_build), which no HIP call of any other thread -- of this library or foreign to it -- can disturb.
 # ---------------------------------------------------------------------------------------------
 
 def _graph_stats(api):
@@ -99,8 +99,8 @@ def test_lone_commitment_goes_out_as_a_graph(hip, oracle):
     for _ in range(20):
         assert hip.blob_to_kzg_commitment(blob) == want
     after = _graph_stats(hip)
-    assert after[2] - before[2] >= 19, (before, after)       # launched as a graph (the first call may capture)
-    assert after[1] == before[1], (before, after)            # nobody else inside: no capture was put off
+    assert after[2] - before[2] >= 20, (before, after)       # every call launched as a graph
+    assert after[1] == before[1], (before, after)            # no build failed
     hip.lib.ckzg_hip_set_option(b"commit_graph", 0)
     try:
         mid = _graph_stats(hip)
@@ -110,7 +110,7 @@ def test_lone_commitment_goes_out_as_a_graph(hip, oracle):
         hip.lib.ckzg_hip_set_option(b"commit_graph", 1)
 
 
-def test_captures_are_never_made_while_other_threads_are_inside(hip, oracle):
+def test_graph_builds_survive_busy_library_and_foreign_hip_threads(hip, oracle):
     import threading
     blobs = [rand_blob(402, i) for i in range(4)]
     cm = [hip.blob_to_kzg_commitment(b) for b in blobs]
@@ -135,7 +135,30 @@ def test_captures_are_never_made_while_other_threads_are_inside(hip, oracle):
         except Exception as e:  # noqa: BLE001
             errs.append((t, repr(e)))
 
-    hip.lib.ckzg_hip_set_option(b"commit_graph", 2)   # every commitment call that is alone captures anew
+    # a HIP user that is NOT this library: raw hipMalloc / hipMemcpy / hipFree from its own thread, for the whole test
+    # (what RCCL's watchdog or PyTorch's allocator are to an embedding process)
+    rt = C.CDLL("libamdhip64.so")
+    rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    rt.hipFree.argtypes = [C.c_void_p]
+    stop = threading.Event()
+    foreign = {"loops": 0, "bad": 0}
+
+    def foreign_hip_user():
+        host = C.create_string_buffer(1 << 20)
+        while not stop.is_set():
+            d = C.c_void_p()
+            if rt.hipMalloc(C.byref(d), 1 << 20) != 0:
+                foreign["bad"] += 1
+                continue
+            foreign["bad"] += rt.hipMemcpy(d, host, 1 << 20, 1) != 0      # hipMemcpyHostToDevice
+            foreign["bad"] += rt.hipMemcpy(host, d, 1 << 20, 2) != 0      # hipMemcpyDeviceToHost
+            foreign["bad"] += rt.hipFree(d) != 0
+            foreign["loops"] += 1
+
+    ft = threading.Thread(target=foreign_hip_user)
+    ft.start()
+    hip.lib.ckzg_hip_set_option(b"commit_graph", 2)   # every lone one-blob commitment builds its graph anew
     try:
         before = _graph_stats(hip)
         for rnd in range(25):
@@ -145,9 +168,14 @@ def test_captures_are_never_made_while_other_threads_are_inside(hip, oracle):
             for x in th:
                 x.join()
             assert not errs, errs[:4]
-            assert hip.blob_to_kzg_commitment(blobs[rnd % 4]) == cm[rnd % 4]   # alone: this one does capture
+            assert hip.blob_to_kzg_commitment(blobs[rnd % 4]) == cm[rnd % 4]
         after = _graph_stats(hip)
-        assert after[0] - before[0] >= 25, (before, after)
+        assert after[0] - before[0] >= 25, (before, after)     # graphs were built, also while the others were inside
+        assert after[1] == before[1], (before, after)          # and none of the builds failed
+        assert after[2] - before[2] >= 25, (before, after)
     finally:
         hip.lib.ckzg_hip_set_option(b"commit_graph", 1)
+        stop.set()
+        ft.join()
+    assert foreign["loops"] > 0 and foreign["bad"] == 0, foreign
     assert hip.blob_to_kzg_commitment(blobs[0]) == cm[0]

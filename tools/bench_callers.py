@@ -64,6 +64,8 @@ def main():
                     after = fo.coalesce_stats(k, idx)
                     row = {"op": op_name, "wide": args.wide, "coalesce_active": act, "threads": nt,
                            "calls_per_s": round(st["calls_per_s"], 1), "mean_call_ms": round(st["mean_call_ms"], 3),
+                           "p50_call_ms": round(st["p50_call_ms"], 3), "p99_call_ms": round(st["p99_call_ms"], 3),
+                           "p999_call_ms": round(st["p999_call_ms"], 3),
                            "worst_call_ms": round(st["worst_call_ms"], 3), "not_ok": st["not_ok"]}
                     if after:
                         d = {n: after[n] - before[n] for n in ("calls", "solo", "batches", "batched", "run_us", "retried")}
