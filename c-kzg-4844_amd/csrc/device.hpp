@@ -69,6 +69,7 @@ struct Arena {
         bytes += 64 * 256;
         used = 0;
         if (cap >= bytes) return true;
+        const size_t old_cap = cap;
         if (base) (void)hipFree(base);
         base = nullptr;
         cap = 0;
@@ -77,6 +78,16 @@ struct Arena {
         // gives the block back after every call (a hipMalloc + a synchronising hipFree per call: ~0.5-0.8 ms)
         const size_t slack = (bytes >> 1) < ((size_t)256 << 20) ? (bytes >> 1) : ((size_t)256 << 20);
         size_t want = bytes + slack;
+        // an arena that grows AGAIN doubles (by at most 1 GB): see scratch_reserve (msm.hip) -- every regrowth stalls the
+        // callers of a coalesced batch for a synchronising hipFree + hipMalloc
+        size_t twice = old_cap + (old_cap < ((size_t)1 << 30) ? old_cap : ((size_t)1 << 30));
+        if (twice > ((size_t)3 << 30)) twice = (size_t)3 << 30;   // (never past the size above which ArenaTrim gives the block back)
+        if (old_cap && want < twice && hipMalloc(&base, twice) == hipSuccess) {
+            cap = twice;
+            return true;
+        }
+        (void)hipGetLastError();
+        base = nullptr;
         if (hipMalloc(&base, want) != hipSuccess) {
             // Callers may treat this as "does not fit, do without" (the call-time table of a verification): the
             // runtime keeps the failure as the thread's last error until somebody reads it, and the next

@@ -1,0 +1,274 @@
+// g1_pipe.hpp -- the twiddle multiplication [k]P of the small-batch G1 FFT as a TWO-WAVE pipeline (device only).
+//
+// g1_quad.hpp's left-to-right ladder (xyzz28_mul_glv_naf_quad) is one dependent chain per point: table (15 product
+// steps), then per scalar bit a doubling (3 steps) and, at ~2/5 of the bits, a mixed addition (4 steps) INTO THE SAME
+// accumulator: ~610 dependent steps for the two 128-bit GLV halves.  A lone wave is already issue-bound on its
+// multiply-adds, so the only way to shorten the chain is to take work off it.  Right-to-left evaluation does that:
+//     B_i = 2^i P                      (128 doublings, 3 steps each: the part no algorithm can avoid)
+//     R1 = sum d1_i B_i,  R2 = sum d2_i B_i      (plain NAF digits +-1 of k1, k2; ~43 additions each)
+//     [k]P = R1 + phi(R2),  phi(X, Y, Z) = (beta X, Y, Z)
+// The additions no longer touch the doubling chain, so they run on OTHER waves of the same workgroup: the doubler
+// publishes B_i through an LDS ring at the bits where a digit is non-zero (the digit strings are those of ONE twiddle
+// per workgroup, known to every wave), one adder wave per chain consumes them (measured: with both chains on one wave
+// the 86 additions, ~8 us each with their LDS reads and sign handling, took longer than the doubler's 0.5 ms and
+// bounded the step; 43 per wave do not).  What is left after the last doubling is one addition, the hand-over of R2
+// and R1 + phi(R2): ~400 dependent steps instead of ~610.  All waves keep g1_quad.hpp's four-lanes-per-point form
+// (16 points per wave, replicated state).
+//
+// Infinity: a quad whose input is the point at infinity runs the doubler on zeros and sits out the additions
+// (predicated), so it costs nothing and cannot reach the exceptional-case fallback.
+#pragma once
+#include "g1_quad.hpp"
+
+namespace ckzg {
+namespace quad {
+
+constexpr int NAF2_LEN = 130;     // plain NAF of a value < 2^129
+constexpr int PIPE_SLOTS = 8;     // ring entries; the doubler waits when the adder is this far behind
+
+// Plain (width-2) non-adjacent form of a 128-bit k: digits in {0, +-1}, no two adjacent non-zero, density 1/3.
+HDNI inline void naf2_128(int8_t *out, const uint32_t *k) {
+    uint32_t v[5] = {k[0], k[1], k[2], k[3], 0};
+    for (int i = 0; i < NAF2_LEN; i++) {
+        int d = 0;
+        if (v[0] & 1u) {
+            d = 2 - (int)(v[0] & 3u);   // 1 -> +1, 3 -> -1
+            if (d > 0) {
+                v[0] &= ~1u;            // v -= 1 (v is odd)
+            } else {
+                uint64_t c = 1;         // v += 1
+                for (int j = 0; j < 5 && c; j++) {
+                    uint64_t t = (uint64_t)v[j] + c;
+                    v[j] = (uint32_t)t;
+                    c = t >> 32;
+                }
+            }
+        }
+        out[i] = (int8_t)d;
+        for (int j = 0; j < 4; j++) v[j] = (v[j] >> 1) | (v[j + 1] << 31);
+        v[4] >>= 1;
+    }
+}
+
+// LDS of one pipeline workgroup: the ring holds B_i as Jacobian X | Y | Z | Z^2 (14 limbs each) per quad; word w of a
+// quad's record lives at [w >> 2][quad][w & 3], so the adder's 16-byte reads are conflict-free (the four lanes of a
+// quad read one address, the 16 quads consecutive ones).
+struct PipeShared {
+    uint32_t ring[PIPE_SLOTS][14][16][4];
+    uint32_t r2[14][16][4];   // the k2 chain's sum, handed to the k1 chain's wave for R1 + phi(R2)
+    uint32_t r2inf[16];
+    uint32_t produced;        // events published by the doubler
+    uint32_t consumed[2];     // per adder wave: it needs no event below this index (signed comparison: may run ahead)
+    uint32_t r2done;
+    uint32_t pinf[16];        // input at infinity, per quad (the doubler knows; the adders need it)
+};
+
+__device__ __forceinline__ uint32_t pipe_load(uint32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void pipe_store(uint32_t *p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// highest bit position with a non-zero digit in either string (-1 if none)
+__device__ __forceinline__ int pipe_top(const int8_t *naf1, const int8_t *naf2) {
+    int top = -1;
+    for (int i = 0; i < NAF2_LEN; i++)
+        if (naf1[i] | naf2[i]) top = i;
+    return top;
+}
+
+// The doubler wave.  p: the input (replicated in the quad), quad_id 0..15, ql 0..3.
+__device__ __noinline__ void pipe_doubler(PipeShared &sh, const XYZZ28 &p, bool p_inf, const int8_t *naf1, const int8_t *naf2,
+                                          int quad_id, int ql) {
+    if (ql == 0) sh.pinf[quad_id] = p_inf ? 1u : 0u;
+    JAC28 b = jac28_from_xyzz(p);
+    F28<1, 2> zz = sqr(p.zz);   // jac28_from_xyzz takes Z = ZZ(p)
+    const int top = pipe_top(naf1, naf2);
+    uint32_t ev = 0;
+    for (int i = 0; i <= top; i++) {
+        if (naf1[i] | naf2[i]) {   // uniform over the wave: one twiddle per workgroup
+            for (;;) {   // room in the ring: both adders are past event ev - PIPE_SLOTS
+                const int c0 = (int)pipe_load(&sh.consumed[0]), c1 = (int)pipe_load(&sh.consumed[1]);
+                if ((int)ev - (c0 < c1 ? c0 : c1) < PIPE_SLOTS) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            // lane ql stores element ql of the record: X | Y | Z | Z^2
+            const auto e = qsel(ql, widen<2, 34>(b.x), widen<2, 34>(b.y), widen<2, 34>(b.z), widen<2, 34>(zz));
+            uint32_t(*slot)[16][4] = sh.ring[ev % PIPE_SLOTS];
+#pragma unroll
+            for (int j = 0; j < 14; j++) {
+                const int w = ql * 14 + j;   // (the element's base is a runtime value: plain 4-byte stores)
+                slot[w >> 2][quad_id][w & 3] = e.l[j];
+            }
+            ev++;
+            if ((threadIdx.x & 63) == 0) pipe_store(&sh.produced, ev);
+        }
+        if (i < top) jac28_dbl_quad_zz(b, zz, ql);
+    }
+}
+
+// a <- a + (+-b) for b = (bx, by, bz) Jacobian with bzz = bz^2; zz = Z(a)^2 in and out.  Four product steps (b's Z^3
+// is made in the first).  The partial sums of a NAF never meet their next term (|sum| < 2^i), so the exceptional case
+// is for the final R1 + phi(R2) only; it takes the complete one-lane routine on every copy.
+__device__ __noinline__ void jac28_add_quad_pipe(JAC28 &a, F28<1, 2> &zz, bool &ainf, const F28<1, 34> &bx,
+                                                    const F28<1, 34> &by_in, const F28<2, 4> &bz, const F28<1, 2> &bzz, bool neg,
+                                                    int ql) {
+    F28<1, 0> zero;
+#pragma unroll
+    for (int j = 0; j < 14; j++) zero.l[j] = 0;
+    F28<1, 64> by;
+    {
+        const auto ny = norm(sub(zero, by_in));   // <3,64> -> <1,64>
+#pragma unroll
+        for (int j = 0; j < 14; j++) by.l[j] = neg ? ny.l[j] : by_in.l[j];
+    }
+    if (ainf) {
+        a.x = bx;
+        a.y = widen<1, 34>(mul(by, f28_one()));
+        a.z = bz;
+        zz = bzz;
+        ainf = false;
+        return;
+    }
+    // step 1: X1*ZZ2 | X2*ZZ1 | Z2*ZZ2 | Z1*ZZ1
+    const auto p1 = mul(qsel(ql, widen<2, 34>(a.x), widen<2, 34>(bx), widen<2, 34>(bz), widen<2, 34>(a.z)),
+                        qsel(ql, bzz, zz, bzz, zz));                                  // 14*2+15 ok; 34*2 ok
+    const auto u1 = qread<0>(p1), u2 = qread<1>(p1), zzz2 = qread<2>(p1), zzz1 = qread<3>(p1);
+    const auto h = sub(u2, u1);                                                       // <4,6>
+    // step 2: Y1*ZZZ2 | Y2*ZZZ1 | Z1*Z2 | H*H
+    const auto h64 = widen<4, 64>(h);
+    const auto p2 = mul(qsel(ql, widen<4, 64>(a.y), widen<4, 64>(by), widen<4, 64>(a.z), h64),
+                        qsel(ql, widen<4, 6>(zzz2), widen<4, 6>(zzz1), widen<4, 6>(bz), h));   // 14*16+15 = 239 ok; 64*6 ok
+    const auto s1 = qread<0>(p2), s2 = qread<1>(p2), z1z2 = qread<2>(p2), hh = qread<3>(p2);
+    if (is_zero(hh)) {   // same x: the complete one-lane routine, on every copy
+        JACT28 t;
+        t.x = bx;
+        t.y = by;
+        t.z = bz;
+        t.zz = bzz;
+        t.zzz = zzz2;
+        jac28_add(a, ainf, t);
+        if (!ainf) zz = sqr(a.z);
+        return;
+    }
+    const auto r = sub(s2, s1);                                                       // <4,6>
+    // step 3: H*HH | U1*HH | R*R | Z1Z2*H
+    const auto hh46 = widen<4, 6>(hh);
+    const auto p3 = mul(qsel(ql, h, widen<4, 6>(u1), r, widen<4, 6>(z1z2)), qsel(ql, hh46, hh46, r, h));   // 239 ok; 36 ok
+    const auto hhh = qread<0>(p3), v = qread<1>(p3), rr = qread<2>(p3), z3 = qread<3>(p3);
+    const auto x3 = norm(sub(rr, add(hhh, add(v, v))));                               // <6,10> -> <1,10>
+    const auto dv = sub(v, x3);                                                       // <4,18>
+    const auto s1n = sub(zero, s1);                                                   // <4,4> = -S1
+    // step 4: R*(V - X3) | (-S1)*HHH | Z3*Z3 | (Z3*Z3)
+    const auto rn = widen<4, 6>(norm(r)), sn = widen<4, 6>(s1n), z3l = widen<4, 6>(z3);
+    const auto h18 = widen<4, 18>(hhh), z3r = widen<4, 18>(z3);
+    const auto p4 = mul(qsel(ql, rn, sn, z3l, z3l), qsel(ql, dv, h18, z3r, z3r));     // 239 ok; 108 ok
+    const auto y3 = norm(add(qread<0>(p4), qread<1>(p4)));                            // <2,4> -> <1,4>
+    a.x = widen<1, 34>(x3);
+    a.y = widen<1, 34>(y3);
+    a.z = widen<2, 4>(z3);
+    zz = qread<2>(p4);
+}
+
+// An adder wave.  chain 0 sums the k1 terms, receives the k2 chain's sum and returns [k1]P + phi([k2]P) (replicated in
+// the quad); chain 1 sums the k2 terms and hands them over (out is not written).  naf_own / naf_other: the digit
+// strings of this wave's chain and of the other one (the event numbering counts both).
+__device__ __noinline__ void pipe_adder(XYZZ28 &out, bool &out_inf, PipeShared &sh, const int8_t *naf_own, const int8_t *naf_other,
+                                        int chain, int quad_id, int ql) {
+    JAC28 r;
+    F28<1, 2> zz;
+    bool inf = true;
+    const int top = pipe_top(naf_own, naf_other);
+    uint32_t ev = 0;
+    bool p_inf = false, have_flag = false;
+    const bool leader = (threadIdx.x & 63) == 0;
+    for (int i = 0; i <= top; i++) {
+        const int d = naf_own[i], o = naf_other[i];
+        if (!(d | o)) continue;   // uniform over the wave
+        if (d) {
+            if (leader) pipe_store(&sh.consumed[chain], ev);   // nothing below this event is needed any more
+            while (pipe_load(&sh.produced) <= ev) __builtin_amdgcn_s_sleep(1);
+            if (!have_flag) {
+                p_inf = sh.pinf[quad_id] != 0;
+                have_flag = true;
+            }
+            F28<1, 34> bx, by;
+            F28<2, 4> bz;
+            F28<1, 2> bzz;
+            {
+                const uint32_t(*slot)[16][4] = sh.ring[ev % PIPE_SLOTS];
+                uint32_t w[56];
+#pragma unroll
+                for (int k4 = 0; k4 < 14; k4++) {
+                    const uint4 q = *reinterpret_cast<const uint4 *>(&slot[k4][quad_id][0]);
+                    w[4 * k4] = q.x; w[4 * k4 + 1] = q.y; w[4 * k4 + 2] = q.z; w[4 * k4 + 3] = q.w;
+                }
+#pragma unroll
+                for (int j = 0; j < 14; j++) {
+                    bx.l[j] = w[j];
+                    by.l[j] = w[14 + j];
+                    bz.l[j] = w[28 + j];
+                    bzz.l[j] = w[42 + j];
+                }
+            }
+            if (leader) pipe_store(&sh.consumed[chain], ev + 1);   // (the record is in registers)
+            // per quad: a quad without a point sits the additions out
+            if (!p_inf) jac28_add_quad_pipe(r, zz, inf, bx, by, bz, bzz, d < 0, ql);
+        }
+        ev++;
+    }
+    if (leader) pipe_store(&sh.consumed[chain], 0x3fffffffu);
+    if (!have_flag) {
+        // this chain had no term at all: the flag is there once the doubler has published anything -- or never, if the
+        // other chain is empty too (k = 0), in which case the result is infinity whatever the input
+        if (top >= 0) {
+            while (pipe_load(&sh.produced) == 0) __builtin_amdgcn_s_sleep(1);
+            p_inf = sh.pinf[quad_id] != 0;
+        } else {
+            p_inf = true;
+        }
+    }
+    if (chain == 1) {
+        // hand R2 over: X | Y | Z | Z^2, lane ql stores element ql
+        const auto e = qsel(ql, widen<2, 34>(r.x), widen<2, 34>(r.y), widen<2, 34>(r.z), widen<2, 34>(zz));
+#pragma unroll
+        for (int j = 0; j < 14; j++) {
+            const int w = ql * 14 + j;
+            sh.r2[w >> 2][quad_id][w & 3] = e.l[j];
+        }
+        if (ql == 0) sh.r2inf[quad_id] = (inf || p_inf) ? 1u : 0u;
+        if (leader) pipe_store(&sh.r2done, 1u);
+        return;
+    }
+    while (pipe_load(&sh.r2done) == 0) __builtin_amdgcn_s_sleep(1);
+    bool res_inf = true;
+    if (!p_inf) {
+        if (sh.r2inf[quad_id] == 0) {
+            F28<1, 34> bx, by;
+            F28<2, 4> bz;
+            F28<1, 2> bzz;
+            uint32_t w[56];
+#pragma unroll
+            for (int k4 = 0; k4 < 14; k4++) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(&sh.r2[k4][quad_id][0]);
+                w[4 * k4] = q.x; w[4 * k4 + 1] = q.y; w[4 * k4 + 2] = q.z; w[4 * k4 + 3] = q.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 14; j++) {
+                bx.l[j] = w[j];
+                by.l[j] = w[14 + j];
+                bz.l[j] = w[28 + j];
+                bzz.l[j] = w[42 + j];
+            }
+            bx = widen<1, 34>(mul(bx, f28_const<1, 1>(FP28_BETA_LAMBDA)));   // phi
+            jac28_add_quad_pipe(r, zz, inf, bx, by, bz, bzz, false, ql);
+        }
+        res_inf = inf;
+        if (!res_inf) out = jac28_to_xyzz(r);
+    }
+    out_inf = res_inf;
+}
+
+}  // namespace quad
+}  // namespace ckzg

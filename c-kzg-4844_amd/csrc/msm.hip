@@ -28,6 +28,11 @@ namespace dev {
 
 int scratch_reserve(DeviceCtx *ctx, size_t bytes) {
     if (ctx->scratch.cap >= bytes) return 0;
+    // A slot that has to grow AGAIN grows geometrically: coalesced batches creep upwards with the number of callers
+    // (42 -> 84 -> 160 units), and every regrowth is a device-synchronising hipFree plus a hipMalloc -- tens of
+    // milliseconds during which every caller of the slot's batch waits (the 65-70 ms worst calls of the round-4
+    // 256-caller rows).  Doubling bounds the number of such events per slot by log2(largest / first).
+    const size_t old_cap = ctx->scratch.cap;
     if (ctx->scratch.ptr) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         HIP_TRY(hipFree(ctx->scratch.ptr));
@@ -35,6 +40,10 @@ int scratch_reserve(DeviceCtx *ctx, size_t bytes) {
         ctx->scratch.cap = 0;
     }
     size_t want = bytes + (bytes >> 2);
+    if (old_cap) {
+        const size_t step = old_cap < ((size_t)2 << 30) ? old_cap : ((size_t)2 << 30);   // double, by at most 2 GB
+        if (want < old_cap + step) want = old_cap + step;
+    }
     hipError_t e = hipMalloc(&ctx->scratch.ptr, want);
     if (e != hipSuccess) {
         (void)hipGetLastError();  // the failed attempt must not surface at the next hipGetLastError()
