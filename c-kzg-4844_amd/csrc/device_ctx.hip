@@ -279,7 +279,11 @@ static void requested_widths(int out[3], const KZGSettings *s, const Options &op
     out[2] = pw;
 }
 
-static int auto_direct_max(int proof_wbits) { return proof_wbits >= 15 ? 4 : (proof_wbits >= 11 ? 3 : 2); }
+// Largest batch that takes the FFT-free direct path (fk20.hip).  Round 5's small-batch FK20 (radix-8 steps, three-wave
+// ladders) answers 2..16 blobs in 4.3-5.0 ms whatever the table, so the direct path keeps only what it still wins
+// (same box, profiles/r05_fk20_small_ab.txt): one blob always (1.76 ms on a 16-bit table, 2.99 on 8 bits), two blobs on
+// tables of >= 13 bits (3.08 ms at 16 bits against 4.3; 5.2 ms on 8 bits).
+static int auto_direct_max(int proof_wbits) { return proof_wbits >= 13 ? 2 : 1; }
 
 static C_KZG_RET build_owner(DevicePool *pool, const KZGSettings *s, const Options &opts,
                              const G1Affine *lagrange_brp_affine, const G1Affine *monomial_affine,

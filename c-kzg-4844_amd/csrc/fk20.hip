@@ -380,14 +380,13 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (ql == 0 && live) lad[(size_t)f * R4_LADDERS + ell] = xyzz28_to_xyzz(v, vi);
             return;
         }
-        quad::pipe_doubler(sh, v, vi, naf1, naf2, quad_id, ql);
+        quad::pipe_doubler(sh, v, vi, quad::naf_masks(naf1, naf2), quad_id, ql);
     } else {
         if (e == 0) return;
         XYZZ28 o;
         bool oi = true;
-        const int chain = wave - 1;
-        quad::pipe_adder(o, oi, sh, chain == 0 ? naf1 : naf2, chain == 0 ? naf2 : naf1, chain, quad_id, ql);
-        if (chain == 0 && ql == 0 && live) lad[(size_t)f * R4_LADDERS + ell] = xyzz28_to_xyzz(o, oi);
+        quad::pipe_adder(o, oi, sh, quad::naf_masks(naf1, naf2), wave - 1, quad_id, ql);
+        if (wave == 1 && ql == 0 && live) lad[(size_t)f * R4_LADDERS + ell] = xyzz28_to_xyzz(o, oi);
     }
 }
 
@@ -444,6 +443,246 @@ __global__ __launch_bounds__(64) void k_g1_fft_r4_post(G1XYZZ *out, const G1XYZZ
         dst = w == 0 ? p0 : (w == 1 ? p1 : (w == 2 ? p2 : p3));
     }
     if (ql == 0) out[(size_t)f * 128 + dst] = xyzz28_to_xyzz(r, ri);
+}
+
+// ------------------------------------------------------------------------------------------
+// Radix-8 steps for the smallest batches: THREE butterfly stages per launch pair, still one ladder deep.
+//
+// The six twiddle stages on either side of the truncation are two radix-8 steps instead of three radix-4 ones: four
+// dependent ladders for the two transforms of FK20 instead of six, for 21 ladders per 8-point group instead of
+// 2 x 5 per 2 x 4 points (+68 % ladder work -- free while the chip is mostly idle, i.e. up to 16 blobs with the
+// three-wave ladder).  With N the block size after (DIT) / before (DIF) the step, Q = N/8, E = 128/N, and the eight
+// points of a group at x_m = base + t + Q m (t < Q), sub-block c at base + c Q + t, r = bitrev3(c):
+//   DIF (stages s, s-1, s-2; N = 2^s):     out[base + c Q + t] = w^(E r t) * sum_m x_m w^(16 m r)
+//   DIT (stages s, s+1, s+2; N = 2^(s+2)): out[x_m] = sum_r w^(16 r m) * (w^(E r t) * Y_r),  Y_r = in[base + bitrev3(r) Q + t]
+// (fft.c:164-185 computes the same butterflies recursively.)  Because w^64 = -1, the products that are really needed
+// are, for both directions, L(r, j) = V(r, j) * w^(E r t + 16 r j):
+//   r = 4: j = 0;   r = 2, 6: j = 0, 1;   r odd: j = 0..3            -> 1 + 4 + 16 = 21 ladders
+//   DIF: V(4,0) = sum_m (-1)^m x_m;  V(r,j) = sum_a (-1)^a x_(j+2a) for r = 2, 6;  V(r,j) = x_j - x_(j+4) for r odd
+//        out(r=0) = sum_m x_m;  out(4) = L(4,0);  out(2|6) = L(r,0) + L(r,1);  out(r odd) = sum_j L(r,j)
+//   DIT: V(r,j) = Y_r;  out[x_m] = Y_0 + (-1)^m L(4,0) + (-1)^(m>>1) (L(2,m&1) + L(6,m&1)) + (-1)^(m>>2) sum_(r odd) L(r,m&3)
+// The input combinations are formed by the ladder's doubler wave itself (at most seven quad additions in front of
+// ~390 doubling steps); the sums around the ladders by k_g1_fft_r8_post, one quad per output point.
+// ------------------------------------------------------------------------------------------
+
+constexpr int R8_PER_GROUP = 21;
+constexpr int R8_LADDERS = 16 * R8_PER_GROUP;  // per transform and radix-8 step
+
+__device__ __forceinline__ int bitrev3(int v) { return ((v & 1) << 2) | (v & 2) | ((v >> 2) & 1); }
+
+// ladder ell (0..20) of a group -> (r, j)
+__device__ __forceinline__ void r8_ladder_rj(int ell, int &r, int &j) {
+    if (ell == 0) {
+        r = 4;
+        j = 0;
+    } else if (ell < 3) {
+        r = 2;
+        j = ell - 1;
+    } else if (ell < 5) {
+        r = 6;
+        j = ell - 3;
+    } else {
+        r = 2 * ((ell - 5) >> 2) + 1;
+        j = (ell - 5) & 3;
+    }
+}
+// index of L(r, j) in a group's 21 ladder results
+__device__ __forceinline__ int r8_ladder_index(int r, int j) {
+    if (r == 4) return 0;
+    if (r == 2) return 1 + j;
+    if (r == 6) return 3 + j;
+    return 5 + 4 * (r >> 1) + j;
+}
+// group geometry: s is the step's first stage (the highest for DIF, the lowest for DIT)
+__device__ __forceinline__ void r8_group(int grp, int s, int dif, int &t, int &base, int &Q, int &E) {
+    const int lgN = dif ? s : s + 2;
+    Q = 1 << (lgN - 3);
+    E = 128 >> lgN;
+    const int blk = grp / Q;
+    t = grp - blk * Q;
+    base = blk << lgN;
+}
+
+// G1XYZZ -> raw records (and back at the end of the last step): one lane per point
+__global__ __launch_bounds__(64) void k_g1_to_raw(uint32_t *raw, const G1XYZZ *in, size_t n) {
+    const size_t g = blockIdx.x * (size_t)64 + threadIdx.x;
+    if (g >= n) return;
+    bool inf;
+    const XYZZ28 v = xyzz28_from_xyzz(in[g], inf);
+    quad::raw_store(raw + g * quad::RAW_WORDS, v, inf);
+}
+
+__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_g1_fft_r8_ladder_pipe(
+    uint32_t *lad, const uint32_t *data, const uint32_t *roots_glv, uint32_t nfft, int s, int dif, int inverse) {
+    __shared__ quad::PipeShared sh;
+    constexpr int RW = quad::RAW_WORDS;
+    const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    const int quad_id = lane >> 2, ql = lane & 3;
+    if (threadIdx.x == 0) {
+        sh.produced = 0;
+        sh.consumed[0] = 0;
+        sh.consumed[1] = 0;
+        sh.r2done = 0;
+    }
+    __syncthreads();
+    const size_t q = blockIdx.x * (size_t)16 + quad_id;
+    const uint32_t pad = (nfft + 15u) & ~15u;
+    const uint32_t ell = (uint32_t)(q / pad);
+    uint32_t f = (uint32_t)(q - (size_t)ell * pad);
+    if (ell >= (uint32_t)R8_LADDERS) return;   // uniform over the workgroup (pad is a multiple of 16)
+    const bool live = f < nfft;
+    if (!live) f = nfft - 1;   // quads of the padding repeat the last transform
+    const int grp = (int)ell / R8_PER_GROUP;
+    int r, j, t, base, Q, E;
+    r8_ladder_rj((int)ell % R8_PER_GROUP, r, j);
+    r8_group(grp, s, dif, t, base, Q, E);
+    const int e = (E * r * t + 16 * r * j) & 127;
+    const uint32_t *rec = roots_glv + (size_t)(e == 0 ? 0 : (inverse ? 128 - e : e)) * TW_REC_WORDS;
+    const int8_t *naf1 = reinterpret_cast<const int8_t *>(rec + TW_NAF2_OFF), *naf2 = naf1 + TW_NAF2_STRIDE;
+    uint32_t *dst = lad + ((size_t)f * R8_LADDERS + ell) * RW;
+    if (wave == 0) {
+        const uint32_t *vec = data + ((size_t)f * 128 + base + t) * RW;
+        XYZZ28 v;
+        bool vi;
+        if (dif) {
+            // V(r, j): first term x_j, then alternating signs over the stride the residue class of r fixes
+            const int step = r == 4 ? 1 : ((r & 1) ? 4 : 2), terms = 8 / step;
+            v = quad::raw_load(vec + (size_t)Q * j * RW, vi);
+            for (int a = 1; a < terms; a++) {
+                bool bi;
+                const XYZZ28 b = quad::raw_load(vec + (size_t)Q * (j + step * a) * RW, bi);
+                quad::xyzz28_addsub_quad(v, vi, b, bi, (a & 1) != 0, ql);
+            }
+        } else {
+            v = quad::raw_load(vec + (size_t)Q * bitrev3(r) * RW, vi);
+        }
+        if (e == 0) {   // twiddle 1: the combination is the result, the adder waves have left already
+            if (ql == 0 && live) quad::raw_store(dst, v, vi);
+            return;
+        }
+        quad::pipe_doubler(sh, v, vi, quad::naf_masks(naf1, naf2), quad_id, ql);
+    } else {
+        if (e == 0) return;
+        XYZZ28 o;
+        bool oi = true;
+        quad::pipe_adder(o, oi, sh, quad::naf_masks(naf1, naf2), wave - 1, quad_id, ql);
+        if (wave == 1 && ql == 0 && live) quad::raw_store(dst, o, oi);
+    }
+}
+
+// one DPP quad per OUTPUT point: quad g -> (transform f, group, which of the eight outputs).  final_out: the last step
+// of the transform writes G1XYZZ for the normalisation that follows.
+__global__ __launch_bounds__(64) void k_g1_fft_r8_post(uint32_t *out, G1XYZZ *final_out, const uint32_t *data, const uint32_t *lad,
+                                                      uint32_t nfft, int s, int dif) {
+    constexpr int RW = quad::RAW_WORDS;
+    const size_t g = (blockIdx.x * (size_t)64 + threadIdx.x) >> 2;
+    const int ql = (int)(threadIdx.x & 3);
+    const uint32_t f = (uint32_t)(g >> 7);
+    if (f >= nfft) return;
+    const int grp = (int)((g >> 3) & 15), w = (int)(g & 7);
+    int t, base, Q, E;
+    r8_group(grp, s, dif, t, base, Q, E);
+    const uint32_t *vec = data + ((size_t)f * 128 + base + t) * RW, *L = lad + ((size_t)f * R8_LADDERS + grp * R8_PER_GROUP) * RW;
+    XYZZ28 acc;
+    bool ai;
+    int dst;
+    if (dif) {
+        const int r = bitrev3(w);   // w = sub-block c
+        dst = base + w * Q + t;
+        if (r == 0) {
+            acc = quad::raw_load(vec, ai);
+            for (int m = 1; m < 8; m++) {
+                bool bi;
+                const XYZZ28 b = quad::raw_load(vec + (size_t)Q * m * RW, bi);
+                quad::xyzz28_addsub_quad(acc, ai, b, bi, false, ql);
+            }
+        } else {
+            const int terms = r == 4 ? 1 : ((r & 1) ? 4 : 2);
+            acc = quad::raw_load(L + (size_t)r8_ladder_index(r, 0) * RW, ai);
+            for (int j = 1; j < terms; j++) {
+                bool bi;
+                const XYZZ28 b = quad::raw_load(L + (size_t)r8_ladder_index(r, j) * RW, bi);
+                quad::xyzz28_addsub_quad(acc, ai, b, bi, false, ql);
+            }
+        }
+    } else {
+        const int m = w;
+        dst = base + t + Q * m;
+        acc = quad::raw_load(vec, ai);   // Y_0 (bitrev3(0) = 0)
+        // the seven other terms: (ladder index, sign)
+        for (int k = 0; k < 7; k++) {
+            int idx;
+            bool neg;
+            if (k == 0) {
+                idx = 0;                                   // (-1)^m L(4,0)
+                neg = (m & 1) != 0;
+            } else if (k < 3) {
+                idx = r8_ladder_index(k == 1 ? 2 : 6, m & 1);   // (-1)^(m>>1) L(r, m&1), r = 2, 6
+                neg = ((m >> 1) & 1) != 0;
+            } else {
+                idx = r8_ladder_index(2 * (k - 3) + 1, m & 3);  // (-1)^(m>>2) L(r, m&3), r odd
+                neg = ((m >> 2) & 1) != 0;
+            }
+            bool bi;
+            const XYZZ28 b = quad::raw_load(L + (size_t)idx * RW, bi);
+            quad::xyzz28_addsub_quad(acc, ai, b, bi, neg, ql);
+        }
+    }
+    if (ql == 0) {
+        if (final_out)
+            final_out[(size_t)f * 128 + dst] = xyzz28_to_xyzz(acc, ai);
+        else
+            quad::raw_store(out + ((size_t)f * 128 + dst) * RW, acc, ai);
+    }
+}
+
+// the last DIF stage, the truncation and the first DIT stage on raw records (k_g1_fft_fold): both slots of a pair
+// receive u + v; one quad per pair
+__global__ __launch_bounds__(64) void k_g1_fft_fold_raw(uint32_t *data, size_t npairs) {
+    constexpr int RW = quad::RAW_WORDS;
+    const size_t g = (blockIdx.x * (size_t)64 + threadIdx.x) >> 2;
+    const int ql = (int)(threadIdx.x & 3);
+    if (g >= npairs) return;
+    bool ui, vi;
+    XYZZ28 u = quad::raw_load(data + 2 * g * RW, ui);
+    const XYZZ28 v = quad::raw_load(data + (2 * g + 1) * RW, vi);
+    quad::xyzz28_addsub_quad(u, ui, v, vi, false, ql);
+    if (ql == 0) {
+        quad::raw_store(data + 2 * g * RW, u, ui);
+        quad::raw_store(data + (2 * g + 1) * RW, u, ui);
+    }
+}
+
+// Both transforms of FK20 for a small batch as radix-8 steps on raw records: inverse DIF (7,6,5), (4,3,2), the fold,
+// forward DIT (2,3,4), (5,6,7).  d_u: nfft x 128 points in and out (G1XYZZ); d_a, d_b: nfft x 128 raw records;
+// d_lad: nfft x R8_LADDERS raw records.
+static int g1_fft_r8_fk20(DeviceCtx *ctx, G1XYZZ *d_u, uint32_t *d_a, uint32_t *d_b, uint32_t *d_lad, const uint32_t *d_glv,
+                          size_t nfft) {
+    const size_t pad = (nfft + 15) / 16 * 16;
+    const dim3 lgrid((unsigned)(pad * R8_LADDERS / 16)), pgrid((unsigned)(nfft * 128 * 4 / 64)), block(64);
+    hipLaunchKernelGGL(k_g1_to_raw, dim3((unsigned)((nfft * 128 + 63) / 64)), block, 0, ctx->stream, d_a, d_u, nfft * 128);
+    uint32_t *cur = d_a, *nxt = d_b;
+    auto step = [&](int s, int dif, int inverse, G1XYZZ *final_out) {
+        hipLaunchKernelGGL(k_g1_fft_r8_ladder_pipe, lgrid, dim3(192), 0, ctx->stream, d_lad, cur, d_glv, (uint32_t)nfft, s, dif, inverse);
+        hipLaunchKernelGGL(k_g1_fft_r8_post, pgrid, block, 0, ctx->stream, nxt, final_out, cur, d_lad, (uint32_t)nfft, s, dif);
+        uint32_t *x = cur;
+        cur = nxt;
+        nxt = x;
+    };
+    step(7, 1, 1, nullptr);
+    step(4, 1, 1, nullptr);
+    hipLaunchKernelGGL(k_g1_fft_fold_raw, dim3((unsigned)((nfft * 64 * 4 + 63) / 64)), block, 0, ctx->stream, cur, nfft * 64);
+    step(2, 0, 0, nullptr);
+    step(5, 0, 0, d_u);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// radix-8 triples with the three-wave ladder while its 63 workgroups of three waves per transform and step find a SIMD
+// each (same-box A/B: profiles/r05_fk20_small_ab.txt)
+static size_t r8_max_transforms() {
+    static const size_t v = (size_t)ab_knob("CKZG_HIP_R8_FFT_MAX", 16);
+    return v;
 }
 
 // a radix-4 pass over stage pairs: DIF (s_hi, s_hi-1), ..., down to s_lo; DIT (s_lo, s_lo+1), ... up to s_hi.
@@ -612,6 +851,7 @@ struct Fk20Scratch {
     Fp *prefix;        // [n][128]
     G1XYZZ *r4_tmp;    // [n][128]          (small batches: radix-4 G1 FFT steps)
     G1XYZZ *r4_lad;    // [n][R4_LADDERS]
+    uint32_t *r8_a, *r8_b, *r8_lad;   // raw records (g1_pipe.hpp): [n][128] twice, [n][R8_LADDERS] -- the smallest batches
     size_t bytes;
 };
 
@@ -629,7 +869,16 @@ static Fk20Scratch fk20_layout(uint8_t *base, size_t n, int nwin) {
     s.prefix = reinterpret_cast<Fp *>(base + off);
     off += al(n * 128 * sizeof(Fp));
     s.r4_tmp = s.r4_lad = nullptr;
-    if (n <= r4_max_transforms()) {
+    s.r8_a = s.r8_b = s.r8_lad = nullptr;
+    if (n <= r8_max_transforms()) {
+        const size_t rec = quad::RAW_WORDS * sizeof(uint32_t);
+        s.r8_a = reinterpret_cast<uint32_t *>(base + off);
+        off += al(n * 128 * rec);
+        s.r8_b = reinterpret_cast<uint32_t *>(base + off);
+        off += al(n * 128 * rec);
+        s.r8_lad = reinterpret_cast<uint32_t *>(base + off);
+        off += al(n * R8_LADDERS * rec);
+    } else if (n <= r4_max_transforms()) {
         s.r4_tmp = reinterpret_cast<G1XYZZ *>(base + off);
         off += al(n * 128 * sizeof(G1XYZZ));
         s.r4_lad = reinterpret_cast<G1XYZZ *>(base + off);
@@ -662,14 +911,20 @@ static int fk20_run(DeviceCtx *ctx, uint8_t *d_proofs, const Fr *d_poly, size_t 
     // h = IFFT(u) truncated to its first 64 entries, proofs = FFT(h) (fk20.c:257-269): inverse DIF
     // stages 7..2, the fused stage pair around the truncation, forward DIT stages 2..7
     HIP_TRY(hipEventRecord(ctx->ev[7], ctx->stream));
-    const bool r4 = s.r4_lad != nullptr;   // small batch: stage pairs with independent ladders (6 ladder depths, not 12)
-    rc = r4 ? g1_fft_r4_pairs(ctx, s.u, s.r4_tmp, s.r4_lad, d_rr, n, /*dif=*/true, 7, 2, /*inverse=*/1)
-            : g1_fft_stages(ctx, s.u, d_rr, n, /*dif=*/true, 7, 2, /*inverse=*/1);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_g1_fft_fold, dim3((unsigned)((n * 64 + 63) / 64)), dim3(64), 0, ctx->stream, s.u, n * 64);
-    rc = r4 ? g1_fft_r4_pairs(ctx, s.u, s.r4_tmp, s.r4_lad, d_rr, n, /*dif=*/false, 2, 7, /*inverse=*/0)
-            : g1_fft_stages(ctx, s.u, d_rr, n, /*dif=*/false, 2, 7, /*inverse=*/0);
-    if (rc) return rc;
+    if (s.r8_lad) {
+        // the smallest batches: stage triples on raw records (4 ladder depths)
+        rc = g1_fft_r8_fk20(ctx, s.u, s.r8_a, s.r8_b, s.r8_lad, d_rr, n);
+        if (rc) return rc;
+    } else {
+        const bool r4 = s.r4_lad != nullptr;   // small batch: stage pairs with independent ladders (6 ladder depths, not 12)
+        rc = r4 ? g1_fft_r4_pairs(ctx, s.u, s.r4_tmp, s.r4_lad, d_rr, n, /*dif=*/true, 7, 2, /*inverse=*/1)
+                : g1_fft_stages(ctx, s.u, d_rr, n, /*dif=*/true, 7, 2, /*inverse=*/1);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_g1_fft_fold, dim3((unsigned)((n * 64 + 63) / 64)), dim3(64), 0, ctx->stream, s.u, n * 64);
+        rc = r4 ? g1_fft_r4_pairs(ctx, s.u, s.r4_tmp, s.r4_lad, d_rr, n, /*dif=*/false, 2, 7, /*inverse=*/0)
+                : g1_fft_stages(ctx, s.u, d_rr, n, /*dif=*/false, 2, 7, /*inverse=*/0);
+        if (rc) return rc;
+    }
     HIP_TRY(hipEventRecord(ctx->ev[8], ctx->stream));
     rc = batch_to_affine_device(ctx, s.aff, s.u, s.prefix, n * 128);
     if (rc) return rc;

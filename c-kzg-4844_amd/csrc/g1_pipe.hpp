@@ -9,11 +9,14 @@
 //     [k]P = R1 + phi(R2),  phi(X, Y, Z) = (beta X, Y, Z)
 // The additions no longer touch the doubling chain, so they run on OTHER waves of the same workgroup: the doubler
 // publishes B_i through an LDS ring at the bits where a digit is non-zero (the digit strings are those of ONE twiddle
-// per workgroup, known to every wave), one adder wave per chain consumes them (measured: with both chains on one wave
-// the 86 additions, ~8 us each with their LDS reads and sign handling, took longer than the doubler's 0.5 ms and
-// bounded the step; 43 per wave do not).  What is left after the last doubling is one addition, the hand-over of R2
-// and R1 + phi(R2): ~400 dependent steps instead of ~610.  All waves keep g1_quad.hpp's four-lanes-per-point form
-// (16 points per wave, replicated state).
+// per workgroup, known to every wave), one adder wave per chain consumes them.  What is left after the last doubling
+// is one addition, the hand-over of R2 and R1 + phi(R2): ~400 dependent steps instead of ~610.  All waves keep
+// g1_quad.hpp's four-lanes-per-point form (16 points per wave, replicated state).
+// Measured forms (profiles/r05_fk20_small_ab.txt): both chains on ONE adder wave is bounded by that wave -- its 86
+// additions take 0.7-0.9 ms against the doubler's 0.53 (two register-resident accumulators spill) -- so each chain has
+// its own wave.  Three waves want three of a compute unit's four SIMDs: a radix-4 step of 16 transforms (160
+// workgroups on 256 units) runs at the doubler's pace, 0.53 ms; a radix-8 step (336 workgroups) has units with two
+// workgroups, where a doubler shares its SIMD with somebody's adder: 0.74 ms per step, still fewer steps in total.
 //
 // Infinity: a quad whose input is the point at infinity runs the doubler on zeros and sits out the additions
 // (predicated), so it costs nothing and cannot reach the exceptional-case fallback.
@@ -24,7 +27,7 @@ namespace ckzg {
 namespace quad {
 
 constexpr int NAF2_LEN = 130;     // plain NAF of a value < 2^129
-constexpr int PIPE_SLOTS = 8;     // ring entries; the doubler waits when the adder is this far behind
+constexpr int PIPE_SLOTS = 16;    // ring entries (events of BOTH chains); the doubler waits when an adder is this far behind
 
 // Plain (width-2) non-adjacent form of a 128-bit k: digits in {0, +-1}, no two adjacent non-zero, density 1/3.
 HDNI inline void naf2_128(int8_t *out, const uint32_t *k) {
@@ -63,6 +66,32 @@ struct PipeShared {
     uint32_t pinf[16];        // input at infinity, per quad (the doubler knows; the adders need it)
 };
 
+// The digit strings of one twiddle as bit masks in scalar registers: a per-bit byte load from memory costs a wave
+// ~0.2 us of latency, 2 x 130 times per wave.
+struct NafMasks {
+    uint64_t nz[2][3], neg[2][3];   // [chain][word]: digit non-zero / negative at bit i
+    int top;                        // highest bit with a non-zero digit in either chain (-1: none)
+};
+__device__ __forceinline__ NafMasks naf_masks(const int8_t *naf1, const int8_t *naf2) {
+    NafMasks m;
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int w = 0; w < 3; w++) m.nz[c][w] = m.neg[c][w] = 0;
+    m.top = -1;
+    for (int i = 0; i < NAF2_LEN; i++) {
+        const int d1 = naf1[i], d2 = naf2[i];
+        const uint64_t bit = 1ull << (i & 63);
+        if (d1) m.nz[0][i >> 6] |= bit;
+        if (d1 < 0) m.neg[0][i >> 6] |= bit;
+        if (d2) m.nz[1][i >> 6] |= bit;
+        if (d2 < 0) m.neg[1][i >> 6] |= bit;
+        if (d1 | d2) m.top = i;
+    }
+    return m;
+}
+__device__ __forceinline__ bool mask_bit(const uint64_t (&w)[3], int i) { return ((w[i >> 6] >> (i & 63)) & 1ull) != 0; }
+
 __device__ __forceinline__ uint32_t pipe_load(uint32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -70,24 +99,83 @@ __device__ __forceinline__ void pipe_store(uint32_t *p, uint32_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// highest bit position with a non-zero digit in either string (-1 if none)
-__device__ __forceinline__ int pipe_top(const int8_t *naf1, const int8_t *naf2) {
-    int top = -1;
-    for (int i = 0; i < NAF2_LEN; i++)
-        if (naf1[i] | naf2[i]) top = i;
-    return top;
+// ---- points between the launches of a small-batch transform: RAW records ----
+// 56 limbs of the 28-bit domain (x, y, zz, zzz of an XYZZ28) and the infinity flag, as they stand in registers.  A G1XYZZ
+// (12 x 32-bit limbs, 2^384 domain) costs four Montgomery products to read and four plus a final reduction to write --
+// per TERM of the sums around the ladders, that was a third of a radix-8 step.
+constexpr int RAW_WORDS = 57;
+
+__device__ __forceinline__ XYZZ28 raw_load(const uint32_t *p, bool &inf) {
+    XYZZ28 r;
+    uint32_t *d = reinterpret_cast<uint32_t *>(&r);
+#pragma unroll
+    for (int k = 0; k < 56; k++) d[k] = p[k];
+    inf = p[56] != 0;
+    return r;
+}
+__device__ __forceinline__ void raw_store(uint32_t *p, const XYZZ28 &v, bool inf) {
+    const uint32_t *s = reinterpret_cast<const uint32_t *>(&v);
+#pragma unroll
+    for (int k = 0; k < 56; k++) p[k] = s[k];
+    p[56] = inf ? 1u : 0u;
+}
+
+// a <- a + b or a - b: xyzz28_add_quad with the sign folded into the operand selection (xyzz28_neg costs a product)
+__device__ __forceinline__ void xyzz28_addsub_quad(XYZZ28 &a, bool &ainf, const XYZZ28 &b, bool binf, bool neg, int ql) {
+    if (binf) return;
+    F28<1, 0> zero;
+#pragma unroll
+    for (int j = 0; j < 14; j++) zero.l[j] = 0;
+    F28<1, 10> by;
+    {
+        const auto ny = norm(sub(zero, b.y));   // <3,8> -> <1,8>
+#pragma unroll
+        for (int j = 0; j < 14; j++) by.l[j] = neg ? ny.l[j] : b.y.l[j];
+    }
+    if (ainf) {
+        a = b;
+        a.y = widen<1, 6>(mul(by, f28_one()));
+        ainf = false;
+        return;
+    }
+    // step 1: X1*ZZ2 | X2*ZZ1 | Y1*ZZZ2 | Y2*ZZZ1
+    const auto p1 = mul(qsel(ql, a.x, b.x, widen<1, 10>(a.y), by), qsel(ql, b.zz, a.zz, b.zzz, a.zzz));  // 14+15 ok; 20 ok
+    const auto u1 = qread<0>(p1), u2 = qread<1>(p1), s1 = qread<2>(p1), s2 = qread<3>(p1);
+    const auto p = sub(u2, u1);   // <4,6>
+    const auto r = sub(s2, s1);   // <4,6>
+    // step 2: P*P | ZZ1*ZZ2 | ZZZ1*ZZZ2 | R*R
+    const auto zz1 = widen<4, 6>(a.zz), zz2 = widen<4, 6>(b.zz), zzz1 = widen<4, 6>(a.zzz), zzz2 = widen<4, 6>(b.zzz);
+    const auto p2 = mul(qsel(ql, p, zz1, zzz1, r), qsel(ql, p, zz2, zzz2, r));   // 14*16+15 = 239 ok; 36 ok
+    const auto pp = qread<0>(p2), zzab = qread<1>(p2), zzzab = qread<2>(p2), rr = qread<3>(p2);
+    if (is_zero(pp)) {  // same x: the complete one-lane routine, on every copy
+        xyzz28_add(a, ainf, neg ? xyzz28_neg(b) : b, binf);
+        return;
+    }
+    // step 3: P*PP | U1*PP | ZZ1ZZ2*PP
+    const auto p3 = mul(qsel(ql, p, widen<4, 6>(u1), widen<4, 6>(zzab), p), pp);   // 14*4+15 ok; 12 ok
+    const auto ppp = qread<0>(p3), q = qread<1>(p3), zz3 = qread<2>(p3);
+    const auto x3 = norm(sub(rr, add(ppp, add(q, q))));   // <6,10> -> <1,10>
+    const auto d = sub(q, x3);                            // <4,18>
+    const auto s1n = sub(zero, s1);                       // <4,4> = -S1
+    // step 4: R*(Q - X3) | (-S1)*PPP | ZZZ1ZZZ2*PPP ; Y3 is the sum of the first two
+    const auto rn = widen<4, 6>(norm(r)), sn = widen<4, 6>(s1n), zn = widen<4, 6>(zzzab);
+    const auto ppp18 = widen<4, 18>(ppp);
+    const auto p4 = mul(qsel(ql, rn, sn, zn, rn), qsel(ql, d, ppp18, ppp18, d));   // 239 ok; 108 ok
+    const auto y3 = norm(add(qread<0>(p4), qread<1>(p4)));   // <2,4> -> <1,4>
+    a.x = x3;
+    a.y = widen<1, 6>(y3);
+    a.zz = zz3;
+    a.zzz = qread<2>(p4);
 }
 
 // The doubler wave.  p: the input (replicated in the quad), quad_id 0..15, ql 0..3.
-__device__ __noinline__ void pipe_doubler(PipeShared &sh, const XYZZ28 &p, bool p_inf, const int8_t *naf1, const int8_t *naf2,
-                                          int quad_id, int ql) {
+__device__ __noinline__ void pipe_doubler(PipeShared &sh, const XYZZ28 &p, bool p_inf, const NafMasks &m, int quad_id, int ql) {
     if (ql == 0) sh.pinf[quad_id] = p_inf ? 1u : 0u;
     JAC28 b = jac28_from_xyzz(p);
     F28<1, 2> zz = sqr(p.zz);   // jac28_from_xyzz takes Z = ZZ(p)
-    const int top = pipe_top(naf1, naf2);
     uint32_t ev = 0;
-    for (int i = 0; i <= top; i++) {
-        if (naf1[i] | naf2[i]) {   // uniform over the wave: one twiddle per workgroup
+    for (int i = 0; i <= m.top; i++) {
+        if (mask_bit(m.nz[0], i) || mask_bit(m.nz[1], i)) {   // uniform over the wave: one twiddle per workgroup
             for (;;) {   // room in the ring: both adders are past event ev - PIPE_SLOTS
                 const int c0 = (int)pipe_load(&sh.consumed[0]), c1 = (int)pipe_load(&sh.consumed[1]);
                 if ((int)ev - (c0 < c1 ? c0 : c1) < PIPE_SLOTS) break;
@@ -104,14 +192,14 @@ __device__ __noinline__ void pipe_doubler(PipeShared &sh, const XYZZ28 &p, bool 
             ev++;
             if ((threadIdx.x & 63) == 0) pipe_store(&sh.produced, ev);
         }
-        if (i < top) jac28_dbl_quad_zz(b, zz, ql);
+        if (i < m.top) jac28_dbl_quad_zz(b, zz, ql);
     }
 }
 
 // a <- a + (+-b) for b = (bx, by, bz) Jacobian with bzz = bz^2; zz = Z(a)^2 in and out.  Four product steps (b's Z^3
 // is made in the first).  The partial sums of a NAF never meet their next term (|sum| < 2^i), so the exceptional case
 // is for the final R1 + phi(R2) only; it takes the complete one-lane routine on every copy.
-__device__ __noinline__ void jac28_add_quad_pipe(JAC28 &a, F28<1, 2> &zz, bool &ainf, const F28<1, 34> &bx,
+__device__ __forceinline__ void jac28_add_quad_pipe(JAC28 &a, F28<1, 2> &zz, bool &ainf, const F28<1, 34> &bx,
                                                     const F28<1, 34> &by_in, const F28<2, 4> &bz, const F28<1, 2> &bzz, bool neg,
                                                     int ql) {
     F28<1, 0> zero;
@@ -172,64 +260,79 @@ __device__ __noinline__ void jac28_add_quad_pipe(JAC28 &a, F28<1, 2> &zz, bool &
 }
 
 // An adder wave.  chain 0 sums the k1 terms, receives the k2 chain's sum and returns [k1]P + phi([k2]P) (replicated in
-// the quad); chain 1 sums the k2 terms and hands them over (out is not written).  naf_own / naf_other: the digit
-// strings of this wave's chain and of the other one (the event numbering counts both).
-__device__ __noinline__ void pipe_adder(XYZZ28 &out, bool &out_inf, PipeShared &sh, const int8_t *naf_own, const int8_t *naf_other,
-                                        int chain, int quad_id, int ql) {
+// the quad); chain 1 sums the k2 terms and hands them over (out is not written).  The hand-over is the last pass of
+// the SAME loop, so that the addition has one call site: it is ~16 KB of code (two copies and the doubler's loop no
+// longer share the instruction cache), and as a called function its operands went through scratch memory.
+__device__ __noinline__ void pipe_adder(XYZZ28 &out, bool &out_inf, PipeShared &sh, const NafMasks &m, int chain, int quad_id,
+                                        int ql) {
     JAC28 r;
     F28<1, 2> zz;
     bool inf = true;
-    const int top = pipe_top(naf_own, naf_other);
     uint32_t ev = 0;
-    bool p_inf = false, have_flag = false;
+    bool p_inf = m.top < 0, have_flag = m.top < 0;   // k = 0: infinity whatever the input
     const bool leader = (threadIdx.x & 63) == 0;
-    for (int i = 0; i <= top; i++) {
-        const int d = naf_own[i], o = naf_other[i];
-        if (!(d | o)) continue;   // uniform over the wave
-        if (d) {
+    const uint64_t(&own_nz)[3] = chain ? m.nz[1] : m.nz[0];
+    const uint64_t(&own_neg)[3] = chain ? m.neg[1] : m.neg[0];
+    const uint64_t(&other_nz)[3] = chain ? m.nz[0] : m.nz[1];
+    for (int i = 0; i <= m.top + 1; i++) {
+        const bool closing = i == m.top + 1;
+        const uint32_t(*rec)[16][4];
+        if (!closing) {
+            const bool own = mask_bit(own_nz, i);
+            if (!(own || mask_bit(other_nz, i))) continue;   // uniform over the wave
+            if (!own) {
+                ev++;
+                continue;
+            }
             if (leader) pipe_store(&sh.consumed[chain], ev);   // nothing below this event is needed any more
             while (pipe_load(&sh.produced) <= ev) __builtin_amdgcn_s_sleep(1);
-            if (!have_flag) {
-                p_inf = sh.pinf[quad_id] != 0;
-                have_flag = true;
-            }
-            F28<1, 34> bx, by;
-            F28<2, 4> bz;
-            F28<1, 2> bzz;
-            {
-                const uint32_t(*slot)[16][4] = sh.ring[ev % PIPE_SLOTS];
-                uint32_t w[56];
-#pragma unroll
-                for (int k4 = 0; k4 < 14; k4++) {
-                    const uint4 q = *reinterpret_cast<const uint4 *>(&slot[k4][quad_id][0]);
-                    w[4 * k4] = q.x; w[4 * k4 + 1] = q.y; w[4 * k4 + 2] = q.z; w[4 * k4 + 3] = q.w;
-                }
-#pragma unroll
-                for (int j = 0; j < 14; j++) {
-                    bx.l[j] = w[j];
-                    by.l[j] = w[14 + j];
-                    bz.l[j] = w[28 + j];
-                    bzz.l[j] = w[42 + j];
-                }
-            }
-            if (leader) pipe_store(&sh.consumed[chain], ev + 1);   // (the record is in registers)
-            // per quad: a quad without a point sits the additions out
-            if (!p_inf) jac28_add_quad_pipe(r, zz, inf, bx, by, bz, bzz, d < 0, ql);
+            rec = sh.ring[ev % PIPE_SLOTS];
+        } else {
+            if (leader) pipe_store(&sh.consumed[chain], 0x3fffffffu);
+            if (chain == 1) break;
+            while (pipe_load(&sh.r2done) == 0) __builtin_amdgcn_s_sleep(1);
+            rec = sh.r2;
         }
-        ev++;
-    }
-    if (leader) pipe_store(&sh.consumed[chain], 0x3fffffffu);
-    if (!have_flag) {
-        // this chain had no term at all: the flag is there once the doubler has published anything -- or never, if the
-        // other chain is empty too (k = 0), in which case the result is infinity whatever the input
-        if (top >= 0) {
+        if (!have_flag) {
+            // (a chain without a term of its own gets here at the hand-over; the doubler has published by then)
             while (pipe_load(&sh.produced) == 0) __builtin_amdgcn_s_sleep(1);
             p_inf = sh.pinf[quad_id] != 0;
-        } else {
-            p_inf = true;
+            have_flag = true;
         }
+        F28<1, 34> bx, by;
+        F28<2, 4> bz;
+        F28<1, 2> bzz;
+        {
+            uint32_t w[56];
+#pragma unroll
+            for (int k4 = 0; k4 < 14; k4++) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(&rec[k4][quad_id][0]);
+                w[4 * k4] = q.x; w[4 * k4 + 1] = q.y; w[4 * k4 + 2] = q.z; w[4 * k4 + 3] = q.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 14; j++) {
+                bx.l[j] = w[j];
+                by.l[j] = w[14 + j];
+                bz.l[j] = w[28 + j];
+                bzz.l[j] = w[42 + j];
+            }
+        }
+        bool skip = p_inf, neg = false;   // per quad: a quad without a point sits the additions out
+        if (!closing) {
+            if (leader) pipe_store(&sh.consumed[chain], ev + 1);   // (the record is in registers)
+            ev++;
+            neg = mask_bit(own_neg, i);
+        } else {
+            skip = skip || sh.r2inf[quad_id] != 0;
+            bx = widen<1, 34>(mul(bx, f28_const<1, 1>(FP28_BETA_LAMBDA)));   // phi
+        }
+        if (!skip) jac28_add_quad_pipe(r, zz, inf, bx, by, bz, bzz, neg, ql);
     }
     if (chain == 1) {
+        if (!have_flag) {   // the k2 chain had no term: its flag comes with the first event, which exists (top >= 0 here)
+            while (pipe_load(&sh.produced) == 0) __builtin_amdgcn_s_sleep(1);
+            p_inf = sh.pinf[quad_id] != 0;
+        }
         // hand R2 over: X | Y | Z | Z^2, lane ql stores element ql
         const auto e = qsel(ql, widen<2, 34>(r.x), widen<2, 34>(r.y), widen<2, 34>(r.z), widen<2, 34>(zz));
 #pragma unroll
@@ -241,32 +344,8 @@ __device__ __noinline__ void pipe_adder(XYZZ28 &out, bool &out_inf, PipeShared &
         if (leader) pipe_store(&sh.r2done, 1u);
         return;
     }
-    while (pipe_load(&sh.r2done) == 0) __builtin_amdgcn_s_sleep(1);
-    bool res_inf = true;
-    if (!p_inf) {
-        if (sh.r2inf[quad_id] == 0) {
-            F28<1, 34> bx, by;
-            F28<2, 4> bz;
-            F28<1, 2> bzz;
-            uint32_t w[56];
-#pragma unroll
-            for (int k4 = 0; k4 < 14; k4++) {
-                const uint4 q = *reinterpret_cast<const uint4 *>(&sh.r2[k4][quad_id][0]);
-                w[4 * k4] = q.x; w[4 * k4 + 1] = q.y; w[4 * k4 + 2] = q.z; w[4 * k4 + 3] = q.w;
-            }
-#pragma unroll
-            for (int j = 0; j < 14; j++) {
-                bx.l[j] = w[j];
-                by.l[j] = w[14 + j];
-                bz.l[j] = w[28 + j];
-                bzz.l[j] = w[42 + j];
-            }
-            bx = widen<1, 34>(mul(bx, f28_const<1, 1>(FP28_BETA_LAMBDA)));   // phi
-            jac28_add_quad_pipe(r, zz, inf, bx, by, bz, bzz, false, ql);
-        }
-        res_inf = inf;
-        if (!res_inf) out = jac28_to_xyzz(r);
-    }
+    const bool res_inf = p_inf || inf;
+    if (!res_inf) out = jac28_to_xyzz(r);
     out_inf = res_inf;
 }
 

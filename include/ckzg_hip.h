@@ -44,9 +44,9 @@ extern "C" {
  *   "proof_wbits"   window width of the table over the 4096 monomial points used by the low-latency
  *                   (no G1 FFT) cell-proof path; default 8 (0.8 GB), 0 disables the path
  *   "direct_max"    largest batch that takes the low-latency proof path; larger batches use FK20, which
- *                   does ~10x fewer point additions but costs ~6 ms for any small batch (6 dependent
- *                   ladder launches).  -1 (default): 2 / 3 / 4 blobs for a proof table of <= 10 / <= 14 /
- *                   >= 15 bits, the measured hand-over points; 0 disables the path
+ *                   does ~10x fewer point additions but costs ~4.3 ms for any small batch (4 dependent
+ *                   ladder launches).  -1 (default): 1 blob, 2 blobs for a proof table of >= 13 bits, the
+ *                   measured hand-over points; 0 disables the path
  *   "async_tables"  1: progressive widening.  load_trusted_setup builds the tables at the library's default widths
  *                   (10 / 8 / 8 bits: ~0.4 s) and returns a fully working KZGSettings; a background thread then builds
  *                   the requested wider tables one at a time (commitment, proof, FK20) and publishes each when it is

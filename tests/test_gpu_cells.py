@@ -79,7 +79,7 @@ def test_direct_and_fk20_paths_agree(hip, hip_fk20):
 
 
 def test_large_batch_takes_fk20_and_16_lane_msm_path(hip):
-    # 40 blobs > direct_max (10 with the default 8-bit proof table): FK20 path with 5120 small MSMs ->
+    # 40 blobs > direct_max: FK20 path (one-lane radix-4 G1 FFT steps at this size) with 5120 small MSMs ->
     # the 16-lanes-per-vector kernel
     n = 40
     base = [rand_blob(32, i) for i in range(4)]
@@ -96,3 +96,29 @@ def test_large_batch_takes_fk20_and_16_lane_msm_path(hip):
         c, p = single[i % 4]
         assert b"".join(c) == cells.raw[i * 128 * 2048:(i + 1) * 128 * 2048]
         assert b"".join(p) == proofs.raw[i * 128 * 48:(i + 1) * 128 * 48]
+
+
+@pytest.mark.parametrize("n", [2, 3, 5, 9, 16, 17, 24, 32, 33])
+def test_small_batches_take_every_g1_fft_form(hip, oracle, n):
+    """The two G1 transforms of FK20 have four forms by batch size (fk20.hip): radix-8 steps on raw records with the
+    three-wave ladder (<= 16 blobs), radix-4 steps with the three-wave ladder (<= 32), radix-4 steps with the one-wave
+    quad ladder (<= 128), radix-2 stages beyond.  Every form against the one-blob path (itself checked against the
+    oracle on every vector), one blob of each batch against the oracle directly; a zero blob (all proofs at infinity:
+    every ladder input is the point at infinity) and a constant polynomial ride along."""
+    base = [rand_blob(77, i) for i in range(3)] + [bytes(131072), (b"\x00" * 31 + b"\x07") * 4096]
+    blobs = [base[i % 5] for i in range(n)]
+    cells = C.create_string_buffer(n * 128 * 2048)
+    proofs = C.create_string_buffer(n * 128 * 48)
+    status = C.create_string_buffer(n)
+    f = hip.lib.ckzg_hip_compute_cells_and_kzg_proofs_batch
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p]
+    assert f(cells, proofs, status, b"".join(blobs), n, C.addressof(hip.s)) == 0
+    assert status.raw == bytes(n)
+    single = [hip.compute_cells_and_kzg_proofs(b) for b in base]
+    for i in range(n):
+        c, p = single[i % 5]
+        assert b"".join(c) == cells.raw[i * 128 * 2048:(i + 1) * 128 * 2048], i
+        assert b"".join(p) == proofs.raw[i * 128 * 48:(i + 1) * 128 * 48], i
+    ec, ep = oracle.compute_cells_and_kzg_proofs(base[1])
+    assert b"".join(ep) == proofs.raw[128 * 48:2 * 128 * 48] and b"".join(ec) == cells.raw[128 * 2048:2 * 128 * 2048]
