@@ -570,6 +570,49 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// The same radix-8 ladders on ONE wave per 16 ladders (g1_quad.hpp's left-to-right ladder): for batches whose
+// three-wave workgroups would no longer find a SIMD per wave (17 blobs upwards) the shorter chain of the pipeline is
+// lost to sharing, but four ladder depths instead of six are not.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_g1_fft_r8_ladder(
+    uint32_t *lad, const uint32_t *data, const uint32_t *roots_glv, uint32_t nfft, int s, int dif, int inverse) {
+    constexpr int RW = quad::RAW_WORDS;
+    const size_t q = (blockIdx.x * (size_t)64 + threadIdx.x) >> 2;
+    const int ql = (int)(threadIdx.x & 3);
+    const uint32_t pad = (nfft + 15u) & ~15u;
+    const uint32_t ell = (uint32_t)(q / pad);
+    uint32_t f = (uint32_t)(q - (size_t)ell * pad);
+    if (ell >= (uint32_t)R8_LADDERS) return;
+    const bool live = f < nfft;
+    if (!live) f = nfft - 1;   // quads of the padding repeat the last transform
+    const int grp = (int)ell / R8_PER_GROUP;
+    int r, j, t, base, Q, E;
+    r8_ladder_rj((int)ell % R8_PER_GROUP, r, j);
+    r8_group(grp, s, dif, t, base, Q, E);
+    const int e = (E * r * t + 16 * r * j) & 127;
+    const uint32_t *vec = data + ((size_t)f * 128 + base + t) * RW;
+    XYZZ28 v;
+    bool vi;
+    if (dif) {
+        const int step = r == 4 ? 1 : ((r & 1) ? 4 : 2), terms = 8 / step;
+        v = quad::raw_load(vec + (size_t)Q * j * RW, vi);
+        for (int a = 1; a < terms; a++) {
+            bool bi;
+            const XYZZ28 b = quad::raw_load(vec + (size_t)Q * (j + step * a) * RW, bi);
+            quad::xyzz28_addsub_quad(v, vi, b, bi, (a & 1) != 0, ql);
+        }
+    } else {
+        v = quad::raw_load(vec + (size_t)Q * bitrev3(r) * RW, vi);
+    }
+    XYZZ28 o = v;
+    bool oi = vi;
+    if (e != 0) {
+        const uint32_t *rec = roots_glv + (size_t)(inverse ? 128 - e : e) * TW_REC_WORDS;
+        const int8_t *naf = reinterpret_cast<const int8_t *>(rec + 8);
+        quad::xyzz28_mul_glv_naf_quad(o, oi, v, vi, naf, naf + GLV_NAF_LEN, ql);
+    }
+    if (ql == 0 && live) quad::raw_store(lad + ((size_t)f * R8_LADDERS + ell) * RW, o, oi);
+}
+
 // one DPP quad per OUTPUT point: quad g -> (transform f, group, which of the eight outputs).  final_out: the last step
 // of the transform writes G1XYZZ for the normalisation that follows.
 __global__ __launch_bounds__(64) void k_g1_fft_r8_post(uint32_t *out, G1XYZZ *final_out, const uint32_t *data, const uint32_t *lad,
@@ -653,6 +696,18 @@ __global__ __launch_bounds__(64) void k_g1_fft_fold_raw(uint32_t *data, size_t n
     }
 }
 
+// Hand-over points (same-box A/Bs: profiles/r05_fk20_small_ab.txt).  Three-wave ladders while their 21 workgroups per
+// transform and step mostly find a SIMD per wave (<= 16 transforms: 336 workgroups); radix-8 steps with the one-wave
+// ladder while a step's waves fit the chip about once (<= 48 transforms: 1008 waves); radix-4 / radix-2 beyond.
+static size_t r8_pipe_max_transforms() {
+    static const size_t v = (size_t)ab_knob("CKZG_HIP_R8_PIPE_MAX", 16);
+    return v;
+}
+static size_t r8_max_transforms() {
+    static const size_t v = (size_t)ab_knob("CKZG_HIP_R8_FFT_MAX", 48);
+    return v;
+}
+
 // Both transforms of FK20 for a small batch as radix-8 steps on raw records: inverse DIF (7,6,5), (4,3,2), the fold,
 // forward DIT (2,3,4), (5,6,7).  d_u: nfft x 128 points in and out (G1XYZZ); d_a, d_b: nfft x 128 raw records;
 // d_lad: nfft x R8_LADDERS raw records.
@@ -662,8 +717,13 @@ static int g1_fft_r8_fk20(DeviceCtx *ctx, G1XYZZ *d_u, uint32_t *d_a, uint32_t *
     const dim3 lgrid((unsigned)(pad * R8_LADDERS / 16)), pgrid((unsigned)(nfft * 128 * 4 / 64)), block(64);
     hipLaunchKernelGGL(k_g1_to_raw, dim3((unsigned)((nfft * 128 + 63) / 64)), block, 0, ctx->stream, d_a, d_u, nfft * 128);
     uint32_t *cur = d_a, *nxt = d_b;
+    const bool pipe = nfft <= r8_pipe_max_transforms();
     auto step = [&](int s, int dif, int inverse, G1XYZZ *final_out) {
-        hipLaunchKernelGGL(k_g1_fft_r8_ladder_pipe, lgrid, dim3(192), 0, ctx->stream, d_lad, cur, d_glv, (uint32_t)nfft, s, dif, inverse);
+        if (pipe)
+            hipLaunchKernelGGL(k_g1_fft_r8_ladder_pipe, lgrid, dim3(192), 0, ctx->stream, d_lad, cur, d_glv, (uint32_t)nfft, s, dif, inverse);
+        else
+            hipLaunchKernelGGL(k_g1_fft_r8_ladder, dim3((unsigned)(pad * R8_LADDERS * 4 / 64)), block, 0, ctx->stream, d_lad, cur, d_glv,
+                               (uint32_t)nfft, s, dif, inverse);
         hipLaunchKernelGGL(k_g1_fft_r8_post, pgrid, block, 0, ctx->stream, nxt, final_out, cur, d_lad, (uint32_t)nfft, s, dif);
         uint32_t *x = cur;
         cur = nxt;
@@ -676,13 +736,6 @@ static int g1_fft_r8_fk20(DeviceCtx *ctx, G1XYZZ *d_u, uint32_t *d_a, uint32_t *
     step(5, 0, 0, d_u);
     HIP_TRY(hipGetLastError());
     return 0;
-}
-
-// radix-8 triples with the three-wave ladder while its 63 workgroups of three waves per transform and step find a SIMD
-// each (same-box A/B: profiles/r05_fk20_small_ab.txt)
-static size_t r8_max_transforms() {
-    static const size_t v = (size_t)ab_knob("CKZG_HIP_R8_FFT_MAX", 16);
-    return v;
 }
 
 // a radix-4 pass over stage pairs: DIF (s_hi, s_hi-1), ..., down to s_lo; DIT (s_lo, s_lo+1), ... up to s_hi.

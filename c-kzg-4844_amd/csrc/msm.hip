@@ -978,7 +978,14 @@ int msm_small_vectors_device(DeviceCtx *ctx, const FixedBaseTable &t, G1XYZZ *d_
     // over: 8 lanes each, whose fold is one level shorter
     static const long forced_lpv = ab_knob("CKZG_HIP_SMALL_LPV", 0);
     const long lpv = forced_lpv ? forced_lpv : (nvec >= 65536 ? 8 : 16);
-    if (nvec >= 4096 && lpv == 4) {
+    // one wave per vector below this many vectors (measured, 8-bit table: 4096 vectors = 32 blobs take 2.4 ms with 16
+    // lanes per vector -- 1024 waves, 128 additions per lane -- against two rounds of the one-wave form)
+    static const size_t wave_max = (size_t)ab_knob("CKZG_HIP_SMALL_WAVE_MAX", 8192);
+    if (nvec < wave_max) {
+        hipLaunchKernelGGL(k_msm_small<64>, dim3((unsigned)nvec), dim3(64), 0, ctx->stream, d_out, t.d_table,
+                           d_digits, (uint32_t)nvec, pairs_per_vec, t.wbits - 1, ppv, (uint32_t)t.npoints,
+                           vecs_per_group, small_prio_bit());
+    } else if (nvec >= 4096 && lpv == 4) {
         hipLaunchKernelGGL(k_msm_small<4>, dim3((unsigned)((nvec + 15) / 16)), dim3(64), 0, ctx->stream, d_out,
                            t.d_table, d_digits, (uint32_t)nvec, pairs_per_vec, t.wbits - 1, ppv,
                            (uint32_t)t.npoints, vecs_per_group, small_prio_bit());

@@ -54,26 +54,12 @@ def oracle():
     api.close()
 
 
-def _torch_hip_first():
-    """Tests that hand torch device pointers to the library need ONE HIP runtime in the process.  torch brings its own
-    copy of libamdhip64 (torch/lib); if the library has already pulled in /opt/rocm's, torch's later initialisation finds
-    "No HIP GPUs" (seen when tests/test_gpu_round4.py ran before any torch-using file).  Initialising torch first makes
-    its copy the one both use -- which is what the suite's default order did by accident."""
-    try:
-        import torch
-        if torch.cuda.is_available():
-            torch.cuda.init()
-    except Exception:  # noqa: BLE001 -- tests that need torch fail by themselves
-        pass
-
-
 @pytest.fixture(scope="session")
 def hip():
     """The product: libckzg_hip.so through the reference's C-ABI.  Fails loudly if absent."""
     from kzg_ctypes import Kzg
     if not os.path.exists(HIP_SO):
         pytest.fail("libckzg_hip.so is not built: run python -c 'import __graft_entry__ as g; g.build()'")
-    _torch_hip_first()
     api = Kzg(HIP_SO, "", precompute=0)
     yield api
     api.close()
