@@ -403,6 +403,11 @@ static_assert(sizeof(std::atomic<uint32_t>) == sizeof(uint32_t), "futex word");
 inline void futex_wait(std::atomic<uint32_t> *w, uint32_t expected) {
     (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAIT_PRIVATE, expected, nullptr, nullptr, 0);
 }
+// the same with a relative timeout (returns on a wake, a changed value, a signal or after `ns` nanoseconds)
+inline void futex_wait_for(std::atomic<uint32_t> *w, uint32_t expected, long ns) {
+    struct timespec ts = {ns / 1000000000L, ns % 1000000000L};
+    (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAIT_PRIVATE, expected, &ts, nullptr, 0);
+}
 inline void futex_wake(std::atomic<uint32_t> *w, int count) {
     (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAKE_PRIVATE, count, nullptr, nullptr, 0);
 }

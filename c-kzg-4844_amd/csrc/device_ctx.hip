@@ -656,9 +656,14 @@ C_KZG_RET create_settings_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affin
             // Up to three concurrent commitment / blob-proof callers also stay on their own: a one-blob launch leaves most
             // of the device idle, and three of them overlap better than batches of one or two taking turns (measured,
             // default tables: 3 threads 8.9 k commitments/s alone vs 5.7 k coalesced; from 6 threads the batches win).
+            // Cells / proofs / recovery launches take 4-5 ms for 1..16 units (the G1 transforms of FK20 are latency), so
+            // callers that come back together share ONE launch: combiner.hpp "gathering", up to 150 us
+            // (profiles/r05_callers_gather_ab.txt).
             const bool verify = i == CB_VERIFY_BLOB, light = i == CB_COMMIT || i == CB_BLOB_PROOF;
+            const bool fk20 = !verify && !light;
             sc->comb[i] = new Combiner(shape[i].units, shape[i].units * shape[i].in_per, shape[i].units * shape[i].out_per,
-                                       verify ? 2 * act : act, verify ? nslots : (light ? 3 : 0));
+                                       verify ? 2 * act : act, verify ? nslots : (light ? 3 : 0),
+                                       fk20 ? (int)dev::ab_knob("CKZG_HIP_COALESCE_GATHER_US", 150) : 0);
         }
     }
     sc->load.ms[LP_SLOTS] += slots_clk.lap();

@@ -98,12 +98,13 @@ int main(int argc, char **argv) {
     std::atomic<long> wrong{0}, solos{0};
     // scenarios: plain; few-callers-go-alone threshold; only ONE batch buffer could be allocated (the others fail: callers
     // wait for the buffer or go alone); every fifth launch fails as a whole (its members all see the error, later
-    // launches are unaffected)
-    for (int scenario = 0; scenario < 4; scenario++) {
+    // launches are unaffected); gathering
+    for (int scenario = 0; scenario < 5; scenario++) {
         const int solo_below = scenario == 1 ? 4 : 0;
         g_allocs_left.store(scenario == 2 ? 3 : 1L << 40);    // 2 buffers of the first batch + h_in of the second
         std::atomic<long> launches{0}, failed_calls{0};
-        Combiner cb(/*max_batch=*/32, /*in=*/32 * 8, /*out=*/32 * 8, /*max_active=*/2, solo_below);
+        // scenario 4: an operation that gathers (idle-path callers with recent company wait up to 200 us for each other)
+        Combiner cb(/*max_batch=*/32, /*in=*/32 * 8, /*out=*/32 * 8, /*max_active=*/2, solo_below, /*gather_us=*/scenario == 4 ? 200 : 0);
         std::vector<std::thread> th;
         for (int t = 0; t < threads; t++) {
             th.emplace_back([&, t]() {

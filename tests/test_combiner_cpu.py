@@ -1,8 +1,8 @@
 """The combiner's state machine (csrc/combiner.hpp) without a GPU.
 
 tests/native/combiner_stress.cpp drives the real header -- host functions stand in for the launches, malloc for the
-page-locked buffers -- through four scenarios (plain, go-alone threshold, batch-buffer allocation failing, whole launches
-failing) and checks that every caller gets the answer to ITS input.  Built plain and under ThreadSanitizer: the batch
+page-locked buffers -- through five scenarios (plain, go-alone threshold, batch-buffer allocation failing, whole launches
+failing, gathering) and checks that every caller gets the answer to ITS input.  Built plain and under ThreadSanitizer: the batch
 state word, reference counts and copy counter are lock-free, and the GPU suite's TSan pass (tools/run_sanitized.sh tsan)
 only sees the schedules a real device produces.
 """
@@ -32,7 +32,7 @@ def test_combiner_protocol(tmp_path, threads, calls):
     exe = _build(tmp_path, "cstress", [])
     r = subprocess.run([exe, str(threads), str(calls)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr[-2000:]
-    assert r.stdout.count("wrong 0") == 4, r.stdout
+    assert r.stdout.count("wrong 0") == 5, r.stdout
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
