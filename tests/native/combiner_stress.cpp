@@ -93,6 +93,74 @@ static int burst_then_few() {
     return solo_after >= 1700 ? 0 : 5;   // (the first few calls after the burst may still join a batch)
 }
 
+// Queueing: with more callers than a launch takes, how long a call waits is measured in LAUNCH GENERATIONS (launches
+// started between its submit() and its own launch).  Batches are first in, first out, a caller joins the oldest open
+// batch it fits, and callers that had to wait for a buffer are admitted oldest first (tickets), so the mean is a few
+// generations; this gate keeps it there and bounds the worst case.  (On a test box the worst case also contains the
+// operating system: 96 runnable threads on a handful of cores can keep a thread off the CPU for a few dozen 100-us
+// "launches" before it even reaches submit(), which is why the bound is not tighter.  The tail the round-4 review saw
+// on the GPU -- worst call 10-14x the mean at 256 callers -- came from buffers growing inside launches: scratch_reserve.)
+static int starvation() {
+    const int threads = 96, calls = 80;
+    std::atomic<long> generation{0};
+    std::atomic<long> worst_wait{0}, total_wait{0}, served{0};
+    for (int gather = 0; gather < 2; gather++) {
+        Combiner cb(/*max_batch=*/16, /*in=*/16 * 8, /*out=*/16 * 8, /*max_active=*/2, /*solo_below=*/0, /*gather_us=*/gather ? 100 : 0);
+        std::vector<std::thread> th;
+        for (int t = 0; t < threads; t++) {
+            th.emplace_back([&, t]() {
+                for (int c = 0; c < calls; c++) {
+                    const long g0 = generation.load(std::memory_order_acquire);
+                    uint64_t in = (uint64_t)t << 32 | (uint64_t)c, out = 0;
+                    long my_gen = -1;
+                    (void)guarded([&]() -> C_KZG_RET {
+                        return cb.submit(
+                            nullptr, 0,
+                            [&]() -> C_KZG_RET {
+                                my_gen = generation.fetch_add(1, std::memory_order_acq_rel);
+                                usleep(80);
+                                out = mix(in, 3);
+                                return C_KZG_OK;
+                            },
+                            [&](uint8_t *h_in, size_t idx) { memcpy(h_in + idx * 8, &in, 8); },
+                            [&](const uint8_t *h_in, uint8_t *h_out, uint8_t *, size_t n) -> C_KZG_RET {
+                                const uint64_t gen = (uint64_t)generation.fetch_add(1, std::memory_order_acq_rel);
+                                for (size_t i = 0; i < n; i++) {
+                                    uint64_t v;
+                                    memcpy(&v, h_in + i * 8, 8);
+                                    v = mix(v, 3) ^ (gen << 48);   // the launch's generation rides in the top bits
+                                    memcpy(h_out + i * 8, &v, 8);
+                                }
+                                usleep(100);
+                                return C_KZG_OK;
+                            },
+                            [&](const uint8_t *h_out, size_t idx, size_t) { memcpy(&out, h_out + idx * 8, 8); });
+                    });
+                    if (my_gen < 0) {   // served by a batch launch: recover its generation from the top bits
+                        my_gen = (long)((out ^ mix(in, 3)) >> 48);
+                        out ^= (uint64_t)my_gen << 48;
+                    }
+                    if (out != mix(in, 3)) abort();
+                    const long waited = ((my_gen - g0) & 0xffff);
+                    total_wait.fetch_add(waited);
+                    served.fetch_add(1);
+                    long w = worst_wait.load();
+                    while (waited > w && !worst_wait.compare_exchange_weak(w, waited)) {
+                    }
+                }
+            });
+        }
+        for (auto &x : th) x.join();
+        const Combiner::Stats st = cb.stats();
+        printf("starvation (gather %d): solo %llu batches %llu batched %llu largest %llu\n", gather, (unsigned long long)st.solo,
+               (unsigned long long)st.batches, (unsigned long long)st.batched, (unsigned long long)st.largest);
+    }
+    const double mean = (double)total_wait.load() / (double)served.load();
+    printf("starvation: %ld calls, launches between submit and own launch: mean %.2f, worst %ld\n", served.load(), mean, worst_wait.load());
+    // 96 callers over batches of <= 16 and two places: ~ threads / 16 generations on average
+    return mean <= 2.0 * (threads / 16 + 2) && worst_wait.load() <= 150 ? 0 : 6;
+}
+
 int main(int argc, char **argv) {
     const int threads = argc > 1 ? atoi(argv[1]) : 48, calls = argc > 2 ? atoi(argv[2]) : 400;
     std::atomic<long> wrong{0}, solos{0};
@@ -170,5 +238,6 @@ int main(int argc, char **argv) {
         }
     }
     if (wrong.load()) return 1;
-    return burst_then_few();
+    if (int rc = burst_then_few()) return rc;
+    return threads >= 48 ? starvation() : 0;
 }
