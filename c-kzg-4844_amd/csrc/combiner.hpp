@@ -41,6 +41,9 @@
 #define CKZG_COMBINER_PINNED_ALLOC(pp, bytes) (hipHostMalloc((void **)(pp), (bytes), hipHostMallocPortable) == hipSuccess)
 #define CKZG_COMBINER_PINNED_FREE(p) ((void)hipHostFree(p))
 #endif
+#ifndef CKZG_COMBINER_RESERVE_SCALE
+#define CKZG_COMBINER_RESERVE_SCALE(max_units, n) ::ckzg::dev::ReserveScale reserve_hint_((max_units), (n))
+#endif
 
 namespace ckzg {
 namespace api {
@@ -322,7 +325,11 @@ class Combiner {
         while (b->copied.load(std::memory_order_acquire) != n) std::this_thread::yield();   // members still copying in: microseconds
         memset(b->status.data(), 0, n);
         const auto t_run = std::chrono::steady_clock::now();
-        C_KZG_RET r = guarded([&]() -> C_KZG_RET { return run((const uint8_t *)b->h_in, b->h_out, b->status.data(), n); });
+        C_KZG_RET r;
+        {
+            CKZG_COMBINER_RESERVE_SCALE(max_batch, n);   // buffers that grow in this launch grow for the largest batch
+            r = guarded([&]() -> C_KZG_RET { return run((const uint8_t *)b->h_in, b->h_out, b->status.data(), n); });
+        }
         const uint64_t run_us =
             (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_run).count();
         if (r == C_KZG_BADARGS) {

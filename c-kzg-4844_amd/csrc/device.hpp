@@ -60,6 +60,32 @@ struct Scratch {
 
 // Bump allocator over one persistent HBM block: the verification entry points need a dozen small
 // temporaries per call, and hipMalloc/hipFree (which synchronises) cost more than their kernels.
+// Reservation hint of the calling thread: "this call serves n units, calls of up to max_units will follow on the same
+// slot" (combiner.hpp sets it around a batch launch).  An arena / the scratch area that has to GROW during such a call
+// grows to what the largest batch will need -- sizes are linear in the units -- so that a slot pays the synchronising
+// hipFree + hipMalloc once, in its first batch, instead of again whenever the batches have crept up (the 35-80 ms worst
+// calls of 256 concurrent callers against means of 5-7 ms).  Capped at 1 GB on top of the need; 1.0 outside batches.
+inline double &reserve_scale() {
+    static thread_local double s = 1.0;
+    return s;
+}
+struct ReserveScale {
+    double old;
+    ReserveScale(size_t max_units, size_t n) : old(reserve_scale()) {
+        const double f = n ? (double)max_units / (double)n : 1.0;
+        reserve_scale() = f < 1.0 ? 1.0 : f;
+    }
+    ~ReserveScale() { reserve_scale() = old; }
+    ReserveScale(const ReserveScale &) = delete;
+    ReserveScale &operator=(const ReserveScale &) = delete;
+};
+inline size_t reserve_scaled(size_t bytes) {
+    const double f = reserve_scale();
+    if (f <= 1.0) return bytes;
+    const double want = (double)bytes * f, cap = (double)bytes + (double)((size_t)1 << 30);
+    return (size_t)(want < cap ? want : cap);
+}
+
 struct Arena {
     void *base = nullptr;
     size_t cap = 0, used = 0;
@@ -78,6 +104,15 @@ struct Arena {
         // gives the block back after every call (a hipMalloc + a synchronising hipFree per call: ~0.5-0.8 ms)
         const size_t slack = (bytes >> 1) < ((size_t)256 << 20) ? (bytes >> 1) : ((size_t)256 << 20);
         size_t want = bytes + slack;
+        if (reserve_scaled(bytes) > want && reserve_scaled(bytes) <= ((size_t)3 << 30)) {
+            // a batch of a coalescing operation: room for the largest batch at once (fall back to the need if it fails)
+            if (hipMalloc(&base, reserve_scaled(bytes)) == hipSuccess) {
+                cap = reserve_scaled(bytes);
+                return true;
+            }
+            (void)hipGetLastError();
+            base = nullptr;
+        }
         // an arena that grows AGAIN doubles (by at most 1 GB): see scratch_reserve (msm.hip) -- every regrowth stalls the
         // callers of a coalesced batch for a synchronising hipFree + hipMalloc
         size_t twice = old_cap + (old_cap < ((size_t)1 << 30) ? old_cap : ((size_t)1 << 30));

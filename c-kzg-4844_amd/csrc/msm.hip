@@ -40,6 +40,7 @@ int scratch_reserve(DeviceCtx *ctx, size_t bytes) {
         ctx->scratch.cap = 0;
     }
     size_t want = bytes + (bytes >> 2);
+    if (reserve_scaled(bytes) > want) want = reserve_scaled(bytes);   // a batch of a coalescing operation (device.hpp)
     if (old_cap) {
         const size_t step = old_cap < ((size_t)2 << 30) ? old_cap : ((size_t)2 << 30);   // double, by at most 2 GB
         if (want < old_cap + step) want = old_cap + step;
