@@ -350,6 +350,9 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int e = r4_exponent(k, t, s, dif) & 127;
     const uint32_t *rec = roots_glv + (size_t)(e == 0 ? 0 : (inverse ? 128 - e : e)) * TW_REC_WORDS;
     const int8_t *naf1 = reinterpret_cast<const int8_t *>(rec + TW_NAF2_OFF), *naf2 = naf1 + TW_NAF2_STRIDE;
+    quad::NafMasks m_ab[2];   // (one twiddle per workgroup here: the same masks for both halves of a wave)
+    m_ab[0] = e != 0 ? quad::naf_masks(naf1, naf2) : quad::naf_masks_none();
+    m_ab[1] = m_ab[0];
     if (wave == 0) {
         const G1XYZZ *vec = data + (size_t)f * 128;
         XYZZ28 v;
@@ -380,12 +383,12 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (ql == 0 && live) lad[(size_t)f * R4_LADDERS + ell] = xyzz28_to_xyzz(v, vi);
             return;
         }
-        quad::pipe_doubler(sh, v, vi, quad::naf_masks(naf1, naf2), quad_id, ql);
+        quad::pipe_doubler(sh, v, vi, m_ab[0], m_ab[1], quad_id, ql);
     } else {
         if (e == 0) return;
         XYZZ28 o;
         bool oi = true;
-        quad::pipe_adder(o, oi, sh, quad::naf_masks(naf1, naf2), wave - 1, quad_id, ql);
+        quad::pipe_adder(o, oi, sh, m_ab[0], m_ab[1], wave - 1, quad_id, ql);
         if (wave == 1 && ql == 0 && live) lad[(size_t)f * R4_LADDERS + ell] = xyzz28_to_xyzz(o, oi);
     }
 }
@@ -512,8 +515,11 @@ __global__ __launch_bounds__(64) void k_g1_to_raw(uint32_t *raw, const G1XYZZ *i
     quad::raw_store(raw + g * quad::RAW_WORDS, v, inf);
 }
 
+// two != 0 (batches of <= 8 transforms): a workgroup serves TWO ladder indices, eight transforms each -- quads 0..7 ladder
+// 2 * blockIdx.x, quads 8..15 ladder 2 * blockIdx.x + 1 (g1_pipe.hpp: two twiddles per wave) -- so that a step is 168
+// workgroups and each has a compute unit to itself.
 __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_g1_fft_r8_ladder_pipe(
-    uint32_t *lad, const uint32_t *data, const uint32_t *roots_glv, uint32_t nfft, int s, int dif, int inverse) {
+    uint32_t *lad, const uint32_t *data, const uint32_t *roots_glv, uint32_t nfft, int s, int dif, int inverse, int two) {
     __shared__ quad::PipeShared sh;
     constexpr int RW = quad::RAW_WORDS;
     const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
@@ -525,20 +531,45 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         sh.r2done = 0;
     }
     __syncthreads();
-    const size_t q = blockIdx.x * (size_t)16 + quad_id;
-    const uint32_t pad = (nfft + 15u) & ~15u;
-    const uint32_t ell = (uint32_t)(q / pad);
-    uint32_t f = (uint32_t)(q - (size_t)ell * pad);
-    if (ell >= (uint32_t)R8_LADDERS) return;   // uniform over the workgroup (pad is a multiple of 16)
+    // the (up to) two ladder indices of this workgroup and this quad's own (ell, f)
+    uint32_t ell_a, ell_b, ell, f;
+    if (two) {
+        ell_a = 2 * blockIdx.x;
+        ell_b = ell_a + 1;
+        ell = quad_id < 8 ? ell_a : ell_b;
+        f = (uint32_t)(quad_id & 7);
+    } else {
+        const size_t q = blockIdx.x * (size_t)16 + quad_id;
+        const uint32_t pad = (nfft + 15u) & ~15u;
+        ell_a = ell_b = ell = (uint32_t)(q / pad);   // (pad is a multiple of 16: one ladder index per workgroup)
+        f = (uint32_t)(q - (size_t)ell * pad);
+    }
+    if (ell_a >= (uint32_t)R8_LADDERS) return;   // uniform over the workgroup
     const bool live = f < nfft;
     if (!live) f = nfft - 1;   // quads of the padding repeat the last transform
-    const int grp = (int)ell / R8_PER_GROUP;
+    // twiddle exponents of the two ladder indices (uniform) and of this quad
+    int e_ab[2];
+    quad::NafMasks m_ab[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint32_t el = h ? ell_b : ell_a;
+        int r, j, t, base, Q, E;
+        r8_ladder_rj((int)el % R8_PER_GROUP, r, j);
+        r8_group((int)el / R8_PER_GROUP, s, dif, t, base, Q, E);
+        e_ab[h] = (E * r * t + 16 * r * j) & 127;
+        if (e_ab[h] != 0) {
+            const uint32_t *rec = roots_glv + (size_t)(inverse ? 128 - e_ab[h] : e_ab[h]) * TW_REC_WORDS;
+            const int8_t *naf1 = reinterpret_cast<const int8_t *>(rec + TW_NAF2_OFF);
+            m_ab[h] = quad::naf_masks(naf1, naf1 + TW_NAF2_STRIDE);
+        } else {
+            m_ab[h] = quad::naf_masks_none();
+        }
+    }
+    const bool any_ladder = e_ab[0] != 0 || e_ab[1] != 0;
+    const bool my_ladder = (ell == ell_a ? e_ab[0] : e_ab[1]) != 0;   // (per quad) twiddle 1: the combination is the result
     int r, j, t, base, Q, E;
     r8_ladder_rj((int)ell % R8_PER_GROUP, r, j);
-    r8_group(grp, s, dif, t, base, Q, E);
-    const int e = (E * r * t + 16 * r * j) & 127;
-    const uint32_t *rec = roots_glv + (size_t)(e == 0 ? 0 : (inverse ? 128 - e : e)) * TW_REC_WORDS;
-    const int8_t *naf1 = reinterpret_cast<const int8_t *>(rec + TW_NAF2_OFF), *naf2 = naf1 + TW_NAF2_STRIDE;
+    r8_group((int)ell / R8_PER_GROUP, s, dif, t, base, Q, E);
     uint32_t *dst = lad + ((size_t)f * R8_LADDERS + ell) * RW;
     if (wave == 0) {
         const uint32_t *vec = data + ((size_t)f * 128 + base + t) * RW;
@@ -548,7 +579,8 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // V(r, j): first term x_j, then alternating signs over the stride the residue class of r fixes
             const int step = r == 4 ? 1 : ((r & 1) ? 4 : 2), terms = 8 / step;
             v = quad::raw_load(vec + (size_t)Q * j * RW, vi);
-            for (int a = 1; a < terms; a++) {
+            for (int a = 1; a < 8; a++) {   // (uniform trip count: the two halves of a wave may differ in `terms`)
+                if (a >= terms) continue;
                 bool bi;
                 const XYZZ28 b = quad::raw_load(vec + (size_t)Q * (j + step * a) * RW, bi);
                 quad::xyzz28_addsub_quad(v, vi, b, bi, (a & 1) != 0, ql);
@@ -556,17 +588,16 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         } else {
             v = quad::raw_load(vec + (size_t)Q * bitrev3(r) * RW, vi);
         }
-        if (e == 0) {   // twiddle 1: the combination is the result, the adder waves have left already
-            if (ql == 0 && live) quad::raw_store(dst, v, vi);
-            return;
-        }
-        quad::pipe_doubler(sh, v, vi, quad::naf_masks(naf1, naf2), quad_id, ql);
+        if (!my_ladder && ql == 0 && live) quad::raw_store(dst, v, vi);
+        if (!any_ladder) return;   // (the adder waves have left already)
+        // quads without a ladder of their own ride along as points at infinity: the adders skip them
+        quad::pipe_doubler(sh, v, vi || !my_ladder, m_ab[0], m_ab[1], quad_id, ql);
     } else {
-        if (e == 0) return;
+        if (!any_ladder) return;
         XYZZ28 o;
         bool oi = true;
-        quad::pipe_adder(o, oi, sh, quad::naf_masks(naf1, naf2), wave - 1, quad_id, ql);
-        if (wave == 1 && ql == 0 && live) quad::raw_store(dst, o, oi);
+        quad::pipe_adder(o, oi, sh, m_ab[0], m_ab[1], wave - 1, quad_id, ql);
+        if (wave == 1 && my_ladder && ql == 0 && live) quad::raw_store(dst, o, oi);
     }
 }
 
@@ -718,9 +749,13 @@ static int g1_fft_r8_fk20(DeviceCtx *ctx, G1XYZZ *d_u, uint32_t *d_a, uint32_t *
     hipLaunchKernelGGL(k_g1_to_raw, dim3((unsigned)((nfft * 128 + 63) / 64)), block, 0, ctx->stream, d_a, d_u, nfft * 128);
     uint32_t *cur = d_a, *nxt = d_b;
     const bool pipe = nfft <= r8_pipe_max_transforms();
+    static const size_t two_max = (size_t)ab_knob("CKZG_HIP_R8_TWO_MAX", 8);
     auto step = [&](int s, int dif, int inverse, G1XYZZ *final_out) {
-        if (pipe)
-            hipLaunchKernelGGL(k_g1_fft_r8_ladder_pipe, lgrid, dim3(192), 0, ctx->stream, d_lad, cur, d_glv, (uint32_t)nfft, s, dif, inverse);
+        if (pipe && nfft <= two_max)   // two ladder indices per workgroup: 168 workgroups, one per compute unit
+            hipLaunchKernelGGL(k_g1_fft_r8_ladder_pipe, dim3((unsigned)(R8_LADDERS / 2)), dim3(192), 0, ctx->stream, d_lad, cur, d_glv,
+                               (uint32_t)nfft, s, dif, inverse, 1);
+        else if (pipe)
+            hipLaunchKernelGGL(k_g1_fft_r8_ladder_pipe, lgrid, dim3(192), 0, ctx->stream, d_lad, cur, d_glv, (uint32_t)nfft, s, dif, inverse, 0);
         else
             hipLaunchKernelGGL(k_g1_fft_r8_ladder, dim3((unsigned)(pad * R8_LADDERS * 4 / 64)), block, 0, ctx->stream, d_lad, cur, d_glv,
                                (uint32_t)nfft, s, dif, inverse);

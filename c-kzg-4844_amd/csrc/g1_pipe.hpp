@@ -72,25 +72,48 @@ struct NafMasks {
     uint64_t nz[2][3], neg[2][3];   // [chain][word]: digit non-zero / negative at bit i
     int top;                        // highest bit with a non-zero digit in either chain (-1: none)
 };
+// (every index into the mask arrays is a compile-time constant after unrolling: a run-time index -- or a reference
+// selected at run time -- keeps the struct in memory, and the compiler then parks one copy PER THREAD in LDS: +20 KB)
 __device__ __forceinline__ NafMasks naf_masks(const int8_t *naf1, const int8_t *naf2) {
+    NafMasks m;
+    m.top = -1;
+#pragma unroll
+    for (int w = 0; w < 3; w++) {
+        uint64_t nz1 = 0, ng1 = 0, nz2 = 0, ng2 = 0;
+        for (int b = 0; b < 64; b++) {
+            const int i = 64 * w + b;
+            if (i >= NAF2_LEN) break;
+            const int d1 = naf1[i], d2 = naf2[i];
+            const uint64_t bit = 1ull << b;
+            if (d1) nz1 |= bit;
+            if (d1 < 0) ng1 |= bit;
+            if (d2) nz2 |= bit;
+            if (d2 < 0) ng2 |= bit;
+            if (d1 | d2) m.top = i;
+        }
+        m.nz[0][w] = nz1;
+        m.neg[0][w] = ng1;
+        m.nz[1][w] = nz2;
+        m.neg[1][w] = ng2;
+    }
+    return m;
+}
+__device__ __forceinline__ NafMasks naf_masks_none() {
     NafMasks m;
 #pragma unroll
     for (int c = 0; c < 2; c++)
 #pragma unroll
         for (int w = 0; w < 3; w++) m.nz[c][w] = m.neg[c][w] = 0;
     m.top = -1;
-    for (int i = 0; i < NAF2_LEN; i++) {
-        const int d1 = naf1[i], d2 = naf2[i];
-        const uint64_t bit = 1ull << (i & 63);
-        if (d1) m.nz[0][i >> 6] |= bit;
-        if (d1 < 0) m.neg[0][i >> 6] |= bit;
-        if (d2) m.nz[1][i >> 6] |= bit;
-        if (d2 < 0) m.neg[1][i >> 6] |= bit;
-        if (d1 | d2) m.top = i;
-    }
     return m;
 }
-__device__ __forceinline__ bool mask_bit(const uint64_t (&w)[3], int i) { return ((w[i >> 6] >> (i & 63)) & 1ull) != 0; }
+__device__ __forceinline__ bool mask_bit(const uint64_t (&w)[3], int i) {
+    const uint64_t word = i < 64 ? w[0] : (i < 128 ? w[1] : w[2]);
+    return ((word >> (i & 63)) & 1ull) != 0;
+}
+// digit of chain c (a run-time value, uniform over the wave) at bit i non-zero / negative
+__device__ __forceinline__ bool naf_nz(const NafMasks &m, int c, int i) { return c ? mask_bit(m.nz[1], i) : mask_bit(m.nz[0], i); }
+__device__ __forceinline__ bool naf_neg(const NafMasks &m, int c, int i) { return c ? mask_bit(m.neg[1], i) : mask_bit(m.neg[0], i); }
 
 __device__ __forceinline__ uint32_t pipe_load(uint32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -168,14 +191,23 @@ __device__ __forceinline__ void xyzz28_addsub_quad(XYZZ28 &a, bool &ainf, const 
     a.zzz = qread<2>(p4);
 }
 
+// A wave may serve TWO twiddles -- quads 0..7 the ladders of mA, quads 8..15 those of mB (batches of <= 8 transforms:
+// the workgroups of a radix-8 step halve, 336 -> 168, and every three-wave workgroup finds a compute unit to itself).
+// The doubling chain does not depend on the scalar at all; it publishes at the bits where ANY of the four digit strings
+// is non-zero, and an adder wave's quads take part in an addition only where their own twiddle's digit is non-zero
+// (the addition then runs with part of the wave masked off: ~5/9 of the bits per chain instead of 1/3, still well
+// under the doubling chain's time).  One twiddle per wave: mA and mB are the same masks.
+//
 // The doubler wave.  p: the input (replicated in the quad), quad_id 0..15, ql 0..3.
-__device__ __noinline__ void pipe_doubler(PipeShared &sh, const XYZZ28 &p, bool p_inf, const NafMasks &m, int quad_id, int ql) {
+__device__ __forceinline__ void pipe_doubler(PipeShared &sh, const XYZZ28 &p, bool p_inf, const NafMasks &mA, const NafMasks &mB,
+                                          int quad_id, int ql) {
     if (ql == 0) sh.pinf[quad_id] = p_inf ? 1u : 0u;
     JAC28 b = jac28_from_xyzz(p);
     F28<1, 2> zz = sqr(p.zz);   // jac28_from_xyzz takes Z = ZZ(p)
     uint32_t ev = 0;
-    for (int i = 0; i <= m.top; i++) {
-        if (mask_bit(m.nz[0], i) || mask_bit(m.nz[1], i)) {   // uniform over the wave: one twiddle per workgroup
+    const int top = mA.top > mB.top ? mA.top : mB.top;
+    for (int i = 0; i <= top; i++) {
+        if (mask_bit(mA.nz[0], i) || mask_bit(mA.nz[1], i) || mask_bit(mB.nz[0], i) || mask_bit(mB.nz[1], i)) {   // uniform over the wave
             for (;;) {   // room in the ring: both adders are past event ev - PIPE_SLOTS
                 const int c0 = (int)pipe_load(&sh.consumed[0]), c1 = (int)pipe_load(&sh.consumed[1]);
                 if ((int)ev - (c0 < c1 ? c0 : c1) < PIPE_SLOTS) break;
@@ -192,7 +224,7 @@ __device__ __noinline__ void pipe_doubler(PipeShared &sh, const XYZZ28 &p, bool 
             ev++;
             if ((threadIdx.x & 63) == 0) pipe_store(&sh.produced, ev);
         }
-        if (i < m.top) jac28_dbl_quad_zz(b, zz, ql);
+        if (i < top) jac28_dbl_quad_zz(b, zz, ql);
     }
 }
 
@@ -263,23 +295,25 @@ __device__ __forceinline__ void jac28_add_quad_pipe(JAC28 &a, F28<1, 2> &zz, boo
 // the quad); chain 1 sums the k2 terms and hands them over (out is not written).  The hand-over is the last pass of
 // the SAME loop, so that the addition has one call site: it is ~16 KB of code (two copies and the doubler's loop no
 // longer share the instruction cache), and as a called function its operands went through scratch memory.
-__device__ __noinline__ void pipe_adder(XYZZ28 &out, bool &out_inf, PipeShared &sh, const NafMasks &m, int chain, int quad_id,
-                                        int ql) {
+__device__ __forceinline__ void pipe_adder(XYZZ28 &out, bool &out_inf, PipeShared &sh, const NafMasks &mA, const NafMasks &mB, int chain,
+                                        int quad_id, int ql) {
     JAC28 r;
     F28<1, 2> zz;
     bool inf = true;
     uint32_t ev = 0;
-    bool p_inf = m.top < 0, have_flag = m.top < 0;   // k = 0: infinity whatever the input
+    const int top = mA.top > mB.top ? mA.top : mB.top;
+    bool p_inf = top < 0, have_flag = top < 0;   // k = 0: infinity whatever the input
     const bool leader = (threadIdx.x & 63) == 0;
-    const uint64_t(&own_nz)[3] = chain ? m.nz[1] : m.nz[0];
-    const uint64_t(&own_neg)[3] = chain ? m.neg[1] : m.neg[0];
-    const uint64_t(&other_nz)[3] = chain ? m.nz[0] : m.nz[1];
-    for (int i = 0; i <= m.top + 1; i++) {
-        const bool closing = i == m.top + 1;
+    const bool second = quad_id >= 8;   // which twiddle this quad's ladder belongs to (the same masks twice: no difference)
+    for (int i = 0; i <= top + 1; i++) {
+        const bool closing = i == top + 1;
         const uint32_t(*rec)[16][4];
+        bool mine = true;   // this quad's own digit is non-zero (per lane)
         if (!closing) {
-            const bool own = mask_bit(own_nz, i);
-            if (!(own || mask_bit(other_nz, i))) continue;   // uniform over the wave
+            const bool own_a = naf_nz(mA, chain, i), own_b = naf_nz(mB, chain, i);
+            const bool own = own_a || own_b;
+            if (!(own || naf_nz(mA, 1 - chain, i) || naf_nz(mB, 1 - chain, i))) continue;   // uniform over the wave
+            mine = second ? own_b : own_a;
             if (!own) {
                 ev++;
                 continue;
@@ -317,11 +351,11 @@ __device__ __noinline__ void pipe_adder(XYZZ28 &out, bool &out_inf, PipeShared &
                 bzz.l[j] = w[42 + j];
             }
         }
-        bool skip = p_inf, neg = false;   // per quad: a quad without a point sits the additions out
+        bool skip = p_inf || !mine, neg = false;   // per quad: a quad without a point (or without a digit here) sits it out
         if (!closing) {
             if (leader) pipe_store(&sh.consumed[chain], ev + 1);   // (the record is in registers)
             ev++;
-            neg = mask_bit(own_neg, i);
+            neg = second ? naf_neg(mB, chain, i) : naf_neg(mA, chain, i);
         } else {
             skip = skip || sh.r2inf[quad_id] != 0;
             bx = widen<1, 34>(mul(bx, f28_const<1, 1>(FP28_BETA_LAMBDA)));   // phi
