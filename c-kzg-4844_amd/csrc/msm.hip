@@ -316,8 +316,11 @@ __global__ __launch_bounds__(64) void k_table_steps(G1Affine *table, const G1Aff
 
 int batch_to_affine_device(DeviceCtx *ctx, G1Affine *d_out, const G1XYZZ *d_in, Fp *d_prefix, size_t n) {
     if (n == 0) return 0;
-    // short runs when there are few points (latency), long runs when there are many (throughput)
-    int L = n >= ((size_t)1 << 20) ? 128 : (n >= ((size_t)1 << 14) ? 16 : 4);
+    // short runs when there are few points (latency), long runs when there are many (throughput); up to 4096 points
+    // (the proofs of a batch of <= 32 blobs) every point has a lane and an inversion of its own: the lanes are idle
+    // anyway and the run of four cost 207 us against ~36 us for the one inversion it contains
+    static const size_t solo_max = (size_t)ab_knob("CKZG_HIP_TO_AFFINE_SOLO_MAX", 4096);
+    int L = n >= ((size_t)1 << 20) ? 128 : (n >= ((size_t)1 << 14) ? 16 : (n > solo_max ? 4 : 1));
     size_t threads = (n + L - 1) / L;
     hipLaunchKernelGGL(k_batch_to_affine, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, ctx->stream,
                        d_out, d_in, d_prefix, n, L, 0);
