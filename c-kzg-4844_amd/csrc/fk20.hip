@@ -515,12 +515,12 @@ __global__ __launch_bounds__(64) void k_g1_to_raw(uint32_t *raw, const G1XYZZ *i
     quad::raw_store(raw + g * quad::RAW_WORDS, v, inf);
 }
 
-// two != 0 (batches of <= 8 transforms): a workgroup serves TWO ladder indices, eight transforms each -- quads 0..7 ladder
+// two = 1 (batches of <= 8 transforms): a workgroup serves TWO ladder indices, eight transforms each -- quads 0..7 ladder
 // 2 * blockIdx.x, quads 8..15 ladder 2 * blockIdx.x + 1 (g1_pipe.hpp: two twiddles per wave) -- so that a step is 168
-// workgroups and each has a compute unit to itself.
-__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_g1_fft_r8_ladder_pipe(
-    uint32_t *lad, const uint32_t *data, const uint32_t *roots_glv, uint32_t nfft, int s, int dif, int inverse, int two) {
-    __shared__ quad::PipeShared sh;
+// workgroups and each has a compute unit to itself.  two = 2 (9..16 transforms, launched with 128 threads): the two-wave
+// form -- one adder wave for both chains, its sums parked in LDS -- whose 336 workgroups fit two to a compute unit.
+__device__ __forceinline__ void r8_ladder_pipe_body(quad::PipeShared &sh, uint32_t *lad, const uint32_t *data, const uint32_t *roots_glv,
+                                                    uint32_t nfft, int s, int dif, int inverse, int two) {
     constexpr int RW = quad::RAW_WORDS;
     const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
     const int quad_id = lane >> 2, ql = lane & 3;
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __syncthreads();
     // the (up to) two ladder indices of this workgroup and this quad's own (ell, f)
     uint32_t ell_a, ell_b, ell, f;
-    if (two) {
+    if (two == 1) {
         ell_a = 2 * blockIdx.x;
         ell_b = ell_a + 1;
         ell = quad_id < 8 ? ell_a : ell_b;
@@ -591,14 +591,30 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (!my_ladder && ql == 0 && live) quad::raw_store(dst, v, vi);
         if (!any_ladder) return;   // (the adder waves have left already)
         // quads without a ladder of their own ride along as points at infinity: the adders skip them
-        quad::pipe_doubler(sh, v, vi || !my_ladder, m_ab[0], m_ab[1], quad_id, ql);
+        quad::pipe_doubler(sh, v, vi || !my_ladder, m_ab[0], m_ab[1], quad_id, ql, two == 2);
     } else {
         if (!any_ladder) return;
         XYZZ28 o;
         bool oi = true;
-        quad::pipe_adder(o, oi, sh, m_ab[0], m_ab[1], wave - 1, quad_id, ql);
+        if (two == 2)
+            quad::pipe_adder_dual(o, oi, sh, m_ab[0], quad_id, ql);
+        else
+            quad::pipe_adder(o, oi, sh, m_ab[0], m_ab[1], wave - 1, quad_id, ql);
         if (wave == 1 && my_ladder && ql == 0 && live) quad::raw_store(dst, o, oi);
     }
+}
+
+__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_g1_fft_r8_ladder_pipe(
+    uint32_t *lad, const uint32_t *data, const uint32_t *roots_glv, uint32_t nfft, int s, int dif, int inverse, int two) {
+    __shared__ quad::PipeShared sh;
+    r8_ladder_pipe_body(sh, lad, data, roots_glv, nfft, s, dif, inverse, two);
+}
+// the two-wave form with the whole register file per wave (one wave per SIMD: two workgroups per compute unit can
+// never share a SIMD, and the adder wave -- one accumulator, the operand and the addition's temporaries -- does not spill)
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_g1_fft_r8_ladder_pipe2(
+    uint32_t *lad, const uint32_t *data, const uint32_t *roots_glv, uint32_t nfft, int s, int dif, int inverse) {
+    __shared__ quad::PipeShared sh;
+    r8_ladder_pipe_body(sh, lad, data, roots_glv, nfft, s, dif, inverse, 2);
 }
 
 // The same radix-8 ladders on ONE wave per 16 ladders (g1_quad.hpp's left-to-right ladder): for batches whose
@@ -750,10 +766,13 @@ static int g1_fft_r8_fk20(DeviceCtx *ctx, G1XYZZ *d_u, uint32_t *d_a, uint32_t *
     uint32_t *cur = d_a, *nxt = d_b;
     const bool pipe = nfft <= r8_pipe_max_transforms();
     static const size_t two_max = (size_t)ab_knob("CKZG_HIP_R8_TWO_MAX", 8);
+    static const bool dual = ab_knob("CKZG_HIP_R8_DUAL", 1) != 0;
     auto step = [&](int s, int dif, int inverse, G1XYZZ *final_out) {
-        if (pipe && nfft <= two_max)   // two ladder indices per workgroup: 168 workgroups, one per compute unit
+        if (pipe && nfft <= two_max) {   // two ladder indices per workgroup: 168 workgroups, one per compute unit
             hipLaunchKernelGGL(k_g1_fft_r8_ladder_pipe, dim3((unsigned)(R8_LADDERS / 2)), dim3(192), 0, ctx->stream, d_lad, cur, d_glv,
                                (uint32_t)nfft, s, dif, inverse, 1);
+        } else if (pipe && dual)   // two-wave workgroups: two to a compute unit, a SIMD per wave
+            hipLaunchKernelGGL(k_g1_fft_r8_ladder_pipe2, lgrid, dim3(128), 0, ctx->stream, d_lad, cur, d_glv, (uint32_t)nfft, s, dif, inverse);
         else if (pipe)
             hipLaunchKernelGGL(k_g1_fft_r8_ladder_pipe, lgrid, dim3(192), 0, ctx->stream, d_lad, cur, d_glv, (uint32_t)nfft, s, dif, inverse, 0);
         else

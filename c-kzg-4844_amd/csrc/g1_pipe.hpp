@@ -59,6 +59,7 @@ HDNI inline void naf2_128(int8_t *out, const uint32_t *k) {
 struct PipeShared {
     uint32_t ring[PIPE_SLOTS][14][16][4];
     uint32_t r2[14][16][4];   // the k2 chain's sum, handed to the k1 chain's wave for R1 + phi(R2)
+    uint32_t r1[14][16][4];   // two-wave form only: the k1 chain's sum lives here between its additions (r2 likewise)
     uint32_t r2inf[16];
     uint32_t produced;        // events published by the doubler
     uint32_t consumed[2];     // per adder wave: it needs no event below this index (signed comparison: may run ahead)
@@ -200,7 +201,7 @@ __device__ __forceinline__ void xyzz28_addsub_quad(XYZZ28 &a, bool &ainf, const 
 //
 // The doubler wave.  p: the input (replicated in the quad), quad_id 0..15, ql 0..3.
 __device__ __forceinline__ void pipe_doubler(PipeShared &sh, const XYZZ28 &p, bool p_inf, const NafMasks &mA, const NafMasks &mB,
-                                          int quad_id, int ql) {
+                                          int quad_id, int ql, bool one_adder = false) {
     if (ql == 0) sh.pinf[quad_id] = p_inf ? 1u : 0u;
     JAC28 b = jac28_from_xyzz(p);
     F28<1, 2> zz = sqr(p.zz);   // jac28_from_xyzz takes Z = ZZ(p)
@@ -209,7 +210,7 @@ __device__ __forceinline__ void pipe_doubler(PipeShared &sh, const XYZZ28 &p, bo
     for (int i = 0; i <= top; i++) {
         if (mask_bit(mA.nz[0], i) || mask_bit(mA.nz[1], i) || mask_bit(mB.nz[0], i) || mask_bit(mB.nz[1], i)) {   // uniform over the wave
             for (;;) {   // room in the ring: both adders are past event ev - PIPE_SLOTS
-                const int c0 = (int)pipe_load(&sh.consumed[0]), c1 = (int)pipe_load(&sh.consumed[1]);
+                const int c0 = (int)pipe_load(&sh.consumed[0]), c1 = one_adder ? c0 : (int)pipe_load(&sh.consumed[1]);
                 if ((int)ev - (c0 < c1 ? c0 : c1) < PIPE_SLOTS) break;
                 __builtin_amdgcn_s_sleep(1);
             }
@@ -380,6 +381,90 @@ __device__ __forceinline__ void pipe_adder(XYZZ28 &out, bool &out_inf, PipeShare
     }
     const bool res_inf = p_inf || inf;
     if (!res_inf) out = jac28_to_xyzz(r);
+    out_inf = res_inf;
+}
+
+// The TWO-wave form: one adder wave for both chains, with the two sums parked in LDS between their additions so that
+// only one accumulator is in registers at a time (with both in registers the wave spilled and its 86 additions took
+// 0.7-0.9 ms against the doubler's 0.53: profiles/r05_fk20_small_ab.txt).  Why it exists at all: workgroups of two
+// waves always find a SIMD per wave -- two of them fit a compute unit -- where a radix-8 step of 9..16 transforms
+// (336 three-wave workgroups on 256 units) leaves doublers sharing a SIMD with somebody's adder.  The adder is then
+// about as long as the doubling chain (86 x ~5.8 us), so the step is bounded by whichever of the two stalls the other.
+__device__ __forceinline__ void pipe_acc_store(uint32_t (*dst)[16][4], const JAC28 &a, const F28<1, 2> &zz, int quad_id, int ql) {
+    const auto e = qsel(ql, widen<2, 34>(a.x), widen<2, 34>(a.y), widen<2, 34>(a.z), widen<2, 34>(zz));
+#pragma unroll
+    for (int j = 0; j < 14; j++) {
+        const int w = ql * 14 + j;
+        dst[w >> 2][quad_id][w & 3] = e.l[j];
+    }
+}
+__device__ __forceinline__ void pipe_rec_load(F28<1, 34> &x, F28<1, 34> &y, F28<2, 4> &z, F28<1, 2> &zz, const uint32_t (*src)[16][4],
+                                              int quad_id) {
+    uint32_t w[56];
+#pragma unroll
+    for (int k4 = 0; k4 < 14; k4++) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(&src[k4][quad_id][0]);
+        w[4 * k4] = q.x; w[4 * k4 + 1] = q.y; w[4 * k4 + 2] = q.z; w[4 * k4 + 3] = q.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 14; j++) {
+        x.l[j] = w[j];
+        y.l[j] = w[14 + j];
+        z.l[j] = w[28 + j];
+        zz.l[j] = w[42 + j];
+    }
+}
+
+__device__ __forceinline__ void pipe_adder_dual(XYZZ28 &out, bool &out_inf, PipeShared &sh, const NafMasks &m, int quad_id, int ql) {
+    bool inf0 = true, inf1 = true;   // (per quad only through p_inf: one twiddle per wave, every chain starts at the same bit)
+    uint32_t ev = 0;
+    bool p_inf = m.top < 0;   // k = 0: infinity whatever the input
+    const bool leader = (threadIdx.x & 63) == 0;
+    JAC28 a;            // the accumulator in hand; after the closing pass: the result
+    F28<1, 2> az;
+    bool ai = true;
+    for (int i = 0; i <= m.top + 1; i++) {
+        const bool closing = i == m.top + 1;
+        bool want0 = false, want1 = false;
+        F28<1, 34> bx, by;
+        F28<2, 4> bz;
+        F28<1, 2> bzz;
+        if (!closing) {
+            want0 = mask_bit(m.nz[0], i);
+            want1 = mask_bit(m.nz[1], i);
+            if (!(want0 | want1)) continue;   // uniform over the wave
+            while (pipe_load(&sh.produced) <= ev) __builtin_amdgcn_s_sleep(1);
+            if (ev == 0) p_inf = sh.pinf[quad_id] != 0;
+            pipe_rec_load(bx, by, bz, bzz, sh.ring[ev % PIPE_SLOTS], quad_id);
+            ev++;
+            if (leader) pipe_store(&sh.consumed[0], ev);   // (the record is in registers)
+        } else {
+            // R1 += phi(R2), phi(X, Y, Z) = (beta X, Y, Z)
+            want0 = true;
+            if (!inf1) {
+                pipe_rec_load(bx, by, bz, bzz, sh.r2, quad_id);
+                bx = widen<1, 34>(mul(bx, f28_const<1, 1>(FP28_BETA_LAMBDA)));
+            }
+        }
+#pragma unroll 1
+        for (int c = 0; c < 2; c++) {
+            if (!(c ? want1 : want0)) continue;
+            const bool skip = p_inf || (closing && inf1);
+            uint32_t(*acc)[16][4] = c ? sh.r2 : sh.r1;
+            ai = c ? inf1 : inf0;
+            if (!ai) pipe_rec_load(a.x, a.y, a.z, az, acc, quad_id);
+            if (!skip) jac28_add_quad_pipe(a, az, ai, bx, by, bz, bzz, !closing && naf_neg(m, c, i), ql);
+            if (!closing) {
+                if (!skip) pipe_acc_store(acc, a, az, quad_id, ql);
+                if (!p_inf) {
+                    if (c) inf1 = ai;
+                    else inf0 = ai;
+                }
+            }
+        }
+    }
+    const bool res_inf = p_inf || ai;
+    if (!res_inf) out = jac28_to_xyzz(a);
     out_inf = res_inf;
 }
 
