@@ -620,8 +620,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // The same radix-8 ladders on ONE wave per 16 ladders (g1_quad.hpp's left-to-right ladder): for batches whose
 // three-wave workgroups would no longer find a SIMD per wave (17 blobs upwards) the shorter chain of the pipeline is
 // lost to sharing, but four ladder depths instead of six are not.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_g1_fft_r8_ladder(
-    uint32_t *lad, const uint32_t *data, const uint32_t *roots_glv, uint32_t nfft, int s, int dif, int inverse) {
+__device__ __forceinline__ void r8_ladder_body(uint32_t *lad, const uint32_t *data, const uint32_t *roots_glv, uint32_t nfft, int s, int dif,
+                                               int inverse) {
     constexpr int RW = quad::RAW_WORDS;
     const size_t q = (blockIdx.x * (size_t)64 + threadIdx.x) >> 2;
     const int ql = (int)(threadIdx.x & 3);
@@ -658,6 +658,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         quad::xyzz28_mul_glv_naf_quad(o, oi, v, vi, naf, naf + GLV_NAF_LEN, ql);
     }
     if (ql == 0 && live) quad::raw_store(lad + ((size_t)f * R8_LADDERS + ell) * RW, o, oi);
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_g1_fft_r8_ladder(
+    uint32_t *lad, const uint32_t *data, const uint32_t *roots_glv, uint32_t nfft, int s, int dif, int inverse) {
+    r8_ladder_body(lad, data, roots_glv, nfft, s, dif, inverse);
+}
+// the same with the whole register file per wave, for batches whose waves fit the chip once (<= 48 transforms)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_g1_fft_r8_ladder_full(
+    uint32_t *lad, const uint32_t *data, const uint32_t *roots_glv, uint32_t nfft, int s, int dif, int inverse) {
+    r8_ladder_body(lad, data, roots_glv, nfft, s, dif, inverse);
 }
 
 // one DPP quad per OUTPUT point: quad g -> (transform f, group, which of the eight outputs).  final_out: the last step
@@ -767,6 +777,7 @@ static int g1_fft_r8_fk20(DeviceCtx *ctx, G1XYZZ *d_u, uint32_t *d_a, uint32_t *
     const bool pipe = nfft <= r8_pipe_max_transforms();
     static const size_t two_max = (size_t)ab_knob("CKZG_HIP_R8_TWO_MAX", 8);
     static const bool dual = ab_knob("CKZG_HIP_R8_DUAL", 1) != 0;
+    static const bool one_full = ab_knob("CKZG_HIP_R8_ONE_FULL", 1) != 0;
     auto step = [&](int s, int dif, int inverse, G1XYZZ *final_out) {
         if (pipe && nfft <= two_max) {   // two ladder indices per workgroup: 168 workgroups, one per compute unit
             hipLaunchKernelGGL(k_g1_fft_r8_ladder_pipe, dim3((unsigned)(R8_LADDERS / 2)), dim3(192), 0, ctx->stream, d_lad, cur, d_glv,
@@ -775,6 +786,9 @@ static int g1_fft_r8_fk20(DeviceCtx *ctx, G1XYZZ *d_u, uint32_t *d_a, uint32_t *
             hipLaunchKernelGGL(k_g1_fft_r8_ladder_pipe2, lgrid, dim3(128), 0, ctx->stream, d_lad, cur, d_glv, (uint32_t)nfft, s, dif, inverse);
         else if (pipe)
             hipLaunchKernelGGL(k_g1_fft_r8_ladder_pipe, lgrid, dim3(192), 0, ctx->stream, d_lad, cur, d_glv, (uint32_t)nfft, s, dif, inverse, 0);
+        else if (one_full)
+            hipLaunchKernelGGL(k_g1_fft_r8_ladder_full, dim3((unsigned)(pad * R8_LADDERS * 4 / 64)), block, 0, ctx->stream, d_lad, cur, d_glv,
+                               (uint32_t)nfft, s, dif, inverse);
         else
             hipLaunchKernelGGL(k_g1_fft_r8_ladder, dim3((unsigned)(pad * R8_LADDERS * 4 / 64)), block, 0, ctx->stream, d_lad, cur, d_glv,
                                (uint32_t)nfft, s, dif, inverse);
