@@ -100,9 +100,9 @@ def test_large_batch_takes_fk20_and_16_lane_msm_path(hip):
 
 @pytest.mark.parametrize("n", [2, 3, 5, 9, 16, 17, 24, 32, 33])
 def test_small_batches_take_every_g1_fft_form(hip, oracle, n):
-    """The two G1 transforms of FK20 have four forms by batch size (fk20.hip): radix-8 steps on raw records with the
-    three-wave ladder (<= 16 blobs), radix-4 steps with the three-wave ladder (<= 32), radix-4 steps with the one-wave
-    quad ladder (<= 128), radix-2 stages beyond.  Every form against the one-blob path (itself checked against the
+    """The two G1 transforms of FK20 take the form that fits the batch (fk20.hip): radix-8 steps on raw records with the
+    three-wave ladder and two twiddles per workgroup (<= 8 blobs), with the two-wave ladder (9..16), with the one-wave
+    quad ladder (17..48); radix-4 steps with the one-wave quad ladder (<= 128), radix-2 stages beyond.  Every form against the one-blob path (itself checked against the
     oracle on every vector), one blob of each batch against the oracle directly; a zero blob (all proofs at infinity:
     every ladder input is the point at infinity) and a constant polynomial ride along."""
     base = [rand_blob(77, i) for i in range(3)] + [bytes(131072), (b"\x00" * 31 + b"\x07") * 4096]
