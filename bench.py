@@ -487,6 +487,8 @@ def verify_and_recover_rows(L, hip, base):
     # ("host_threads" = cpus // N).  What the emulation cannot see is N ranks contending for host memory bandwidth.
     shares = {}
     budget = int(L._fn("ckzg_hip_host_thread_budget", [])())
+    if EFFECTIVE_CORES:
+        budget = min(budget, EFFECTIVE_CORES)   # what the host really delivers (parallel speed-up of this run's cpu_baseline)
     try:
         for nr in (2, 4, 8):
             hip.lib.ckzg_hip_set_option(b"host_threads", max(1, budget // nr))
@@ -804,7 +806,9 @@ def concurrency_rows(mod, hip, blobs_u8, seconds=0.4, threads=(1, 8, 32, 128, 25
         for nt in threads:
             ins = [ub[t % 32] for t in range(nt)]
             aux = [cm[t % 32] + pr[t % 32] for t in range(nt)] if op == fo.OP_VERIFY_BLOB else None
-            fo.run(hip, mod.HIP_SO, op, ins, seconds=0.2, aux=aux)   # warm-up: arenas, page-locked batch buffers
+            # warm-up: arenas, page-locked batch buffers -- a crowd touches all eight stream slots and up to six batch
+            # buffers per operation before the steady state the row is about
+            fo.run(hip, mod.HIP_SO, op, ins, seconds=0.5 if nt >= 128 else 0.2, aux=aux)
             before = fo.coalesce_stats(hip, idx)
             st, rets, _ = fo.run(hip, mod.HIP_SO, op, ins, seconds=seconds, aux=aux)
             after = fo.coalesce_stats(hip, idx)
@@ -820,6 +824,8 @@ def concurrency_rows(mod, hip, blobs_u8, seconds=0.4, threads=(1, 8, 32, 128, 25
         out[name] = rows
     return out
 
+
+EFFECTIVE_CORES = None   # set by main() from the cpu_baseline of the run, before the secondary rows
 
 LAST_LINE_BUDGET = 4000   # characters; the driver keeps an ~8 KB stdout tail and parses the LAST line (round 4's 25 KB line was cut: parsed = null)
 
@@ -1125,6 +1131,14 @@ def main():
             small.close()
         return sec
 
+    cpu_base = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu_base = cpu_baseline()
+            global EFFECTIVE_CORES
+            EFFECTIVE_CORES = max(1, int(round(cpu_base["all_cores"]["value"] / cpu_base["value"])))
+        except Exception as e:  # the oracle is only a reported baseline
+            cpu_base = {"error": str(e)}
     if rank == 0 and world == 1 and not args.no_secondary:
         try:
             secondary = secondary_rows()
@@ -1223,11 +1237,8 @@ def main():
             line["numa"] = numa
         if sharded is not None:
             line["sharded_rows"] = sharded
-        if not args.no_cpu_baseline and world == 1:
-            try:
-                line["cpu_baseline"] = cpu_baseline()
-            except Exception as e:  # the oracle is only a reported baseline
-                line["cpu_baseline"] = {"error": str(e)}
+        if cpu_base is not None:
+            line["cpu_baseline"] = cpu_base
         # the 1/2/4/8-GPU curve this host should give, per BASELINE config, and what bounds it
         if world == 1:
             eff = None

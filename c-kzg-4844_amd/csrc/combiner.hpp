@@ -187,6 +187,18 @@ class Combiner {
                     // leaving meanwhile); callers that would need the same buffer go alone for that while, as they
                     // would without a combiner.
                     if (allocating) {
+                        if (peak > 8) {
+                            // a crowd: going alone would put hundreds of one-unit calls in line for the eight stream
+                            // slots (measured at 256 callers: 65 ms for the calls that met an allocation) -- wait the
+                            // 10-30 ms the allocation takes and join the new batch
+                            if (!have_ticket) {
+                                have_ticket = true;
+                                ticket = next_ticket++;
+                            }
+                            cv_pool.wait_for(lock, std::chrono::milliseconds(2));
+                            if (ticket >= serving) serving = ticket + 1;   // (woken by the allocator, or impatient: look again)
+                            continue;
+                        }
                         admitted();
                         lock.unlock();
                         return guarded([&]() -> C_KZG_RET { return solo(); });
