@@ -322,77 +322,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (ql == 0 && live) lad[(size_t)f * R4_LADDERS + ell] = xyzz28_to_xyzz(o, oi);
 }
 
-// The same ladders as a three-wave pipeline (g1_pipe.hpp): a workgroup of 192 threads serves the 16 quads of one
-// (group, ladder) index -- wave 0 forms the input combination and runs the doubling chain, waves 1 and 2 the addition
-// chains of the two GLV halves -- so the dependent chain of a radix-4 step is ~400 product steps instead of ~610.
-__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_g1_fft_r4_ladder_pipe(
-    G1XYZZ *lad, const G1XYZZ *data, const uint32_t *roots_glv, uint32_t nfft, int s, int dif, int inverse) {
-    __shared__ quad::PipeShared sh;
-    const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
-    const int quad_id = lane >> 2, ql = lane & 3;
-    if (threadIdx.x == 0) {
-        sh.produced = 0;
-        sh.consumed[0] = 0;
-        sh.consumed[1] = 0;
-        sh.r2done = 0;
-    }
-    __syncthreads();
-    const size_t q = blockIdx.x * (size_t)16 + quad_id;
-    const uint32_t pad = (nfft + 15u) & ~15u;
-    const uint32_t ell = (uint32_t)(q / pad);
-    uint32_t f = (uint32_t)(q - (size_t)ell * pad);
-    if (ell >= (uint32_t)R4_LADDERS) return;   // uniform over the workgroup (pad is a multiple of 16)
-    const bool live = f < nfft;
-    if (!live) f = nfft - 1;
-    const int grp = (int)ell / 5, k = (int)ell % 5;
-    int t, p0, p1, p2, p3;
-    r4_group(grp, s, dif, t, p0, p1, p2, p3);
-    const int e = r4_exponent(k, t, s, dif) & 127;
-    const uint32_t *rec = roots_glv + (size_t)(e == 0 ? 0 : (inverse ? 128 - e : e)) * TW_REC_WORDS;
-    const int8_t *naf1 = reinterpret_cast<const int8_t *>(rec + TW_NAF2_OFF), *naf2 = naf1 + TW_NAF2_STRIDE;
-    quad::NafMasks m_ab[2];   // (one twiddle per workgroup here: the same masks for both halves of a wave)
-    m_ab[0] = e != 0 ? quad::naf_masks(naf1, naf2) : quad::naf_masks_none();
-    m_ab[1] = m_ab[0];
-    if (wave == 0) {
-        const G1XYZZ *vec = data + (size_t)f * 128;
-        XYZZ28 v;
-        bool vi;
-        if (dif) {
-            bool i1, i2, i3;
-            if (k == 0 || k == 2) {         // a0 - a2
-                v = xyzz28_from_xyzz(vec[p0], vi);
-                XYZZ28 b = xyzz28_from_xyzz(vec[p2], i2);
-                r4_add(v, vi, xyzz28_neg(b), i2, ql);
-            } else if (k == 1 || k == 3) {  // a1 - a3
-                v = xyzz28_from_xyzz(vec[p1], vi);
-                XYZZ28 b = xyzz28_from_xyzz(vec[p3], i3);
-                r4_add(v, vi, xyzz28_neg(b), i3, ql);
-            } else {                        // (a0 + a2) - (a1 + a3)
-                v = xyzz28_from_xyzz(vec[p0], vi);
-                XYZZ28 b = xyzz28_from_xyzz(vec[p2], i2);
-                r4_add(v, vi, b, i2, ql);
-                XYZZ28 c = xyzz28_from_xyzz(vec[p1], i1), d = xyzz28_from_xyzz(vec[p3], i3);
-                r4_add(c, i1, d, i3, ql);
-                r4_add(v, vi, xyzz28_neg(c), i1, ql);
-            }
-        } else {
-            const int src = k == 0 ? p1 : ((k == 1 || k == 3) ? p2 : p3);
-            v = xyzz28_from_xyzz(vec[src], vi);
-        }
-        if (e == 0) {   // twiddle 1: the combination is the result, the adder wave has left already
-            if (ql == 0 && live) lad[(size_t)f * R4_LADDERS + ell] = xyzz28_to_xyzz(v, vi);
-            return;
-        }
-        quad::pipe_doubler(sh, v, vi, m_ab[0], m_ab[1], quad_id, ql);
-    } else {
-        if (e == 0) return;
-        XYZZ28 o;
-        bool oi = true;
-        quad::pipe_adder(o, oi, sh, m_ab[0], m_ab[1], wave - 1, quad_id, ql);
-        if (wave == 1 && ql == 0 && live) lad[(size_t)f * R4_LADDERS + ell] = xyzz28_to_xyzz(o, oi);
-    }
-}
-
 // one DPP quad per OUTPUT point (its two or three additions are latency, g1_quad.hpp): quad g -> (transform f,
 // group, which of the four outputs)
 __global__ __launch_bounds__(64) void k_g1_fft_r4_post(G1XYZZ *out, const G1XYZZ *data, const G1XYZZ *lad, uint32_t nfft,
@@ -815,16 +744,11 @@ static int g1_fft_r4_pairs(DeviceCtx *ctx, G1XYZZ *d_data, G1XYZZ *d_tmp, G1XYZZ
     const dim3 lgrid((unsigned)(pad * R4_LADDERS * 4 / 64)), pgrid((unsigned)(nfft * 128 * 4 / 64)), block(64);
     G1XYZZ *cur = d_data, *nxt = d_tmp;
     for (int s = s_from; dif ? s >= s_to + 1 : s + 1 <= s_to; s += dif ? -2 : 2) {
-        // the two-wave pipeline (g1_pipe.hpp) shortens a step's dependent chain by a third; same-box A/B in
-        // profiles/r05_fk20_small_ab.txt
-        // (n = 4..16: G1 FFTs 5.2 -> 3.7 ms; 32: 5.3 -> 5.1; 64: 6.5 -> 7.8 -- three waves per 16 ladders want a SIMD each)
-        static const size_t pipe_max = (size_t)ab_knob("CKZG_HIP_R4_PIPE_MAX", 32);
-        if (nfft <= pipe_max)
-            hipLaunchKernelGGL(k_g1_fft_r4_ladder_pipe, dim3((unsigned)(pad * R4_LADDERS / 16)), dim3(192), 0, ctx->stream, d_lad, cur,
-                               d_glv, (uint32_t)nfft, s, dif ? 1 : 0, inverse);
-        else
-            hipLaunchKernelGGL(k_g1_fft_r4_ladder, lgrid, block, 0, ctx->stream, d_lad, cur, d_glv, (uint32_t)nfft, s, dif ? 1 : 0,
-                               inverse);
+        // (round 5 first put the three-wave ladder of g1_pipe.hpp here -- radix-4 step 0.87 -> 0.53 ms, profiles/r05_fk20_small_ab.txt --
+        // before the radix-8 forms took over every batch size at which a pipeline's waves find a SIMD each; the batches that
+        // still come here, 49..128 transforms, are past that point)
+        hipLaunchKernelGGL(k_g1_fft_r4_ladder, lgrid, block, 0, ctx->stream, d_lad, cur, d_glv, (uint32_t)nfft, s, dif ? 1 : 0,
+                           inverse);
         hipLaunchKernelGGL(k_g1_fft_r4_post, pgrid, block, 0, ctx->stream, nxt, cur, d_lad, (uint32_t)nfft, s, dif ? 1 : 0);
         G1XYZZ *x = cur;
         cur = nxt;
