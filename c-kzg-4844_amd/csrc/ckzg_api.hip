@@ -646,9 +646,11 @@ static C_KZG_RET cells_and_proofs_batch_on(dev::DeviceCtx *ctx, Cell *cells, KZG
         }
         if (hipMemcpyAsync(d_blobs.p, h_in, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
             return C_KZG_ERROR;
-        int rc = dev::cells_and_proofs_device(ctx, d_cells, d_proofs, d_status, d_blobs.p, n);
+        bool cells_copied = false;   // (the device function may copy the cells out itself, underneath the proof kernels)
+        int rc = dev::cells_and_proofs_device(ctx, d_cells, d_proofs, d_status, d_blobs.p, n, cells && proofs ? h : nullptr, &cells_copied);
         if (rc) return (C_KZG_RET)rc;
-        if (hipMemcpyAsync(h, d_out.p, n * out_per, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return C_KZG_ERROR;
+        const size_t done = cells_copied ? n * cells_per : 0;
+        if (hipMemcpyAsync(h + done, d_out.p + done, n * out_per - done, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return C_KZG_ERROR;
         // (not the polling wait of the one-blob commitment: this call runs kernels on two streams, and a thread that polls
         // the runtime slows the runtime's own hand-over between them -- measured 1.63 -> 1.80 ms)
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) return C_KZG_ERROR;

@@ -1126,7 +1126,8 @@ int bad_to_status_enqueue(DeviceCtx *ctx, uint8_t *d_status, const uint32_t *d_b
 }
 
 int cells_and_proofs_device(DeviceCtx *ctx, uint8_t *d_cells, uint8_t *d_proofs, uint8_t *d_status,
-                            const uint8_t *d_blobs, size_t n) {
+                            const uint8_t *d_blobs, size_t n, uint8_t *h_cells, bool *cells_copied) {
+    if (cells_copied) *cells_copied = false;
     if (n == 0) return 0;
     // process in chunks so scratch stays bounded (about 1.2 MB per blob); the G1 FFT launches one
     // wave per blob, so a chunk should be several times the chip's 1024 SIMDs to keep them busy
@@ -1162,6 +1163,10 @@ int cells_and_proofs_device(DeviceCtx *ctx, uint8_t *d_cells, uint8_t *d_proofs,
         if (!rc) rc = fr_to_bytes_batch(ctx, d_cells, d_ext, n * N_EXT);
         ctx->stream = main_stream;
         if (rc) return rc;
+        if (h_cells) {   // the bulk of the output crosses PCIe underneath the proof kernels
+            HIP_TRY(hipMemcpyAsync(h_cells, d_cells, n * (size_t)N_EXT * 32, hipMemcpyDeviceToHost, ctx->copy_stream));
+            if (cells_copied) *cells_copied = true;
+        }
         HIP_TRY(hipEventRecord(ctx->stage_ev[1], ctx->copy_stream));
         rc = proofs_stage_enqueue(ctx, d_proofs, d_poly, n, fk_base, direct);
         if (rc) return rc;
