@@ -1,4 +1,4 @@
-// g1_pipe.hpp -- the twiddle multiplication [k]P of the small-batch G1 FFT as a TWO-WAVE pipeline (device only).
+// g1_pipe.hpp -- the twiddle multiplication [k]P of the small-batch G1 FFT as a pipeline of waves (device only).
 //
 // g1_quad.hpp's left-to-right ladder (xyzz28_mul_glv_naf_quad) is one dependent chain per point: table (15 product
 // steps), then per scalar bit a doubling (3 steps) and, at ~2/5 of the bits, a mixed addition (4 steps) INTO THE SAME
@@ -12,11 +12,17 @@
 // per workgroup, known to every wave), one adder wave per chain consumes them.  What is left after the last doubling
 // is one addition, the hand-over of R2 and R1 + phi(R2): ~400 dependent steps instead of ~610.  All waves keep
 // g1_quad.hpp's four-lanes-per-point form (16 points per wave, replicated state).
-// Measured forms (profiles/r05_fk20_small_ab.txt): both chains on ONE adder wave is bounded by that wave -- its 86
-// additions take 0.7-0.9 ms against the doubler's 0.53 (two register-resident accumulators spill) -- so each chain has
-// its own wave.  Three waves want three of a compute unit's four SIMDs: a radix-4 step of 16 transforms (160
-// workgroups on 256 units) runs at the doubler's pace, 0.53 ms; a radix-8 step (336 workgroups) has units with two
-// workgroups, where a doubler shares its SIMD with somebody's adder: 0.74 ms per step, still fewer steps in total.
+// Three forms, by what a step's workgroups find on the chip (measured: profiles/r05_fk20_small_ab.txt; where waves land:
+// tools/ubench/wave_placement.hip -- the waves of one workgroup never share a SIMD, workgroups go one per compute unit
+// until the 256 are taken, a second workgroup on a unit does not pick the idle SIMDs):
+//   * three waves, TWO twiddles per workgroup (<= 8 transforms): 168 workgroups per radix-8 step, a compute unit each;
+//     the step runs at the doubler's pace (~0.55 ms).
+//   * two waves -- one adder for both chains, its two sums parked in LDS between their additions -- in a kernel with
+//     the whole register file per wave (9..16 transforms, 336 workgroups, two per unit, a SIMD per wave by
+//     construction).  With the usual 256 registers the adder spilled, its additions took ~11 us instead of ~7 and it
+//     bounded the step.
+//   * three waves, one twiddle (the first form built; 336 workgroups leave units with two workgroups, where a doubler
+//     shares its SIMD with somebody's adder: 0.74 ms per step) -- kept for the A/B builds.
 //
 // Infinity: a quad whose input is the point at infinity runs the doubler on zeros and sits out the additions
 // (predicated), so it costs nothing and cannot reach the exceptional-case fallback.
