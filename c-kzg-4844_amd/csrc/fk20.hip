@@ -270,9 +270,9 @@ __device__ __forceinline__ int r4_exponent(int k, int t, int s, int dif) {
     }
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_g1_fft_r4_ladder(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_g1_fft_r4_ladder(
     G1XYZZ *lad, const G1XYZZ *data, const uint32_t *roots_glv, uint32_t nfft, int s, int dif, int inverse) {
-    const size_t q = (blockIdx.x * (size_t)64 + threadIdx.x) >> 2;
+    const size_t q = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 2;
     const int ql = (int)(threadIdx.x & 3);
     const uint32_t pad = (nfft + 15u) & ~15u;
     const uint32_t ell = (uint32_t)(q / pad);
@@ -552,7 +552,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 __device__ __forceinline__ void r8_ladder_body(uint32_t *lad, const uint32_t *data, const uint32_t *roots_glv, uint32_t nfft, int s, int dif,
                                                int inverse) {
     constexpr int RW = quad::RAW_WORDS;
-    const size_t q = (blockIdx.x * (size_t)64 + threadIdx.x) >> 2;
+    // (workgroups of four waves: the waves of ONE workgroup never share a SIMD, while single-wave workgroups are
+    // doubled up on SIMDs that are already taken -- tools/ubench/wave_placement.hip)
+    const size_t q = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 2;
     const int ql = (int)(threadIdx.x & 3);
     const uint32_t pad = (nfft + 15u) & ~15u;
     const uint32_t ell = (uint32_t)(q / pad);
@@ -589,12 +591,12 @@ __device__ __forceinline__ void r8_ladder_body(uint32_t *lad, const uint32_t *da
     if (ql == 0 && live) quad::raw_store(lad + ((size_t)f * R8_LADDERS + ell) * RW, o, oi);
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_g1_fft_r8_ladder(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_g1_fft_r8_ladder(
     uint32_t *lad, const uint32_t *data, const uint32_t *roots_glv, uint32_t nfft, int s, int dif, int inverse) {
     r8_ladder_body(lad, data, roots_glv, nfft, s, dif, inverse);
 }
 // the same with the whole register file per wave, for batches whose waves fit the chip once (<= 48 transforms)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_g1_fft_r8_ladder_full(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_g1_fft_r8_ladder_full(
     uint32_t *lad, const uint32_t *data, const uint32_t *roots_glv, uint32_t nfft, int s, int dif, int inverse) {
     r8_ladder_body(lad, data, roots_glv, nfft, s, dif, inverse);
 }
@@ -707,6 +709,7 @@ static int g1_fft_r8_fk20(DeviceCtx *ctx, G1XYZZ *d_u, uint32_t *d_a, uint32_t *
     static const size_t two_max = (size_t)ab_knob("CKZG_HIP_R8_TWO_MAX", 8);
     static const bool dual = ab_knob("CKZG_HIP_R8_DUAL", 1) != 0;
     static const bool one_full = ab_knob("CKZG_HIP_R8_ONE_FULL", 1) != 0;
+    static const unsigned wg1 = (unsigned)ab_knob("CKZG_HIP_LADDER_WG", 256);   // threads per workgroup of the one-wave ladder kernels
     auto step = [&](int s, int dif, int inverse, G1XYZZ *final_out) {
         if (pipe && nfft <= two_max) {   // two ladder indices per workgroup: 168 workgroups, one per compute unit
             hipLaunchKernelGGL(k_g1_fft_r8_ladder_pipe, dim3((unsigned)(R8_LADDERS / 2)), dim3(192), 0, ctx->stream, d_lad, cur, d_glv,
@@ -716,10 +719,10 @@ static int g1_fft_r8_fk20(DeviceCtx *ctx, G1XYZZ *d_u, uint32_t *d_a, uint32_t *
         else if (pipe)
             hipLaunchKernelGGL(k_g1_fft_r8_ladder_pipe, lgrid, dim3(192), 0, ctx->stream, d_lad, cur, d_glv, (uint32_t)nfft, s, dif, inverse, 0);
         else if (one_full)
-            hipLaunchKernelGGL(k_g1_fft_r8_ladder_full, dim3((unsigned)(pad * R8_LADDERS * 4 / 64)), block, 0, ctx->stream, d_lad, cur, d_glv,
-                               (uint32_t)nfft, s, dif, inverse);
+            hipLaunchKernelGGL(k_g1_fft_r8_ladder_full, dim3((unsigned)(pad * R8_LADDERS * 4 / wg1)), dim3(wg1), 0, ctx->stream, d_lad, cur,
+                               d_glv, (uint32_t)nfft, s, dif, inverse);
         else
-            hipLaunchKernelGGL(k_g1_fft_r8_ladder, dim3((unsigned)(pad * R8_LADDERS * 4 / 64)), block, 0, ctx->stream, d_lad, cur, d_glv,
+            hipLaunchKernelGGL(k_g1_fft_r8_ladder, dim3((unsigned)(pad * R8_LADDERS * 4 / wg1)), dim3(wg1), 0, ctx->stream, d_lad, cur, d_glv,
                                (uint32_t)nfft, s, dif, inverse);
         hipLaunchKernelGGL(k_g1_fft_r8_post, pgrid, block, 0, ctx->stream, nxt, final_out, cur, d_lad, (uint32_t)nfft, s, dif);
         uint32_t *x = cur;
@@ -741,13 +744,15 @@ static int g1_fft_r8_fk20(DeviceCtx *ctx, G1XYZZ *d_u, uint32_t *d_a, uint32_t *
 static int g1_fft_r4_pairs(DeviceCtx *ctx, G1XYZZ *d_data, G1XYZZ *d_tmp, G1XYZZ *d_lad, const uint32_t *d_glv, size_t nfft,
                            bool dif, int s_from, int s_to, int inverse) {
     const size_t pad = (nfft + 15) / 16 * 16;
-    const dim3 lgrid((unsigned)(pad * R4_LADDERS * 4 / 64)), pgrid((unsigned)(nfft * 128 * 4 / 64)), block(64);
+    // (the ladder kernel in workgroups of four waves: see r8_ladder_body)
+    static const unsigned wg1 = (unsigned)ab_knob("CKZG_HIP_LADDER_WG", 256);
+    const dim3 lgrid((unsigned)((pad * R4_LADDERS * 4 + wg1 - 1) / wg1)), lblock(wg1), pgrid((unsigned)(nfft * 128 * 4 / 64)), block(64);
     G1XYZZ *cur = d_data, *nxt = d_tmp;
     for (int s = s_from; dif ? s >= s_to + 1 : s + 1 <= s_to; s += dif ? -2 : 2) {
         // (round 5 first put the three-wave ladder of g1_pipe.hpp here -- radix-4 step 0.87 -> 0.53 ms, profiles/r05_fk20_small_ab.txt --
         // before the radix-8 forms took over every batch size at which a pipeline's waves find a SIMD each; the batches that
         // still come here, 49..128 transforms, are past that point)
-        hipLaunchKernelGGL(k_g1_fft_r4_ladder, lgrid, block, 0, ctx->stream, d_lad, cur, d_glv, (uint32_t)nfft, s, dif ? 1 : 0,
+        hipLaunchKernelGGL(k_g1_fft_r4_ladder, lgrid, lblock, 0, ctx->stream, d_lad, cur, d_glv, (uint32_t)nfft, s, dif ? 1 : 0,
                            inverse);
         hipLaunchKernelGGL(k_g1_fft_r4_post, pgrid, block, 0, ctx->stream, nxt, cur, d_lad, (uint32_t)nfft, s, dif ? 1 : 0);
         G1XYZZ *x = cur;
