@@ -171,13 +171,13 @@ struct DeviceCtx {
     hipEvent_t table_ev = nullptr;      // "the call-time table is complete" (verification; created on first use)
     std::vector<hipEvent_t> chunk_ev;   // per-chunk events of the pipelined verification (grown on demand, kept)
     hipEvent_t ev[12] = {};       // timing events
-    // The one-blob blob_to_kzg_commitment as a captured graph (copy in, flag reset, recoding, accumulate, fold +
-    // finalize, copy out: six dependent nodes launched with ONE submission), valid while everything its nodes point at
-    // stays where it was; re-captured otherwise (ckzg_api.hip: commit_batch_on).
+    // The one-blob blob_to_kzg_commitment as a graph built node by node (copy in, flag reset, recoding, accumulate, fold +
+    // finalize, copy out: six dependent nodes launched with ONE submission; msm.hip: commit_one_graph_build), valid while
+    // everything its nodes point at stays where it was; rebuilt otherwise (ckzg_api.hip: commit_batch_on).
     struct OneCommitGraph {
         hipGraphExec_t exec = nullptr;
         const void *key[7] = {};
-        bool unusable = false;    // capture or instantiation failed once on this slot: plain launches from then on
+        bool unusable = false;    // construction or instantiation failed once on this slot: plain launches from then on
     } one_commit;
     float last_ms[6] = {-1, -1, -1, -1, -1, -1};  // see ckzg_hip_last_kernel_ms
     // Fr tables for NTTs and evaluation (Montgomery form, 8 x u32)
