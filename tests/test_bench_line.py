@@ -69,3 +69,14 @@ def test_oversized_extras_are_dropped_not_the_head():
     out = b.compact_line(full, None)
     assert len(json.dumps(out)) <= b.LAST_LINE_BUDGET
     assert out["roofline"]["frac"] and out["cpu_baseline"]["value"]
+
+
+def test_round5_record_also_fits():
+    """the full record of a round-5 run (one-rank shares, percentiles in every caller row: 29 KB)"""
+    b = _bench()
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_last_bench_full_record.json")))
+    out = b.compact_line(full, "gpurun_out/bench_secondary.json")
+    assert len(json.dumps(out)) < b.LAST_LINE_BUDGET
+    assert out["roofline"]["traffic"] and out["roofline"]["traffic_source"].startswith("profiles/r05_final_pmc")
+    assert out["cpu_baseline"]["all_cores"]["driver"].startswith("pthreads")
+    assert out["baseline_configs"]["configs[4]_recover_256_ms"] == full["baseline_configs"]["configs[4]"]
