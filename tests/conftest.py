@@ -24,6 +24,26 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Order of the suite (the driver runs it with -x under a wall-clock limit): what pins parity first -- the reference's
+# golden vectors through the C-ABI, then the BASELINE configurations at full size --, the rest in the middle, and the
+# tests that provoke trouble on purpose (concurrency stress, fuzzing, failure injection, sanitizer passes) last, so that
+# a stall or a failure there cannot erase the parity record collected before it (round 5: the allocation-failure walk,
+# second in alphabetical order, did not come back on the driver's box and no parity test ran).
+_ORDER = {
+    "test_c_link": 0, "test_gpu_vectors": 1, "test_gpu_commitment": 2, "test_gpu_cells": 3,
+    "test_gpu_wide_tables": 4, "test_gpu_full_size": 5,
+    "test_gpu_fuzz": 16, "test_gpu_coalesce": 17, "test_gpu_deadlines": 18,
+    "test_gpu_alloc_failures": 19, "test_sanitizers": 20,
+}
+
+
+def pytest_collection_modifyitems(config, items):
+    def rank(item):
+        mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        return _ORDER.get(mod, 10)
+    items.sort(key=rank)   # (stable: the order inside a rank is the collection order)
+
+
 def pytest_sessionstart(session):
     """A checkout without build products (they are git-ignored) still gets a usable suite: build what is
     missing once, the way __graft_entry__.build() does.  hipcc cross-compiles gfx950 without a GPU."""

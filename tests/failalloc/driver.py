@@ -106,6 +106,17 @@ OPS.update({
 only = os.environ.get("FAILALLOC_ONLY")
 if only:
     OPS = {n: f for n, f in OPS.items() if n in only.split(",")}
+# FAILALLOC_SECTIONS: which walks this process runs (tests/test_gpu_alloc_failures.py runs each in a process of its own,
+# under its own deadline); default: all of them
+ALL_SECTIONS = ("ops", "load", "ops_streams_events", "load_streams_events", "fan_out", "coalesced_callers", "widening")
+SECTIONS = tuple(x for x in os.environ.get("FAILALLOC_SECTIONS", ",".join(ALL_SECTIONS)).split(",") if x)
+assert all(x in ALL_SECTIONS for x in SECTIONS), SECTIONS
+
+
+def progress(msg):
+    """where a stalled run was: the last of these lines on stderr names the case (tests/watchdog.py prints the tail)"""
+    sys.stderr.write("[failalloc] %s\n" % msg)
+    sys.stderr.flush()
 
 problems = []
 # Leak checks compare hipMemGetInfo's free figure with the one taken after a SUCCESSFUL run of the same thing: the
@@ -156,6 +167,7 @@ def walk_ops(cls, allowed, stickies, key):
             fired_total = 0
             n_alloc = None
             for nth in range(0, 64):
+                progress("%s: %s, failure %d, sticky=%d" % (key, name, nth, sticky))
                 k = load()
                 fa.failalloc_arm(nth, sticky)
                 got, code = None, 0
@@ -201,6 +213,7 @@ def walk_load(cls, allowed, stickies, key):
         injected, n_alloc, leaked = 0, None, 0
         nth = 0
         while nth < 4000:
+            progress("load (%s): failure %d, sticky=%d" % (key, nth, sticky))
             fa.failalloc_arm(nth, sticky)
             code, k = 0, None
             try:
@@ -230,107 +243,135 @@ def walk_load(cls, allowed, stickies, key):
 
 
 report["ops"], report["ops_streams_events"] = {}, {}
-walk_ops(0, (0, C_KZG_MALLOC), (0, 1), "ops")
-walk_load(0, (0, C_KZG_MALLOC), (0, 1), "ops")
+if "ops" in SECTIONS:
+    walk_ops(0, (0, C_KZG_MALLOC), (0, 1), "ops")
+if "load" in SECTIONS:
+    walk_load(0, (0, C_KZG_MALLOC), (0, 1), "ops")
 # streams and events that cannot be created: an internal error (C_KZG_ERROR) or, as the runtime reports it here,
 # out of memory; same rules otherwise
-walk_ops(1, (0, C_KZG_ERROR, C_KZG_MALLOC), (0,), "ops_streams_events")
-walk_load(1, (0, C_KZG_ERROR, C_KZG_MALLOC), (0,), "ops_streams_events")
+if "ops_streams_events" in SECTIONS:
+    walk_ops(1, (0, C_KZG_ERROR, C_KZG_MALLOC), (0,), "ops_streams_events")
+if "load_streams_events" in SECTIONS:
+    walk_load(1, (0, C_KZG_ERROR, C_KZG_MALLOC), (0,), "ops_streams_events")
 
-# ---- two table sets ("replicas": the one-GPU stand-in for "devices"): the load builds both, a batch fans out over
-# ---- both with one worker thread each, and a failure on either side must come back as C_KZG_MALLOC just the same
-k = load(options={"replicas": 2})
-want_fan = (commit_batch(k, 40), k.verify_blob_kzg_proof_batch(many, many_c, many_p))
-k.close()
-watch = LeakWatch()
-injected = 0
-for nth in range(0, 96):
-    fa.failalloc_arm(nth, 0)
-    code, k = 0, None
-    try:
-        k = load(options={"replicas": 2})
-    except KzgError as e:
-        code = ret_code(e)
-    load_fired = fa.failalloc_fired()
-    if k is not None and not load_fired:   # the load is through: the failure lands in the fanned-out calls
-        got = None
+
+def section_fan_out():
+    """two table sets ("replicas": the one-GPU stand-in for "devices"): the load builds both, a batch fans out over
+    both with one worker thread each, and a failure on either side must come back as C_KZG_MALLOC just the same"""
+    k = load(options={"replicas": 2})
+    want_fan = (commit_batch(k, 40), k.verify_blob_kzg_proof_batch(many, many_c, many_p))
+    k.close()
+    watch = LeakWatch()
+    injected = 0
+    for nth in range(0, 96):
+        progress("fan-out: failure %d" % nth)
+        fa.failalloc_arm(nth, 0)
+        code, k = 0, None
         try:
-            got = (commit_batch(k, 40), k.verify_blob_kzg_proof_batch(many, many_c, many_p))
+            k = load(options={"replicas": 2})
         except KzgError as e:
             code = ret_code(e)
-        if got is not None and got != want_fan:
-            problems.append("fan-out: wrong result with failed allocation %d" % nth)
-    fired = fa.failalloc_fired()
-    fa.failalloc_disarm()
-    if k is not None:
-        try:
-            if (commit_batch(k, 40), k.verify_blob_kzg_proof_batch(many, many_c, many_p)) != want_fan:
-                problems.append("fan-out: wrong result on the calls after failed allocation %d" % nth)
-        except KzgError as e:
-            problems.append("fan-out: calls after failed allocation %d -> %s" % (nth, e))
+        load_fired = fa.failalloc_fired()
+        if k is not None and not load_fired:   # the load is through: the failure lands in the fanned-out calls
+            got = None
+            try:
+                got = (commit_batch(k, 40), k.verify_blob_kzg_proof_batch(many, many_c, many_p))
+            except KzgError as e:
+                code = ret_code(e)
+            if got is not None and got != want_fan:
+                problems.append("fan-out: wrong result with failed allocation %d" % nth)
+        fired = fa.failalloc_fired()
+        fa.failalloc_disarm()
+        if k is not None:
+            try:
+                if (commit_batch(k, 40), k.verify_blob_kzg_proof_batch(many, many_c, many_p)) != want_fan:
+                    problems.append("fan-out: wrong result on the calls after failed allocation %d" % nth)
+            except KzgError as e:
+                problems.append("fan-out: calls after failed allocation %d -> %s" % (nth, e))
+            k.close()
+        if not fired:
+            break
+        injected += 1
+        if code not in (0, C_KZG_MALLOC):
+            problems.append("fan-out: allocation %d failed -> C_KZG_RET %s" % (nth, code))
+        watch.check("fan-out, failed allocation %d" % nth)
+    k0.lib.ckzg_hip_set_option(b"replicas", 1)
+    report["fan_out"] = {"failures_injected": injected}
+
+
+def section_coalesced_callers():
+    """concurrent one-blob callers (csrc/combiner.hpp): 24 native threads share batch launches while the n-th
+    allocation from now on fails (sticky: the page-locked batch buffers, the arenas and staging of the slots the
+    launches lease, whatever comes n-th).  Every call must come back with the right commitment or with C_KZG_MALLOC
+    -- no hang, no crash, no wrong bytes -- and once allocations work again so must every caller."""
+    import importlib.util
+    _pkg = os.path.join(os.path.dirname(os.path.dirname(HERE)), "c-kzg-4844_amd")
+    _spec = importlib.util.spec_from_file_location("ckzg_fanout", os.path.join(_pkg, "fanout.py"))
+    fo = importlib.util.module_from_spec(_spec)
+    _spec.loader.exec_module(fo)
+    watch = LeakWatch()
+    threads = 24
+    ins = [many[t % 40] for t in range(threads)]
+    want_cm = [many_c[t % 40] for t in range(threads)]
+    coalesce_injected, coalesce_batches = 0, 0
+    for nth in list(range(0, 12)) + [16, 24, 40]:
+        progress("coalesced callers: allocations fail from the %d-th" % nth)
+        k = load()
+        fa.failalloc_arm(nth, 1)
+        st, rets, outs = fo.run(k, LIB, fo.OP_COMMIT, ins, max_calls=6)
+        fired = fa.failalloc_fired()
+        fa.failalloc_disarm()
+        for t in range(threads):
+            if rets[t] == 0 and outs[t] != want_cm[t]:
+                problems.append("coalesced callers, allocations failing from the %d-th: thread %d got OK with WRONG bytes" % (nth, t))
+            elif rets[t] not in (0, C_KZG_MALLOC):
+                problems.append("coalesced callers, allocations failing from the %d-th: thread %d -> C_KZG_RET %d" % (nth, t, rets[t]))
+        progress("coalesced callers: allocations work again (failed from the %d-th)" % nth)
+        st2, rets2, outs2 = fo.run(k, LIB, fo.OP_COMMIT, ins, max_calls=4)
+        if rets2 != [0] * threads or outs2 != want_cm:
+            problems.append("coalesced callers: wrong results after allocations work again (failed from the %d-th)" % nth)
+        cs = fo.coalesce_stats(k, 0)
+        coalesce_batches += cs["batches"] if cs else 0
         k.close()
-    if not fired:
-        break
-    injected += 1
-    if code not in (0, C_KZG_MALLOC):
-        problems.append("fan-out: allocation %d failed -> C_KZG_RET %s" % (nth, code))
-    watch.check("fan-out, failed allocation %d" % nth)
-k0.lib.ckzg_hip_set_option(b"replicas", 1)
-report["fan_out"] = {"failures_injected": injected}
+        coalesce_injected += 1 if fired else 0
+        watch.check("coalesced callers, allocations failing from the %d-th" % nth)
+    report["coalesced_callers"] = {"levels_with_failures": coalesce_injected, "batch_launches": coalesce_batches}
 
-# ---- concurrent one-blob callers (csrc/combiner.hpp): 24 native threads share batch launches while the n-th allocation
-# ---- from now on fails (sticky: the page-locked batch buffers, the arenas and staging of the slots the launches lease,
-# ---- whatever comes n-th).  Every call must come back with the right commitment or with C_KZG_MALLOC -- no hang, no
-# ---- crash, no wrong bytes -- and once allocations work again so must every caller.
-import importlib.util  # noqa: E402
-_pkg = os.path.join(os.path.dirname(os.path.dirname(HERE)), "c-kzg-4844_amd")
-_spec = importlib.util.spec_from_file_location("ckzg_fanout", os.path.join(_pkg, "fanout.py"))
-fo = importlib.util.module_from_spec(_spec)
-_spec.loader.exec_module(fo)
-watch = LeakWatch()
-threads = 24
-ins = [many[t % 40] for t in range(threads)]
-want_cm = [many_c[t % 40] for t in range(threads)]
-coalesce_injected, coalesce_batches = 0, 0
-for nth in list(range(0, 12)) + [16, 24, 40]:
-    k = load()
-    fa.failalloc_arm(nth, 1)
-    st, rets, outs = fo.run(k, LIB, fo.OP_COMMIT, ins, max_calls=6)
-    fired = fa.failalloc_fired()
+
+def section_widening():
+    """background widening under an exhausted device: the tables stay at whatever width was reached, calls go on"""
+    watch = LeakWatch()
+    progress("widening: load")
+    k = load(options={"async_tables": 1, "commit_wbits": 13, "proof_wbits": 11, "fk20_wbits": 10})
+    fa.failalloc_arm(0, 1)
+    k.lib.ckzg_hip_wait_tables.argtypes = [C.c_void_p]
+    progress("widening: wait_tables")
+    k.lib.ckzg_hip_wait_tables(k.sp)
     fa.failalloc_disarm()
-    for t in range(threads):
-        if rets[t] == 0 and outs[t] != want_cm[t]:
-            problems.append("coalesced callers, allocations failing from the %d-th: thread %d got OK with WRONG bytes" % (nth, t))
-        elif rets[t] not in (0, C_KZG_MALLOC):
-            problems.append("coalesced callers, allocations failing from the %d-th: thread %d -> C_KZG_RET %d" % (nth, t, rets[t]))
-    st2, rets2, outs2 = fo.run(k, LIB, fo.OP_COMMIT, ins, max_calls=4)
-    if rets2 != [0] * threads or outs2 != want_cm:
-        problems.append("coalesced callers: wrong results after allocations work again (failed from the %d-th)" % nth)
-    cs = fo.coalesce_stats(k, 0)
-    coalesce_batches += cs["batches"] if cs else 0
+    progress("widening: calls after")
+    try:
+        if k.blob_to_kzg_commitment(blob) != commitment:
+            problems.append("widening: wrong commitment after the widener ran out of memory")
+        if k.compute_cells_and_kzg_proofs(blob) != (cells, cproofs):
+            problems.append("widening: wrong cells/proofs after the widener ran out of memory")
+    except KzgError as e:
+        problems.append("widening: %s" % e)
+    for o, v in (("async_tables", 0), ("commit_wbits", 10), ("proof_wbits", 8), ("fk20_wbits", 0)):
+        k.lib.ckzg_hip_set_option(o.encode(), v)
     k.close()
-    coalesce_injected += 1 if fired else 0
-    watch.check("coalesced callers, allocations failing from the %d-th" % nth)
-report["coalesced_callers"] = {"levels_with_failures": coalesce_injected, "batch_launches": coalesce_batches}
+    watch.check("after the widening run")
+    report["widening"] = {"ran": True}
 
-# ---- background widening under an exhausted device: the tables stay at whatever width was reached, calls go on
-k = load(options={"async_tables": 1, "commit_wbits": 13, "proof_wbits": 11, "fk20_wbits": 10})
-fa.failalloc_arm(0, 1)
-k.lib.ckzg_hip_wait_tables.argtypes = [C.c_void_p]
-k.lib.ckzg_hip_wait_tables(k.sp)
-fa.failalloc_disarm()
-try:
-    if k.blob_to_kzg_commitment(blob) != commitment:
-        problems.append("widening: wrong commitment after the widener ran out of memory")
-    if k.compute_cells_and_kzg_proofs(blob) != (cells, cproofs):
-        problems.append("widening: wrong cells/proofs after the widener ran out of memory")
-except KzgError as e:
-    problems.append("widening: %s" % e)
-for o, v in (("async_tables", 0), ("commit_wbits", 10), ("proof_wbits", 8), ("fk20_wbits", 0)):
-    k.lib.ckzg_hip_set_option(o.encode(), v)
-k.close()
-watch.check("after the widening run")
+
+if "fan_out" in SECTIONS:
+    section_fan_out()
+if "coalesced_callers" in SECTIONS:
+    section_coalesced_callers()
+if "widening" in SECTIONS:
+    section_widening()
+report["sections"] = list(SECTIONS)
 report["max_free_delta_bytes"] = max_delta
 report["problems"] = problems
+progress("done")
 print(json.dumps(report))
 sys.exit(1 if problems else 0)

@@ -8,6 +8,7 @@ import pytest
 
 from conftest import ROOT
 from kzg_ctypes import HIP_SO, TRUSTED_SETUP
+from watchdog import run_watched
 
 EXE = os.path.join(ROOT, "examples", "commit")
 
@@ -30,7 +31,7 @@ def test_c_program_compiles_and_links_against_the_library():
 @pytest.mark.gpu
 def test_c_program_runs_and_matches_oracle(oracle):
     _build()
-    out = subprocess.run([EXE, TRUSTED_SETUP], capture_output=True, text=True, timeout=300)
+    out = run_watched([EXE, TRUSTED_SETUP], timeout=240, name="c_link_example")
     assert out.returncode == 0, out.stdout + out.stderr
     blob = bytearray(131072)
     for i in range(4096):

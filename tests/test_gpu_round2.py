@@ -579,8 +579,8 @@ def _run_bench(extra_env, args):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update(extra_env)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True,
-                       timeout=600)
+    from watchdog import run_watched
+    r = run_watched([sys.executable, os.path.join(root, "bench.py")] + args, env=env, timeout=280, name="bench_child")
     assert r.returncode == 0, r.stderr[-2000:]
     # stdout: ONE compact line (the driver's contract, < 4 KB); the full record is one stderr line
     out = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

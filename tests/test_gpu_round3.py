@@ -142,7 +142,8 @@ print(json.dumps(out))
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
-    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    from watchdog import run_watched
+    r = run_watched([sys.executable, "-c", code], cwd=root, env=env, timeout=280, name="round3_pipelined_verify")
     assert r.returncode == 0, r.stderr[-2000:]
     res = json.loads(r.stdout.strip().splitlines()[-1])
     assert res == {"300": [True, False], "513": [True, False]}
@@ -410,7 +411,8 @@ print(json.dumps(out))
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
-    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    from watchdog import run_watched
+    r = run_watched([sys.executable, "-c", code], cwd=root, env=env, timeout=280, name="round3_forms")
     assert r.returncode == 0, r.stderr[-2000:]
     res = json.loads(r.stdout.strip().splitlines()[-1])
     from test_gpu_commitment import rand_blob

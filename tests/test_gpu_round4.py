@@ -34,8 +34,9 @@ def test_batch_verification_when_hbm_is_too_full_for_the_call_time_table():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "oom_fallback_probe.py"), "900", "330"],
-                       capture_output=True, text=True, timeout=600, cwd=root)
+    from watchdog import run_watched
+    r = run_watched([sys.executable, os.path.join(root, "tools", "oom_fallback_probe.py"), "900", "330"], timeout=280,
+                    cwd=root, name="oom_fallback_probe")
     rows = [json.loads(line) for line in r.stdout.splitlines() if line.startswith("{") and '"rc"' in line]
     assert r.returncode == 0 and len(rows) == 2, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
     for row in rows:

@@ -49,7 +49,10 @@ def kernels_of(obj):
     out = []
     with tempfile.TemporaryDirectory() as t:
         fat = os.path.join(t, "k.fatbin")
-        r = subprocess.run([LLVM + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, obj], capture_output=True, text=True)
+        # (an explicit output operand: without one llvm-objcopy rewrites `obj` in place, and the product's object files
+        # came out newer than libckzg_hip.so -- the next `make` relinked for nothing)
+        r = subprocess.run([LLVM + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, obj, os.path.join(t, "discard.o")],
+                           capture_output=True, text=True)
         if r.returncode != 0 or not os.path.exists(fat) or os.path.getsize(fat) == 0:
             return []
         blob = open(fat, "rb").read()
