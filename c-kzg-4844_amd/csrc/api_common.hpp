@@ -262,6 +262,7 @@ int pool_of_pointers(const SettingsCtx *sc, const void *const *ptrs, int count);
 C_KZG_RET create_settings_ctx(KZGSettings *s, const G1Affine *lagrange_brp_affine,
                               const G1Affine *monomial_affine);
 void destroy_settings_ctx(const KZGSettings *s);
+void debug_dump(int fd);                     // ckzg_hip_debug_dump
 void start_widening(const KZGSettings *s);   // "async_tables": after the warm-up calls of the load
 // blocks until the background widening of an "async_tables" load has finished (returns at once otherwise)
 void wait_for_tables(const KZGSettings *s);
@@ -397,13 +398,11 @@ C_KZG_RET for_each_device_shard(const KZGSettings *s, uint64_t n, uint64_t min_s
 }
 
 // Sleeping on a 32-bit word instead of spinning on it (the combiner's batches, the transcript hasher of a pipelined
-// verification, the waits for pool jobs): futex_wait returns on a wake, a changed value or a signal -- callers
+// verification, the waits for pool jobs): a futex wait returns on a wake, a changed value or a signal -- callers
 // re-check in a loop; the happens-before edge is the acquire load / release store of the word itself.
 static_assert(sizeof(std::atomic<uint32_t>) == sizeof(uint32_t), "futex word");
-inline void futex_wait(std::atomic<uint32_t> *w, uint32_t expected) {
-    (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAIT_PRIVATE, expected, nullptr, nullptr, 0);
-}
-// the same with a relative timeout (returns on a wake, a changed value, a signal or after `ns` nanoseconds)
+// relative timeout: returns on a wake, a changed value, a signal or after `ns` nanoseconds -- there is no form
+// without one (device.hpp: bounded waits); the callers re-check their word in a loop
 inline void futex_wait_for(std::atomic<uint32_t> *w, uint32_t expected, long ns) {
     struct timespec ts = {ns / 1000000000L, ns % 1000000000L};
     (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAIT_PRIVATE, expected, &ts, nullptr, 0);
@@ -411,9 +410,59 @@ inline void futex_wait_for(std::atomic<uint32_t> *w, uint32_t expected, long ns)
 inline void futex_wake(std::atomic<uint32_t> *w, int count) {
     (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAKE_PRIVATE, count, nullptr, nullptr, 0);
 }
+// Two kinds of host waits:
+//  (1) for ANOTHER CALLER's progress or for the device (a batch of the combiner, a stream slot, a published chunk):
+//      wait_word_until -- sleeps in slices of at most 50 ms (a lost wake-up costs a slice, not the call), gives up at
+//      the deadline and returns false; the caller returns C_KZG_ERROR.
+//  (2) for HOST WORK OF THIS CALL that running threads of this library are doing with pointers into the caller's
+//      buffers or this frame (staging-copy parts, hashing jobs): the call cannot return before they have let go, and the
+//      work is finite by construction (memcpy, SHA-256 over bytes that are there), so wait_host_work_done keeps waiting
+//      -- in slices as well, and it says so on stderr once the deadline has passed, so that a stall is never silent.
+constexpr long WAIT_SLICE_NS = 50L * 1000 * 1000;
+// until pred(value of *w) holds; false: deadline (the word is left as it is)
+template <class Pred>
+inline bool wait_word_until(std::atomic<uint32_t> *w, Pred &&pred, const char *what) {
+    uint32_t v = w->load(std::memory_order_acquire);
+    if (pred(v)) return true;
+    dev::WaitNote note(what, w);
+    for (;;) {
+        futex_wait_for(w, v, WAIT_SLICE_NS);
+        v = w->load(std::memory_order_acquire);
+        if (pred(v)) return true;
+        if (note.expired()) return false;
+    }
+}
 // block until *w == 0 (the countdown of outstanding pool jobs of a call); the job that takes it to 0 calls futex_wake
-inline void wait_until_zero(std::atomic<uint32_t> *w) {
-    for (uint32_t v; (v = w->load(std::memory_order_acquire)) != 0;) futex_wait(w, v);
+inline void wait_host_work_done(std::atomic<uint32_t> *w, const char *what = "host jobs of this call") {
+    uint32_t v = w->load(std::memory_order_acquire);
+    if (v == 0) return;
+    dev::WaitNote note(what, w);
+    bool said = false;
+    for (; (v = w->load(std::memory_order_acquire)) != 0;) {
+        futex_wait_for(w, v, WAIT_SLICE_NS);
+        if (!said && note.waited_us() > dev::wait_deadline_ms() * 1000) {
+            said = true;
+            fprintf(stderr, "[ckzg-hip] %s: still %u outstanding after %lld ms (host work holding this call's buffers; "
+                            "the call cannot return before it has finished)\n", what, v, (long long)dev::wait_deadline_ms());
+        }
+    }
+}
+// The idle wait of a SERVICE thread (pool workers parked until there is a job, a result drain parked until its owner
+// pushes or closes): nobody's call is waiting on it, it is meant to last as long as nothing is asked of the thread.
+template <class CV, class Lock, class Pred>
+inline void park_until(CV &cv, Lock &lock, Pred &&pred) {
+    while (!pred()) (void)cv.wait_for(lock, std::chrono::seconds(1));
+}
+// condition variable, same rules as wait_word_until; false: deadline
+template <class CV, class Lock, class Pred>
+inline bool cv_wait_bounded(CV &cv, Lock &lock, Pred &&pred, const char *what, const void *obj = nullptr) {
+    if (pred()) return true;
+    dev::WaitNote note(what, obj);
+    for (;;) {
+        (void)cv.wait_for(lock, std::chrono::nanoseconds(WAIT_SLICE_NS));
+        if (pred()) return true;
+        if (note.expired()) return false;
+    }
 }
 
 // pageable <-> pinned staging copy.  One core moves ~10 GB/s, which would make a copy (13 ms per
@@ -467,7 +516,7 @@ class CopyHelpers {
             Job j;
             {
                 std::unique_lock<std::mutex> lock(mu);
-                cv.wait(lock, [&]() { return !q.empty(); });
+                park_until(cv, lock, [&]() { return !q.empty(); });
                 j = q.front();
                 q.pop_front();
             }
@@ -533,7 +582,7 @@ class WorkerPool {
             std::function<void()> job;
             {
                 std::unique_lock<std::mutex> lock(mu);
-                cv.wait(lock, [&]() { return !q.empty(); });
+                park_until(cv, lock, [&]() { return !q.empty(); });
                 job = std::move(q.front());
                 q.pop_front();
             }
@@ -572,23 +621,14 @@ inline void staged_copy(void *dst, const void *src, size_t bytes) {
         }
     }
     memcpy(dst, src, part < bytes ? part : bytes);
-    wait_until_zero(&pending);
+    wait_host_work_done(&pending, "staging-copy parts");
 }
 
 // The wait that ends a ONE-unit call.  hipStreamSynchronize parks the thread on an interrupt, and being woken costs
 // 15-30 us of a 250 us call; polling the stream for the few hundred microseconds such a call lasts costs a fraction
 // of one core (the combiner lets at most `coalesce_active` callers per operation get here at a time).  After 2 ms the
-// call is not a latency call any more and the thread blocks as usual.
-inline hipError_t wait_stream_low_latency(hipStream_t stream) {
-    const auto t0 = std::chrono::steady_clock::now();
-    for (int spins = 0;; spins++) {
-        const hipError_t e = hipStreamQuery(stream);
-        if (e != hipErrorNotReady) return e;
-        if ((spins & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
-    }
-    (void)hipGetLastError();   // hipErrorNotReady is not an error
-    return hipStreamSynchronize(stream);
-}
+// call is not a latency call any more and the thread sleeps between polls (device.hpp: bounded_device_wait).
+inline hipError_t wait_stream_low_latency(hipStream_t stream) { return dev::sync_stream(stream, 2000); }
 
 // true if the caller's host buffer is page-locked (hipHostMalloc / hipHostRegister): such a buffer is DMA'd
 // from directly, chunk by chunk, without the staging copy a pageable one needs
@@ -676,10 +716,11 @@ class OutPipe {
         return true;
     }
     size_t pushed_count() const { return pushed; }
-    // blocks until the first `count` pushed items have reached host memory
+    // blocks until the first `count` pushed items have reached host memory (or the drain has failed: finish() says so;
+    // the worker's own waits for the device are bounded, so a drain that cannot go on fails instead of standing still)
     void wait_for(size_t count) {
         std::unique_lock<std::mutex> lock(mu);
-        cv.wait(lock, [&]() { return drained >= count || failed; });
+        if (!cv_wait_bounded(cv, lock, [&]() { return drained >= count || failed; }, "result drain", this)) failed = true;
     }
     C_KZG_RET finish() {
         if (started) {
@@ -712,12 +753,12 @@ class OutPipe {
             Item it;
             {
                 std::unique_lock<std::mutex> lock(mu);
-                cv.wait(lock, [&]() { return !q.empty() || closing; });
+                park_until(cv, lock, [&]() { return !q.empty() || closing; });
                 if (q.empty()) break;
                 it = q.front();
                 q.pop_front();
             }
-            ok = ok && hipEventSynchronize(it.ready) == hipSuccess;
+            ok = ok && dev::sync_event(it.ready) == hipSuccess;
             (void)hipEventDestroy(it.ready);
             // pieces through the pinned double buffer: the DMA of piece i+1 runs under the host copy of piece i
             const size_t np = (it.bytes + PIECE - 1) / PIECE;
@@ -730,7 +771,7 @@ class OutPipe {
             if (ok) issue(0);
             for (size_t i = 0; i < np && ok; i++) {
                 if (i + 1 < np) issue(i + 1);
-                ok = ok && hipEventSynchronize(piece_ev[i & 1]) == hipSuccess;
+                ok = ok && dev::sync_event(piece_ev[i & 1]) == hipSuccess;
                 const size_t off = i * PIECE, len = it.bytes - off < PIECE ? it.bytes - off : PIECE;
                 if (ok) staged_copy((uint8_t *)it.dst + off, ctx->h_out[i & 1], len);
             }
@@ -776,11 +817,11 @@ struct ABuf {
     ABuf(dev::Arena &a, size_t count) : p(a.get<T>(count)), stream(a.stream) {}
     bool up(const T *h, size_t count) {
         return hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, stream) == hipSuccess &&
-               hipStreamSynchronize(stream) == hipSuccess;
+               dev::sync_stream(stream) == hipSuccess;
     }
     bool down(T *h, size_t count) const {
         return hipMemcpyAsync(h, p, count * sizeof(T), hipMemcpyDeviceToHost, stream) == hipSuccess &&
-               hipStreamSynchronize(stream) == hipSuccess;
+               dev::sync_stream(stream) == hipSuccess;
     }
 };
 using dev::Arena;

@@ -89,6 +89,9 @@ extern "C" C_KZG_RET ckzg_hip_set_option(const char *key, int64_t value) {
     } else if (!strcmp(key, "coalesce_active")) {
         if (value < 1 || value > 8) return C_KZG_BADARGS;
         g_opts.coalesce_active = (int)value;
+    } else if (!strcmp(key, "wait_deadline_ms")) {
+        if (value < 1 || value > 86400000) return C_KZG_BADARGS;
+        dev::wait_deadline_ms_ref().store(value);   // read at wait time
     } else if (!strcmp(key, "direct_max")) {
         if (value < -1 || value > 4096) return C_KZG_BADARGS;
         g_opts.direct_max = (int)value;
@@ -461,7 +464,7 @@ static C_KZG_RET commit_batch_on(dev::DeviceCtx *ctx, KZGCommitment *out, uint8_
             const C_KZG_RET rc = enqueue_all();
             if (rc != C_KZG_OK) return rc;
         }
-        if ((n == 1 ? wait_stream_low_latency(ctx->stream) : hipStreamSynchronize(ctx->stream)) != hipSuccess) return C_KZG_ERROR;
+        if ((n == 1 ? wait_stream_low_latency(ctx->stream) : dev::sync_stream(ctx->stream)) != hipSuccess) return C_KZG_ERROR;
         if (launched) {
             for (int i = 0; i < 4; i++) ctx->last_ms[i] = -1.0f;   // (events recorded by graph nodes carry no readable time stamps)
         } else {
@@ -484,7 +487,7 @@ static C_KZG_RET commit_batch_on(dev::DeviceCtx *ctx, KZGCommitment *out, uint8_
         bool ok = true;
         if (pending[b]) {
             // the pinned buffer is free once its DMA finished; the device buffer once its kernels did
-            ok = ok && hipEventSynchronize(copied[b]) == hipSuccess;
+            ok = ok && dev::sync_event(copied[b]) == hipSuccess;
             ok = ok && hipStreamWaitEvent(ctx->copy_stream, consumed[b], 0) == hipSuccess;
         }
         const void *h_src = blobs + off;
@@ -514,7 +517,7 @@ static C_KZG_RET commit_batch_on(dev::DeviceCtx *ctx, KZGCommitment *out, uint8_
         if (rc) ret = (C_KZG_RET)rc;
     }
     tr.mark("staging loop (copies + enqueues)");
-    if (hipStreamSynchronize(ctx->copy_stream) != hipSuccess) ret = ret == C_KZG_OK ? C_KZG_ERROR : ret;
+    if (dev::sync_stream(ctx->copy_stream) != hipSuccess) ret = ret == C_KZG_OK ? C_KZG_ERROR : ret;
     // results: one async copy on the compute stream into pinned memory (free again: every input DMA is done)
     uint8_t *h_res = static_cast<uint8_t *>(ctx->h_stage[0]);
     const bool pinned_res = n * 49 <= ctx->h_stage_bytes;
@@ -525,7 +528,7 @@ static C_KZG_RET commit_batch_on(dev::DeviceCtx *ctx, KZGCommitment *out, uint8_
     }
     if (ret == C_KZG_OK && hipMemcpyAsync(h_res, d_out.p, n * 49, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
         ret = C_KZG_ERROR;
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess) ret = ret == C_KZG_OK ? C_KZG_ERROR : ret;
+    if (dev::sync_stream(ctx->stream) != hipSuccess) ret = ret == C_KZG_OK ? C_KZG_ERROR : ret;
     tr.mark("wait for the GPU");
     if (ret != C_KZG_OK) return ret;
     memcpy(out, h_res, n * 48);
@@ -653,7 +656,7 @@ static C_KZG_RET cells_and_proofs_batch_on(dev::DeviceCtx *ctx, Cell *cells, KZG
         if (hipMemcpyAsync(h + done, d_out.p + done, n * out_per - done, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return C_KZG_ERROR;
         // (not the polling wait of the one-blob commitment: this call runs kernels on two streams, and a thread that polls
         // the runtime slows the runtime's own hand-over between them -- measured 1.63 -> 1.80 ms)
-        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return C_KZG_ERROR;
+        if (dev::sync_stream(ctx->stream) != hipSuccess) return C_KZG_ERROR;
         if (!pinned_io) {
             if (cells) memcpy(cells, h, n * cells_per);
             if (proofs) memcpy(proofs, h + (cells ? n * cells_per : 0), n * proofs_per);
@@ -702,8 +705,8 @@ static C_KZG_RET cells_and_proofs_batch_on(dev::DeviceCtx *ctx, Cell *cells, KZG
         OutPipe &p;
         ~StreamDrain() {
             (void)p.finish();
-            (void)hipStreamSynchronize(c->copy_stream);
-            (void)hipStreamSynchronize(c->stream);
+            (void)dev::sync_stream(c->copy_stream);
+            (void)dev::sync_stream(c->stream);
         }
     } drain{ctx, pipe};
     bool pending[2] = {false, false};
@@ -719,7 +722,7 @@ static C_KZG_RET cells_and_proofs_batch_on(dev::DeviceCtx *ctx, Cell *cells, KZG
             const int b = (int)(sub_index & 1);
             bool ok = true;
             if (pending[b]) {
-                ok = ok && hipEventSynchronize(copied[b]) == hipSuccess;
+                ok = ok && dev::sync_event(copied[b]) == hipSuccess;
                 ok = ok && hipStreamWaitEvent(ctx->copy_stream, consumed[b], 0) == hipSuccess;
             }
             const void *h_src = blobs + off + so;
@@ -750,7 +753,7 @@ static C_KZG_RET cells_and_proofs_batch_on(dev::DeviceCtx *ctx, Cell *cells, KZG
         mark.push_back(pipe.pushed_count());
     }
     if (pipe.finish() != C_KZG_OK) return C_KZG_ERROR;
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return C_KZG_ERROR;
+    if (dev::sync_stream(ctx->stream) != hipSuccess) return C_KZG_ERROR;
     for (uint64_t i = 0; i < n; i++) {
         if (status) status[i] = st[i];
         if (st[i]) ret = C_KZG_BADARGS;
@@ -876,10 +879,19 @@ extern "C" int ckzg_hip_coalesce_stats(const KZGSettings *s, int op, uint64_t *o
     SettingsCtx *sc = settings_of(s, false);
     if (!sc || !out || op < 0 || op >= (int)CB_COUNT || !sc->comb[op]) return 0;
     const Combiner::Stats st = sc->comb[op]->stats();
-    const uint64_t v[7] = {st.calls, st.solo, st.batches, st.batched, st.largest, st.run_us, st.retried};
-    int k = n < 7 ? n : 7;
+    const uint64_t v[9] = {st.calls, st.solo, st.batches, st.batched, st.largest, st.run_us, st.retried, st.rescued, st.gave_up};
+    int k = n < 9 ? n : 9;
     for (int i = 0; i < k; i++) out[i] = v[i];
     return k;
+}
+
+extern "C" void ckzg_hip_debug_dump(int fd) { debug_dump(fd); }
+
+extern "C" int ckzg_hip_wait_stats(uint64_t *out, int n) {
+    const uint64_t v[3] = {(uint64_t)dev::wait_deadline_ms(), dev::expired_waits_ref().load(), dev::wedged_devices_ref().load()};
+    const int k = n < 3 ? (n < 0 ? 0 : n) : 3;
+    for (int i = 0; out && i < k; i++) out[i] = v[i];
+    return out ? k : 0;
 }
 
 extern "C" int ckzg_hip_num_devices(const KZGSettings *s) {

@@ -278,7 +278,7 @@ void parallel_for(size_t n, const std::function<void(size_t)> &fn) {
             sh.active.fetch_sub(1, std::memory_order_relaxed);
     }
     loop();
-    wait_until_zero(&sh.active);   // (asleep, not spinning: the stragglers may need this core)
+    wait_host_work_done(&sh.active, "parallel_for jobs");   // (asleep, not spinning: the stragglers may need this core)
 }
 
 // Several variable-base lincombs sum_i k_i P_i in ONE launch.  Job j takes n points starting at
@@ -356,7 +356,7 @@ C_KZG_RET gpu_lincomb_multi(dev::DeviceCtx *ctx, G1Jac *outs, const LincombJob *
         for (int j = 0; j < njobs; j++) job_off[j] = (uint32_t)off[j];
         job_off[njobs] = (uint32_t)total;
         RC(dev::bucket_msm_enqueue(ctx, d_out.p, d_p.p, (const uint32_t *)d_k.p, total, job_off.data(), njobs, wbits, d_bucket));
-        OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
+        OKB(dev::sync_stream(ctx->stream) == hipSuccess);
     } else {
         const size_t per = quad ? 8 : 32;
         std::vector<uint32_t> part_off(njobs + 1);
@@ -406,7 +406,7 @@ struct TranscriptHasher {
     TranscriptHasher &operator=(const TranscriptHasher &) = delete;
     void wait() {
         if (on_pool) {
-            wait_until_zero(&running);
+            wait_host_work_done(&running, "transcript hasher job");   // (the job's own waits are bounded: it ends)
         } else if (t.joinable()) {
             t.join();
         }
@@ -433,10 +433,12 @@ struct TranscriptHasher {
             for (size_t c = 0; c < nch; c++) {
                 // asleep until the caller publishes the next chunk (12 ms of a spinning pool worker per pipelined
                 // verification otherwise)
-                uint32_t seen;
-                while ((seen = published.load(std::memory_order_acquire)) <= c) futex_wait(&published, seen);
-                if (seen == ABORT) return;   // the owner is being destroyed: nobody will ask for the digest
-                if (hipEventSynchronize(landed[c]) != hipSuccess) {
+                if (!wait_word_until(&published, [c](uint32_t v) { return v > c; }, "transcript hasher: next chunk published")) {
+                    failed = true;
+                    return;
+                }
+                if (published.load(std::memory_order_acquire) == ABORT) return;   // the owner is being destroyed: nobody will ask for the digest
+                if (dev::sync_event(landed[c]) != hipSuccess) {
                     failed = true;
                     return;
                 }
@@ -491,7 +493,7 @@ struct OrderedHasher {
     // nothing of this object (or of z / blobs / cb) may be touched by a worker once the call has returned
     ~OrderedHasher() {
         next.store(n, std::memory_order_relaxed);   // an abandoned call: the workers stop at their next blob
-        wait_until_zero(&active);
+        wait_host_work_done(&active, "challenge hashing jobs");
     }
     void start(Fr *z, const Blob *blobs, const Bytes48 *cb) {
         size_t nt = (size_t)host_thread_budget();
@@ -520,10 +522,11 @@ struct OrderedHasher {
             }
         }
     }
-    void wait_chunk(size_t c) const {
+    // false: the chunk's challenges were not there by the deadline (the call fails; the destructor stops the workers)
+    bool wait_chunk(size_t c) const {
         const size_t lo = c * chunk, want = (n - lo < chunk ? n - lo : chunk);
         auto *w = const_cast<std::atomic<uint32_t> *>(&done[c]);
-        for (uint32_t v; (v = w->load(std::memory_order_acquire)) < want;) futex_wait(w, v);
+        return wait_word_until(w, [want](uint32_t v) { return v >= want; }, "challenge hashing: chunk complete");
     }
 };
 
@@ -644,7 +647,7 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     struct StreamDrain {
         hipStream_t s;
         ~StreamDrain() {
-            if (s) (void)hipStreamSynchronize(s);
+            if (s) (void)dev::sync_stream(s);
         }
     } drain{ctx->copy_stream};
     if (use_table) {
@@ -710,7 +713,7 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
             if (src_pinned) {
                 OKB(hipStreamWaitEvent(ctx->stream, chunk_copied[c], 0) == hipSuccess);
             } else {
-                if (used[b]) OKB(hipEventSynchronize(copied[b]) == hipSuccess);   // the DMA out of this staging buffer is done
+                if (used[b]) OKB(dev::sync_event(copied[b]) == hipSuccess);   // the DMA out of this staging buffer is done
                 staged_copy(ctx->h_stage[b], blobs + off, k * BYTES_PER_BLOB);
                 OKB(hipMemcpyAsync(d_blobs_own.p + off * BYTES_PER_BLOB, ctx->h_stage[b], k * BYTES_PER_BLOB, hipMemcpyHostToDevice,
                                    ctx->copy_stream) == hipSuccess);
@@ -724,7 +727,7 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
             // thread never waits for the hashers while there is a copy to issue
             if (c >= 1) {
                 const size_t po = (c - 1) * CH;
-                hasher.wait_chunk(c - 1);
+                OKB(hasher.wait_chunk(c - 1));
                 OKB(hipMemcpyAsync(d_z.p + po, z.data() + po, CH * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
                 RC(dev::eval_poly_batch_device(ctx, d_y.p + po, d_poly.p + po * FIELD_ELEMENTS_PER_BLOB, d_z.p + po, CH));
                 OKB(hipMemcpyAsync(h_y_bytes + po * sizeof(Fr), d_y.p + po, CH * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess);
@@ -734,7 +737,7 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
         }
         {
             const size_t po = (nch - 1) * CH, k = n - po;
-            hasher.wait_chunk(nch - 1);
+            OKB(hasher.wait_chunk(nch - 1));
             OKB(hipMemcpyAsync(d_z.p + po, z.data() + po, k * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
             RC(dev::eval_poly_batch_device(ctx, d_y.p + po, d_poly.p + po * FIELD_ELEMENTS_PER_BLOB, d_z.p + po, k));
             OKB(hipMemcpyAsync(h_y_bytes + po * sizeof(Fr), d_y.p + po, k * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess);
@@ -744,7 +747,7 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
         OKB(hipMemcpyAsync(h_bad, d_bad.p, n * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess);
         OKB(hipMemcpyAsync(h_st, d_st.p, 2 * n, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess);
         tr.mark("chunked H2D + bytes_to_fr + evaluation enqueued (challenges hashed in order on host threads)");
-        OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
+        OKB(dev::sync_stream(ctx->stream) == hipSuccess);
         tr.mark("wait for GPU");
         for (size_t i = 0; i < 2 * n; i++) {
             if (h_st[i]) return C_KZG_BADARGS;
@@ -789,7 +792,7 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
         OKB(hipStreamWaitEvent(ctx->stream, ctx->stage_ev[0], 0) == hipSuccess);   // the validated points and their status
         OKB(hipEventRecord(ctx->ev[2], ctx->stream) == hipSuccess);
     }
-    OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
+    OKB(dev::sync_stream(ctx->stream) == hipSuccess);
     tr.mark("wait for GPU");
     if (!small) {
         std::vector<uint8_t> st(2 * n);
@@ -811,7 +814,7 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     if (!resident) {
         RC(dev::eval_poly_batch_device(ctx, d_y.p, d_poly.p, d_z.p, n));
         if (n == 1) ps = verify_proof_side(z[0], hp[0], prepared_of(ctx));   // host work underneath the GPU's evaluation
-        OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
+        OKB(dev::sync_stream(ctx->stream) == hipSuccess);
     }
     OKB(d_y.down(y.data(), n));
     }
@@ -863,7 +866,7 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
         for (int j = 0; j < 3; j++) lc[j] = jac_from_xyzz(hs[j]);
         if (resident) {
             float a = 0, b = 0;
-            OKB(hipEventRecord(ctx->ev[4], ctx->stream) == hipSuccess && hipEventSynchronize(ctx->ev[4]) == hipSuccess);
+            OKB(hipEventRecord(ctx->ev[4], ctx->stream) == hipSuccess && dev::sync_event(ctx->ev[4]) == hipSuccess);
             if (hipEventElapsedTime(&a, ctx->ev[1], ctx->ev[2]) == hipSuccess &&
                 hipEventElapsedTime(&b, ctx->ev[3], ctx->ev[4]) == hipSuccess) {
                 ctx->last_ms[3] = a + b;
@@ -899,7 +902,7 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
             // kernel-only time of the resident form (ckzg_hip_last_kernel_ms, which = 3): validation + conversion +
             // challenges + evaluation, and the three sums; the host transcript between them is not GPU time
             float a = 0, b = 0;
-            OKB(hipEventRecord(ctx->ev[4], ctx->stream) == hipSuccess && hipEventSynchronize(ctx->ev[4]) == hipSuccess);
+            OKB(hipEventRecord(ctx->ev[4], ctx->stream) == hipSuccess && dev::sync_event(ctx->ev[4]) == hipSuccess);
             if (hipEventElapsedTime(&a, ctx->ev[1], ctx->ev[2]) == hipSuccess &&
                 hipEventElapsedTime(&b, ctx->ev[3], ctx->ev[4]) == hipSuccess) {
                 ctx->last_ms[3] = a + b;
@@ -910,7 +913,7 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     }
     }
     if (split_validation) {
-        OKB(hipEventSynchronize(ctx->stage_ev[1]) == hipSuccess);
+        OKB(dev::sync_event(ctx->stage_ev[1]) == hipSuccess);
         std::vector<uint8_t> st2(2 * n);
         OKB(d_st2.down(st2.data(), 2 * n));
         for (size_t i = 0; i < 2 * n; i++) {
@@ -1027,7 +1030,7 @@ static C_KZG_RET blob_proof_batch_on(dev::DeviceCtx *ctx, KZGProof *proofs, uint
             d_hit.p);
         struct StreamDrain {  // the second stream must be idle before the arena is reused, on every exit path
             hipStream_t s;
-            ~StreamDrain() { (void)hipStreamSynchronize(s); }
+            ~StreamDrain() { (void)dev::sync_stream(s); }
         } drain{ctx->copy_stream};
         std::vector<Fr> z(m);
         std::vector<uint8_t> pst(m);
@@ -1071,7 +1074,7 @@ static C_KZG_RET blob_proof_batch_on(dev::DeviceCtx *ctx, KZGProof *proofs, uint
             RC(dev::eval_quotient_batch_device(ctx, d_y.p, d_q.p, d_hit.p, d_poly.p, d_z.p, k));
             RC(dev::msm_commit_table_raw_device(ctx, d_out.p, d_q.p, k));
             if (k > SMALL_VERIFY_N) {
-                OKB(hipStreamSynchronize(ctx->copy_stream) == hipSuccess);
+                OKB(dev::sync_stream(ctx->copy_stream) == hipSuccess);
                 OKB(d_pst.down(pst.data(), k));
             }
             OKB(d_bad.down(bad.data(), k) && d_hit.down(hit.data(), k));
@@ -1322,7 +1325,7 @@ static C_KZG_RET recover_cells_gpu(dev::DeviceCtx *ctx, Fr *d_e, size_t count, c
     RC(dev::fr_ntt_batch(ctx, d_e, count, 13, false, true, true));       // coset_ifft ...
     RC(dev::fr_mul_inplace_device(ctx, d_e, ctx->d_unshift, tot, n));    // ... unscale by 7^-i
     RC(dev::fr_ntt_batch(ctx, d_e, count, 13, true, false, false));      // evaluations, cell order
-    OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
+    OKB(dev::sync_stream(ctx->stream) == hipSuccess);
     return C_KZG_OK;
 }
 
@@ -1362,7 +1365,7 @@ static C_KZG_RET recover_batch_on(dev::DeviceCtx *ctx, Cell *recovered_cells, KZ
         OutPipe &p;
         ~Drain() {
             (void)p.finish();
-            (void)hipStreamSynchronize(c->stream);
+            (void)dev::sync_stream(c->stream);
         }
     } drain{ctx, pipe};
     std::vector<size_t> mark;
@@ -1378,7 +1381,7 @@ static C_KZG_RET recover_batch_on(dev::DeviceCtx *ctx, Cell *recovered_cells, KZ
         OKB(hipMemsetAsync(d_bad.p, 0, k * 4, ctx->stream) == hipSuccess);
         RC(dev::scatter_cells_device(ctx, d_img, d_in.p, d_idx.p, (uint32_t)num_cells, k));
         RC(dev::bytes_to_fr_batch(ctx, d_e.p, d_bad.p, d_img, k * n, (uint32_t)n));
-        OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
+        OKB(dev::sync_stream(ctx->stream) == hipSuccess);
         OKB(d_bad.down(bad.data(), k));
         bool any_bad = false;
         for (size_t i = 0; i < k; i++) {
@@ -1395,7 +1398,7 @@ static C_KZG_RET recover_batch_on(dev::DeviceCtx *ctx, Cell *recovered_cells, KZ
             if (piped) {
                 OKB(pipe.push(d_img, recovered_cells + off * CELLS_PER_EXT_BLOB, k * n * 32));
             } else {
-                OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
+                OKB(dev::sync_stream(ctx->stream) == hipSuccess);
                 OKB(hipMemcpy(recovered_cells + off * CELLS_PER_EXT_BLOB, d_img, k * n * 32, hipMemcpyDeviceToHost) == hipSuccess);
             }
         }
@@ -1418,7 +1421,7 @@ static C_KZG_RET recover_batch_on(dev::DeviceCtx *ctx, Cell *recovered_cells, KZ
     }
     OKB(hipEventRecord(ctx->ev[4], ctx->stream) == hipSuccess);
     if (pipe.finish() != C_KZG_OK) return C_KZG_ERROR;
-    OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
+    OKB(dev::sync_stream(ctx->stream) == hipSuccess);
     {   // ckzg_hip_last_kernel_ms: 3 = the device section of the call, 1 / 4 = k_msm_small / G1 FFTs of the last chunk
         float ms;
         if (hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[4]) == hipSuccess) ctx->last_ms[3] = ms;
@@ -1595,7 +1598,7 @@ static C_KZG_RET verify_cells_on(dev::DeviceCtx *ctx, bool *ok, const Bytes48 *c
         std::atomic<uint32_t> running{0};   // futex word
         bool submitted = false;
         void wait() {
-            if (submitted) wait_until_zero(&running);
+            if (submitted) wait_host_work_done(&running, "cell transcript hash job");
         }
         ~HashJob() { wait(); }   // nothing the worker reads or writes may die before it is through
     } hash_job;
@@ -1645,7 +1648,7 @@ static C_KZG_RET verify_cells_on(dev::DeviceCtx *ctx, bool *ok, const Bytes48 *c
     struct StreamDrain {
         hipStream_t s;
         ~StreamDrain() {
-            if (s) (void)hipStreamSynchronize(s);
+            if (s) (void)dev::sync_stream(s);
         }
     } drain{ctx->copy_stream};
     if (use_table) {
@@ -1682,7 +1685,7 @@ static C_KZG_RET verify_cells_on(dev::DeviceCtx *ctx, bool *ok, const Bytes48 *c
     // checked here, underneath it.  A small one (ladder sums): the subgroup test (~1 ms of dependent doublings) keeps
     // running on the second stream next to the sums, and the flags are checked after those.
     auto flags_ok = [&]() -> C_KZG_RET {
-        OKB(hipEventSynchronize(ctx->stage_ev[3]) == hipSuccess && hipEventSynchronize(ctx->stage_ev[1]) == hipSuccess);
+        OKB(dev::sync_event(ctx->stage_ev[3]) == hipSuccess && dev::sync_event(ctx->stage_ev[1]) == hipSuccess);
         for (size_t i = 0; i < n + nc; i++) {
             if (h_st[i] || h_st2[i]) return C_KZG_BADARGS;  // bad encoding / off the curve / outside G1
         }
@@ -1820,7 +1823,7 @@ extern "C" C_KZG_RET ckzg_hip_g1_lincomb(g1_t *out, const g1_t *p, const fr_t *c
         // the kernels use the endomorphism: only valid on the prime-order subgroup (every caller inside the
         // library passes validated points; an outside caller gets the check here)
         RC(dev::subgroup_g1_batch_device(ctx, d_st.p, d_pts.p, len));
-        OKB(hipStreamSynchronize(ctx->stream) == hipSuccess);
+        OKB(dev::sync_stream(ctx->stream) == hipSuccess);
         std::vector<uint8_t> st(len);
         OKB(d_st.down(st.data(), len));
         for (uint8_t b : st) {

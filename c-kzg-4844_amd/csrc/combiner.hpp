@@ -30,6 +30,7 @@
 #include <condition_variable>
 #include <deque>
 #include <mutex>
+#include <optional>
 #include <thread>
 #include <vector>
 
@@ -110,10 +111,36 @@ class Combiner {
         uint64_t largest = 0;      // units in the largest launch
         uint64_t run_us = 0;       // wall time the batch launches took (lease + copies + kernels), microseconds
         uint64_t retried = 0;      // calls a batch launch could not answer and that ran alone afterwards
+        uint64_t rescued = 0;      // open batches of an idle device released by a member's periodic look (must stay 0 for an
+                                   // operation that does not gather: the net under the protocol, never a path of it)
+        uint64_t gave_up = 0;      // calls that left with C_KZG_ERROR at the wait deadline
     };
     Stats stats() {
         std::lock_guard<detail::AdaptiveMutex> lock(mu);
         return st;
+    }
+
+    // diagnostics (ckzg_hip_debug_dump): the state of the queue, without waiting for the mutex -- the dump may be asked
+    // for BECAUSE somebody holds it for good
+    void dump(int fd, const char *name) {
+        if (!mu.try_lock()) {
+            dprintf(fd, "  combiner %s: mutex held -- inside=%d\n", name, inside.load(std::memory_order_relaxed));
+            return;
+        }
+        dprintf(fd, "  combiner %s: inside=%d active=%d peak=%d pending=%zu batches=%zu free=%zu allocating=%d alloc_failed=%d "
+                    "tickets next=%llu serving=%llu | calls=%llu solo=%llu launches=%llu batched=%llu\n",
+                name, inside.load(std::memory_order_relaxed), active, peak, pending.size(), all.size(), free_list.size(), (int)allocating,
+                (int)alloc_failed, (unsigned long long)next_ticket, (unsigned long long)serving, (unsigned long long)st.calls,
+                (unsigned long long)st.solo, (unsigned long long)st.batches, (unsigned long long)st.batched);
+        static const char *const names[] = {"OPEN", "RELEASED", "RUNNING", "DONE"};
+        for (Batch *b : all) {
+            bool queued = false;
+            for (Batch *q : pending) queued = queued || q == b;
+            const uint32_t stt = b->state.load(std::memory_order_relaxed);
+            dprintf(fd, "    batch %p: state=%s n=%zu copied=%zu refs=%u queued=%d\n", (void *)b, stt < 4 ? names[stt] : "?", b->n,
+                    b->copied.load(std::memory_order_relaxed), b->refs.load(std::memory_order_relaxed), (int)queued);
+        }
+        mu.unlock();
     }
 
     // status value a batch path gives a unit it cannot answer for inside the batch (a verification batch that did not
@@ -137,6 +164,7 @@ class Combiner {
         } leave{inside};
         Batch *b = nullptr;
         bool release_now = false, gathering = false;
+        bool no_memory_now = false;   // THIS caller has just seen an allocation fail (its own state: nobody else's business)
         // Callers that had to wait for a batch buffer are served roughly in the order they came: a waiter takes a ticket,
         // every batch buffer that comes back admits the oldest max_batch tickets (`serving` advances by that much), and
         // a newcomer queues behind the tickets that are out.  (Without it the woken waiters raced newcomers for the
@@ -145,7 +173,12 @@ class Combiner {
         bool have_ticket = false;
         uint64_t ticket = 0;
         auto admitted = [&]() { have_ticket = false; };
+        // No wait in here is unbounded (device.hpp: bounded waits): the queueing phase as a whole -- for a batch buffer, a
+        // launch place, a turn in the line, an allocation another caller is making -- gives up at the deadline with
+        // C_KZG_ERROR for THIS caller, who has joined nothing yet.
+        std::optional<dev::WaitNote> queueing;
         for (;;) {
+            if (queueing && queueing->expired()) return C_KZG_ERROR;
             // (the bounded wait below is the safety valve: a ticket that no returning buffer admits -- its group found
             // room elsewhere -- proceeds after a millisecond)
             if (have_ticket ? ticket >= serving : serving < next_ticket) {
@@ -153,6 +186,7 @@ class Combiner {
                     have_ticket = true;
                     ticket = next_ticket++;
                 }
+                if (!queueing) queueing.emplace("combiner: a turn in the line for a batch buffer", this);
                 if (cv_pool.wait_for(lock, std::chrono::milliseconds(1)) == std::cv_status::timeout && ticket >= serving)
                     serving = ticket + 1;
                 continue;
@@ -195,6 +229,7 @@ class Combiner {
                                 have_ticket = true;
                                 ticket = next_ticket++;
                             }
+                            if (!queueing) queueing.emplace("combiner: another caller's batch-buffer allocation", this);
                             cv_pool.wait_for(lock, std::chrono::milliseconds(2));
                             if (ticket >= serving) serving = ticket + 1;   // (woken by the allocator, or impatient: look again)
                             continue;
@@ -213,10 +248,16 @@ class Combiner {
                         free_list.push_back(nb);   // (capacity reserved)
                     } else {
                         alloc_failed = true;       // do not try again on every call
-                        alloc_failed_now = true;
+                        no_memory_now = true;
                     }
                     cv_pool.notify_all();
-                    if (nb) continue;   // the world has moved on meanwhile: look again (idle path, a joinable batch, ...)
+                    // The world has moved on while the mutex was released: look again (idle path, a joinable batch, ...),
+                    // ALSO when the allocation failed.  Round 5 fell through in that case and took a batch that had come
+                    // back to the free list meanwhile -- on a device that had gone idle meanwhile as well: the batch was
+                    // opened with no launch in flight to release it, and its opener slept for good.  That was the stall
+                    // of the round-5 driver run (tests/test_gpu_alloc_failures.py, the coalesced callers; reproduced on
+                    // the CPU by tests/native/combiner_stress.cpp: failed_allocation_on_a_device_gone_idle).
+                    continue;
                 }
                 b = fresh_batch();
                 if (b) {
@@ -230,7 +271,7 @@ class Combiner {
                     if (!queued) {
                         free_list.push_back(b);   // (capacity reserved)
                         b = nullptr;
-                        alloc_failed_now = true;
+                        no_memory_now = true;
                     }
                 }
             }
@@ -247,9 +288,8 @@ class Combiner {
                 admitted();
                 break;
             }
-            if (all.empty() || alloc_failed_now) {
+            if (all.empty() || no_memory_now) {
                 // no page-locked memory / no memory for the bookkeeping: this call goes alone, unqueued
-                alloc_failed_now = false;
                 admitted();
                 lock.unlock();
                 return guarded([&]() -> C_KZG_RET { return solo(); });
@@ -259,7 +299,10 @@ class Combiner {
                 ticket = next_ticket++;
             }
             if (ticket < serving) {
-                cv_pool.wait(lock);   // admitted, but nothing to take yet
+                // admitted, but nothing to take yet: a buffer coming back or a launch ending notifies; in slices, so that a
+                // notification that went missing costs a slice and not the call
+                if (!queueing) queueing.emplace("combiner: a batch buffer or a launch place", this);
+                (void)cv_pool.wait_for(lock, std::chrono::nanoseconds(WAIT_SLICE_NS));
             }
         }
         const size_t idx = b->n++;
@@ -271,6 +314,30 @@ class Combiner {
         // the opener of a batch of a gathering operation looks after it: while the batch is open it wakes every gather_ns,
         // and if the device is idle by then (nothing in flight to release the batch when it ends) it releases it itself
         const bool caretaker = gather_ns > 0 && idx == 0;
+        // The open batch of a device that has gone idle is released by whoever notices: its opener within gather_ns (a
+        // gathering operation), any member within a slice otherwise -- by the protocol that cannot happen to an
+        // operation that does not gather (a batch is only opened while a launch is in flight, and every launch that
+        // ends releases the oldest open batch), so this is the net under the protocol, not a path of it.
+        auto release_if_device_idle = [&](bool by_the_opener_in_time) {
+            bool mine = false;
+            lock.lock();
+            if (active == 0 && !pending.empty() && pending.front() == b) {
+                pending.pop_front();
+                active++;
+                mine = true;
+                if (!by_the_opener_in_time) {
+                    st.rescued++;
+                    fprintf(stderr, "[ckzg-hip] combiner: an open batch (%zu members) sat on an idle device and was released by a "
+                                    "member's periodic look: peak=%d inside=%d pending=%zu free=%zu calls=%llu solo=%llu launches=%llu\n",
+                            b->n, peak, inside.load(std::memory_order_relaxed), pending.size(), free_list.size(),
+                            (unsigned long long)st.calls, (unsigned long long)st.solo, (unsigned long long)st.batches);
+                }
+            }
+            lock.unlock();
+            if (mine) release(b);
+        };
+        std::optional<dev::WaitNote> waiting;
+        bool gave_up = false;
         for (;;) {
             uint32_t s = b->state.load(std::memory_order_acquire);
             if (s == DONE) break;
@@ -284,18 +351,44 @@ class Combiner {
             if (s == OPEN && caretaker) {
                 futex_wait_for(&b->state, s, gather_ns);
                 if (b->state.load(std::memory_order_acquire) != OPEN) continue;
-                bool mine = false;
-                lock.lock();
-                if (active == 0 && !pending.empty() && pending.front() == b) {
-                    pending.pop_front();
-                    active++;
-                    mine = true;
-                }
-                lock.unlock();
-                if (mine) release(b);
+                release_if_device_idle(true);
                 continue;
             }
-            futex_wait(&b->state, s);
+            // asleep until the state word changes -- in slices: a wake-up that went missing costs a slice, not the call
+            if (!waiting) waiting.emplace("combiner: the batch this call joined", b);
+            futex_wait_for(&b->state, s, WAIT_SLICE_NS);
+            if (b->state.load(std::memory_order_acquire) != s) continue;
+            if (s == OPEN) release_if_device_idle(false);
+            if (waiting->expired()) {
+                // OPEN: nothing released the batch and the device never went idle (launches of other keys keep it busy and
+                // this batch is not the oldest); RUNNING: the member that runs it has not come back (a device wait of its
+                // own would have expired first).  This caller gets C_KZG_ERROR; the others have deadlines of their own.
+                gave_up = true;
+                break;
+            }
+        }
+        if (gave_up) {
+            lock.lock();
+            st.gave_up++;
+            if (b->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+                // the last member to leave: a batch nobody is left to run must not stay in the queue (a launch that
+                // ends would release it to nobody and its launch place would never come back)
+                const uint32_t st = b->state.load(std::memory_order_acquire);
+                if (st == OPEN) {
+                    for (auto it = pending.begin(); it != pending.end(); ++it) {
+                        if (*it == b) {
+                            pending.erase(it);
+                            break;
+                        }
+                    }
+                }
+                if (st == OPEN || st == DONE) {
+                    free_list.push_back(b);   // (capacity reserved)
+                    cv_pool.notify_all();
+                }
+            }
+            lock.unlock();
+            return C_KZG_ERROR;
         }
         const size_t n = b->n;
         const bool retry = b->status[idx] == RETRY_SOLO;
@@ -334,11 +427,21 @@ class Combiner {
     template <class Run>
     void run_batch(Batch *b, Run &run) {
         const size_t n = b->n;
-        while (b->copied.load(std::memory_order_acquire) != n) std::this_thread::yield();   // members still copying in: microseconds
+        bool inputs_in = true;
+        if (b->copied.load(std::memory_order_acquire) != n) {   // members still copying in: microseconds
+            dev::WaitNote copying("combiner: members copying their inputs in", b);
+            while (b->copied.load(std::memory_order_acquire) != n) {
+                std::this_thread::yield();
+                if (copying.expired()) {
+                    inputs_in = false;
+                    break;
+                }
+            }
+        }
         memset(b->status.data(), 0, n);
         const auto t_run = std::chrono::steady_clock::now();
-        C_KZG_RET r;
-        {
+        C_KZG_RET r = C_KZG_ERROR;
+        if (inputs_in) {
             CKZG_COMBINER_RESERVE_SCALE(max_batch, n);   // buffers that grow in this launch grow for the largest batch
             r = guarded([&]() -> C_KZG_RET { return run((const uint8_t *)b->h_in, b->h_out, b->status.data(), n); });
         }
@@ -485,7 +588,7 @@ class Combiner {
     int active = 0;                    // launches in flight (solo calls and batches)
     std::atomic<int> inside{0};        // threads inside submit()
     int peak = 0;                      // recent maximum of `inside` (decays by an eighth per batch launch)
-    bool alloc_failed = false, alloc_failed_now = false, allocating = false;
+    bool alloc_failed = false, allocating = false;
     uint64_t next_ticket = 0, serving = 0;   // the line of callers waiting for a batch buffer (first come, first served)
     Stats st;
 };

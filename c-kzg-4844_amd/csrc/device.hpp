@@ -8,9 +8,13 @@
 #include <vector>
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <ctime>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include "g1.hpp"
 
 namespace ckzg {
@@ -41,6 +45,133 @@ inline long ab_knob(const char *env, long dflt) {
 #else
 constexpr long ab_knob(const char *, long dflt) { return dflt; }
 #endif
+
+// ---------------------------------------------------------------------------------------------------------------
+// Bounded waits.  The reference never waits on anything (src/eip4844/eip4844.c:264-280 is straight-line code; an
+// internal failure is C_KZG_ERROR, returned: src/common/ret.h:24-29).  This library waits for the GPU, for pool
+// threads and for other callers, and NONE of those waits may be unbounded: a caller of a consensus client must get an
+// answer or an error.  Every wait goes through one of the forms below (tests/test_wait_sites.py greps the product for
+// the raw ones) and gives up after `wait_deadline_ms` -- option "wait_deadline_ms" / env CKZG_HIP_WAIT_DEADLINE_MS,
+// default 30 s: three orders of magnitude above the longest wait of any call the bench or the tests make, so that
+// profilers, sanitizers and oversubscribed hosts do not trip it -- with one line on stderr that names what was waited for.
+//   * device waits (sync_stream / sync_event): hipStreamSynchronize has no timed form, so the stream is polled
+//     (hipStreamQuery): spinning at first, then asleep for 1/32 of the time waited so far (at most 1 ms) per step -- a
+//     wait ends within ~3 % of the moment the work did.  A device wait that expires marks the device WEDGED: its
+//     kernels may still be running and writing, so the slot is never handed out again, later calls on that device fail
+//     at once with C_KZG_ERROR instead of queueing behind it, and free_trusted_setup leaks the device state instead
+//     of calling into a runtime that would block.
+//   * host waits (futexes, condition variables): api_common.hpp.
+// Waits that are in progress are noted in a small table for ckzg_hip_debug_dump.
+// ---------------------------------------------------------------------------------------------------------------
+inline std::atomic<int64_t> &wait_deadline_ms_ref() {
+    static std::atomic<int64_t> v{[]() -> int64_t {
+        const char *e = getenv("CKZG_HIP_WAIT_DEADLINE_MS");
+        const long x = e && *e ? atol(e) : 0;
+        return x >= 1 ? (int64_t)x : (int64_t)30000;
+    }()};
+    return v;
+}
+inline int64_t wait_deadline_ms() { return wait_deadline_ms_ref().load(std::memory_order_relaxed); }
+inline std::atomic<uint64_t> &wedged_devices_ref() {
+    static std::atomic<uint64_t> m{0};
+    return m;
+}
+inline bool device_wedged(int device) {
+    return device >= 0 && device < 64 && ((wedged_devices_ref().load(std::memory_order_relaxed) >> device) & 1) != 0;
+}
+inline std::atomic<uint64_t> &expired_waits_ref() {   // waits that hit their deadline since the library was loaded
+    static std::atomic<uint64_t> n{0};
+    return n;
+}
+inline int64_t monotonic_us() {
+    return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// what a thread of this library is waiting for right now (diagnostics only: ckzg_hip_debug_dump)
+struct WaitNoteSlot {
+    std::atomic<const char *> what{nullptr};
+    std::atomic<const void *> obj{nullptr};
+    std::atomic<int64_t> since_us{0};
+    std::atomic<long> tid{0};
+};
+constexpr int WAIT_NOTES = 256;
+inline WaitNoteSlot *wait_notes() {
+    static WaitNoteSlot t[WAIT_NOTES];
+    return t;
+}
+struct WaitNote {
+    WaitNoteSlot *slot = nullptr;
+    int64_t t0;
+    const char *what;
+    const void *obj;
+    WaitNote(const char *w, const void *o) : t0(monotonic_us()), what(w), obj(o) {
+        static thread_local long tid = (long)syscall(SYS_gettid);
+        WaitNoteSlot *t = wait_notes();
+        for (int i = 0, at = (int)(tid % WAIT_NOTES); i < WAIT_NOTES; i++, at = (at + 1) % WAIT_NOTES) {
+            const char *none = nullptr;
+            if (t[at].what.compare_exchange_strong(none, w, std::memory_order_acq_rel)) {
+                t[at].obj.store(o, std::memory_order_relaxed);
+                t[at].since_us.store(t0, std::memory_order_relaxed);
+                t[at].tid.store(tid, std::memory_order_relaxed);
+                slot = &t[at];
+                break;
+            }
+        }
+    }
+    ~WaitNote() {
+        if (slot) slot->what.store(nullptr, std::memory_order_release);
+    }
+    WaitNote(const WaitNote &) = delete;
+    WaitNote &operator=(const WaitNote &) = delete;
+    int64_t waited_us() const { return monotonic_us() - t0; }
+    // true once the deadline has passed (says so on stderr, once per wait)
+    bool expired() {
+        if (waited_us() <= wait_deadline_ms() * 1000) return false;
+        if (!said) {
+            said = true;
+            expired_waits_ref().fetch_add(1, std::memory_order_relaxed);
+            fprintf(stderr, "[ckzg-hip] wait deadline exceeded (%lld ms): %s (%p) -- giving up with C_KZG_ERROR\n",
+                    (long long)wait_deadline_ms(), what, obj);
+        }
+        return true;
+    }
+    bool said = false;
+};
+inline void sleep_us(int64_t us) {
+    struct timespec ts = {(time_t)(us / 1000000), (long)(us % 1000000) * 1000L};
+    (void)nanosleep(&ts, nullptr);
+}
+
+// query() -> hipSuccess / hipErrorNotReady / an error.  spin_us: how long to poll without sleeping (a one-unit call
+// that lasts 250 us must not pay a sleep's granularity; a 10-ms batch may).
+template <class Query>
+inline hipError_t bounded_device_wait(Query &&query, const char *what, const void *obj, int64_t spin_us) {
+    hipError_t e = query();
+    if (e != hipErrorNotReady) return e;
+    WaitNote note(what, obj);
+    for (;;) {
+        e = query();
+        if (e != hipErrorNotReady) break;
+        const int64_t waited = note.waited_us();
+        if (waited < spin_us) continue;
+        if (note.expired()) {
+            int d = -1;
+            if (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64) wedged_devices_ref().fetch_or((uint64_t)1 << d, std::memory_order_relaxed);
+            (void)hipGetLastError();
+            return hipErrorLaunchTimeOut;
+        }
+        const int64_t step = waited / 32;
+        sleep_us(step < 20 ? 20 : (step > 1000 ? 1000 : step));
+    }
+    (void)hipGetLastError();   // hipErrorNotReady is not an error, but the runtime remembers it as the thread's last one
+    return e;
+}
+inline hipError_t sync_stream(hipStream_t s, int64_t spin_us = 100) {
+    return bounded_device_wait([s]() { return hipStreamQuery(s); }, "stream", (const void *)s, spin_us);
+}
+inline hipError_t sync_event(hipEvent_t ev, int64_t spin_us = 100) {
+    return bounded_device_wait([ev]() { return hipEventQuery(ev); }, "event", (const void *)ev, spin_us);
+}
 
 struct FixedBaseTable {
     G1Affine *d_table = nullptr;

@@ -45,7 +45,16 @@ SettingsCtx *settings_of(const KZGSettings *s, bool complain) {
 
 void Lease::take(DevicePool *p) {
     std::unique_lock<std::mutex> lock(p->mu);
-    p->cv.wait(lock, [p]() { return !p->free_slots.empty(); });
+    // every slot busy: wait for one, but not for ever (a call that cannot get a stream slot by the deadline fails with
+    // C_KZG_ERROR: every caller of the Lease checks ctx), and not at all on a device whose last wait expired
+    if (dev::device_wedged(p->device) ||
+        !cv_wait_bounded(p->cv, lock, [p]() { return !p->free_slots.empty() || dev::device_wedged(p->device); }, "stream slot", p) ||
+        dev::device_wedged(p->device)) {
+        static std::atomic<bool> said{false};
+        if (dev::device_wedged(p->device) && !said.exchange(true))
+            fprintf(stderr, "[ckzg-hip] device %d did not answer within the wait deadline earlier: calls on it fail with C_KZG_ERROR\n", p->device);
+        return;
+    }
     int idx = p->free_slots.back();
     p->free_slots.pop_back();
     ctx = p->slots[idx];
@@ -99,6 +108,11 @@ Lease::Lease(const KZGSettings *s, int pool_index) {
 
 Lease::~Lease() {
     if (!pool || !ctx) return;
+    // a slot whose device stopped answering is never handed out again: its kernels may still be running on its buffers
+    if (dev::device_wedged(pool->device)) {
+        pool->cv.notify_all();
+        return;
+    }
     {
         std::lock_guard<std::mutex> lock(pool->mu);
         pool->free_slots.push_back(ctx->slot);
@@ -164,8 +178,8 @@ static int fit_wbits(const char *what, int wbits, int floor_bits, int npoints) {
 static void destroy_slot(dev::DeviceCtx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    if (ctx->stream) (void)dev::sync_stream(ctx->stream);
+    if (ctx->copy_stream) (void)dev::sync_stream(ctx->copy_stream);
     if (ctx->owns_tables) {   // (the fixed-base tables themselves belong to the pool: destroy_pool)
         if (ctx->d_lagr) (void)hipFree(ctx->d_lagr);
         if (ctx->d_xext) (void)hipFree(ctx->d_xext);
@@ -219,6 +233,14 @@ static void destroy_settings(SettingsCtx *sc) {
     DeviceGuard guard;   // destroy_slot selects each slot's device; the caller's comes back afterwards
     sc->cancel_widening.store(true);   // a background table build stops at its next launch
     if (sc->widener.joinable()) sc->widener.join();
+    for (auto *p : sc->pools) {
+        if (p && dev::device_wedged(p->device)) {
+            // kernels of this context may still be running (or stuck): hipFree / hipStreamDestroy would wait for them.
+            // The device state is leaked; the process is expected to report the C_KZG_ERROR it got and restart.
+            fprintf(stderr, "[ckzg-hip] free_trusted_setup: device %d stopped answering earlier, its GPU state is left in place\n", p->device);
+            return;
+        }
+    }
     for (auto &c : sc->comb) {
         delete c;   // (page-locked batch buffers)
         c = nullptr;
@@ -361,7 +383,7 @@ static C_KZG_RET build_owner(DevicePool *pool, const KZGSettings *s, const Optio
         if (!rc) rc = dev::subgroup_g1_batch_device(ctx, (uint8_t *)d_st.p + NUM_G1_POINTS, ctx->d_mono, NUM_G1_POINTS);
         if (rc) return (C_KZG_RET)rc;
         std::vector<uint8_t> st(2 * NUM_G1_POINTS);
-        CTX_TRY(hipStreamSynchronize(ctx->stream));
+        CTX_TRY(dev::sync_stream(ctx->stream));
         CTX_TRY(hipMemcpy(st.data(), d_st.p, st.size(), hipMemcpyDeviceToHost));
         for (uint8_t b : st) {
             if (b) {
@@ -470,7 +492,7 @@ static void widen_pool(SettingsCtx *sc, DevicePool *pool) {
         if (j.which == 2 && user_direct_max < 0) pool->pub.direct_max = auto_direct_max(wbits);
         pool->pub.version++;
     }
-    (void)hipStreamSynchronize(b.stream);
+    (void)dev::sync_stream(b.stream);
     (void)hipStreamDestroy(b.stream);
 }
 
@@ -706,8 +728,9 @@ void start_widening(const KZGSettings *s) {
 void wait_for_tables(const KZGSettings *s) {
     SettingsCtx *sc = settings_of(s, false);
     if (!sc) return;
+    // (the widener ends by itself: its launches poll `cancel_widening`, its device waits are bounded)
     std::unique_lock<std::mutex> lock(sc->widen_mu);
-    sc->widen_cv.wait(lock, [sc]() { return sc->widening_done; });
+    while (!sc->widening_done) (void)sc->widen_cv.wait_for(lock, std::chrono::milliseconds(50));
 }
 
 bool tables_ready(const KZGSettings *s) {
@@ -715,6 +738,49 @@ bool tables_ready(const KZGSettings *s) {
     if (!sc) return true;
     std::lock_guard<std::mutex> lock(sc->widen_mu);
     return sc->widening_done;
+}
+
+// What the library is waiting for, for a process that has stopped making progress (tests/watchdog.py calls it from
+// a signal handler of the stalled child; an application may call it from a watchdog thread).  Takes no lock it could
+// wait for: everything is try-locked, and what is held is reported as held.
+void debug_dump(int fd) {
+    dprintf(fd, "== ckzg_hip_debug_dump: wait deadline %lld ms, waits expired so far %llu, devices that stopped answering: mask 0x%llx\n",
+            (long long)dev::wait_deadline_ms(), (unsigned long long)dev::expired_waits_ref().load(),
+            (unsigned long long)dev::wedged_devices_ref().load());
+    const int64_t now = dev::monotonic_us();
+    dev::WaitNoteSlot *notes = dev::wait_notes();
+    int waits = 0;
+    for (int i = 0; i < dev::WAIT_NOTES; i++) {
+        const char *what = notes[i].what.load(std::memory_order_acquire);
+        if (!what) continue;
+        waits++;
+        dprintf(fd, "  thread %ld waits for: %s (%p), %.1f ms so far\n", notes[i].tid.load(std::memory_order_relaxed), what,
+                notes[i].obj.load(std::memory_order_relaxed), (double)(now - notes[i].since_us.load(std::memory_order_relaxed)) / 1000.0);
+    }
+    if (!waits) dprintf(fd, "  no thread is inside a wait of this library\n");
+    if (!g_reg_mu.try_lock_shared()) {
+        dprintf(fd, "  registry of loaded KZGSettings: locked exclusively (a load or a free is in progress)\n");
+        return;
+    }
+    static const char *const op_names[CB_COUNT] = {"commit", "cells", "proofs", "cells+proofs", "blob_proof", "recover", "verify_blob"};
+    for (auto &kv : registry()) {
+        SettingsCtx *sc = kv.second;
+        dprintf(fd, " KZGSettings %p: %zu table set(s), leases so far %llu\n", kv.first, sc->pools.size(),
+                (unsigned long long)sc->lease_seq.load(std::memory_order_relaxed));
+        for (DevicePool *p : sc->pools) {
+            if (p->mu.try_lock()) {
+                dprintf(fd, "  pool on device %d: %zu of %zu stream slots free\n", p->device, p->free_slots.size(), p->slots.size());
+                p->mu.unlock();
+            } else {
+                dprintf(fd, "  pool on device %d: mutex held\n", p->device);
+            }
+        }
+        for (int op = 0; op < (int)CB_COUNT; op++) {
+            if (sc->comb[op]) sc->comb[op]->dump(fd, op_names[op]);
+        }
+    }
+    g_reg_mu.unlock_shared();
+    dprintf(fd, "== end of ckzg_hip_debug_dump\n");
 }
 
 void destroy_settings_ctx(const KZGSettings *s) {

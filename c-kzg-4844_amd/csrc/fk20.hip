@@ -880,7 +880,7 @@ int fk20_setup_device(DeviceCtx *ctx, const G1Affine *d_monomial, G1Affine *h_xe
     }
     if (!rc) rc = batch_to_affine_device(ctx, ctx->d_xext, d_cols, d_prefix, npts);
     // the scratch is freed when this function returns: nothing may still be running on it, error or not
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = 2;
+    if (dev::sync_stream(ctx->stream) != hipSuccess && !rc) rc = 2;
     if (rc) return rc;
     if (h_xext) HIP_TRY(hipMemcpy(h_xext, ctx->d_xext, npts * sizeof(G1Affine), hipMemcpyDeviceToHost));
     return 0;
@@ -1076,7 +1076,7 @@ int fk20_proofs_device(DeviceCtx *ctx, uint8_t *d_proofs, const Fr *d_poly_monom
         rc = fk20_run(ctx, d_proofs, d_poly_monomial, n, static_cast<uint8_t *>(ctx->scratch.ptr));
     }
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(dev::sync_stream(ctx->stream));
     return 0;
 }
 
@@ -1199,7 +1199,7 @@ int cells_and_proofs_device(DeviceCtx *ctx, uint8_t *d_cells, uint8_t *d_proofs,
     }
     HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(dev::sync_stream(ctx->stream));
     float ms;
     if (hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[4]) == hipSuccess) ctx->last_ms[3] = ms;
     if (d_proofs && !direct && hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6]) == hipSuccess) ctx->last_ms[1] = ms;

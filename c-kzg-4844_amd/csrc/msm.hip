@@ -34,7 +34,7 @@ int scratch_reserve(DeviceCtx *ctx, size_t bytes) {
     // 256-caller rows).  Doubling bounds the number of such events per slot by log2(largest / first).
     const size_t old_cap = ctx->scratch.cap;
     if (ctx->scratch.ptr) {
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(dev::sync_stream(ctx->stream));
         HIP_TRY(hipFree(ctx->scratch.ptr));
         ctx->scratch.ptr = nullptr;
         ctx->scratch.cap = 0;
@@ -353,10 +353,10 @@ static int enqueue_affine_chain_table(hipStream_t stream, const FixedBaseTable &
     const size_t chains_per_launch = cancel ? (size_t)4 * t.npoints : nchains;
     for (size_t c0 = 0; c0 < nchains; c0 += chains_per_launch) {
         if (cancel && cancel->load(std::memory_order_relaxed)) {
-            (void)hipStreamSynchronize(stream);
+            (void)dev::sync_stream(stream);
             return 5;
         }
-        if (cancel && c0) HIP_TRY(hipStreamSynchronize(stream));
+        if (cancel && c0) HIP_TRY(dev::sync_stream(stream));
         const size_t nc = nchains - c0 < chains_per_launch ? nchains - c0 : chains_per_launch;
         const size_t units = nc * nseg, threads = (units + LSEG - 1) / LSEG;
         hipLaunchKernelGGL(k_table_seeds, dim3((unsigned)((units + 63) / 64)), dim3(64), 0, stream, d_table + c0 * t.half,
@@ -397,7 +397,7 @@ int build_fixed_base_table(DeviceCtx *ctx, FixedBaseTable *t, const G1Affine *d_
         if (rc) return rc;
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(dev::sync_stream(ctx->stream));
     t->d_table = d_table;
     table.p = nullptr;
     if (times_ms) {
@@ -1221,7 +1221,7 @@ int commit_blobs_device(DeviceCtx *ctx, uint8_t *d_out48, uint8_t *d_status, con
 #endif
     rc = commit_blobs_enqueue(ctx, d_out48, d_status, d_blobs, n);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(dev::sync_stream(ctx->stream));
     commit_collect_times(ctx);
 #ifdef CKZG_MSM_TRACE
     if (d_trace) {
@@ -1259,7 +1259,7 @@ int msm_commit_table_raw_device(DeviceCtx *ctx, uint8_t *d_out48, const uint32_t
                        d_digits, d_scalars, total, t.wbits, t.twin);
     rc = run_msm(ctx, t, d_out48, nullptr, d_digits, nullptr, d_partials, n, ppb);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(dev::sync_stream(ctx->stream));
     commit_collect_times(ctx);
     return 0;
 }

@@ -472,7 +472,7 @@ int lincomb_multi_device(DeviceCtx *ctx, G1Affine *d_out, G1XYZZ *d_partials, ui
     }
     hipLaunchKernelGGL(k_lincomb_final, dim3(njobs), dim3(64), 0, ctx->stream, d_out, d_partials, d_off, njobs);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(dev::sync_stream(ctx->stream));
     return 0;
 }
 

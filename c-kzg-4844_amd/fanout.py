@@ -72,7 +72,7 @@ def coalesce_stats(kzg, op_index):
     f = kzg.lib.ckzg_hip_coalesce_stats
     f.restype = C.c_int
     f.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.c_int]
-    v = (C.c_uint64 * 7)()
-    k = f(C.addressof(kzg.s), op_index, v, 7)
-    names = ("calls", "solo", "batches", "batched", "largest", "run_us", "retried")
-    return {n: int(v[i]) for i, n in enumerate(names)} if k == 7 else None
+    v = (C.c_uint64 * 9)()
+    k = f(C.addressof(kzg.s), op_index, v, 9)
+    names = ("calls", "solo", "batches", "batched", "largest", "run_us", "retried", "rescued", "gave_up")
+    return {n: int(v[i]) for i, n in enumerate(names)} if k == 9 else None

@@ -88,6 +88,14 @@ extern "C" {
  *                   point decompression at load).  0 (default): the CPUs of the process's affinity mask divided by the
  *                   processes that share the host (LOCAL_WORLD_SIZE or the MPI / Slurm node-local rank counts; else
  *                   WORLD_SIZE clamped to the visible GPUs; 1 otherwise).  The helper pools are sized by it when they start (first use).
+ *   "wait_deadline_ms"  longest time any wait inside the library may last, in milliseconds (default 30000; env
+ *                   CKZG_HIP_WAIT_DEADLINE_MS).  The reference never waits (src/eip4844/eip4844.c:264-280 is straight-line
+ *                   code); this library waits for the GPU, for a free stream slot and -- coalesced callers -- for the
+ *                   launch another caller runs.  None of these waits is unbounded: past the deadline the call that waited
+ *                   returns C_KZG_ERROR (src/common/ret.h:24-29: an internal failure, returned) and one line on stderr
+ *                   names what it waited for.  A DEVICE wait that expires marks the device as not answering: its kernels
+ *                   may still be running, so later calls on it fail at once with C_KZG_ERROR instead of queueing behind
+ *                   them, and free_trusted_setup leaves the device state in place.  Takes effect immediately.
  * A width that does not fit the free HBM is narrowed at load time (ckzg_hip_table_wbits reports the result).
  * Returns C_KZG_BADARGS for an unknown key or out-of-range value. */
 C_KZG_RET ckzg_hip_set_option(const char *key, int64_t value);
@@ -200,8 +208,20 @@ int ckzg_hip_tables_ready(const KZGSettings *s);
  * compute_cells_and_kzg_proofs with cells only / proofs only / both, 4 compute_blob_kzg_proof,
  * 5 recover_cells_and_kzg_proofs, 6 verify_blob_kzg_proof.  Fills at most n of: calls, calls that ran alone (idle
  * path), batch launches, calls served by batch launches, units in the largest launch, microseconds spent inside batch
- * launches, calls a batch could not answer and that ran alone afterwards (verifications only).  Returns the number filled (0: coalescing off). */
+ * launches, calls a batch could not answer and that ran alone afterwards (verifications only), open batches that sat on
+ * an idle device until a member's periodic look released them (the net under the queueing protocol: 0 unless the
+ * protocol has a hole), calls that left with C_KZG_ERROR at the wait deadline.  Returns the number filled (0: coalescing off). */
 int ckzg_hip_coalesce_stats(const KZGSettings *s, int op, uint64_t *out, int n);
+
+/* What the library is waiting for right now, written to file descriptor fd: every thread inside one of the library's
+ * waits (what for, since when), per loaded KZGSettings the free stream slots and the queue state of every coalesced
+ * operation.  For a process that has stopped making progress: takes no lock it could wait for (what is held is
+ * reported as held), may be called from any thread, also while other calls are stuck.  Needs no GPU. */
+void ckzg_hip_debug_dump(int fd);
+
+/* out[0] the wait deadline in ms, out[1] waits that hit it since the library was loaded, out[2] bit mask of devices
+ * marked as not answering.  Fills at most n entries and returns how many.  Needs no GPU. */
+int ckzg_hip_wait_stats(uint64_t *out, int n);
 
 /* Bytes of HBM held by the context's tables. */
 uint64_t ckzg_hip_table_bytes(const KZGSettings *s);

@@ -130,9 +130,13 @@ max_delta = 0
 
 
 class LeakWatch:
-    def __init__(self):
+    """steps: how many one-off growths of the runtime's own pools this walk may see (a leak comes back with every
+    failure; a pool grows once per code path that runs for the first time in the process)"""
+
+    def __init__(self, steps=1):
         self.base = fa.failalloc_free_bytes()
-        self.first = None
+        self.firsts = []
+        self.steps = steps
 
     def check(self, what):
         global max_delta
@@ -140,13 +144,12 @@ class LeakWatch:
         if d <= LEAK:
             max_delta = max(max_delta, d)
             return 0
-        if self.first is None:
-            self.first = (what, d)
+        if len(self.firsts) < self.steps:
+            self.firsts.append((what, d))
             self.base -= d
             return 0
         max_delta = max(max_delta, d)
-        problems.append("%s: %d bytes of device memory not returned (after a first step of %d bytes at: %s)" %
-                        (what, d, self.first[1], self.first[0]))
+        problems.append("%s: %d bytes of device memory not returned (after earlier steps %s)" % (what, d, self.firsts))
         return d
 
 
@@ -261,7 +264,10 @@ def section_fan_out():
     k = load(options={"replicas": 2})
     want_fan = (commit_batch(k, 40), k.verify_blob_kzg_proof_batch(many, many_c, many_p))
     k.close()
-    watch = LeakWatch()
+    # (in a process of its own this walk is the first to send a verification down BOTH of its fallback paths -- the
+    # call-time table that does not fit, then the ladder sums' scratch: two one-off growths of the runtime's pools,
+    # 310 MB and 788 MB; the monolithic round-5 driver had been through them in the walks before)
+    watch = LeakWatch(steps=2)
     injected = 0
     for nth in range(0, 96):
         progress("fan-out: failure %d" % nth)
@@ -332,6 +338,10 @@ def section_coalesced_callers():
             problems.append("coalesced callers: wrong results after allocations work again (failed from the %d-th)" % nth)
         cs = fo.coalesce_stats(k, 0)
         coalesce_batches += cs["batches"] if cs else 0
+        if cs and (cs["rescued"] or cs["gave_up"]):
+            problems.append("coalesced callers, allocations failing from the %d-th: the queueing protocol needed its net "
+                            "(open batches released by a member's periodic look: %d, calls that gave up at the deadline: %d)" %
+                            (nth, cs["rescued"], cs["gave_up"]))
         k.close()
         coalesce_injected += 1 if fired else 0
         watch.check("coalesced callers, allocations failing from the %d-th" % nth)

@@ -7,8 +7,11 @@
 #include <cstdlib>
 #include <atomic>
 #include <cstdint>
+#include <unistd.h>
 static std::atomic<long> g_allocs_left{1L << 40};   // the scenario "the page-locked pool runs dry" counts this down
+static std::atomic<int> g_alloc_us{0};              // a page-locked allocation takes milliseconds (hipHostMalloc: 10-30 ms for 33 MB)
 static bool test_alloc(uint8_t **pp, size_t bytes) {
+    if (g_alloc_us.load()) usleep(g_alloc_us.load());
     if (g_allocs_left.fetch_sub(1) <= 0) return false;
     return (*pp = static_cast<uint8_t *>(malloc(bytes))) != nullptr;
 }
@@ -21,6 +24,7 @@ static bool test_alloc(uint8_t **pp, size_t bytes) {
 #include <unistd.h>
 
 using namespace ckzg::api;
+namespace dev = ckzg::dev;
 
 namespace ckzg {
 namespace api {
@@ -161,6 +165,148 @@ static int starvation() {
     return mean <= 2.0 * (threads / 16 + 2) && worst_wait.load() <= 150 ? 0 : 6;
 }
 
+// THE STALL OF THE ROUND-5 DRIVER RUN.  A caller that needs a new batch buffer allocates it with the mutex released
+// (milliseconds of hipHostMalloc).  When the allocation FAILED, round 5's submit() carried on where it was instead of
+// looking again: it took a batch that had come back to the free list meanwhile and opened it -- although the launch that
+// had been in flight when it decided to allocate had ended meanwhile too.  A batch opened on an idle device is released
+// by nobody; its opener slept for good (futex_wait on the OPEN state word, no timeout: the one native thread left in
+// profiles/r06_stall_coalesced_callers.txt).  Short runs of the commitment combiner's shape (24 callers x 6 calls, up to
+// three callers on their own) with slow allocations that start failing after 0..7 of them: every call must come back,
+// and WITHOUT the net under the protocol (Stats::rescued) or the wait deadline (Stats::gave_up) having been needed.
+static int failed_allocation_on_a_device_gone_idle() {
+    const int rounds = 120, threads = 24, calls = 6;
+    uint64_t rescued = 0, gave_up = 0;
+    std::atomic<long> wrong{0};
+    for (int r = 0; r < rounds; r++) {
+        g_allocs_left.store(r % 9 == 8 ? (1L << 40) : (r % 9));
+        g_alloc_us.store(2000 + (r % 5) * 4000);
+        Combiner cb(/*max_batch=*/256, /*in=*/256 * 8, /*out=*/256 * 8, /*max_active=*/2, /*solo_below=*/3);
+        std::vector<std::thread> th;
+        for (int t = 0; t < threads; t++) {
+            th.emplace_back([&, t]() {
+                std::mt19937_64 rng((uint64_t)r * 100 + t);
+                for (int c = 0; c < calls; c++) {
+                    const uint64_t in = rng();
+                    uint64_t out = 0;
+                    const int solo_us = 200 + (int)(rng() % 800), run_us = 500 + (int)(rng() % 3000);
+                    const C_KZG_RET rc = guarded([&]() -> C_KZG_RET {
+                        return cb.submit(
+                            nullptr, 0,
+                            [&]() -> C_KZG_RET {
+                                usleep(solo_us);
+                                out = mix(in, 5);
+                                return C_KZG_OK;
+                            },
+                            [&](uint8_t *h_in, size_t idx) { memcpy(h_in + idx * 8, &in, 8); },
+                            [&](const uint8_t *h_in, uint8_t *h_out, uint8_t *, size_t n) -> C_KZG_RET {
+                                usleep(run_us);
+                                for (size_t i = 0; i < n; i++) {
+                                    uint64_t v;
+                                    memcpy(&v, h_in + i * 8, 8);
+                                    v = mix(v, 5);
+                                    memcpy(h_out + i * 8, &v, 8);
+                                }
+                                return C_KZG_OK;
+                            },
+                            [&](const uint8_t *h_out, size_t idx, size_t) { memcpy(&out, h_out + idx * 8, 8); });
+                    });
+                    if (rc != C_KZG_OK || out != mix(in, 5)) wrong.fetch_add(1);
+                }
+            });
+        }
+        for (auto &x : th) x.join();
+        const Combiner::Stats st = cb.stats();
+        rescued += st.rescued;
+        gave_up += st.gave_up;
+    }
+    g_allocs_left.store(1L << 40);
+    g_alloc_us.store(0);
+    printf("failed_allocation_on_a_device_gone_idle: %d runs, wrong %ld, open batches rescued %llu, calls that gave up %llu\n", rounds,
+           wrong.load(), (unsigned long long)rescued, (unsigned long long)gave_up);
+    return wrong.load() || rescued || gave_up ? 8 : 0;
+}
+
+// The member that runs a batch does not come back (a device wait that never ends, a thread that was descheduled for
+// good): every OTHER member must come back with C_KZG_ERROR once the wait deadline has passed -- the reference's
+// convention for an internal failure (src/common/ret.h:24-29), and what a caller of a library that cannot block expects
+// (src/eip4844/eip4844.c:264-280 is straight-line code) -- the stuck launch's own caller gets its result when (if) it
+// ends, and the combiner serves later callers as before: nothing leaks a launch place or a batch buffer.
+static int runner_never_comes_back() {
+    dev::wait_deadline_ms_ref().store(300);
+    const int threads = 12;
+    std::atomic<int> stall_left{1};           // the first batch launch stalls
+    std::atomic<bool> stalling{false};
+    std::atomic<long> errors{0}, wrong{0}, slow_errors{0};
+    Combiner cb(/*max_batch=*/16, /*in=*/16 * 8, /*out=*/16 * 8, /*max_active=*/1);
+    auto call = [&](uint64_t in, uint64_t &out) -> C_KZG_RET {
+        return guarded([&]() -> C_KZG_RET {
+            return cb.submit(
+                nullptr, 0,
+                [&]() -> C_KZG_RET {
+                    usleep(20000);   // long enough for everybody else to queue up behind it
+                    out = mix(in, 9);
+                    return C_KZG_OK;
+                },
+                [&](uint8_t *h_in, size_t idx) { memcpy(h_in + idx * 8, &in, 8); },
+                [&](const uint8_t *h_in, uint8_t *h_out, uint8_t *, size_t n) -> C_KZG_RET {
+                    if (n >= 2 && stall_left.fetch_sub(1) == 1) {
+                        stalling.store(true);
+                        usleep(1500000);   // five deadlines
+                        stalling.store(false);
+                    }
+                    for (size_t i = 0; i < n; i++) {
+                        uint64_t v;
+                        memcpy(&v, h_in + i * 8, 8);
+                        v = mix(v, 9);
+                        memcpy(h_out + i * 8, &v, 8);
+                    }
+                    return C_KZG_OK;
+                },
+                [&](const uint8_t *h_out, size_t idx, size_t) { memcpy(&out, h_out + idx * 8, 8); });
+        });
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; t++) {
+        th.emplace_back([&, t]() {
+            for (int c = 0; c < 3; c++) {
+                const uint64_t in = (uint64_t)t * 1000 + c;
+                uint64_t out = 0;
+                const auto t0 = std::chrono::steady_clock::now();
+                const C_KZG_RET r = call(in, out);
+                const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                if (r == C_KZG_ERROR) {
+                    errors.fetch_add(1);
+                    if (ms > 1200.0) slow_errors.fetch_add(1);   // an error must arrive AT the deadline, not when the stall ends
+                } else if (r != C_KZG_OK || out != mix(in, 9)) {
+                    wrong.fetch_add(1);
+                }
+            }
+        });
+    }
+    for (auto &x : th) x.join();
+    // afterwards: the combiner works as before
+    long after_wrong = 0;
+    std::vector<std::thread> th2;
+    std::atomic<long> after_bad{0};
+    for (int t = 0; t < threads; t++) {
+        th2.emplace_back([&, t]() {
+            for (int c = 0; c < 20; c++) {
+                const uint64_t in = 777000 + (uint64_t)t * 100 + c;
+                uint64_t out = 0;
+                if (call(in, out) != C_KZG_OK || out != mix(in, 9)) after_bad.fetch_add(1);
+            }
+        });
+    }
+    for (auto &x : th2) x.join();
+    after_wrong = after_bad.load();
+    dev::wait_deadline_ms_ref().store(30000);
+    printf("runner_never_comes_back: %ld callers got C_KZG_ERROR at the deadline (%ld late), wrong %ld, wrong afterwards %ld, "
+           "expired waits %llu\n", errors.load(), slow_errors.load(), wrong.load(), after_wrong,
+           (unsigned long long)dev::expired_waits_ref().load());
+    if (errors.load() < 1 || slow_errors.load() || wrong.load() || after_wrong) return 7;
+    return 0;
+}
+
 int main(int argc, char **argv) {
     const int threads = argc > 1 ? atoi(argv[1]) : 48, calls = argc > 2 ? atoi(argv[2]) : 400;
     std::atomic<long> wrong{0}, solos{0};
@@ -239,5 +385,7 @@ int main(int argc, char **argv) {
     }
     if (wrong.load()) return 1;
     if (int rc = burst_then_few()) return rc;
+    if (int rc = runner_never_comes_back()) return rc;
+    if (int rc = failed_allocation_on_a_device_gone_idle()) return rc;
     return threads >= 48 ? starvation() : 0;
 }

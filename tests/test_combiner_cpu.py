@@ -2,7 +2,8 @@
 
 tests/native/combiner_stress.cpp drives the real header -- host functions stand in for the launches, malloc for the
 page-locked buffers -- through five scenarios (plain, go-alone threshold, batch-buffer allocation failing, whole launches
-failing, gathering) and checks that every caller gets the answer to ITS input.  Built plain and under ThreadSanitizer: the batch
+failing, gathering), the burst / starvation checks, a launch whose runner does not come back (wait deadline) and the
+schedule that stalled the round-5 driver run (an allocation that fails while the device goes idle) and checks that every caller gets the answer to ITS input.  Built plain and under ThreadSanitizer: the batch
 state word, reference counts and copy counter are lock-free, and the GPU suite's TSan pass (tools/run_sanitized.sh tsan)
 only sees the schedules a real device produces.
 """
@@ -32,7 +33,11 @@ def test_combiner_protocol(tmp_path, threads, calls):
     exe = _build(tmp_path, "cstress", [])
     r = subprocess.run([exe, str(threads), str(calls)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr[-2000:]
-    assert r.stdout.count("wrong 0") == 5, r.stdout
+    assert sum(1 for ln in r.stdout.splitlines() if ln.startswith("scenario") and ln.endswith("wrong 0")) == 5, r.stdout
+    # the two round-6 scenarios: a runner that does not come back fails the OTHER members at the wait deadline; a failed
+    # batch-buffer allocation on a device that has gone idle meanwhile (the round-5 driver stall) no longer strands a caller
+    assert "runner_never_comes_back:" in r.stdout and "(0 late), wrong 0, wrong afterwards 0" in r.stdout, r.stdout
+    assert "wrong 0, open batches rescued 0, calls that gave up 0" in r.stdout, r.stdout
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")

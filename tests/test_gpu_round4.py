@@ -45,40 +45,68 @@ def test_batch_verification_when_hbm_is_too_full_for_the_call_time_table():
     assert rows[0]["free_mb"] >= 800 and rows[1]["free_mb"] <= 340, rows   # the second level cannot have held the table
 
 
-def test_device_entry_points_reject_pointers_that_are_not_on_their_gpu(hip, material):
-    import torch
+_POINTER_CHECKS = r'''
+import ctypes as C, json, sys
+import torch                       # FIRST: its copy of the HIP runtime becomes the one the library binds to as well
+torch.cuda.init()
+sys.path.insert(0, "tests")
+from kzg_ctypes import HIP_SO, Kzg
+blob, cm0, pr0 = (bytes.fromhex(x) for x in json.loads(sys.stdin.read()))
+hip = Kzg(HIP_SO, "", precompute=0)
+lib = hip.lib
+p, u64 = C.c_void_p, C.c_uint64
+d_blob = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda()
+d_out = torch.zeros(48, dtype=torch.uint8, device="cuda")
+d_st = torch.zeros(1, dtype=torch.uint8, device="cuda")
+h_out = C.create_string_buffer(48)
+f = lib.ckzg_hip_blob_to_kzg_commitment_batch_device
+f.restype = C.c_int
+f.argtypes = [p, p, p, u64, p]
+sp = C.addressof(hip.s)
+assert f(d_out.data_ptr(), d_st.data_ptr(), d_blob.data_ptr(), 1, sp) == 0
+assert bytes(d_out.cpu().numpy().tobytes()) == cm0
+assert f(d_out.data_ptr(), None, d_blob.data_ptr(), 1, sp) == 0                       # the status array is optional
+assert f(C.cast(h_out, p), d_st.data_ptr(), d_blob.data_ptr(), 1, sp) == 1            # host output buffer
+assert f(d_out.data_ptr(), d_st.data_ptr(), C.cast(C.c_char_p(blob), p), 1, sp) == 1  # host blobs
+assert f(None, d_st.data_ptr(), d_blob.data_ptr(), 1, sp) == 1
+g = lib.ckzg_hip_compute_cells_and_kzg_proofs_batch_device
+g.restype = C.c_int
+g.argtypes = [p, p, p, p, u64, p]
+d_proofs = torch.zeros(128 * 48, dtype=torch.uint8, device="cuda")
+h_cells = C.create_string_buffer(128 * 2048)
+assert g(None, d_proofs.data_ptr(), d_st.data_ptr(), d_blob.data_ptr(), 1, sp) == 0
+assert g(C.cast(h_cells, p), d_proofs.data_ptr(), d_st.data_ptr(), d_blob.data_ptr(), 1, sp) == 1
+v = lib.ckzg_hip_verify_blob_kzg_proof_batch_device
+v.restype = C.c_int
+v.argtypes = [p, p, p, p, u64, p]
+ok = C.c_bool(False)
+d_c = torch.frombuffer(bytearray(cm0), dtype=torch.uint8).cuda()
+d_p = torch.frombuffer(bytearray(pr0), dtype=torch.uint8).cuda()
+assert v(C.byref(ok), d_blob.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), 1, sp) == 0 and ok.value
+assert v(C.byref(ok), d_blob.data_ptr(), C.cast(C.c_char_p(cm0), p), d_p.data_ptr(), 1, sp) == 1
+hip.close()
+print("POINTER_CHECKS_OK")
+'''
+
+
+def test_device_entry_points_reject_pointers_that_are_not_on_their_gpu(material, tmp_path):
+    """The caller's device buffers come from torch here, so torch and the library must share ONE HIP runtime: torch
+    brings its own copy of libamdhip64 (torch/lib, same soname), and whichever copy a process loads first is the one both
+    bind to.  A process that has already loaded /opt/rocm's copy through the library -- this pytest session, once any
+    fixture has run -- ends up with two runtimes, torch's pointers unknown to the library's and, on some boxes, torch
+    finding "No HIP GPUs" (round-6 run 1: the test ran after the parity files for the first time).  The checks therefore
+    run in a process of their own that imports torch first, as an application embedding both would."""
+    import json
+    import os
+    import sys
+    from watchdog import run_watched
     blobs, cm, pr = material
-    lib = hip.lib
-    p, u64 = C.c_void_p, C.c_uint64
-    d_blob = torch.frombuffer(bytearray(blobs[0]), dtype=torch.uint8).cuda()
-    d_out = torch.zeros(48, dtype=torch.uint8, device="cuda")
-    d_st = torch.zeros(1, dtype=torch.uint8, device="cuda")
-    h_out = C.create_string_buffer(48)
-    f = lib.ckzg_hip_blob_to_kzg_commitment_batch_device
-    f.restype = C.c_int
-    f.argtypes = [p, p, p, u64, p]
-    sp = C.addressof(hip.s)
-    assert f(d_out.data_ptr(), d_st.data_ptr(), d_blob.data_ptr(), 1, sp) == 0
-    assert bytes(d_out.cpu().numpy().tobytes()) == cm[0]
-    assert f(d_out.data_ptr(), None, d_blob.data_ptr(), 1, sp) == 0                       # the status array is optional
-    assert f(C.cast(h_out, p), d_st.data_ptr(), d_blob.data_ptr(), 1, sp) == 1            # host output buffer
-    assert f(d_out.data_ptr(), d_st.data_ptr(), C.cast(C.c_char_p(blobs[0]), p), 1, sp) == 1   # host blobs
-    assert f(None, d_st.data_ptr(), d_blob.data_ptr(), 1, sp) == 1
-    g = lib.ckzg_hip_compute_cells_and_kzg_proofs_batch_device
-    g.restype = C.c_int
-    g.argtypes = [p, p, p, p, u64, p]
-    d_proofs = torch.zeros(128 * 48, dtype=torch.uint8, device="cuda")
-    h_cells = C.create_string_buffer(128 * 2048)
-    assert g(None, d_proofs.data_ptr(), d_st.data_ptr(), d_blob.data_ptr(), 1, sp) == 0
-    assert g(C.cast(h_cells, p), d_proofs.data_ptr(), d_st.data_ptr(), d_blob.data_ptr(), 1, sp) == 1
-    v = lib.ckzg_hip_verify_blob_kzg_proof_batch_device
-    v.restype = C.c_int
-    v.argtypes = [p, p, p, p, u64, p]
-    ok = C.c_bool(False)
-    d_c = torch.frombuffer(bytearray(cm[0]), dtype=torch.uint8).cuda()
-    d_p = torch.frombuffer(bytearray(pr[0]), dtype=torch.uint8).cuda()
-    assert v(C.byref(ok), d_blob.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), 1, sp) == 0 and ok.value
-    assert v(C.byref(ok), d_blob.data_ptr(), C.cast(C.c_char_p(cm[0]), p), d_p.data_ptr(), 1, sp) == 1
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inp = tmp_path / "in.json"
+    inp.write_text(json.dumps([blobs[0].hex(), cm[0].hex(), pr[0].hex()]))
+    r = run_watched([sys.executable, "-c", "import sys; sys.stdin = open(%r); exec(%r)" % (str(inp), _POINTER_CHECKS)],
+                    cwd=root, timeout=280, name="round4_pointer_checks")
+    assert r.returncode == 0 and "POINTER_CHECKS_OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
 
 
 # ---------------------------------------------------------------------------------------------
