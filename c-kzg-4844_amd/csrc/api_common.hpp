@@ -104,30 +104,29 @@ inline int host_thread_budget() {
         // (A cgroup CPU quota is deliberately NOT applied: it is a budget of CPU time per 100 ms period, and a call that
         // hashes 512 MB in a 12 ms burst on 32 threads stays inside a 16-core quota -- capping the pool at 16 threads
         // made the 4096-blob verification 18.1 instead of 12.5 ms on exactly such a box.)
-        // ranks on THIS node: only node-local variables are trusted as they are (torchrun, Open MPI, MPICH / Intel MPI,
-        // MVAPICH, Slurm).  WORLD_SIZE counts the ranks of the whole job -- 64 on an 8-node launch by mpirun / srun, which
-        // export no LOCAL_WORLD_SIZE -- so it is clamped to the GPUs this process can see (one process per GPU; 8 when
-        // the count is unknown: no node of this platform holds more).
+        // ranks on THIS node: only node-local variables are trusted as they are (torchrun, Open MPI, MPICH / Intel MPI /
+        // PMI, MVAPICH, Slurm -- whose per-node counts may read "8(x2)": the leading number is taken).  WORLD_SIZE counts
+        // the ranks of the whole job -- 64 on an 8-node launch by mpirun / srun, which export no LOCAL_WORLD_SIZE -- so it
+        // is clamped to 8: no node of this platform holds more GPUs, and one process per GPU is the shape.  (Round 5
+        // clamped it to the devices VISIBLE to the process: a launcher that binds one GPU per rank --
+        // ROCR_VISIBLE_DEVICES, srun --gpu-bind -- then made every rank take the whole machine, and a host-only query
+        // initialised the HIP runtime from a static initialiser.  No HIP call here.)
         auto positive = [](const char *name) -> int {
             const char *v = getenv(name);
             if (!v || !*v) return 0;
             char *end = nullptr;
             const long x = strtol(v, &end, 10);
-            return (end == v || x < 1 || x > 1 << 20) ? 0 : (int)x;
+            // ("8(x2)", "8,7": Slurm's compressed lists -- the first count; anything else after the digits is garbage)
+            if (end == v || (*end != '\0' && *end != '(' && *end != ',')) return 0;
+            return (x < 1 || x > 1 << 20) ? 0 : (int)x;
         };
         int ranks = 0;
-        for (const char *name : {"LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS", "MV2_COMM_WORLD_LOCAL_SIZE",
-                                 "SLURM_NTASKS_PER_NODE"}) {
+        for (const char *name : {"LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS", "PMI_LOCAL_SIZE",
+                                 "MV2_COMM_WORLD_LOCAL_SIZE", "SLURM_NTASKS_PER_NODE", "SLURM_STEP_TASKS_PER_NODE",
+                                 "SLURM_TASKS_PER_NODE"}) {
             if ((ranks = positive(name)) > 0) break;
         }
-        if (ranks == 0 && (ranks = positive("WORLD_SIZE")) > 0) {
-            int gpus = 0;
-            if (hipGetDeviceCount(&gpus) != hipSuccess || gpus < 1) {
-                (void)hipGetLastError();
-                gpus = 8;
-            }
-            if (ranks > gpus) ranks = gpus;
-        }
+        if (ranks == 0 && (ranks = positive("WORLD_SIZE")) > 8) ranks = 8;
         if (ranks < 1) ranks = 1;
         const int share = cpus / ranks;
         return share < 1 ? 1 : share;

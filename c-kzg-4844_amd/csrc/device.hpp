@@ -34,6 +34,7 @@ constexpr int N_CELLS_EXT = 128;   // CELLS_PER_EXT_BLOB
 // and each scalar yields nwin = 2*twin signed digits in [-half, half]: windows 0..twin-1 are the k2
 // (phi) half, twin..nwin-1 the k1 half.  The MSM is a plain sum of npoints*nwin table entries -- no
 // buckets, no doublings, no data-dependent scatter -- at half the memory of a 255-bit table.
+
 // The tuning constants of the product are constants.  The A/B build (-DCKZG_AB: tools/build_variant.sh) reads them
 // from the environment instead, once per process, so that tools/ab_*.sh can sweep one constant on one box; the
 // measured sweeps that chose the defaults are under profiles/.  No losing variant lives in the product.
@@ -160,7 +161,11 @@ inline hipError_t bounded_device_wait(Query &&query, const char *what, const voi
             (void)hipGetLastError();
             return hipErrorLaunchTimeOut;
         }
-        const int64_t step = waited / 32;
+        // (A/B, profiles/r06_sync_poll_ab.txt: spinning for the whole wait -- the floor any wait can reach -- against
+        // steps of 1/16, 1/32, 1/64 of the time waited so far)
+        static const int64_t div = ab_knob("CKZG_HIP_SYNC_STEP_DIV", 32);
+        if (div <= 0) continue;   // A/B only: never sleep
+        const int64_t step = waited / div;
         sleep_us(step < 20 ? 20 : (step > 1000 ? 1000 : step));
     }
     (void)hipGetLastError();   // hipErrorNotReady is not an error, but the runtime remembers it as the thread's last one
@@ -216,6 +221,20 @@ inline size_t reserve_scaled(size_t bytes) {
     const double want = (double)bytes * f, cap = (double)bytes + (double)((size_t)1 << 30);
     return (size_t)(want < cap ? want : cap);
 }
+// Room taken ahead of need (the reservation above, the geometric regrowth of arenas and scratch) is a bet on later
+// calls: it may only be placed with memory nobody is short of.  With the tables sized to the free HBM at load time
+// (238 GB for the wide set) the extra gigabytes of eight slots could otherwise be what a LATER allocation -- another
+// slot's scratch, the call-time table of a verification -- fails for (round-5 advisor finding).  So: nothing is taken
+// ahead unless it is at most an eighth of the HBM that is free right now; the need itself is never reduced.
+inline size_t speculative_bytes(size_t need, size_t ahead) {
+    if (ahead <= need) return need;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+        (void)hipGetLastError();
+        return need;
+    }
+    return ahead <= free_b / 8 ? ahead : need;
+}
 
 struct Arena {
     void *base = nullptr;
@@ -235,7 +254,8 @@ struct Arena {
         // gives the block back after every call (a hipMalloc + a synchronising hipFree per call: ~0.5-0.8 ms)
         const size_t slack = (bytes >> 1) < ((size_t)256 << 20) ? (bytes >> 1) : ((size_t)256 << 20);
         size_t want = bytes + slack;
-        if (reserve_scaled(bytes) > want && reserve_scaled(bytes) <= ((size_t)3 << 30)) {
+        if (reserve_scaled(bytes) > want && reserve_scaled(bytes) <= ((size_t)3 << 30) &&
+            speculative_bytes(want, reserve_scaled(bytes)) > want) {
             // a batch of a coalescing operation: room for the largest batch at once (fall back to the need if it fails)
             if (hipMalloc(&base, reserve_scaled(bytes)) == hipSuccess) {
                 cap = reserve_scaled(bytes);
@@ -248,7 +268,7 @@ struct Arena {
         // callers of a coalesced batch for a synchronising hipFree + hipMalloc
         size_t twice = old_cap + (old_cap < ((size_t)1 << 30) ? old_cap : ((size_t)1 << 30));
         if (twice > ((size_t)3 << 30)) twice = (size_t)3 << 30;   // (never past the size above which ArenaTrim gives the block back)
-        if (old_cap && want < twice && hipMalloc(&base, twice) == hipSuccess) {
+        if (old_cap && want < twice && speculative_bytes(want, twice) > want && hipMalloc(&base, twice) == hipSuccess) {
             cap = twice;
             return true;
         }

@@ -45,6 +45,7 @@ int scratch_reserve(DeviceCtx *ctx, size_t bytes) {
         const size_t step = old_cap < ((size_t)2 << 30) ? old_cap : ((size_t)2 << 30);   // double, by at most 2 GB
         if (want < old_cap + step) want = old_cap + step;
     }
+    want = speculative_bytes(bytes + (bytes >> 4), want);   // ahead of need only while HBM is plentiful (device.hpp)
     hipError_t e = hipMalloc(&ctx->scratch.ptr, want);
     if (e != hipSuccess) {
         (void)hipGetLastError();  // the failed attempt must not surface at the next hipGetLastError()

@@ -35,6 +35,18 @@ def gather_rows(local, n_total, group=None):
     return torch.cat([parts[r][: hi - lo] for r, (lo, hi) in enumerate(bounds)], dim=0)
 
 
+def gather_to_rank0(local, group=None):
+    """The "trivial gather" of the sharded commitment path: every rank's [rows, width] results (equal shards) to rank 0,
+    which gets [world * rows, width]; the other ranks get None.  One RCCL gather over xGMI ("nccl" backend, device
+    tensors, enqueued behind the producing work: the caller goes on); gloo (CPU tests) gathers host copies."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if dist.get_backend(group) != "nccl":
+        local = local.cpu()
+    parts = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
+    dist.gather(local, parts, dst=0, group=group)
+    return torch.cat(parts, dim=0) if rank == 0 else None
+
+
 def sharded_map(compute, n_total, width, device, group=None):
     """Run compute(lo, hi) -> uint8 tensor [hi-lo, width] on this rank's shard and gather."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)

@@ -86,8 +86,8 @@ extern "C" {
  *                   lone call.  Takes effect immediately.
  *   "host_threads"  host threads one process of this library may keep busy per call (challenge hashing, staging copies,
  *                   point decompression at load).  0 (default): the CPUs of the process's affinity mask divided by the
- *                   processes that share the host (LOCAL_WORLD_SIZE or the MPI / Slurm node-local rank counts; else
- *                   WORLD_SIZE clamped to the visible GPUs; 1 otherwise).  The helper pools are sized by it when they start (first use).
+ *                   processes that share the host (LOCAL_WORLD_SIZE or the MPI / PMI / Slurm node-local rank counts; else
+ *                   WORLD_SIZE clamped to 8, the GPUs of one node; 1 otherwise).  The helper pools are sized by it when they start (first use).
  *   "wait_deadline_ms"  longest time any wait inside the library may last, in milliseconds (default 30000; env
  *                   CKZG_HIP_WAIT_DEADLINE_MS).  The reference never waits (src/eip4844/eip4844.c:264-280 is straight-line
  *                   code); this library waits for the GPU, for a free stream slot and -- coalesced callers -- for the

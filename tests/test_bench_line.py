@@ -41,6 +41,8 @@ def test_last_line_is_small_and_carries_the_contract():
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["sample"]
     assert "predicted_scaling" not in out and "secondary" not in out      # the model and the sweeps stay out
+    # both forms of the headline travel in the one line: resident (the contract's `value`) and PCIe-inclusive
+    assert "value_host_pointer" in out and "resident" in out["value_semantics"] and "H2D+D2H" in out["value_semantics"]
     assert out["baseline_configs"]["configs[2]"]["wide_tables_ms_per_call"] == full["baseline_configs"]["configs[2]"]["wide_tables_ms_per_call"]
 
 

@@ -288,8 +288,18 @@ def test_single_calls_spread_over_the_pools(hip, hip2):
     assert hip2.compute_cells_and_kzg_proofs(b) == hip.compute_cells_and_kzg_proofs(b)
 
 
-@pytest.mark.skipif("__import__('torch').cuda.device_count() < 2", reason="needs two visible GPUs")
+def _visible_gpus():
+    """through the library's own runtime (ckzg_hip_device_count).  NOT through torch: torch brings a second copy of the HIP
+    runtime (torch/lib/libamdhip64.so), a process can only have ONE runtime that owns the GPU, and importing torch into
+    this pytest process made later dlopen("libamdhip64.so") calls of the suite resolve to that dead second copy."""
+    lib = C.CDLL(HIP_SO)
+    lib.ckzg_hip_device_count.restype = C.c_int
+    return int(lib.ckzg_hip_device_count())
+
+
 def test_two_real_devices(hip):
+    if _visible_gpus() < 2:
+        pytest.skip("needs two visible GPUs")
     api = Kzg(HIP_SO, "", precompute=0, options={"devices": 3, "commit_wbits": 8})
     _restore(api)
     try:

@@ -166,7 +166,12 @@ def test_graph_builds_survive_busy_library_and_foreign_hip_threads(hip, oracle):
 
     # a HIP user that is NOT this library: raw hipMalloc / hipMemcpy / hipFree from its own thread, for the whole test
     # (what RCCL's watchdog or PyTorch's allocator are to an embedding process)
-    rt = C.CDLL("libamdhip64.so")
+    # ... through the SAME runtime the library runs on (a process has one runtime that owns the GPU): the copy of
+    # libamdhip64 that is mapped already, by its path -- a bare dlopen("libamdhip64.so") can resolve to another copy that a
+    # test imported earlier (torch/lib carries one under exactly that name) and that could never initialise
+    loaded = sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln and "/torch/" not in ln})
+    assert loaded, "the library's HIP runtime is not mapped?"
+    rt = C.CDLL(loaded[0])
     rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
     rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     rt.hipFree.argtypes = [C.c_void_p]

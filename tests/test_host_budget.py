@@ -18,7 +18,7 @@ CODE = ("import ctypes as C, os\n"
 
 
 def _run(env_extra, affinity=None):
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "LOCAL_WORLD_SIZE")}
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "LOCAL_WORLD_SIZE") and not k.startswith(("SLURM_", "PMI_", "OMPI_"))}
     env.update(env_extra)
     cmd = [sys.executable, "-c", CODE]
     if affinity is not None:
@@ -53,18 +53,22 @@ def test_budget_divides_by_the_ranks_on_the_host():
 
 def test_job_wide_world_size_is_clamped_to_one_node():
     """WORLD_SIZE = 64 from mpirun / srun on 8 nodes (no LOCAL_WORLD_SIZE) must not leave each rank cpus / 64 threads:
-    at most one rank per visible GPU shares this host (8 when no GPU can be counted, as on this CPU box)."""
-    import ctypes as C
+    at most 8 ranks share a host (one process per GPU, 8 GPUs per node).  The clamp does not depend on the devices
+    VISIBLE to the process -- a launcher that binds one GPU per rank would otherwise give every rank the whole machine
+     -- and the query initialises no GPU runtime."""
     cpus, one, _, _ = _run({})
-    try:
-        n = C.c_int(0)
-        gpus = n.value if C.CDLL("libamdhip64.so").hipGetDeviceCount(C.byref(n)) == 0 and n.value > 0 else 8
-    except OSError:
-        gpus = 8
-    _, auto, _, _ = _run({"WORLD_SIZE": "64"})
-    assert auto == max(1, one // min(64, gpus)), (one, auto, gpus)
+    for visible in (None, "0"):
+        extra = {} if visible is None else {"ROCR_VISIBLE_DEVICES": visible, "HIP_VISIBLE_DEVICES": visible}
+        _, auto, _, _ = _run(dict(extra, WORLD_SIZE="64"))
+        assert auto == max(1, one // 8), (one, auto, visible)
+        _, auto, _, _ = _run(dict(extra, WORLD_SIZE="4"))
+        assert auto == max(1, one // 4), (one, auto, visible)
+    # Slurm's compressed per-node lists and PMI's local size
+    for name, val, ranks in (("SLURM_TASKS_PER_NODE", "8(x2)", 8), ("SLURM_STEP_TASKS_PER_NODE", "4,3", 4), ("PMI_LOCAL_SIZE", "2", 2)):
+        _, auto, _, _ = _run({"WORLD_SIZE": "64", name: val})
+        assert auto == max(1, one // ranks), (name, val, auto)
     # garbage is ignored, not atoi'ed
-    for junk in ("", "abc", "-3", "0", "99999999999999999999"):
+    for junk in ("", "abc", "-3", "0", "99999999999999999999", "8x"):
         _, auto, _, _ = _run({"WORLD_SIZE": junk})
         assert auto == one, junk
 

@@ -41,6 +41,12 @@ WORKER = textwrap.dedent('''
     def verify_bad(lo, hi):
         return 0, orc.verify_blob_kzg_proof_batch(blobs[lo:hi], commits[lo:hi], bad[lo:hi])
     ret2, ok2 = mg.sharded_verify(verify_bad, n, torch.device("cpu"))
+    # the gather of the commitment bench (equal shards, results to rank 0 only)
+    mine = torch.full((3, 48), 10 + rank, dtype=torch.uint8)
+    at0 = mg.gather_to_rank0(mine)
+    assert (at0 is None) == (rank != 0)
+    if rank == 0:
+        assert at0.shape == (6, 48) and at0[:3].eq(10).all() and at0[3:].eq(11).all()
     if rank == 0:
         single = [orc.blob_to_kzg_commitment(b) for b in blobs]
         assert commits == single, "sharded gather differs from single process"
@@ -56,7 +62,7 @@ def test_world_size_2_gloo(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29531", str(script)]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
     assert "MULTI_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 

@@ -6,6 +6,9 @@
   verify_wide   ckzg_hip_verify_blob_kzg_proof_batch_device, 4096 blobs x 3 (k_sha256_challenges, k_eval_barycentric,
                 validation, call-time table) + recover_cells_and_kzg_proofs batch of 256 rows x 2, 16/16/13-bit tables
   verify_default the same on the library's default tables
+  cells_small_default / cells_small_wide   compute_cells_and_kzg_proofs batches of 2, 8, 16, 32, 64 and 128 blobs x 6 each
+                (resident): every form the two G1 transforms of FK20 take for small batches (fk20.hip: three-wave /
+                two-wave pipelines, one-wave radix-8, radix-4 pairs) and k_msm_small's one-wave-per-vector form
 Prints one JSON line with the wall-clock of what it ran."""
 import ctypes as C
 import json
@@ -24,6 +27,8 @@ def main():
     import __graft_entry__ as ge
     mod = ge.load_package()
     opts = dict(bench.WIDE) if row.endswith("_wide") else {}
+    if row.startswith("cells_small"):
+        opts["direct_max"] = 0   # every size through FK20 (the low-latency path would take 1-2 blobs)
     hip = mod.Kzg(mod.HIP_SO, options=opts)
     L = bench.Lib(hip.lib)
     sp = C.addressof(hip.s)
@@ -31,7 +36,23 @@ def main():
     g = torch.Generator(device=dev)
     g.manual_seed(0xC4B64844)
     out = {"row": row, "tables": bench.tables_of(L, hip)}
-    if row.startswith("cells"):
+    if row.startswith("cells_small"):
+        nb = 128
+        blobs = torch.randint(0, 256, (nb, 4096, 32), dtype=torch.uint8, device=dev, generator=g)
+        blobs[:, :, 0] = 0
+        status = torch.empty((nb,), dtype=torch.uint8, device=dev)
+        cells = torch.empty((nb, 128, 2048), dtype=torch.uint8, device=dev)
+        proofs = torch.empty((nb, 128, 48), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        for n in (2, 8, 16, 32, 64, 128):
+            ts = []
+            for _ in range(7):
+                t = time.perf_counter()
+                rc = L.cells_dev(cells.data_ptr(), proofs.data_ptr(), status.data_ptr(), blobs.data_ptr(), n, sp)
+                ts.append(time.perf_counter() - t)
+                assert rc == 0
+            out["cells_and_proofs_n%d_ms" % n] = round(min(ts[1:]) * 1e3, 3)
+    elif row.startswith("cells"):
         nb = 2048
         blobs = torch.randint(0, 256, (nb, 4096, 32), dtype=torch.uint8, device=dev, generator=g)
         blobs[:, :, 0] = 0

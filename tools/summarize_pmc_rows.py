@@ -50,7 +50,7 @@ def main():
         pass
     for (name, grid, wg), v in sorted(kern.items(), key=lambda kv: -sum(kv[1]["ms"])):
         share = sum(v["ms"]) / total
-        if share < 0.005:
+        if share < float(os.environ.get("PMC_MIN_SHARE", "0.005")):
             continue
         e = {"kernel": name, "grid": grid, "workgroup": wg, "launches": len(v["ms"]),
              "mean_ms": round(sum(v["ms"]) / len(v["ms"]), 4), "share_of_trace": round(share, 4)}
