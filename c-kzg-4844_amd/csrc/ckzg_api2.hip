@@ -317,11 +317,6 @@ C_KZG_RET gpu_lincomb_multi(dev::DeviceCtx *ctx, G1Jac *outs, const LincombJob *
     if (algo == 0) {
         static const int forced = (int)dev::ab_knob("CKZG_HIP_LINCOMB", 0);
         algo = forced ? forced : (max_job >= bucket_min_terms() ? 2 : 1);
-        if (algo == 2 && !dev::bucket_msm_available()) algo = 1;   // the product build has no bucket kernels
-    }
-    if (algo == 2 && !dev::bucket_msm_available()) {
-        fprintf(stderr, "[ckzg-hip] algo = 2 (bucket MSM) is experimental and not in this build: make buckets\n");
-        return C_KZG_BADARGS;
     }
     // ladders: four lanes per half-term (k_lincomb_partial_quad) while 8 lanes per term still fit the chip in
     // about two waves per SIMD; beyond that the one-lane-per-half form does fewer lane-products in total

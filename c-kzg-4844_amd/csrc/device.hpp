@@ -145,29 +145,39 @@ inline void sleep_us(int64_t us) {
 
 // query() -> hipSuccess / hipErrorNotReady / an error.  spin_us: how long to poll without sleeping (a one-unit call
 // that lasts 250 us must not pay a sleep's granularity; a 10-ms batch may).
+// Sleeping in steps of 1/32 of the time waited so far ends a wait ~1.6 % late on average (a 1024-blob commitment
+// step: +0.16 ms of 10.0, profiles/r06_sync_poll_ab.txt).  Most waits of a thread repeat -- a server thread makes the
+// same call over and over -- so the thread remembers how long its last wait of this kind took and polls WITHOUT
+// sleeping from 7/8 of that time on, for at most another 3/16 of it: a steady caller's wait ends when the work does, for
+// a fifth of a core while it waits; a wait that is nothing like the last one falls back to the steps.
 template <class Query>
 inline hipError_t bounded_device_wait(Query &&query, const char *what, const void *obj, int64_t spin_us) {
     hipError_t e = query();
     if (e != hipErrorNotReady) return e;
+    static thread_local int64_t last_us[2] = {0, 0};   // [0] batch waits, [1] the one-unit latency waits
+    int64_t &last = last_us[spin_us > 1000 ? 1 : 0];
+    static const int64_t div = ab_knob("CKZG_HIP_SYNC_STEP_DIV", 32);          // (A/B: 0 = never sleep, the floor)
+    static const bool predict = ab_knob("CKZG_HIP_SYNC_PREDICT", 1) != 0;
+    const int64_t spin_from = predict && last > 400 ? last - last / 8 : INT64_MAX, spin_to = last + last / 16 + 50;
     WaitNote note(what, obj);
     for (;;) {
         e = query();
         if (e != hipErrorNotReady) break;
         const int64_t waited = note.waited_us();
-        if (waited < spin_us) continue;
+        if (waited < spin_us || (waited >= spin_from && waited <= spin_to)) continue;
         if (note.expired()) {
             int d = -1;
             if (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64) wedged_devices_ref().fetch_or((uint64_t)1 << d, std::memory_order_relaxed);
             (void)hipGetLastError();
             return hipErrorLaunchTimeOut;
         }
-        // (A/B, profiles/r06_sync_poll_ab.txt: spinning for the whole wait -- the floor any wait can reach -- against
-        // steps of 1/16, 1/32, 1/64 of the time waited so far)
-        static const int64_t div = ab_knob("CKZG_HIP_SYNC_STEP_DIV", 32);
-        if (div <= 0) continue;   // A/B only: never sleep
-        const int64_t step = waited / div;
-        sleep_us(step < 20 ? 20 : (step > 1000 ? 1000 : step));
+        if (div <= 0) continue;   // A/B only
+        int64_t step = waited / div;
+        step = step < 20 ? 20 : (step > 1000 ? 1000 : step);
+        if (waited < spin_from && waited + step > spin_from) step = spin_from - waited;   // do not sleep into the polling window
+        sleep_us(step < 5 ? 5 : step);
     }
+    last = note.waited_us();
     (void)hipGetLastError();   // hipErrorNotReady is not an error, but the runtime remembers it as the thread's last one
     return e;
 }
@@ -471,8 +481,8 @@ int subgroup_g1_batch_device(DeviceCtx *ctx, uint8_t *d_status, const G1Affine *
 // d_off: njobs + 1 words of device scratch
 int lincomb_multi_device(DeviceCtx *ctx, G1Affine *d_out, G1XYZZ *d_partials, uint32_t *d_off, const G1Affine *d_pts,
                          const uint32_t *d_scalars, size_t total, const uint32_t *h_part_off, int njobs, bool quad);
-// pippenger.hip: the same sums by bucket accumulation (enqueue-only; see bucket_msm_enqueue).  EXPERIMENTAL: only
-// libckzg_hip_buckets.so (make buckets) holds the kernels, the product has stubs (bucket_msm_available() == false)
+// pippenger.hip: the same sums by bucket accumulation (enqueue-only; see bucket_msm_enqueue).  In the product since round 6,
+// used on request only (ckzg_hip_g1_lincomb, algo = 2): the library's own sums take the ladders (pippenger.hip says why)
 bool bucket_msm_available();
 size_t bucket_msm_scratch_bytes(size_t total, int njobs, int wbits);
 int bucket_msm_wbits(size_t max_job_terms);

@@ -1,14 +1,14 @@
 // pippenger.hip -- variable-base multi-scalar multiplication over BLS12-381 G1 by bucket accumulation.
 //
-// EXPERIMENTAL, NOT IN THE DEFAULT BUILD.  The kernels below are compiled only with -DCKZG_WITH_BUCKETS
-// (`make buckets` -> libckzg_hip_buckets.so, the library the bucket tests and tools/bench_lincomb.sh load); the
-// product libckzg_hip.so carries three small stubs instead and ckzg_hip_g1_lincomb(algo = 2) answers
-// C_KZG_BADARGS there.  Why: at every size the c-kzg API can produce (n <= ~10^4 terms per sum, three or four sums
-// per call) both algorithms end in the same ~128 sequential doublings (~1.4 ms of one lane), and the per-term
-// ladders won the same-box A/B at every n from 128 to 65,536 (profiles/r02_lincomb_ab.txt: n = 8192 13.0 vs
-// 15.0 ms, n = 65,536 86.6 vs 99.6 ms for the call).  A regime where buckets win needs n >> 10^5 terms over
-// shared points AND a sort-based scatter instead of the gather-by-comparison below (whose sweeps cost
-// n x buckets comparisons); no caller of this library has such sums.  Kept as a tested reference point.
+// IN THE PRODUCT SINCE ROUND 6, ON REQUEST ONLY: ckzg_hip_g1_lincomb(algo = 2) runs these kernels (the bucket method is
+// what the reference's g1_lincomb_fast is, src/common/lincomb.c:65-123 -> blst_p1s_mult_pippenger, and what north_star
+// names); the library's OWN variable-base sums keep the per-term GLV ladders of verify.hip.  Why: at every size the
+// c-kzg API can produce (n <= ~10^4 terms per sum, three or four sums per call) both algorithms end in the same ~128
+// sequential doublings (~1.4 ms of one lane), and the ladders won the same-box A/B at every n from 128 to 65,536
+// (profiles/r02_lincomb_ab.txt: n = 8192 13.0 vs 15.0 ms, n = 65,536 86.6 vs 99.6 ms for the call).  A regime where
+// buckets win needs n >> 10^5 terms over shared points AND a sort-based scatter instead of the gather-by-comparison
+// below (whose sweeps cost n x buckets comparisons); no caller of this library has such sums.  (Rounds 2-5 kept the
+// kernels in a second library, libckzg_hip_buckets.so, and the product answered C_KZG_BADARGS to algo = 2.)
 //
 // Replaces g1_lincomb_fast -> blst_p1s_mult_pippenger (src/common/lincomb.c:65-123) for sums whose bases
 // are NOT fixed by the trusted setup: the proofs / commitments of verify_cell_kzg_proof_batch
@@ -38,21 +38,6 @@
 #include "dev_inline.hpp"
 #include "g1_28.hpp"
 
-#ifndef CKZG_WITH_BUCKETS
-
-namespace ckzg {
-namespace dev {
-bool bucket_msm_available() { return false; }
-size_t bucket_msm_scratch_bytes(size_t, int, int) { return 0; }
-int bucket_msm_wbits(size_t) { return 8; }
-int bucket_msm_enqueue(DeviceCtx *, G1Affine *, const G1Affine *, const uint32_t *, size_t, const uint32_t *, int, int, uint8_t *) {
-    fprintf(stderr, "[ckzg-hip] the bucket MSM kernels are not in this build (make buckets -> libckzg_hip_buckets.so)\n");
-    return 1;   // C_KZG_BADARGS
-}
-}  // namespace dev
-}  // namespace ckzg
-
-#else  // CKZG_WITH_BUCKETS
 
 namespace ckzg {
 namespace dev {
@@ -312,4 +297,3 @@ int bucket_msm_enqueue(DeviceCtx *ctx, G1Affine *d_out, const G1Affine *d_pts, c
 }  // namespace dev
 }  // namespace ckzg
 
-#endif  // CKZG_WITH_BUCKETS

@@ -178,7 +178,8 @@ C_KZG_RET ckzg_hip_recover_cells_and_kzg_proofs_batch(Cell *recovered_cells, KZG
  * library's own verify_*_batch paths call the same kernels on points they have already validated; here every
  * point must lie in the prime-order subgroup (or be the identity), otherwise C_KZG_BADARGS -- the reference
  * function accepts any curve point.  algo: 0 = what the library's own calls use (ladders, form chosen by size),
- * 1 = GLV ladders, form by size, 2 = bucket accumulation (pippenger.hip), 3 = ladders with one lane per GLV
+ * 1 = GLV ladders, form by size, 2 = bucket accumulation (pippenger.hip: the reference's method; slower than the ladders
+ * below ~10^5 terms, which is why the library's own calls do not take it), 3 = ladders with one lane per GLV
  * half-term, 4 = ladders with four lanes per half-term (g1_quad.hpp). */
 C_KZG_RET ckzg_hip_g1_lincomb(g1_t *out, const g1_t *p, const fr_t *coeffs, uint64_t len, int algo,
                               const KZGSettings *s);

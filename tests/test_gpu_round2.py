@@ -386,22 +386,16 @@ def _lincomb(hip, pts, scalars_mont, algo):
 
 
 @pytest.fixture(scope="module")
-def hip_buckets():
-    """libckzg_hip_buckets.so (make buckets): the product plus the EXPERIMENTAL bucket kernels of pippenger.hip."""
-    import os
-    so = os.path.join(os.path.dirname(HIP_SO), "libckzg_hip_buckets.so")
-    if not os.path.exists(so):
-        pytest.fail("libckzg_hip_buckets.so is not built: make -C c-kzg-4844_amd buckets (or __graft_entry__.build())")
-    api = Kzg(so, "", precompute=0, options={"commit_wbits": 8, "proof_wbits": 0})
-    _restore(api)
-    yield api
-    api.close()
+def hip_buckets(hip):
+    """The bucket kernels of pippenger.hip are part of the product since round 6 (ckzg_hip_g1_lincomb, algo = 2); rounds
+    2-5 kept them in a second library and the product refused algo = 2."""
+    return hip
 
 
-def test_product_build_has_no_bucket_kernels(hip):
-    # algo = 2 is refused by the product (pippenger.hip: experimental, not in the default build) ...
-    rc, _ = _lincomb(hip, [bytes(144)], [bytes(32)], 2)
-    assert rc == 1
+def test_product_build_runs_the_bucket_kernels_on_request(hip):
+    # algo = 2 on the identity with the zero scalar: the empty bucket set, through every bucket kernel
+    rc, out = _lincomb(hip, [bytes(144)], [bytes(32)], 2)
+    assert rc == 0 and out.raw[96:144] == bytes(48)      # Z = 0: the identity
 
 
 @pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 700, 5000])

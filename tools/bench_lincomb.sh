@@ -3,10 +3,10 @@
 # A/B of the two variable-base sum paths inside verify_cell_kzg_proof_batch, one process each (the choice is
 # read once per process): CKZG_HIP_LINCOMB=1 per-term GLV ladders (verify.hip), =2 bucket kernels
 # (pippenger.hip).  PROFILE=1 adds a rocprofv3 kernel trace of the n=8192 and n=65536 cases.
-# The bucket kernels are EXPERIMENTAL and live in libckzg_hip_buckets.so only (make -C c-kzg-4844_amd buckets).
+# (the bucket kernels are in the product since round 6; the A/B build carries them as well)
 # Run on the GPU box via gpurun from the repo root; output in gpurun_out/lincomb/.
 export TMPDIR=/tmp
-export CKZG_HIP_SO=c-kzg-4844_amd/libckzg_hip_buckets.so
+export CKZG_HIP_SO=${CKZG_HIP_SO:-c-kzg-4844_amd/libckzg_hip_ab.so}
 O=gpurun_out/lincomb
 rm -rf $O && mkdir -p $O
 for algo in 1 2; do

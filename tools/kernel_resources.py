@@ -19,7 +19,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "c-kzg-4844_amd", "csrc")
 LLVM = "/opt/rocm/lib/llvm/bin"
-FILES = ["msm", "ntt", "fk20", "verify", "ckzg_api", "ckzg_api2", "device_ctx"]
+FILES = ["msm", "ntt", "fk20", "verify", "pippenger", "ckzg_api", "ckzg_api2", "device_ctx"]
 
 
 def demangle(names):
