@@ -128,6 +128,22 @@ __device__ __forceinline__ uint32_t pipe_load(uint32_t *p) {
 __device__ __forceinline__ void pipe_store(uint32_t *p, uint32_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// A wait between the waves of ONE workgroup.  They are resident together, so the wait ends unless the protocol is
+// wrong -- and if it is, the wave must not occupy the device for ever (round-5 advisor finding; the host side of the
+// library has had no unbounded wait since round 6 either: device.hpp).  The longest legitimate wait is one doubling
+// chain of the partner wave, tens of microseconds; after 2^24 looks (seconds) the wave traps and the launch fails
+// (hipErrorLaunchFailure -> C_KZG_ERROR at the call).  The flag words are read by every lane from one address:
+// readfirstlane makes the condition -- and with it the look counter -- scalar, so the bound costs no vector register.
+constexpr uint32_t PIPE_SPIN_LIMIT = 1u << 24;
+__device__ __forceinline__ uint32_t pipe_load_uniform(uint32_t *p) { return __builtin_amdgcn_readfirstlane(pipe_load(p)); }
+template <class Ready>
+__device__ __forceinline__ void pipe_wait(Ready &&ready) {
+    uint32_t looks = 0;
+    while (!ready()) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++looks > PIPE_SPIN_LIMIT) __builtin_trap();
+    }
+}
 
 // ---- points between the launches of a small-batch transform: RAW records ----
 // 56 limbs of the 28-bit domain (x, y, zz, zzz of an XYZZ28) and the infinity flag, as they stand in registers.  A G1XYZZ
@@ -215,11 +231,10 @@ __device__ __forceinline__ void pipe_doubler(PipeShared &sh, const XYZZ28 &p, bo
     const int top = mA.top > mB.top ? mA.top : mB.top;
     for (int i = 0; i <= top; i++) {
         if (mask_bit(mA.nz[0], i) || mask_bit(mA.nz[1], i) || mask_bit(mB.nz[0], i) || mask_bit(mB.nz[1], i)) {   // uniform over the wave
-            for (;;) {   // room in the ring: both adders are past event ev - PIPE_SLOTS
-                const int c0 = (int)pipe_load(&sh.consumed[0]), c1 = one_adder ? c0 : (int)pipe_load(&sh.consumed[1]);
-                if ((int)ev - (c0 < c1 ? c0 : c1) < PIPE_SLOTS) break;
-                __builtin_amdgcn_s_sleep(1);
-            }
+            pipe_wait([&]() {   // room in the ring: both adders are past event ev - PIPE_SLOTS
+                const int c0 = (int)pipe_load_uniform(&sh.consumed[0]), c1 = one_adder ? c0 : (int)pipe_load_uniform(&sh.consumed[1]);
+                return (int)ev - (c0 < c1 ? c0 : c1) < PIPE_SLOTS;
+            });
             // lane ql stores element ql of the record: X | Y | Z | Z^2
             const auto e = qsel(ql, widen<2, 34>(b.x), widen<2, 34>(b.y), widen<2, 34>(b.z), widen<2, 34>(zz));
             uint32_t(*slot)[16][4] = sh.ring[ev % PIPE_SLOTS];
@@ -326,17 +341,17 @@ __device__ __forceinline__ void pipe_adder(XYZZ28 &out, bool &out_inf, PipeShare
                 continue;
             }
             if (leader) pipe_store(&sh.consumed[chain], ev);   // nothing below this event is needed any more
-            while (pipe_load(&sh.produced) <= ev) __builtin_amdgcn_s_sleep(1);
+            pipe_wait([&]() { return pipe_load_uniform(&sh.produced) > ev; });
             rec = sh.ring[ev % PIPE_SLOTS];
         } else {
             if (leader) pipe_store(&sh.consumed[chain], 0x3fffffffu);
             if (chain == 1) break;
-            while (pipe_load(&sh.r2done) == 0) __builtin_amdgcn_s_sleep(1);
+            pipe_wait([&]() { return pipe_load_uniform(&sh.r2done) != 0; });
             rec = sh.r2;
         }
         if (!have_flag) {
             // (a chain without a term of its own gets here at the hand-over; the doubler has published by then)
-            while (pipe_load(&sh.produced) == 0) __builtin_amdgcn_s_sleep(1);
+            pipe_wait([&]() { return pipe_load_uniform(&sh.produced) != 0; });
             p_inf = sh.pinf[quad_id] != 0;
             have_flag = true;
         }
@@ -371,7 +386,7 @@ __device__ __forceinline__ void pipe_adder(XYZZ28 &out, bool &out_inf, PipeShare
     }
     if (chain == 1) {
         if (!have_flag) {   // the k2 chain had no term: its flag comes with the first event, which exists (top >= 0 here)
-            while (pipe_load(&sh.produced) == 0) __builtin_amdgcn_s_sleep(1);
+            pipe_wait([&]() { return pipe_load_uniform(&sh.produced) != 0; });
             p_inf = sh.pinf[quad_id] != 0;
         }
         // hand R2 over: X | Y | Z | Z^2, lane ql stores element ql
@@ -439,7 +454,7 @@ __device__ __forceinline__ void pipe_adder_dual(XYZZ28 &out, bool &out_inf, Pipe
             want0 = mask_bit(m.nz[0], i);
             want1 = mask_bit(m.nz[1], i);
             if (!(want0 | want1)) continue;   // uniform over the wave
-            while (pipe_load(&sh.produced) <= ev) __builtin_amdgcn_s_sleep(1);
+            pipe_wait([&]() { return pipe_load_uniform(&sh.produced) > ev; });
             if (ev == 0) p_inf = sh.pinf[quad_id] != 0;
             pipe_rec_load(bx, by, bz, bzz, sh.ring[ev % PIPE_SLOTS], quad_id);
             ev++;

@@ -35,15 +35,30 @@ def gather_rows(local, n_total, group=None):
     return torch.cat([parts[r][: hi - lo] for r, (lo, hi) in enumerate(bounds)], dim=0)
 
 
+_GATHER_UNSUPPORTED = False
+
+
 def gather_to_rank0(local, group=None):
     """The "trivial gather" of the sharded commitment path: every rank's [rows, width] results (equal shards) to rank 0,
     which gets [world * rows, width]; the other ranks get None.  One RCCL gather over xGMI ("nccl" backend, device
-    tensors, enqueued behind the producing work: the caller goes on); gloo (CPU tests) gathers host copies."""
+    tensors, enqueued behind the producing work: the caller goes on); gloo (CPU tests) gathers host copies.
+    A backend build without `gather` raises the same error on every rank: from then on the rows travel by all-gather
+    (every rank receives them, rank 0 keeps them) -- the same bytes arrive at rank 0 either way."""
+    global _GATHER_UNSUPPORTED
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     if dist.get_backend(group) != "nccl":
         local = local.cpu()
-    parts = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
-    dist.gather(local, parts, dst=0, group=group)
+    if not _GATHER_UNSUPPORTED:
+        try:
+            parts = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
+            dist.gather(local, parts, dst=0, group=group)
+            return torch.cat(parts, dim=0) if rank == 0 else None
+        except (RuntimeError, NotImplementedError) as e:
+            if "gather" not in str(e).lower() and "support" not in str(e).lower():
+                raise
+            _GATHER_UNSUPPORTED = True
+    parts = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(parts, local, group=group)
     return torch.cat(parts, dim=0) if rank == 0 else None
 
 
