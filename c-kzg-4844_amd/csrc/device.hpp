@@ -344,6 +344,7 @@ struct DeviceCtx {
     // Fr tables for NTTs and evaluation (Montgomery form, 8 x u32)
     Fr *d_roots = nullptr;        // w^i, 8193 entries
     Fr *d_brp_roots = nullptr;    // 8192
+    uint32_t *d_brp_roots29 = nullptr;   // the first 4096 of them as fr29.hpp's nine 29-bit limbs, then 1/brp_roots[2m], m < 2048
     uint32_t *d_roots_raw = nullptr;  // GLV halves {k1, k2} of w^(64 i), i <= 128 (twiddles of the G1 FFT)
     // FK20
     FixedBaseTable fk20;          // over x_ext_fft columns: point index = col*64 + row
@@ -456,6 +457,10 @@ int commit_one_graph_build(DeviceCtx *ctx, hipGraphExec_t *exec_out, uint8_t *d_
 // after a synchronised commit_blobs_enqueue: its event pairs -> ctx->last_ms[0..3] (digits, accumulate, finalize, all)
 void commit_collect_times(DeviceCtx *ctx);
 // verify.hip
+// d_out[ROOTS29_ENTRIES][9] <- the evaluation domain in fr29.hpp's form (4096 roots, then the 2048 inverses of the
+// even-indexed ones), from ctx->d_brp_roots; on ctx->stream.  Enqueue-only.
+constexpr int ROOTS29_ENTRIES = 4096 + 2048;
+int roots29_build(DeviceCtx *ctx, uint32_t *d_out);
 int eval_poly_batch_device(DeviceCtx *ctx, Fr *d_y, const Fr *d_poly, const Fr *d_z, size_t n);
 // d_sc[3][2n][8] <- the scalar vectors of a blob batch's three sums over a call-time table of (commitments, proofs),
 // from the batch challenge r and the blobs' challenges d_z (verify.hip: k_rlc_scalars).  Enqueue-only.

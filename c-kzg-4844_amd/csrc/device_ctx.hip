@@ -185,6 +185,7 @@ static void destroy_slot(dev::DeviceCtx *ctx) {
         if (ctx->d_xext) (void)hipFree(ctx->d_xext);
         if (ctx->d_roots) (void)hipFree(ctx->d_roots);
         if (ctx->d_brp_roots) (void)hipFree(ctx->d_brp_roots);
+        if (ctx->d_brp_roots29) (void)hipFree(ctx->d_brp_roots29);
         if (ctx->d_roots_raw) (void)hipFree(ctx->d_roots_raw);
         if (ctx->d_mono) (void)hipFree(ctx->d_mono);
         if (ctx->d_shift) (void)hipFree(ctx->d_shift);
@@ -345,6 +346,9 @@ static C_KZG_RET build_owner(DevicePool *pool, const KZGSettings *s, const Optio
     CTX_TRY(hipMalloc(&ctx->d_brp_roots, dev::N_EXT * sizeof(Fr)));
     CTX_TRY(hipMemcpy(ctx->d_roots, s->roots_of_unity, (dev::N_EXT + 1) * sizeof(Fr), hipMemcpyHostToDevice));
     CTX_TRY(hipMemcpy(ctx->d_brp_roots, s->brp_roots_of_unity, dev::N_EXT * sizeof(Fr), hipMemcpyHostToDevice));
+    CTX_TRY(hipMalloc(&ctx->d_brp_roots29, (size_t)dev::ROOTS29_ENTRIES * 9 * sizeof(uint32_t)));
+    if (dev::roots29_build(ctx, ctx->d_brp_roots29) != 0) return C_KZG_ERROR;
+    CTX_TRY(dev::sync_stream(ctx->stream));
 
     // coset shift factors for recovery: 7^i and 7^-i
     {
@@ -535,6 +539,7 @@ static C_KZG_RET clone_slot(dev::DeviceCtx **out, const dev::DeviceCtx *owner, i
     c->d_lagr = owner->d_lagr;
     c->d_roots = owner->d_roots;
     c->d_brp_roots = owner->d_brp_roots;
+    c->d_brp_roots29 = owner->d_brp_roots29;
     c->d_roots_raw = owner->d_roots_raw;
     c->d_xext = owner->d_xext;
     c->d_mono = owner->d_mono;

@@ -434,3 +434,92 @@ extern "C" void hs_msm_glv_emulate(G1Jac *r, const G1Affine *pts, const uint32_t
     }
     *r = jac_from_affine(xyzz28_to_affine(total, tinf));
 }
+
+// ---- Fr on 29-bit limbs (fr29.hpp) and the barycentric evaluation built on it, replayed thread by thread ----
+#include "fr29.hpp"
+extern "C" void hs_fr29_mul(Fr *r, const Fr *a, const Fr *b) { *r = fr29_to_fr(fr29_mul(fr29_from_fr(*a), fr29_from_fr(*b))); }
+// the radix travels with the operand: (a 2^256) (b 2^261) / 2^261 is the library's form of a b
+extern "C" void hs_fr29_mul_mixed(Fr *r, const Fr *a, const Fr *b) {
+    fr29_unpack(r->l, fr29_canonical<0>(fr29_mul(fr29_pack(a->l), fr29_from_fr(*b))));
+}
+extern "C" void hs_fr29_roundtrip(Fr *r, const Fr *a) { *r = fr29_to_fr(fr29_from_fr(*a)); }
+extern "C" void hs_fr29_inv(Fr *r, const Fr *a) { *r = fr29_to_fr(fr29_inv(fr29_from_fr(*a))); }
+extern "C" void hs_fr29_sub(Fr *r, const Fr *a, const Fr *b) {
+    *r = fr29_to_fr(fr29_sub_canonical(fr29_from_fr(*a), fr29_from_fr(*b)));
+}
+// sum of n values through the lazy additions and the closing ladder (n <= 32)
+extern "C" void hs_fr29_sum(Fr *r, const Fr *a, int n) {
+    Fr29 s;
+    for (int i = 0; i < 9; i++) s.l[i] = 0;
+    for (int k = 0; k < n; k++) {
+        Fr29 t = fr29_pack(a[k].l);
+        for (int j = 0; j < 9; j++) s.l[j] += t.l[j];
+        if ((k & 3) == 3) fr29_carry(s);
+    }
+    fr29_carry(s);
+    *r = ev29::to_fr_radix256(s);
+}
+// One blob through the kernel's algorithm (verify.hip: k_eval_barycentric): 512 threads of 8 terms, one inversion
+// per lane of the first wave for the eight waves' products.  Returns the index of the domain point equal to z (y =
+// p[hit]) or -1; di_out (may be null): 4096 x 8 words, 1/(z - w_i) in the 2^261 radix, canonical.
+extern "C" int hs_fr29_eval(Fr *y, uint32_t *di_out, const Fr *poly, const Fr *z, const Fr *brp_roots) {
+    constexpr int T = 64 * ev29::WAVES, NB = 4096;
+    static_assert(T * ev29::PER == NB, "geometry");
+    std::vector<Fr29> roots29(NB), pre((size_t)T * ev29::PER), acc(T), parked(T), inv(T);
+    for (int i = 0; i < NB; i++) roots29[i] = fr29_from_fr(brp_roots[i]);
+    const Fr29 z29 = fr29_from_fr(*z);
+    int hit = -1;
+    for (int t = 0; t < T; t++) {
+        int h = ev29::forward(&pre[(size_t)t * ev29::PER], acc[t], z29, roots29.data(), t, T);
+        if (h >= 0) hit = h;
+    }
+    if (hit >= 0) {
+        *y = poly[hit];
+        return hit;
+    }
+    for (int l = 0; l < 64; l++)
+        ev29::invert_across([&](int w) { return acc[l + 64 * w]; }, [&](int w, const Fr29 &v) { parked[l + 64 * w] = v; },
+                            [&](int w) { return parked[l + 64 * w]; }, [&](int w, const Fr29 &v) { inv[l + 64 * w] = v; },
+                            [](const Fr29 &v) { return fr29_inv(v); });
+    Fr sum = Fr::zero();
+    for (int t = 0; t < T; t++)
+        sum = add(sum, ev29::to_fr_radix256(ev29::backward(&pre[(size_t)t * ev29::PER], inv[t], z29, roots29.data(), poly, t, T, di_out)));
+    *y = ev29::scale(sum, ev29::vanishing_over_n(z29));
+    return -1;
+}
+
+// One blob through k_eval_tree<LOG_PER>'s algorithm: 4096 >> LOG_PER threads each fold 2^LOG_PER leaves, six levels
+// of lane exchanges inside a wave (both lanes of a pair compute the parent), the waves' values by thread 0.
+template <int LOG_PER>
+static void eval_tree_emulate(Fr *y, const Fr *poly, const Fr *z, const Fr *brp_roots) {
+    constexpr int NB = 4096, T = NB >> LOG_PER, W = T / 64;
+    std::vector<Fr29> tab(NB / 2), v(T), nv(T);
+    for (int m = 0; m < NB / 2; m++) tab[m] = fr29_inv(fr29_from_fr(brp_roots[2 * m]));
+    for (auto &t : tab) t = fr29_canonical<0>(t);
+    Fr29 zp[12];
+    zp[0] = fr29_from_fr(*z);
+    for (int l = 1; l < 12; l++) zp[l] = fr29_mul(zp[l - 1], zp[l - 1]);
+    for (int t = 0; t < T; t++)
+        v[t] = ev29::tree_canonical<LOG_PER>(
+            ev29::tree_node<LOG_PER>([&](int i) { return fr29_pack(poly[i].l); }, tab.data(), zp, t << LOG_PER));
+    for (int k = 0; k < 6; k++) {
+        for (int t = 0; t < T; t++) {
+            const bool odd = (t >> k) & 1;
+            const Fr29 &mine = v[t], &other = v[t ^ (1 << k)];
+            nv[t] = fr29_canonical<1>(ev29::tree_combine<0>(odd ? other : mine, odd ? mine : other,
+                                                            fr29_mul(zp[LOG_PER + k], tab[t >> (k + 1)])));
+        }
+        v.swap(nv);
+    }
+    Fr29 a[W > 1 ? W : 1];
+    for (int w = 0; w < W; w++) a[w] = v[64 * w];
+    int lvl = LOG_PER + 6;
+    for (int n = W; n > 1; n >>= 1, lvl++)
+        for (int m = 0; m < n / 2; m++)
+            a[m] = fr29_canonical<1>(ev29::tree_combine<0>(a[2 * m], a[2 * m + 1], fr29_mul(zp[lvl], tab[m])));
+    *y = ev29::tree_finish(a[0]);
+}
+extern "C" void hs_fr29_eval_tree(Fr *y, const Fr *poly, const Fr *z, const Fr *brp_roots, int log_per) {
+    if (log_per == 6) eval_tree_emulate<6>(y, poly, z, brp_roots);
+    else eval_tree_emulate<4>(y, poly, z, brp_roots);
+}

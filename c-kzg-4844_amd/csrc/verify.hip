@@ -12,6 +12,7 @@
 #include "g1_28.hpp"
 #include "g1_quad.hpp"
 #include "fr_inv.hpp"
+#include "fr29.hpp"
 
 namespace ckzg {
 namespace dev {
@@ -37,10 +38,113 @@ __device__ __noinline__ Fr fr_inv_dev(const Fr &a) { return fr_inv_safegcd(a); }
 // ------------------------------------------------------------------------------------------
 // barycentric evaluation: one 256-thread workgroup per polynomial
 //   y = (z^4096 - 1)/4096 * sum_i p_i w_i / (z - w_i),   or p_m if z == w_m
+// The products run on nine 29-bit limbs (fr29.hpp: 162 multiply-adds a product where the 32-bit CIOS form pays two
+// carry instructions per multiply-add), a term p_i * (w_i / (z - w_i)) comes out in the library's radix because the
+// radix travels with the operand, and the eight waves of a workgroup share ONE inversion: a wave executes an
+// inversion's instructions whether one lane needs it or 64, so what Montgomery's trick has to spread is the number
+// of WAVES that run one -- lane l of the first wave inverts the product of the eight waves' lane-l products, every
+// thread finds its own inverse in shared memory (ev29::invert_across).
 // ------------------------------------------------------------------------------------------
 
-constexpr int EV_THREADS = 256;
-constexpr int EV_PER = N_BLOB / EV_THREADS;  // 16 terms per thread
+constexpr int EV_THREADS = 64 * ev29::WAVES;
+constexpr int EV_PER = ev29::PER;
+static_assert(EV_THREADS * EV_PER == N_BLOB, "one workgroup per polynomial");
+constexpr size_t EVAL_ONE_WAVE_FROM = 256;   // polynomials per launch from which k_eval_tree runs one wave each
+
+__device__ __noinline__ Fr29 fr29_inv_dev(const Fr29 &a) { return fr29_inv(a); }
+
+// the evaluation domain in fr29.hpp's form (canonical, radix 2^261), made once per context: out[i] = brp_roots[i],
+// i < 4096 (k_eval_barycentric), then tab[m] = 1 / brp_roots[2 m], m < 2048 (k_eval_tree)
+__global__ void k_roots29(uint32_t *out, const Fr *brp_roots) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N_BLOB + N_BLOB / 2) return;
+    Fr29 r;
+    if (i < N_BLOB) r = fr29_from_fr(vld_fr(brp_roots + i));
+    else r = fr29_canonical<0>(fr29_inv_dev(fr29_from_fr(vld_fr(brp_roots + 2 * (i - N_BLOB)))));
+#pragma unroll
+    for (int k = 0; k < 9; k++) out[(size_t)i * 9 + k] = r.l[k];
+}
+
+int roots29_build(DeviceCtx *ctx, uint32_t *d_out) {
+    hipLaunchKernelGGL(k_roots29, dim3((ROOTS29_ENTRIES + 255) / 256), dim3(256), 0, ctx->stream, d_out, ctx->d_brp_roots);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// evaluation without inversions (fr29.hpp: ev29::tree_node says why): a thread folds 2^LOG_PER consecutive leaves
+// depth first (a stack of LOG_PER partial nodes in registers), six levels of lane exchanges inside the wave -- both
+// lanes of a pair compute the parent, no lane idles at a branch -- and, where a polynomial has more than one wave,
+// its first thread folds the waves' values.  LOG_PER = 6: ONE wave per polynomial, no shared memory, no barrier --
+// the throughput form (2 x 4095 products + 11 squarings per polynomial); LOG_PER = 4: four waves, the latency form
+// for small batches.
+// ------------------------------------------------------------------------------------------
+template <int LOG_PER>
+__global__ __launch_bounds__(N_BLOB >> LOG_PER) void k_eval_tree(Fr *y_out, const Fr *poly, const Fr *zs,
+                                                                  const uint32_t *tab_words) {
+    constexpr int T = N_BLOB >> LOG_PER, W = T / 64;
+    __shared__ uint32_t sh[9][W];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const Fr *p = poly + (size_t)blockIdx.x * N_BLOB;
+    const Fr29 *tab = reinterpret_cast<const Fr29 *>(tab_words);
+    Fr29 zp[LOG_PER];
+    zp[0] = fr29_from_fr(vld_fr(zs + blockIdx.x));
+#pragma unroll
+    for (int l = 1; l < LOG_PER; l++) zp[l] = fr29_mul(zp[l - 1], zp[l - 1]);
+    Fr29 v = ev29::tree_canonical<LOG_PER>(
+        ev29::tree_node<LOG_PER>([&](int i) { return fr29_pack(vld_fr(p + i).l); }, tab, zp, tid << LOG_PER));
+    Fr29 zc = fr29_mul(zp[LOG_PER - 1], zp[LOG_PER - 1]);
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        Fr29 other;
+#pragma unroll
+        for (int i = 0; i < 9; i++) other.l[i] = (uint32_t)__shfl_xor((int)v.l[i], 1 << k);
+        const bool odd = (lane >> k) & 1;
+        Fr29 e, o;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            e.l[i] = odd ? other.l[i] : v.l[i];
+            o.l[i] = odd ? v.l[i] : other.l[i];
+        }
+        v = fr29_canonical<1>(ev29::tree_combine<0>(e, o, fr29_mul(zc, tab[tid >> (k + 1)])));
+        if (k < 5 || W > 1) zc = fr29_mul(zc, zc);
+    }
+    if (W > 1) {
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) sh[i][tid >> 6] = v.l[i];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            Fr29 a[W];
+#pragma unroll
+            for (int w = 0; w < W; w++) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) a[w].l[i] = sh[i][w];
+            }
+#pragma unroll
+            for (int n = W; n > 1; n >>= 1) {
+#pragma unroll
+                for (int m = 0; m < n / 2; m++)
+                    a[m] = fr29_canonical<1>(ev29::tree_combine<0>(a[2 * m], a[2 * m + 1], fr29_mul(zc, tab[m])));
+                zc = fr29_mul(zc, zc);
+            }
+            v = a[0];
+        }
+    }
+    if (tid == 0) vst_fr(y_out + blockIdx.x, ev29::tree_finish(v));
+}
+
+__device__ __forceinline__ void ev_put(uint32_t (*sh)[EV_THREADS], int col, const Fr29 &v) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) sh[k][col] = v.l[k];
+}
+__device__ __forceinline__ Fr29 ev_get(uint32_t (*sh)[EV_THREADS], int col) {
+    Fr29 v;
+#pragma unroll
+    for (int k = 0; k < 9; k++) v.l[k] = sh[k][col];
+    return v;
+}
 
 // QUOT: additionally write the quotient polynomial of the KZG opening at z in evaluation form,
 //   q_i = (p_i - y)/(w_i - z) = (y - p_i) * 1/(z - w_i)          (eip4844.c:441-456)
@@ -50,29 +154,24 @@ constexpr int EV_PER = N_BLOB / EV_THREADS;  // 16 terms per thread
 template <bool QUOT>
 __global__ __launch_bounds__(EV_THREADS) void k_eval_barycentric(Fr *y_out, uint32_t *q_raw, int *hit_out,
                                                                  const Fr *poly, const Fr *zs,
-                                                                 const Fr *brp_roots) {
-    __shared__ uint32_t sh[8][EV_THREADS];
+                                                                 const uint32_t *roots29_words) {
+    __shared__ uint32_t sh[9][EV_THREADS];    // the threads' products, then their inverses; later the sum tree and y
+    __shared__ uint32_t sh2[9][EV_THREADS];   // the first wave's prefix products over the waves
+    __shared__ uint32_t sh_f[9];              // (z^4096 - 1)/4096
     __shared__ int hit;
     const int tid = threadIdx.x;
     const Fr *p = poly + (size_t)blockIdx.x * N_BLOB;
-    Fr *qinv = reinterpret_cast<Fr *>(q_raw) + (size_t)blockIdx.x * N_BLOB;
-    const Fr z = vld_fr(zs + blockIdx.x);
+    uint32_t *park = q_raw + (size_t)blockIdx.x * N_BLOB * 8;
+    const Fr29 *roots29 = reinterpret_cast<const Fr29 *>(roots29_words);
+    const Fr29 z = fr29_from_fr(vld_fr(zs + blockIdx.x));
     if (tid == 0) hit = -1;
     __syncthreads();
     // Montgomery's trick over the thread's EV_PER denominators.  Only the prefix products are kept: a denominator
-    // is one subtraction from a root the way back loads anyway, and keeping all EV_PER of them as well put 2 x 16 field
-    // elements per thread into scratch memory -- 1.4 GB of spill writes per 4096-blob launch against 0.5 GB of
-    // polynomial (profiles/r04_pmc_verify_wide.json).
-    Fr pre[EV_PER];
-    Fr acc = Fr::one();
-#pragma unroll
-    for (int k = 0; k < EV_PER; k++) {
-        int i = tid + k * EV_THREADS;
-        const Fr den = sub(z, vld_fr(brp_roots + i));
-        if (den.is_zero()) hit = i;  // at most one domain point equals z
-        pre[k] = acc;
-        acc = mul(acc, den);
-    }
+    // is one subtraction from a root the way back loads anyway.
+    Fr29 pre[EV_PER], acc;
+    const int h = ev29::forward(pre, acc, z, roots29, tid, EV_THREADS);
+    if (h >= 0) hit = h;  // at most one domain point equals z
+    ev_put(sh, tid, acc);
     __syncthreads();
     if (hit >= 0) {
         if (tid == 0) {
@@ -82,17 +181,23 @@ __global__ __launch_bounds__(EV_THREADS) void k_eval_barycentric(Fr *y_out, uint
         return;
     }
     if (tid == 0 && hit_out) hit_out[blockIdx.x] = -1;
-    Fr inv = fr_inv_dev(acc);
-    Fr sum = Fr::zero();
+    if (tid < 64) {
+        // the first wave: one inversion per lane for the eight waves' products
+        ev29::invert_across([&](int w) { return ev_get(sh, tid + 64 * w); },
+                            [&](int w, const Fr29 &v) { ev_put(sh2, tid + 64 * w, v); },
+                            [&](int w) { return ev_get(sh2, tid + 64 * w); },
+                            [&](int w, const Fr29 &v) { ev_put(sh, tid + 64 * w, v); },
+                            [](const Fr29 &v) { return fr29_inv_dev(v); });
+    } else if (tid == 64) {
+        // meanwhile one lane of the second wave: the factor in front of the sum
+        const Fr29 f = ev29::vanishing_over_n(z);
 #pragma unroll
-    for (int k = EV_PER - 1; k >= 0; k--) {
-        int i = tid + k * EV_THREADS;
-        const Fr root = vld_fr(brp_roots + i);
-        Fr di = mul(inv, pre[k]);  // 1/(z - w_i)
-        inv = mul(inv, sub(z, root));
-        if (QUOT) vst_fr(qinv + i, di);
-        sum = add(sum, mul(mul(di, root), vld_fr(p + i)));
+        for (int k = 0; k < 9; k++) sh_f[k] = f.l[k];
     }
+    __syncthreads();
+    Fr sum = ev29::to_fr_radix256(
+        ev29::backward(pre, ev_get(sh, tid), z, roots29, p, tid, EV_THREADS, QUOT ? park : nullptr));
+    __syncthreads();   // every thread has read its inverse: the rows are free for the sum
     // workgroup sum
     for (int s = EV_THREADS / 2; s >= 1; s >>= 1) {
         if (tid >= s && tid < 2 * s) {
@@ -109,26 +214,10 @@ __global__ __launch_bounds__(EV_THREADS) void k_eval_barycentric(Fr *y_out, uint
         __syncthreads();
     }
     if (tid == 0) {
-        Fr zn = z;
-        for (int k = 0; k < 12; k++) zn = sqr(zn);  // z^4096
-        Fr f = sub(zn, Fr::one());
-        Fr n_inv = Fr::one();                        // 1/4096 by halving
-        uint32_t m[8];
-        mod_limbs<FrParams>(m);
-        for (int k = 0; k < 12; k++) {
-            uint32_t t[9];
-            uint32_t c = 0;
-            if (n_inv.l[0] & 1u) {
-                c = limbs_add<8>(t, n_inv.l, m);
-            } else {
+        Fr29 f;
 #pragma unroll
-                for (int i = 0; i < 8; i++) t[i] = n_inv.l[i];
-            }
-            t[8] = c;
-#pragma unroll
-            for (int i = 0; i < 8; i++) n_inv.l[i] = (t[i] >> 1) | (t[i + 1] << 31);
-        }
-        Fr y = mul(mul(sum, n_inv), f);
+        for (int k = 0; k < 9; k++) f.l[k] = sh_f[k];
+        const Fr y = ev29::scale(sum, f);
         vst_fr(y_out + blockIdx.x, y);
         if (QUOT) {
 #pragma unroll
@@ -140,23 +229,31 @@ __global__ __launch_bounds__(EV_THREADS) void k_eval_barycentric(Fr *y_out, uint
         Fr y;
 #pragma unroll
         for (int k = 0; k < 8; k++) y.l[k] = sh[k][0];
+        const Fr29 two5 = fr29_const(FR29_2POW5);
 #pragma unroll
         for (int k = 0; k < EV_PER; k++) {
             int i = tid + k * EV_THREADS;
-            Fr q = mul(sub(y, vld_fr(p + i)), vld_fr(qinv + i));
+            // (y - p_i) 2^256 times 2^261/(z - w_i) is q_i 2^256; times 2^5 (an integer) is q_i itself
+            const Fr d = sub(y, vld_fr(p + i));
+            uint4 *slot = reinterpret_cast<uint4 *>(park + (size_t)i * 8);
+            const uint4 lo = slot[0], hi = slot[1];
+            const uint32_t dw[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            const Fr29 q = fr29_canonical<0>(fr29_mul(fr29_mul(fr29_pack(d.l), fr29_pack(dw)), two5));
             uint32_t raw[8];
-            to_raw<FrParams>(raw, q);
-            uint4 *dst = reinterpret_cast<uint4 *>(q_raw + ((size_t)blockIdx.x * N_BLOB + i) * 8);
-            dst[0] = make_uint4(raw[0], raw[1], raw[2], raw[3]);
-            dst[1] = make_uint4(raw[4], raw[5], raw[6], raw[7]);
+            fr29_unpack(raw, q);
+            slot[0] = make_uint4(raw[0], raw[1], raw[2], raw[3]);
+            slot[1] = make_uint4(raw[4], raw[5], raw[6], raw[7]);
         }
     }
 }
 
 int eval_poly_batch_device(DeviceCtx *ctx, Fr *d_y, const Fr *d_poly, const Fr *d_z, size_t n) {
     if (!n) return 0;
-    hipLaunchKernelGGL(k_eval_barycentric<false>, dim3((unsigned)n), dim3(EV_THREADS), 0, ctx->stream, d_y,
-                       (uint32_t *)nullptr, (int *)nullptr, d_poly, d_z, ctx->d_brp_roots);
+    const uint32_t *tab = ctx->d_brp_roots29 + (size_t)N_BLOB * 9;
+    if (n >= EVAL_ONE_WAVE_FROM)
+        hipLaunchKernelGGL(k_eval_tree<6>, dim3((unsigned)n), dim3(64), 0, ctx->stream, d_y, d_poly, d_z, tab);
+    else
+        hipLaunchKernelGGL(k_eval_tree<4>, dim3((unsigned)n), dim3(256), 0, ctx->stream, d_y, d_poly, d_z, tab);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -222,7 +319,7 @@ int eval_quotient_batch_device(DeviceCtx *ctx, Fr *d_y, uint32_t *d_q_raw, int *
                                const Fr *d_z, size_t n) {
     if (!n) return 0;
     hipLaunchKernelGGL(k_eval_barycentric<true>, dim3((unsigned)n), dim3(EV_THREADS), 0, ctx->stream, d_y,
-                       d_q_raw, d_hit, d_poly, d_z, ctx->d_brp_roots);
+                       d_q_raw, d_hit, d_poly, d_z, ctx->d_brp_roots29);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -664,3 +664,85 @@ def test_fixed_base_glv_msm_algorithm_matches_oracle(libs):
                 o.og1_add(s, acc, t)
                 acc = s
         assert o.og1_equal(got, acc), (wbits, lanes)
+
+
+def _brp(i, bits):
+    return int(bin(i)[2:].zfill(bits)[::-1], 2)
+
+
+def test_fr29_arithmetic(libs):
+    """fr29.hpp (Fr on nine 29-bit limbs, radix 2^261: the arithmetic of k_eval_barycentric) against Python integers:
+    products, the mixed-radix product, the canonical subtraction, the lazy sums and the inversion."""
+    o, h = libs
+    rnd = random.Random(2929)
+    r256 = pow(2, 256, R)
+    mont = lambda v: (v * r256 % R).to_bytes(32, "little")
+    unm = lambda b: int.from_bytes(b.raw, "little") * pow(r256, -1, R) % R
+    edge = [0, 1, 2, R - 1, R - 2, (R - 1) // 2, 2 ** 254, 2 ** 32, 2 ** 29 - 1, 2 ** 29, R - 2 ** 29, 2 ** 232, 2 ** 232 - 1]
+    vals = edge + [rnd.randrange(R) for _ in range(400)]
+    for k, a in enumerate(vals):
+        b = vals[(7 * k + 3) % len(vals)]
+        out = _buf(32)
+        h.hs_fr29_roundtrip(out, mont(a))
+        assert out.raw == mont(a)
+        h.hs_fr29_mul(out, mont(a), mont(b))
+        assert out.raw == mont(a * b % R), (a, b)
+        h.hs_fr29_mul_mixed(out, mont(a), mont(b))
+        assert out.raw == mont(a * b % R), (a, b)
+        h.hs_fr29_sub(out, mont(a), mont(b))
+        assert out.raw == mont((a - b) % R), (a, b)
+        if a:
+            h.hs_fr29_inv(out, mont(a))
+            assert unm(out) == pow(a, -1, R), a
+    for n in (1, 2, 3, 4, 5, 8, 15, 16, 17, 32):
+        for worst in (False, True):
+            xs = [R - 1 - i if worst else rnd.randrange(R) for i in range(n)]
+            out = _buf(32)
+            h.hs_fr29_sum(out, b"".join(x.to_bytes(32, "little") for x in xs), n)
+            assert int.from_bytes(out.raw, "little") == sum(xs) % R, (n, worst)
+
+
+def test_fr29_barycentric_evaluation(libs):
+    """the kernel's algorithm replayed thread by thread on the host (prefix products per thread, one inversion per
+    lane of the first wave for four waves' products, terms that come out in the library's radix) against
+    evaluate_polynomial_in_evaluation_form (src/eip4844/eip4844.c:192-240) computed with Python integers;
+    z inside the domain (eip4844.c:208-215), polynomials of extreme values, and the parked inverses."""
+    o, h = libs
+    rnd = random.Random(61)
+    r256 = pow(2, 256, R)
+    w = pow(7, (R - 1) // 4096, R)
+    roots = [pow(w, _brp(i, 12), R) for i in range(4096)]
+    roots_b = b"".join((x * r256 % R).to_bytes(32, "little") for x in roots)
+    n_inv = pow(4096, -1, R)
+
+    def ref(poly, z):
+        if z in roots:
+            return poly[roots.index(z)]
+        s = sum(p * x % R * pow((z - x) % R, -1, R) for p, x in zip(poly, roots)) % R
+        return s * (pow(z, 4096, R) - 1) % R * n_inv % R
+
+    cases = []
+    cases.append(([rnd.randrange(R) for _ in range(4096)], rnd.randrange(R)))
+    cases.append(([R - 1] * 4096, R - 1))
+    cases.append(([0] * 4096, 5))
+    cases.append(([rnd.randrange(R) for _ in range(4096)], 0))
+    cases.append(([rnd.randrange(R) for _ in range(4096)], roots[1234]))
+    cases.append(([rnd.randrange(R) for _ in range(4096)], roots[0]))
+    cases.append(([rnd.randrange(R) for _ in range(4096)], (roots[4095] + 1) % R))
+    for poly, z in cases:
+        pb = b"".join((p * r256 % R).to_bytes(32, "little") for p in poly)
+        y = _buf(32)
+        di = _buf(4096 * 32)
+        hit = h.hs_fr29_eval(y, di, pb, (z * r256 % R).to_bytes(32, "little"), roots_b)
+        assert int.from_bytes(y.raw, "little") == ref(poly, z) * r256 % R
+        # the inversion-free tree (k_eval_tree): one wave per polynomial and four
+        for log_per in (6, 4):
+            y2 = _buf(32)
+            h.hs_fr29_eval_tree(y2, pb, (z * r256 % R).to_bytes(32, "little"), roots_b, log_per)
+            assert y2.raw == y.raw, log_per
+        assert hit == (roots.index(z) if z in roots else -1)
+        if hit < 0:
+            r261 = pow(2, 261, R)
+            for i in (0, 1, 255, 256, 2047, 4095):
+                got = int.from_bytes(di.raw[32 * i:32 * i + 32], "little")
+                assert got == pow((z - roots[i]) % R, -1, R) * r261 % R, i
