@@ -79,7 +79,7 @@ static bool challenges_on_gpu(size_t n) {
     if (t > 32) t = 32;
     const double host_us = (double)n * host_sha_us_per_blob() / (double)t;
     const double copy_us = (double)n * 2.4;     // 55 GB/s
-    const double eval_us = (double)n * 0.46;    // k_bytes_to_fr + k_eval_barycentric, not overlapped in the GPU-hash form
+    const double eval_us = (double)n * 0.21;    // k_eval_tree over the blobs' bytes (0.85 ms at n = 4096), after the GPU hash
     const double gpu_us = GPU_SHA_US * (double)((n + 65535) / 65536);
     return (host_us > copy_us ? host_us : copy_us) > copy_us + gpu_us + eval_us;
 }
@@ -573,7 +573,8 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     dev::FixedBaseTable tbl;
     size_t tbl_bytes = 0, tbl_tmp = 0, sums_scratch = 0;
     Arena &ar = ctx->api_arena;
-    const size_t plain_bytes = (resident ? 0 : n * BYTES_PER_BLOB) + (n * FIELD_ELEMENTS_PER_BLOB + 2 * n) * sizeof(Fr) + n * 4 +
+    // (no converted polynomials: the evaluation reads the blobs' bytes -- verify.hip: k_eval_tree's BYTES form)
+    const size_t plain_bytes = (resident ? 0 : n * BYTES_PER_BLOB) + 2 * n * sizeof(Fr) + n * 4 +
                                2 * n * (48 + 2 + sizeof(G1Affine)) + 8192;
     if (use_table) {
         dev::call_table_geometry(&tbl, (int)(2 * n), call_table_wbits);
@@ -589,26 +590,24 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     if (!use_table) OKM(ar.begin(plain_bytes));
     ABuf<uint8_t> d_ptb(ar, 2 * n * 48), d_st(ar, 2 * n), d_st2(ar, 2 * n), d_blobs_own(ar, resident ? 1 : n * BYTES_PER_BLOB);
     ABuf<G1Affine> d_pts(ar, 2 * n);
-    ABuf<Fr> d_poly(ar, n * FIELD_ELEMENTS_PER_BLOB), d_z(ar, n), d_y(ar, n);
+    ABuf<Fr> d_z(ar, n), d_y(ar, n);
     ABuf<uint32_t> d_bad(ar, n);
-    OKM(d_ptb.p && d_st.p && d_st2.p && d_blobs_own.p && d_pts.p && d_poly.p && d_z.p && d_y.p && d_bad.p);
+    OKM(d_ptb.p && d_st.p && d_st2.p && d_blobs_own.p && d_pts.p && d_z.p && d_y.p && d_bad.p);
     ABuf<uint8_t> d_tbl(ar, use_table ? tbl_bytes : 1), d_tbl_tmp(ar, use_table ? tbl_tmp : 1), d_sums_scr(ar, use_table ? sums_scratch : 1);
     ABuf<uint32_t> d_sc(ar, use_table ? 6 * n * 8 : 1);
     ABuf<G1XYZZ> d_sums(ar, 3);
     OKM(d_tbl.p && d_tbl_tmp.p && d_sums_scr.p && d_sc.p && d_sums.p);
     ArenaTrim trim(ar);
     tr.mark("arena");
-    // resident: the device copies of the inputs ARE the caller's buffers; the transcript needs the 96 bytes of
-    // commitment and proof per blob on the host
-    std::vector<uint8_t> h_cpb;
+    // resident: the device copies of the inputs ARE the caller's buffers, and nothing of them is read on the host -- the
+    // rows of the batch transcript (commitment | z | y | proof) are assembled on the device and come back in one copy
     const uint8_t *d_blob_bytes = resident ? reinterpret_cast<const uint8_t *>(blobs) : d_blobs_own.p;
     const Bytes48 *d_cb = cb, *d_pb = pb;
+    ABuf<uint8_t> d_rows(ar, resident ? n * 160 : 1);
+    OKM(d_rows.p);
     if (resident) {
-        h_cpb.resize(2 * n * 48);
-        OKB(hipMemcpy(h_cpb.data(), d_cb, n * 48, hipMemcpyDeviceToHost) == hipSuccess);
-        OKB(hipMemcpy(h_cpb.data() + n * 48, d_pb, n * 48, hipMemcpyDeviceToHost) == hipSuccess);
-        cb = reinterpret_cast<const Bytes48 *>(h_cpb.data());
-        pb = reinterpret_cast<const Bytes48 *>(h_cpb.data() + n * 48);
+        OKM(ensure_pinned(ctx->h_out, ctx->h_out_bytes, n * 160));   // rows | evaluations + flags
+        cb = pb = nullptr;
         blobs = nullptr;   // never dereferenced on the host
         OKB(hipEventRecord(ctx->ev[1], ctx->stream) == hipSuccess);
     }
@@ -716,15 +715,13 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
                 used[b] = true;
                 OKB(hipStreamWaitEvent(ctx->stream, copied[b], 0) == hipSuccess);
             }
-            RC(dev::bytes_to_fr_batch(ctx, d_poly.p + off * FIELD_ELEMENTS_PER_BLOB, d_bad.p + off,
-                                      d_blobs_own.p + off * BYTES_PER_BLOB, k * FIELD_ELEMENTS_PER_BLOB, FIELD_ELEMENTS_PER_BLOB));
             // the evaluation of chunk c - 1 is enqueued once its challenges exist: one chunk of slack, so that this
             // thread never waits for the hashers while there is a copy to issue
             if (c >= 1) {
                 const size_t po = (c - 1) * CH;
                 OKB(hasher.wait_chunk(c - 1));
                 OKB(hipMemcpyAsync(d_z.p + po, z.data() + po, CH * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
-                RC(dev::eval_poly_batch_device(ctx, d_y.p + po, d_poly.p + po * FIELD_ELEMENTS_PER_BLOB, d_z.p + po, CH));
+                RC(dev::eval_blob_bytes_batch_device(ctx, d_y.p + po, d_bad.p + po, d_blobs_own.p + po * BYTES_PER_BLOB, d_z.p + po, CH));
                 OKB(hipMemcpyAsync(h_y_bytes + po * sizeof(Fr), d_y.p + po, CH * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess);
                 OKB(hipEventRecord(landed[c - 1], ctx->stream) == hipSuccess);
                 transcript.publish(c);
@@ -734,14 +731,14 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
             const size_t po = (nch - 1) * CH, k = n - po;
             OKB(hasher.wait_chunk(nch - 1));
             OKB(hipMemcpyAsync(d_z.p + po, z.data() + po, k * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
-            RC(dev::eval_poly_batch_device(ctx, d_y.p + po, d_poly.p + po * FIELD_ELEMENTS_PER_BLOB, d_z.p + po, k));
+            RC(dev::eval_blob_bytes_batch_device(ctx, d_y.p + po, d_bad.p + po, d_blobs_own.p + po * BYTES_PER_BLOB, d_z.p + po, k));
             OKB(hipMemcpyAsync(h_y_bytes + po * sizeof(Fr), d_y.p + po, k * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess);
             OKB(hipEventRecord(landed[nch - 1], ctx->stream) == hipSuccess);
             transcript.publish(nch);
         }
         OKB(hipMemcpyAsync(h_bad, d_bad.p, n * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess);
         OKB(hipMemcpyAsync(h_st, d_st.p, 2 * n, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess);
-        tr.mark("chunked H2D + bytes_to_fr + evaluation enqueued (challenges hashed in order on host threads)");
+        tr.mark("chunked H2D + evaluation enqueued (challenges hashed in order on host threads)");
         OKB(dev::sync_stream(ctx->stream) == hipSuccess);
         tr.mark("wait for GPU");
         for (size_t i = 0; i < 2 * n; i++) {
@@ -773,22 +770,49 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     if (threaded) hasher.t = std::thread(hash_all);
     if (!resident) OKB(hipMemcpyAsync(d_blobs_own.p, blobs, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
     OKB(hipMemsetAsync(d_bad.p, 0, n * 4, ctx->stream) == hipSuccess);
-    RC(dev::bytes_to_fr_batch(ctx, d_poly.p, d_bad.p, d_blob_bytes, n * FIELD_ELEMENTS_PER_BLOB, FIELD_ELEMENTS_PER_BLOB));
     if (!small && !resident) OKB(hipStreamWaitEvent(ctx->stream, ctx->stage_ev[0], 0) == hipSuccess);  // d_ptb, d_pts, d_st ready
     if (gpu_sha)
         RC(dev::sha256_challenges_device(ctx, d_z.p, d_blob_bytes, resident ? reinterpret_cast<const uint8_t *>(d_cb) : d_ptb.p, n));
-    tr.mark("enqueue H2D + bytes_to_fr (+ GPU validation)");
+    tr.mark("enqueue H2D (+ GPU validation, GPU challenges)");
     if (hasher.t.joinable()) hasher.t.join();
     if (!gpu_sha && !threaded) hash_all();
     tr.mark("host SHA-256 challenges");
     if (resident) {
         // resident inputs: nothing to learn from the host before the evaluation -- enqueue it straight away
-        RC(dev::eval_poly_batch_device(ctx, d_y.p, d_poly.p, d_z.p, n));
-        OKB(hipStreamWaitEvent(ctx->stream, ctx->stage_ev[0], 0) == hipSuccess);   // the validated points and their status
+        RC(dev::eval_blob_bytes_batch_device(ctx, d_y.p, d_bad.p, d_blob_bytes, d_z.p, n));
+        OKB(hipStreamWaitEvent(ctx->stream, ctx->stage_ev[0], 0) == hipSuccess);   // the validated points, their status, d_ptb
+        RC(dev::batch_transcript_rows_device(ctx, d_rows.p, d_ptb.p, d_z.p, d_y.p, n));
         OKB(hipEventRecord(ctx->ev[2], ctx->stream) == hipSuccess);
+        uint8_t *h1 = static_cast<uint8_t *>(ctx->h_out[1]);
+        OKB(hipMemcpyAsync(ctx->h_out[0], d_rows.p, n * 160, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess);
+        OKB(hipMemcpyAsync(h1, d_y.p, n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess);
+        OKB(hipMemcpyAsync(h1 + n * sizeof(Fr), d_bad.p, n * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess);
+        OKB(hipMemcpyAsync(h1 + n * (sizeof(Fr) + 4), d_st.p, 2 * n, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess);
     }
     OKB(dev::sync_stream(ctx->stream) == hipSuccess);
     tr.mark("wait for GPU");
+    if (resident) {
+        const uint8_t *h1 = static_cast<const uint8_t *>(ctx->h_out[1]);
+        const uint8_t *st = h1 + n * (sizeof(Fr) + 4);
+        uint32_t any = 0;
+        for (size_t i = 0; i < 2 * n; i++) any |= st[i];
+        if (any) return C_KZG_BADARGS;
+        const uint32_t *bad = reinterpret_cast<const uint32_t *>(h1 + n * sizeof(Fr));
+        for (size_t i = 0; i < n; i++) any |= bad[i];
+        if (any) return C_KZG_BADARGS;
+        memcpy(y.data(), h1, n * sizeof(Fr));
+        if (!use_table) OKB(d_z.down(z.data(), n));   // the ladder sums take their scalars from the host
+        // r's transcript (eip4844.c:597-680): the header, then the rows as the device left them
+        Sha256 h;
+        uint8_t head[32];
+        memcpy(head, "RCKZGBATCH___V1_", 16);
+        be64(head + 16, FIELD_ELEMENTS_PER_BLOB);
+        be64(head + 24, n);
+        h.update(head, 32);
+        h.update(static_cast<const uint8_t *>(ctx->h_out[0]), n * 160);
+        h.finish(digest);
+        have_digest = true;
+    } else {
     if (!small) {
         std::vector<uint8_t> st(2 * n);
         OKB(d_st.down(st.data(), 2 * n));
@@ -796,22 +820,22 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
             if (st[i]) return C_KZG_BADARGS;
         }
     }
-    std::vector<uint32_t> bad(n);
-    OKB(d_bad.down(bad.data(), n));
-    for (size_t i = 0; i < n; i++) {
-        if (bad[i]) return C_KZG_BADARGS;
-    }
     if (gpu_sha) {
         OKB(d_z.down(z.data(), n));
     } else {
         OKB(d_z.up(z.data(), n));
     }
-    if (!resident) {
-        RC(dev::eval_poly_batch_device(ctx, d_y.p, d_poly.p, d_z.p, n));
-        if (n == 1) ps = verify_proof_side(z[0], hp[0], prepared_of(ctx));   // host work underneath the GPU's evaluation
-        OKB(dev::sync_stream(ctx->stream) == hipSuccess);
+    RC(dev::eval_blob_bytes_batch_device(ctx, d_y.p, d_bad.p, d_blob_bytes, d_z.p, n));
+    if (n == 1) ps = verify_proof_side(z[0], hp[0], prepared_of(ctx));   // host work underneath the GPU's evaluation
+    OKB(dev::sync_stream(ctx->stream) == hipSuccess);
+    // (the evaluation is what reads the field elements: a blob with one >= r is known now, bytes.c:52-70)
+    std::vector<uint32_t> bad(n);
+    OKB(d_bad.down(bad.data(), n));
+    for (size_t i = 0; i < n; i++) {
+        if (bad[i]) return C_KZG_BADARGS;
     }
     OKB(d_y.down(y.data(), n));
+    }
     }
     tr.mark("GPU evaluation (+ the proof's half of the check on the host)");
     if (n == 1 && !resident) {

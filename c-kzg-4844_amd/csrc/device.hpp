@@ -461,7 +461,10 @@ void commit_collect_times(DeviceCtx *ctx);
 // even-indexed ones), from ctx->d_brp_roots; on ctx->stream.  Enqueue-only.
 constexpr int ROOTS29_ENTRIES = 4096 + 2048;
 int roots29_build(DeviceCtx *ctx, uint32_t *d_out);
-int eval_poly_batch_device(DeviceCtx *ctx, Fr *d_y, const Fr *d_poly, const Fr *d_z, size_t n);
+// d_y[i] <- blob i's polynomial at d_z[i] (evaluate_polynomial_in_evaluation_form, eip4844.c:192-240), from the blobs' bytes
+// (n x 131,072, in HBM), conversion and range check folded in: d_bad[i] |= 1 where blob i holds a field element >= r
+// (its y is then meaningless).  Enqueue-only, on ctx->stream.
+int eval_blob_bytes_batch_device(DeviceCtx *ctx, Fr *d_y, uint32_t *d_bad, const uint8_t *d_blob_bytes, const Fr *d_z, size_t n);
 // d_sc[3][2n][8] <- the scalar vectors of a blob batch's three sums over a call-time table of (commitments, proofs),
 // from the batch challenge r and the blobs' challenges d_z (verify.hip: k_rlc_scalars).  Enqueue-only.
 // the same for a cell batch (verify.hip: k_cell_rlc_scalars, k_commit_weights): d_rp[n] <- r^i (Montgomery),
@@ -495,6 +498,9 @@ int bucket_msm_enqueue(DeviceCtx *ctx, G1Affine *d_out, const G1Affine *d_pts, c
                        const uint32_t *h_job_off, int njobs, int wbits, uint8_t *scratch);
 // z_i = hash_to_bls_field(SHA-256(domain | degree | blob_i | commitment_i)) for n blobs in HBM
 int sha256_challenges_device(DeviceCtx *ctx, Fr *d_z, const uint8_t *d_blobs, const uint8_t *d_commit48, size_t n);
+// d_rows[n][160] <- commitment_i | z_i | y_i | proof_i, the per-blob rows of the batch transcript (eip4844.c:597-680);
+// d_pts48: commitments [0, n), proofs [n, 2n), 16-byte aligned.  Enqueue-only, on ctx->stream.
+int batch_transcript_rows_device(DeviceCtx *ctx, uint8_t *d_rows, const uint8_t *d_pts48, const Fr *d_z, const Fr *d_y, size_t n);
 // cells[b][j] (2048 B each) -> image[b][idx[j]] (128 x 2048 B per row, zero-filled by the caller)
 int scatter_cells_device(DeviceCtx *ctx, uint8_t *d_image, const uint8_t *d_cells, const uint32_t *d_idx,
                          uint32_t num_cells, size_t num_rows);

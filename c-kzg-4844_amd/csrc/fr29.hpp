@@ -304,10 +304,10 @@ HD Fr scale(const Fr &sum, const Fr29 &f) {
 // Bounds: a node of level c + 1 is below 2 B_c + 1.4 with children below B_c: 1, 3.3, 7.7, 16.6 r -> reduced to the
 // canonical value at every fourth level; the subtraction adds the multiple 2^k r >= B_c of r.
 // ------------------------------------------------------------------------------------------
-template <int C>   // C = the children's level
+template <int C, bool FLAT = false>   // C = the children's level; FLAT: the product inlined (no call on the device)
 HD Fr29 tree_combine(const Fr29 &e, const Fr29 &o, const Fr29 &x) {
     constexpr int K = (C % 4 == 0) ? 0 : (C % 4 == 1) ? 2 : (C % 4 == 2) ? 3 : 5;
-    const Fr29 t = fr29_mul(x, fr29_sub_below<K>(e, o));
+    const Fr29 t = FLAT ? fr29_mul_inline(x, fr29_sub_below<K>(e, o)) : fr29_mul(x, fr29_sub_below<K>(e, o));
     Fr29 r;
 #pragma unroll
     for (int i = 0; i < 9; i++) r.l[i] = e.l[i] + o.l[i] + t.l[i];
@@ -336,6 +336,27 @@ HD Fr29 tree_node(Leaf leaf, const Fr29 *tab, const Fr29 *zp, int base) {
 HD Fr tree_finish(const Fr29 &root) {
     Fr r;
     fr29_unpack(r.l, fr29_canonical<0>(fr29_mul(root, fr29_const(FR29_INV4096))));
+    return r;
+}
+// The tree over the blob's own bytes (k_eval_tree's BYTES form: blob_to_polynomial, src/eip4844/blob.c:31-38, is
+// folded into the evaluation).  A leaf is the canonical integer of a field element -- radix 1, not 2^256 -- and the
+// whole tree is linear in the leaves, so the radix is put right once, at the root: the factor 2^256 / n.
+// s: the element's eight 32-bit words, least significant first.  An element >= r (bytes_to_bls_field,
+// src/common/bytes.c:52-70, rejects it) sets bad and counts as zero.
+HD Fr29 tree_leaf_from_words(const uint32_t *s, uint32_t &bad) {
+    Fr29 v = fr29_pack(s);
+    int32_t t = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) t = ((int32_t)v.l[i] - (int32_t)FR29_RMUL[0][i]) + (t >> 29);
+    const bool ge = t >= 0;   // no borrow out of the top limb: v >= r
+    bad |= ge ? 1u : 0u;
+#pragma unroll
+    for (int i = 0; i < 9; i++) v.l[i] = ge ? 0u : v.l[i];
+    return v;
+}
+HD Fr tree_finish_from_integers(const Fr29 &root) {
+    Fr r;
+    fr29_unpack(r.l, fr29_canonical<0>(fr29_mul(root, fr29_const(FR29_INV4096_R256))));
     return r;
 }
 

@@ -490,8 +490,10 @@ extern "C" int hs_fr29_eval(Fr *y, uint32_t *di_out, const Fr *poly, const Fr *z
 
 // One blob through k_eval_tree<LOG_PER>'s algorithm: 4096 >> LOG_PER threads each fold 2^LOG_PER leaves, six levels
 // of lane exchanges inside a wave (both lanes of a pair compute the parent), the waves' values by thread 0.
+// bytes != nullptr: the leaves come from the blob's bytes (k_eval_tree's BYTES form); *bad |= 1 for an element >= r.
 template <int LOG_PER>
-static void eval_tree_emulate(Fr *y, const Fr *poly, const Fr *z, const Fr *brp_roots) {
+static void eval_tree_emulate(Fr *y, const Fr *poly, const Fr *z, const Fr *brp_roots, const uint8_t *bytes = nullptr,
+                              uint32_t *bad = nullptr) {
     constexpr int NB = 4096, T = NB >> LOG_PER, W = T / 64;
     std::vector<Fr29> tab(NB / 2), v(T), nv(T);
     for (int m = 0; m < NB / 2; m++) tab[m] = fr29_inv(fr29_from_fr(brp_roots[2 * m]));
@@ -499,9 +501,19 @@ static void eval_tree_emulate(Fr *y, const Fr *poly, const Fr *z, const Fr *brp_
     Fr29 zp[12];
     zp[0] = fr29_from_fr(*z);
     for (int l = 1; l < 12; l++) zp[l] = fr29_mul(zp[l - 1], zp[l - 1]);
+    uint32_t any_bad = 0;
+    auto leaf = [&](int i) {
+        if (!bytes) return fr29_pack(poly[i].l);
+        uint32_t s[8];
+        for (int k = 0; k < 8; k++) {
+            const uint8_t *q = bytes + 32 * i + 4 * (7 - k);
+            s[k] = (uint32_t)q[0] << 24 | (uint32_t)q[1] << 16 | (uint32_t)q[2] << 8 | q[3];
+        }
+        return ev29::tree_leaf_from_words(s, any_bad);
+    };
     for (int t = 0; t < T; t++)
-        v[t] = ev29::tree_canonical<LOG_PER>(
-            ev29::tree_node<LOG_PER>([&](int i) { return fr29_pack(poly[i].l); }, tab.data(), zp, t << LOG_PER));
+        v[t] = ev29::tree_canonical<LOG_PER>(ev29::tree_node<LOG_PER>(leaf, tab.data(), zp, t << LOG_PER));
+    if (bad) *bad |= any_bad;
     for (int k = 0; k < 6; k++) {
         for (int t = 0; t < T; t++) {
             const bool odd = (t >> k) & 1;
@@ -517,7 +529,11 @@ static void eval_tree_emulate(Fr *y, const Fr *poly, const Fr *z, const Fr *brp_
     for (int n = W; n > 1; n >>= 1, lvl++)
         for (int m = 0; m < n / 2; m++)
             a[m] = fr29_canonical<1>(ev29::tree_combine<0>(a[2 * m], a[2 * m + 1], fr29_mul(zp[lvl], tab[m])));
-    *y = ev29::tree_finish(a[0]);
+    *y = bytes ? ev29::tree_finish_from_integers(a[0]) : ev29::tree_finish(a[0]);
+}
+extern "C" void hs_fr29_eval_tree_bytes(Fr *y, uint32_t *bad, const uint8_t *blob, const Fr *z, const Fr *brp_roots, int log_per) {
+    if (log_per == 6) eval_tree_emulate<6>(y, nullptr, z, brp_roots, blob, bad);
+    else eval_tree_emulate<4>(y, nullptr, z, brp_roots, blob, bad);
 }
 extern "C" void hs_fr29_eval_tree(Fr *y, const Fr *poly, const Fr *z, const Fr *brp_roots, int log_per) {
     if (log_per == 6) eval_tree_emulate<6>(y, poly, z, brp_roots);

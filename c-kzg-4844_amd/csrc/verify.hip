@@ -50,6 +50,7 @@ constexpr int EV_THREADS = 64 * ev29::WAVES;
 constexpr int EV_PER = ev29::PER;
 static_assert(EV_THREADS * EV_PER == N_BLOB, "one workgroup per polynomial");
 constexpr size_t EVAL_ONE_WAVE_FROM = 256;   // polynomials per launch from which k_eval_tree runs one wave each
+constexpr size_t EVAL_TWO_PER_SIMD_FROM = 1024;   // ... above which a compute unit takes eight of them at a time
 
 __device__ __noinline__ Fr29 fr29_inv_dev(const Fr29 &a) { return fr29_inv(a); }
 
@@ -72,67 +73,187 @@ int roots29_build(DeviceCtx *ctx, uint32_t *d_out) {
 }
 
 // ------------------------------------------------------------------------------------------
-// evaluation without inversions (fr29.hpp: ev29::tree_node says why): a thread folds 2^LOG_PER consecutive leaves
-// depth first (a stack of LOG_PER partial nodes in registers), six levels of lane exchanges inside the wave -- both
-// lanes of a pair compute the parent, no lane idles at a branch -- and, where a polynomial has more than one wave,
-// its first thread folds the waves' values.  LOG_PER = 6: ONE wave per polynomial, no shared memory, no barrier --
-// the throughput form (2 x 4095 products + 11 squarings per polynomial); LOG_PER = 4: four waves, the latency form
-// for small batches.
+// evaluation without inversions (fr29.hpp: ev29::tree_node says why), straight from the blobs' bytes: the leaves are
+// the big-endian 32-byte field elements as they lie in the blob (blob_to_polynomial, blob.c:31-38, folded in --
+// verification needs the converted polynomial for nothing else, so the conversion kernel, its 131 KB per blob of
+// writes and their re-read are gone); an element >= r sets bad_out[blob] (bytes.c:52-70).
+// A thread folds 2^LOG_PER consecutive leaves depth first, then six levels of lane exchanges inside the wave -- both
+// lanes of a pair compute the parent, no lane idles at a branch -- and, where a polynomial has more than one wave, its
+// first thread folds the waves' values.  LOG_PER = 6: ONE wave per polynomial, eight polynomials per workgroup turn --
+// the throughput form (2 x 4095 products + 11 squarings per polynomial); LOG_PER = 4: four waves per polynomial, the
+// latency form for small batches.
+// What the first form of this kernel lost two thirds of its time to was waiting, not arithmetic: a product was a
+// CALL, a call drains every outstanding load (the callee opens with s_waitcnt 0), so each leaf's load was waited for
+// in full, one after the other (2 KB apart per lane: never a coalesced request).  Now
+//   * a thread's leaves arrive eight at a time (256 B) in registers, the NEXT eight requested before the current
+//     eight are folded, and the fold of eight leaves (seven nodes, fourteen products) contains no call;
+//   * the per-node constants tab[m] = 1 / brp_roots[2 m] (2048 x 36 B) live in LDS, filled once per workgroup and
+//     laid out so that the lanes of a wave read consecutive words at the leaf level: their reads are counted by
+//     lgkmcnt and do not wait for the blob's bytes in flight (vmcnt);
+//   * the upper levels of a thread's subtree (one node per 16 / 32 / 64 leaves) are folded with called products right
+//     after the wait for the tile, when nothing is in flight.
 // ------------------------------------------------------------------------------------------
-template <int LOG_PER>
-__global__ __launch_bounds__(N_BLOB >> LOG_PER) void k_eval_tree(Fr *y_out, const Fr *poly, const Fr *zs,
-                                                                  const uint32_t *tab_words) {
-    constexpr int T = N_BLOB >> LOG_PER, W = T / 64;
-    __shared__ uint32_t sh[9][W];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const Fr *p = poly + (size_t)blockIdx.x * N_BLOB;
+constexpr int EV_TAB_N = N_BLOB / 2;
+__device__ __forceinline__ int ev_tab_pos(int m) { return ((m & 31) << 6) | (m >> 5); }
+__device__ __forceinline__ Fr29 ev_tab_get(const uint32_t (*tab_s)[EV_TAB_N], int m) {
+    const int pos = ev_tab_pos(m);
+    Fr29 r;
+#pragma unroll
+    for (int w = 0; w < 9; w++) r.l[w] = tab_s[w][pos];
+    return r;
+}
+// leaf k of a tile (two uint4 per leaf, as loaded)
+__device__ __forceinline__ Fr29 ev_leaf(const uint4 *tile, int k, uint32_t &bad) {
+    const uint4 a = tile[2 * k], b = tile[2 * k + 1];
+    const uint32_t s[8] = {__builtin_bswap32(b.w), __builtin_bswap32(b.z), __builtin_bswap32(b.y), __builtin_bswap32(b.x),
+                           __builtin_bswap32(a.w), __builtin_bswap32(a.z), __builtin_bswap32(a.y), __builtin_bswap32(a.x)};
+    return ev29::tree_leaf_from_words(s, bad);
+}
+// the level-L node over leaves [K0, K0 + 2^L) of the tile; m0 = index of the tile's first level-1 node among the
+// polynomial's (its first leaf / 2)
+template <int L, int K0>
+__device__ __forceinline__ Fr29 ev_tile_node(const uint4 *tile, const uint32_t (*tab_s)[EV_TAB_N], const Fr29 *zp, int m0,
+                                             uint32_t &bad) {
+    if constexpr (L == 0) {
+        return ev_leaf(tile, K0, bad);
+    } else {
+        const Fr29 e = ev_tile_node<L - 1, K0>(tile, tab_s, zp, m0, bad);
+        const Fr29 o = ev_tile_node<L - 1, K0 + (1 << (L - 1))>(tile, tab_s, zp, m0, bad);
+        // the children's X: z^(2^(L-1)) * tab[(first leaf of the node) >> L]
+        const Fr29 x = fr29_mul_inline(zp[L - 1], ev_tab_get(tab_s, (m0 >> (L - 1)) + (K0 >> L)));
+        return ev29::tree_combine<L - 1, true>(e, o, x);
+    }
+}
+
+constexpr int EV_TILE_LOG = 2, EV_TILE = 1 << EV_TILE_LOG;   // leaves per tile: 128 B per thread in flight, 128 B in use
+
+// One workgroup per compute unit at a time (the table is 72 of its 160 KB of LDS; two workgroups of 75 KB were never
+// co-resident when tried): the throughput form brings its two waves per SIMD in ONE workgroup of eight waves.
+template <int LOG_PER, int THREADS>
+__global__ __launch_bounds__(THREADS, 2) void k_eval_tree(Fr *y_out, uint32_t *bad_out, const uint8_t *blobs, const Fr *zs,
+                                                          const uint32_t *tab_words, unsigned n) {
+    constexpr int PER = 1 << LOG_PER, T = N_BLOB >> LOG_PER, W = T / 64, POLYS = THREADS / T, TILES = PER / EV_TILE;
+    static_assert(LOG_PER == 6 || LOG_PER == 4, "one wave or four per polynomial");
+    __shared__ uint32_t tab_s[9][EV_TAB_N];
+    __shared__ uint32_t sh[9][4];
+    __shared__ uint32_t zp_s[THREADS / 64][LOG_PER][9];   // per wave: z^(2^l), l >= EV_TILE_LOG (the upper levels' factors)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < EV_TAB_N; e += THREADS) {
+        const int pos = ev_tab_pos(e);
+#pragma unroll
+        for (int w = 0; w < 9; w++) tab_s[w][pos] = tab_words[(size_t)e * 9 + w];
+    }
+    __syncthreads();
     const Fr29 *tab = reinterpret_cast<const Fr29 *>(tab_words);
-    Fr29 zp[LOG_PER];
-    zp[0] = fr29_from_fr(vld_fr(zs + blockIdx.x));
+    for (unsigned first = blockIdx.x * POLYS; first < n; first += gridDim.x * POLYS) {
+        const unsigned poly = first + (POLYS > 1 ? (unsigned)wave : 0u);
+        if (POLYS > 1 && poly >= n) break;   // (the whole wave; no barrier below in this form)
+        const int t = POLYS > 1 ? lane : tid;   // the thread's index within its polynomial
+        const uint4 *pb = reinterpret_cast<const uint4 *>(blobs + (size_t)poly * (N_BLOB * 32)) + (size_t)t * (PER * 2);
+        uint4 cur[2 * EV_TILE], nxt[2 * EV_TILE];
 #pragma unroll
-    for (int l = 1; l < LOG_PER; l++) zp[l] = fr29_mul(zp[l - 1], zp[l - 1]);
-    Fr29 v = ev29::tree_canonical<LOG_PER>(
-        ev29::tree_node<LOG_PER>([&](int i) { return fr29_pack(vld_fr(p + i).l); }, tab, zp, tid << LOG_PER));
-    Fr29 zc = fr29_mul(zp[LOG_PER - 1], zp[LOG_PER - 1]);
+        for (int k = 0; k < 2 * EV_TILE; k++) cur[k] = pb[k];
+        Fr29 zp[EV_TILE_LOG], zc;
+        {
+            // every lane computes the powers (uniform per wave); the upper ones are parked in LDS
+            Fr29 p = fr29_from_fr(vld_fr(zs + poly));
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
-        Fr29 other;
+            for (int l = 0; l < LOG_PER; l++) {
+                if (l < EV_TILE_LOG) {
+                    zp[l] = p;
+                } else if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < 9; i++) other.l[i] = (uint32_t)__shfl_xor((int)v.l[i], 1 << k);
-        const bool odd = (lane >> k) & 1;
-        Fr29 e, o;
-#pragma unroll
-        for (int i = 0; i < 9; i++) {
-            e.l[i] = odd ? other.l[i] : v.l[i];
-            o.l[i] = odd ? v.l[i] : other.l[i];
-        }
-        v = fr29_canonical<1>(ev29::tree_combine<0>(e, o, fr29_mul(zc, tab[tid >> (k + 1)])));
-        if (k < 5 || W > 1) zc = fr29_mul(zc, zc);
-    }
-    if (W > 1) {
-        if (lane == 0) {
-#pragma unroll
-            for (int i = 0; i < 9; i++) sh[i][tid >> 6] = v.l[i];
-        }
-        __syncthreads();
-        if (tid == 0) {
-            Fr29 a[W];
-#pragma unroll
-            for (int w = 0; w < W; w++) {
-#pragma unroll
-                for (int i = 0; i < 9; i++) a[w].l[i] = sh[i][w];
+                    for (int w = 0; w < 9; w++) zp_s[wave][l][w] = p.l[w];
+                }
+                p = fr29_mul(p, p);
             }
-#pragma unroll
-            for (int n = W; n > 1; n >>= 1) {
-#pragma unroll
-                for (int m = 0; m < n / 2; m++)
-                    a[m] = fr29_canonical<1>(ev29::tree_combine<0>(a[2 * m], a[2 * m + 1], fr29_mul(zc, tab[m])));
-                zc = fr29_mul(zc, zc);
-            }
-            v = a[0];
+            zc = p;   // z^(2^LOG_PER)
         }
+        auto zp_upper = [&](int l) {
+            Fr29 r;
+#pragma unroll
+            for (int w = 0; w < 9; w++) r.l[w] = zp_s[wave][l][w];
+            return r;
+        };
+        uint32_t bad = 0;
+        Fr29 s2, s3, s4, s5, v;
+        s2 = s3 = s4 = s5 = v = fr29_const(FR29_ONE);
+#pragma unroll 1
+        for (int j = 0; j < TILES; j++) {
+            if (j + 1 < TILES) {
+#pragma unroll
+                for (int k = 0; k < 2 * EV_TILE; k++) nxt[k] = pb[2 * EV_TILE * (j + 1) + k];
+            }
+            // four leaves -> their level-2 node, no call inside
+            v = ev_tile_node<EV_TILE_LOG, 0>(cur, tab_s, zp, t * (PER / 2) + (EV_TILE / 2) * j, bad);
+#pragma unroll
+            for (int k = 0; k < 2 * EV_TILE; k++) cur[k] = nxt[k];
+            // the nodes above it that this tile completes (levels 3 .. LOG_PER), with called products: the tile just
+            // requested has the whole next fold to arrive
+            const int m2 = t * (PER / 8) + (j >> 1);   // index of the level-3 node this tile belongs to
+            if (j & 1) {
+                v = ev29::tree_combine<2>(s2, v, fr29_mul(zp_upper(2), ev_tab_get(tab_s, m2)));
+                if (j & 2) {
+                    v = ev29::tree_combine<3>(s3, v, fr29_mul(zp_upper(3), ev_tab_get(tab_s, m2 >> 1)));
+                    if constexpr (LOG_PER > 4) {
+                        if (j & 4) {
+                            v = ev29::tree_combine<4>(s4, v, fr29_mul(zp_upper(4), ev_tab_get(tab_s, m2 >> 2)));
+                            if (j & 8) v = ev29::tree_combine<5>(s5, v, fr29_mul(zp_upper(5), ev_tab_get(tab_s, m2 >> 3)));
+                            else s5 = v;
+                        } else {
+                            s4 = v;
+                        }
+                    }
+                } else {
+                    s3 = v;
+                }
+            } else {
+                s2 = v;
+            }
+        }
+        v = ev29::tree_canonical<LOG_PER>(v);
+        if (bad) atomicOr(bad_out + poly, 1u);
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            Fr29 other;
+#pragma unroll
+            for (int i = 0; i < 9; i++) other.l[i] = (uint32_t)__shfl_xor((int)v.l[i], 1 << k);
+            const bool odd = (lane >> k) & 1;
+            Fr29 e, o;
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                e.l[i] = odd ? other.l[i] : v.l[i];
+                o.l[i] = odd ? v.l[i] : other.l[i];
+            }
+            v = fr29_canonical<1>(ev29::tree_combine<0>(e, o, fr29_mul(zc, tab[t >> (k + 1)])));
+            if (k < 5 || W > 1) zc = fr29_mul(zc, zc);
+        }
+        if (W > 1) {
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) sh[i][wave] = v.l[i];
+            }
+            __syncthreads();
+            if (tid == 0) {
+                Fr29 a[W];
+#pragma unroll
+                for (int w = 0; w < W; w++) {
+#pragma unroll
+                    for (int i = 0; i < 9; i++) a[w].l[i] = sh[i][w];
+                }
+#pragma unroll
+                for (int nn = W; nn > 1; nn >>= 1) {
+#pragma unroll
+                    for (int m = 0; m < nn / 2; m++)
+                        a[m] = fr29_canonical<1>(ev29::tree_combine<0>(a[2 * m], a[2 * m + 1], fr29_mul(zc, tab[m])));
+                    zc = fr29_mul(zc, zc);
+                }
+                v = a[0];
+            }
+            __syncthreads();   // sh is free for the next polynomial of this workgroup
+        }
+        if (t == 0) vst_fr(y_out + poly, ev29::tree_finish_from_integers(v));
     }
-    if (tid == 0) vst_fr(y_out + blockIdx.x, ev29::tree_finish(v));
 }
 
 __device__ __forceinline__ void ev_put(uint32_t (*sh)[EV_THREADS], int col, const Fr29 &v) {
@@ -247,13 +368,23 @@ __global__ __launch_bounds__(EV_THREADS) void k_eval_barycentric(Fr *y_out, uint
     }
 }
 
-int eval_poly_batch_device(DeviceCtx *ctx, Fr *d_y, const Fr *d_poly, const Fr *d_z, size_t n) {
+int eval_blob_bytes_batch_device(DeviceCtx *ctx, Fr *d_y, uint32_t *d_bad, const uint8_t *d_blob_bytes, const Fr *d_z, size_t n) {
     if (!n) return 0;
     const uint32_t *tab = ctx->d_brp_roots29 + (size_t)N_BLOB * 9;
-    if (n >= EVAL_ONE_WAVE_FROM)
-        hipLaunchKernelGGL(k_eval_tree<6>, dim3((unsigned)n), dim3(64), 0, ctx->stream, d_y, d_poly, d_z, tab);
-    else
-        hipLaunchKernelGGL(k_eval_tree<4>, dim3((unsigned)n), dim3(256), 0, ctx->stream, d_y, d_poly, d_z, tab);
+    if (n > EVAL_TWO_PER_SIMD_FROM) {
+        // eight polynomials per workgroup turn, one workgroup per compute unit; a workgroup that takes several turns
+        // fills its table once
+        const size_t turns = (n + 7) / 8;
+        const unsigned grid = (unsigned)(turns < 256 ? turns : 256);
+        hipLaunchKernelGGL((k_eval_tree<6, 512>), dim3(grid), dim3(512), 0, ctx->stream, d_y, d_bad, d_blob_bytes, d_z, tab, (unsigned)n);
+    } else if (n >= EVAL_ONE_WAVE_FROM) {
+        // up to 1024 polynomials: a wave each with a SIMD to itself (four per compute unit)
+        hipLaunchKernelGGL((k_eval_tree<6, 256>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, d_y, d_bad, d_blob_bytes, d_z,
+                           tab, (unsigned)n);
+    } else {
+        hipLaunchKernelGGL((k_eval_tree<4, 256>), dim3((unsigned)n), dim3(256), 0, ctx->stream, d_y, d_bad, d_blob_bytes, d_z, tab,
+                           (unsigned)n);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -918,6 +1049,36 @@ int sha256_challenges_device(DeviceCtx *ctx, Fr *d_z, const uint8_t *d_blobs, co
     if (!n) return 0;
     hipLaunchKernelGGL(k_sha256_challenges, dim3((unsigned)((n + 63) / 64)), dim3(128), 0, ctx->stream, d_z,
                        d_blobs, d_commit48, n);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// The batch transcript's rows, assembled where their parts already are (resident verification): row i =
+// commitment_i | z_i | y_i | proof_i as the 160 bytes compute_r_powers_for_verify_kzg_proof_batch hashes per blob
+// (src/eip4844/eip4844.c:597-680) -- the host then runs ONE SHA-256 over one contiguous buffer that arrived in one
+// copy, instead of converting 2 n field elements and stitching four arrays.  pts48: commitments [0, n), proofs [n, 2n).
+// ------------------------------------------------------------------------------------------
+__global__ void k_batch_transcript_rows(uint4 *out, const uint4 *pts48, const Fr *z, const Fr *y, size_t n) {
+    const size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    uint4 *row = out + g * 10;
+    const uint4 *c = pts48 + g * 3, *p = pts48 + (n + g) * 3;
+    row[0] = c[0]; row[1] = c[1]; row[2] = c[2];
+    uint32_t raw[8];
+    to_raw<FrParams>(raw, vld_fr(z + g));
+    row[3] = make_uint4(__builtin_bswap32(raw[7]), __builtin_bswap32(raw[6]), __builtin_bswap32(raw[5]), __builtin_bswap32(raw[4]));
+    row[4] = make_uint4(__builtin_bswap32(raw[3]), __builtin_bswap32(raw[2]), __builtin_bswap32(raw[1]), __builtin_bswap32(raw[0]));
+    to_raw<FrParams>(raw, vld_fr(y + g));
+    row[5] = make_uint4(__builtin_bswap32(raw[7]), __builtin_bswap32(raw[6]), __builtin_bswap32(raw[5]), __builtin_bswap32(raw[4]));
+    row[6] = make_uint4(__builtin_bswap32(raw[3]), __builtin_bswap32(raw[2]), __builtin_bswap32(raw[1]), __builtin_bswap32(raw[0]));
+    row[7] = p[0]; row[8] = p[1]; row[9] = p[2];
+}
+
+int batch_transcript_rows_device(DeviceCtx *ctx, uint8_t *d_rows, const uint8_t *d_pts48, const Fr *d_z, const Fr *d_y, size_t n) {
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_batch_transcript_rows, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream,
+                       reinterpret_cast<uint4 *>(d_rows), reinterpret_cast<const uint4 *>(d_pts48), d_z, d_y, n);
     HIP_TRY(hipGetLastError());
     return 0;
 }

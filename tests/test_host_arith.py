@@ -740,9 +740,35 @@ def test_fr29_barycentric_evaluation(libs):
             y2 = _buf(32)
             h.hs_fr29_eval_tree(y2, pb, (z * r256 % R).to_bytes(32, "little"), roots_b, log_per)
             assert y2.raw == y.raw, log_per
+            # the same tree over the blob's bytes (conversion and range check folded in)
+            y3 = _buf(32)
+            bad = (C.c_uint32 * 1)(0)
+            blob = b"".join(p.to_bytes(32, "big") for p in poly)
+            h.hs_fr29_eval_tree_bytes(y3, bad, blob, (z * r256 % R).to_bytes(32, "little"), roots_b, log_per)
+            assert y3.raw == y.raw and bad[0] == 0, log_per
         assert hit == (roots.index(z) if z in roots else -1)
         if hit < 0:
             r261 = pow(2, 261, R)
             for i in (0, 1, 255, 256, 2047, 4095):
                 got = int.from_bytes(di.raw[32 * i:32 * i + 32], "little")
                 assert got == pow((z - roots[i]) % R, -1, R) * r261 % R, i
+
+
+def test_fr29_tree_over_bytes_flags_non_canonical_elements(libs):
+    """k_eval_tree's BYTES form: an element >= r anywhere in the blob sets the flag (bytes_to_bls_field,
+    src/common/bytes.c:52-70); r - 1 does not."""
+    o, h = libs
+    r256 = pow(2, 256, R)
+    w = pow(7, (R - 1) // 4096, R)
+    roots_b = b"".join((pow(w, _brp(i, 12), R) * r256 % R).to_bytes(32, "little") for i in range(4096))
+    z = (12345 * r256 % R).to_bytes(32, "little")
+    for pos in (0, 1, 63, 64, 2047, 4095):
+        for val, want in ((R - 1, 0), (R, 1), (R + 1, 1), (2 ** 256 - 1, 1), (R + 2 ** 232, 1)):
+            elems = [7] * 4096
+            elems[pos] = val
+            blob = b"".join(e.to_bytes(32, "big") for e in elems)
+            for log_per in (6, 4):
+                y = _buf(32)
+                bad = (C.c_uint32 * 1)(0)
+                h.hs_fr29_eval_tree_bytes(y, bad, blob, z, roots_b, log_per)
+                assert bad[0] == want, (pos, hex(val), log_per)
