@@ -457,8 +457,7 @@ def verify_and_recover_rows(L, hip, base):
             raise RuntimeError("resident verify rc=%d ok=%s" % (rc, ok.value))
         prow = "verify_wide" if tables_of(L, hip)["commit_wbits"] >= 16 else "verify_default"
         parts = {"k_sha256_challenges": pmc_kernel(prow, "k_sha256_challenges", streaming=True),
-                 "k_bytes_to_fr": pmc_kernel(prow, "k_bytes_to_fr", pick="grid", streaming=True),
-                 "k_eval_barycentric": pmc_kernel(prow, "k_eval_barycentric<false>", streaming=True),
+                 "k_eval_tree": pmc_kernel(prow, "k_eval_tree<6, 512>", streaming=True),
                  "k_table_chain_x28": pmc_kernel(prow, "k_table_chain_x28"),
                  "k_msm_accumulate_x28": pmc_kernel(prow, "k_msm_accumulate_x28")}
         have = [v for v in parts.values() if v]
@@ -467,9 +466,9 @@ def verify_and_recover_rows(L, hip, base):
                                   "kernel_ms": {"total": round(median(ks), 3), "validate_convert_hash_evaluate": round(median(k0), 3),
                                                 "sums": round(median(k2), 3)},
                                   "roofline": dict(roofline(ALGO_BYTES_VERIFY_BLOB * n, median(ks),
-                                                            "k_sha256_challenges + k_eval_barycentric + k_validate_g1 + k_msm_accumulate_x28 over the call-time table (device time of the call)",
+                                                            "k_sha256_challenges + k_eval_tree (from the blobs' bytes) + k_validate_g1 + k_msm_accumulate_x28 over the call-time table (device time of the call)",
                                                             sum(v["traffic_bytes_per_launch"] for v in have) if have else None),
-                                                   traffic_source="PMC: FETCH_SIZE (x2 for the streaming kernels) + WRITE_SIZE of the five kernels that move the call's bytes, one launch each" if have else None,
+                                                   traffic_source="PMC: FETCH_SIZE (x2 for the streaming kernels) + WRITE_SIZE of the four kernels that move the call's bytes, one launch each" if have else None,
                                                    pmc_per_kernel=parts),
                                   # the call's longest kernel is a dependent chain of 2,050 SHA-256 compressions per blob on ONE wave
                                   # per 64 blobs: its bound is the issue rate of a lone wave (one VALU instruction per 4 cycles)

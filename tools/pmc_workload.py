@@ -3,7 +3,7 @@
   cells_wide    compute_cells_and_kzg_proofs: 1 blob x 5 (low-latency path: k_msm_accumulate over the 16-bit monomial
                 table) and a 2048-blob batch x 2 (FK20: k_msm_small<8>, the G1-FFT ladders, k_ntt_tile), 16/16/13-bit tables
   cells_default the same on the library's default tables
-  verify_wide   ckzg_hip_verify_blob_kzg_proof_batch_device, 4096 blobs x 3 (k_sha256_challenges, k_eval_barycentric,
+  verify_wide   ckzg_hip_verify_blob_kzg_proof_batch_device, 4096 blobs x 3 (k_sha256_challenges, k_eval_tree,
                 validation, call-time table) + recover_cells_and_kzg_proofs batch of 256 rows x 2, 16/16/13-bit tables
   verify_default the same on the library's default tables
   cells_small_default / cells_small_wide   compute_cells_and_kzg_proofs batches of 2, 8, 16, 32, 64 and 128 blobs x 6 each
