@@ -420,3 +420,33 @@ print(json.dumps(out))
     assert res.pop("commitments") == want_cm
     assert res == {"blobs_9": [True, False], "blobs_300": [True, False], "blobs_1100": [True, False],
                    "cells_130": [True, False], "cells_700": [True, False]}
+
+
+@pytest.mark.parametrize("n", [255, 256, 257, 259, 1023, 1025, 1031])
+def test_evaluation_kernel_forms_at_their_switch_points(hip, rt, material, n):
+    """k_eval_tree takes three launch forms by batch size (verify.hip: four waves per blob below 256 blobs, a wave per
+    blob with four blobs per workgroup up to 1024, eight per workgroup above): both sides of each hand-over, with batch
+    sizes that leave a workgroup's last turn ragged (257 = 64 x 4 + 1, 1025 = 128 x 8 + 1, 1031 = 128 x 8 + 7).  The
+    expected verdicts come from the oracle's proofs; a wrong proof and a non-canonical field element are placed in the
+    LAST blob (the ragged wave) and the element walks over a thread's tile positions (evaluate_polynomial_in_evaluation_form,
+    src/eip4844/eip4844.c:192-240; bytes_to_bls_field, src/common/bytes.c:52-70)."""
+    blobs, cm, pr = material
+    bb, cc, pp, order = _inputs(material, n)
+    assert _device(hip, rt, bb, cc, pp, n) == (0, True)
+    assert _host(hip, bb, cc, pp, n) == (0, True)
+    bad = pp[:48 * (n - 1)] + pr[(order[n - 1] + 1) % 8]
+    assert _device(hip, rt, bb, cc, bad, n) == (0, False)
+    assert _host(hip, bb, cc, bad, n) == (0, False)
+    # element index inside the last blob: first / last leaf of a thread, of a tile of four, of the blob
+    for k, elem in enumerate((0, 3, 4, 63, 64, 2049, 4095)):
+        nb = bytearray(bb)
+        at = (n - 1) * 131072 + 32 * elem
+        nb[at:at + 32] = (R + k).to_bytes(32, "big")
+        assert _device(hip, rt, bytes(nb), cc, pp, n)[0] == 1, elem
+        if k % 3 == 0:
+            assert _host(hip, bytes(nb), cc, pp, n)[0] == 1, elem
+    # the largest canonical element is fine (and changes the blob: the proof no longer fits)
+    nb = bytearray(bb)
+    at = (n - 1) * 131072 + 32 * 777
+    nb[at:at + 32] = (R - 1).to_bytes(32, "big")
+    assert _device(hip, rt, bytes(nb), cc, pp, n) == (0, False)
