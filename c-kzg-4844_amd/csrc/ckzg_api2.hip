@@ -611,6 +611,14 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
         blobs = nullptr;   // never dereferenced on the host
         OKB(hipEventRecord(ctx->ev[1], ctx->stream) == hipSuccess);
     }
+    // whatever path leaves this function, the second stream must be idle before the arena is reused
+    // (declared before the first enqueue on it: an early error return drains it too)
+    struct StreamDrain {
+        hipStream_t s;
+        ~StreamDrain() {
+            if (s) (void)dev::sync_stream(s);
+        }
+    } drain{ctx->copy_stream};
     const bool split_validation = !small && !piped && !resident && n < 1024;
     if (!small) {
         // commitments [0,n), proofs [n,2n): decompress + subgroup-check on the GPU, on the second stream
@@ -637,13 +645,6 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
             OKB(hipEventRecord(ctx->stage_ev[0], vs) == hipSuccess);
         }
     }
-    // whatever path leaves this function, the second stream must be idle before the arena is reused
-    struct StreamDrain {
-        hipStream_t s;
-        ~StreamDrain() {
-            if (s) (void)dev::sync_stream(s);
-        }
-    } drain{ctx->copy_stream};
     if (use_table) {
         if (!ctx->aux_stream) OKB(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) == hipSuccess);
         OKB(hipStreamWaitEvent(ctx->aux_stream, ctx->stage_ev[0], 0) == hipSuccess);   // the validated points
