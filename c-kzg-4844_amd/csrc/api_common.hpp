@@ -83,7 +83,7 @@ extern std::atomic<int> g_gpu_sha_min;
 extern std::atomic<int> g_host_threads;
 // read at call time: smallest verify_blob_kzg_proof_batch that takes the pipelined (chunked copy) form; whether the
 // verifications may build their call-time table (0: ladder sums, the path a device too full for the table takes)
-extern std::atomic<int> g_verify_pipe_min, g_verify_call_table;
+extern std::atomic<int> g_verify_pipe_min, g_verify_call_table, g_verify_cu_partition;
 
 // How many host threads ONE process of this library may keep busy for a call (challenge hashing, staging copies,
 // point decompression at load): the CPUs of the process's affinity mask divided by the processes that share the host.

@@ -24,7 +24,7 @@ static std::mutex g_opts_mu;
 static Options g_opts;
 std::atomic<int> g_gpu_sha_min{0};
 std::atomic<int> g_host_threads{0};
-std::atomic<int> g_verify_pipe_min{1024}, g_verify_call_table{1};
+std::atomic<int> g_verify_pipe_min{1024}, g_verify_call_table{1}, g_verify_cu_partition{1};
 static std::atomic<int> g_commit_graph{1};   // option "commit_graph": a lone one-blob commitment goes out as one (explicitly built) graph
 static std::atomic<uint64_t> g_graph_stats[3];   // graphs built, builds that failed (plain launches instead), graph launches
 Options options_snapshot() {
@@ -74,6 +74,9 @@ extern "C" C_KZG_RET ckzg_hip_set_option(const char *key, int64_t value) {
     } else if (!strcmp(key, "verify_call_table")) {
         if (value != 0 && value != 1) return C_KZG_BADARGS;
         g_verify_call_table.store((int)value);
+    } else if (!strcmp(key, "verify_cu_partition")) {
+        if (value != 0 && value != 1) return C_KZG_BADARGS;
+        g_verify_cu_partition.store((int)value);   // read at call time
     } else if (!strcmp(key, "commit_graph")) {
         if (value < 0 || value > 2) return C_KZG_BADARGS;   // (2: diagnostic -- build the graph anew on every call)
         g_commit_graph.store((int)value);  // read at call time

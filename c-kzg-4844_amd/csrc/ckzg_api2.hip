@@ -525,6 +525,39 @@ struct OrderedHasher {
     }
 };
 
+// The masked streams of the compute-unit partition (device.hpp: sha_stream / side_stream), made on first use: a quarter of
+// the compute units for the SHA-256 chain, the rest for what runs underneath it.  The mask bits of a multi-XCD part are
+// dealt round the XCDs, so "the first quarter of the bits" is the same share of every XCD, which is where the workgroups
+// of a launch go as well.  false (and plain streams) where the runtime refuses.
+static bool ensure_cu_partition(dev::DeviceCtx *ctx) {
+    if (ctx->cu_partition_tried) return ctx->sha_stream != nullptr;
+    ctx->cu_partition_tried = true;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus < 64 || cus > 1024) {
+        (void)hipGetLastError();
+        return false;
+    }
+    const int words = (cus + 31) / 32, quarter = cus / 4;
+    uint32_t sha_mask[32] = {}, side_mask[32] = {};
+    for (int b = 0; b < cus; b++) (b < quarter ? sha_mask : side_mask)[b >> 5] |= 1u << (b & 31);
+    hipStream_t made[3] = {nullptr, nullptr, nullptr};
+    bool good = hipExtStreamCreateWithCUMask(&made[0], (uint32_t)words, sha_mask) == hipSuccess &&
+                hipExtStreamCreateWithCUMask(&made[1], (uint32_t)words, side_mask) == hipSuccess &&
+                hipExtStreamCreateWithCUMask(&made[2], (uint32_t)words, side_mask) == hipSuccess;
+    if (!good) {
+        (void)hipGetLastError();
+        for (auto st : made) {
+            if (st) (void)hipStreamDestroy(st);
+        }
+        return false;
+    }
+    ctx->sha_stream = made[0];
+    ctx->side_stream[0] = made[1];
+    ctx->side_stream[1] = made[2];
+    return true;
+}
+
+
 // Shared core of verify_blob_kzg_proof and verify_blob_kzg_proof_batch (eip4844.c:537-595,
 // 697-844).  Per blob, on the GPU: point validation, bytes -> Fr, evaluation at the challenge;
 // then three lincombs over all blobs; host: transcripts and the pairing check
@@ -574,8 +607,8 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     size_t tbl_bytes = 0, tbl_tmp = 0, sums_scratch = 0;
     Arena &ar = ctx->api_arena;
     // (no converted polynomials: the evaluation reads the blobs' bytes -- verify.hip: k_eval_tree's BYTES form)
-    const size_t plain_bytes = (resident ? 0 : n * BYTES_PER_BLOB) + 2 * n * sizeof(Fr) + n * 4 +
-                               2 * n * (48 + 2 + sizeof(G1Affine)) + 8192;
+    const size_t plain_bytes = (resident ? n * 160 : n * BYTES_PER_BLOB) + 2 * n * sizeof(Fr) + n * 4 +
+                               2 * n * (48 + 2 + sizeof(G1Affine)) + 8192;   // (resident: the transcript rows, no blobs)
     if (use_table) {
         dev::call_table_geometry(&tbl, (int)(2 * n), call_table_wbits);
         tbl_bytes = dev::call_table_bytes(tbl);
@@ -620,6 +653,16 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
         }
     } drain{ctx->copy_stream};
     const bool split_validation = !small && !piped && !resident && n < 1024;
+    // Resident form: the hash chain on its own quarter of the compute units, validation and table build on the rest.
+    // Measured (tools/ubench/sha_contention_probe.py, profiles/r06_cu_partition_ab.txt): sharing the chip, the chain of a
+    // 4096-blob batch takes 4.9 ms -- a validation or table wave that lands on a hash wave's SIMD takes issue slots from
+    // it for as long as it lives, and the launch ends with its slowest wave -- against 3.8 ms alone; partitioned, the
+    // call goes 7.5 -> 6.3 ms (2048 blobs: 6.7 -> 5.7).  Below ~640 blobs the side work rarely collides (768 blobs: 3 calls of 16 took the extra 1.1 ms) and the
+    // masked streams only cost their 0.07 ms.
+    static const size_t partition_min = (size_t)dev::ab_knob("CKZG_HIP_CU_PARTITION_MIN", 640);
+    const bool partition = resident && n >= partition_min && g_verify_cu_partition.load(std::memory_order_relaxed) != 0 &&
+                           ensure_cu_partition(ctx);
+    StreamDrain drain_sha{partition ? ctx->sha_stream : nullptr}, drain_val{partition ? ctx->side_stream[0] : nullptr};
     if (!small) {
         // commitments [0,n), proofs [n,2n): decompress + subgroup-check on the GPU, on the second stream
         // so that the ladder kernel runs under the (host-blocking, pageable) copy of the blobs
@@ -630,6 +673,7 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
         // (resident inputs: nothing blocks the host, so the validation ladders always run on the second stream,
         // underneath the challenge hashing -- the longest kernel of that form -- and the evaluation)
         hipStream_t vs = (split_validation || resident) ? ctx->copy_stream : ctx->stream;
+        if (partition) vs = ctx->side_stream[0];
         if (!ctx->stage_ev[0]) OKB(hipEventCreateWithFlags(&ctx->stage_ev[0], hipEventDisableTiming) == hipSuccess);
         if (!ctx->stage_ev[1]) OKB(hipEventCreateWithFlags(&ctx->stage_ev[1], hipEventDisableTiming) == hipSuccess);
         const hipMemcpyKind kind = resident ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
@@ -645,14 +689,22 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
             OKB(hipEventRecord(ctx->stage_ev[0], vs) == hipSuccess);
         }
     }
+    hipStream_t table_stream = nullptr;
     if (use_table) {
-        if (!ctx->aux_stream) OKB(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) == hipSuccess);
-        OKB(hipStreamWaitEvent(ctx->aux_stream, ctx->stage_ev[0], 0) == hipSuccess);   // the validated points
-        RC(dev::call_table_enqueue(ctx->aux_stream, &tbl, d_tbl.p, d_tbl_tmp.p, d_pts.p));
-        if (!ctx->table_ev) OKB(hipEventCreateWithFlags(&ctx->table_ev, hipEventDisableTiming) == hipSuccess);
-        OKB(hipEventRecord(ctx->table_ev, ctx->aux_stream) == hipSuccess);
+        if (partition) {
+            table_stream = ctx->side_stream[1];
+        } else {
+            if (!ctx->aux_stream) OKB(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) == hipSuccess);
+            table_stream = ctx->aux_stream;
+        }
     }
-    StreamDrain drain_aux{use_table ? ctx->aux_stream : nullptr};
+    StreamDrain drain_aux{table_stream};
+    if (use_table) {
+        OKB(hipStreamWaitEvent(table_stream, ctx->stage_ev[0], 0) == hipSuccess);   // the validated points
+        RC(dev::call_table_enqueue(table_stream, &tbl, d_tbl.p, d_tbl_tmp.p, d_pts.p));
+        if (!ctx->table_ev) OKB(hipEventCreateWithFlags(&ctx->table_ev, hipEventDisableTiming) == hipSuccess);
+        OKB(hipEventRecord(ctx->table_ev, table_stream) == hipSuccess);
+    }
     tr.mark("validation (+ call-time table) enqueued");
     std::vector<Fr> z(n), y(n);
     ProofSide ps;
@@ -772,8 +824,15 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     if (!resident) OKB(hipMemcpyAsync(d_blobs_own.p, blobs, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, ctx->stream) == hipSuccess);
     OKB(hipMemsetAsync(d_bad.p, 0, n * 4, ctx->stream) == hipSuccess);
     if (!small && !resident) OKB(hipStreamWaitEvent(ctx->stream, ctx->stage_ev[0], 0) == hipSuccess);  // d_ptb, d_pts, d_st ready
-    if (gpu_sha)
-        RC(dev::sha256_challenges_device(ctx, d_z.p, d_blob_bytes, resident ? reinterpret_cast<const uint8_t *>(d_cb) : d_ptb.p, n));
+    if (gpu_sha) {
+        RC(dev::sha256_challenges_device(ctx, d_z.p, d_blob_bytes, resident ? reinterpret_cast<const uint8_t *>(d_cb) : d_ptb.p, n,
+                                         partition ? ctx->sha_stream : nullptr));
+        if (partition) {
+            // (stage_ev[1] is free in this form: only the split validation of small host-pointer batches records it)
+            OKB(hipEventRecord(ctx->stage_ev[1], ctx->sha_stream) == hipSuccess);
+            OKB(hipStreamWaitEvent(ctx->stream, ctx->stage_ev[1], 0) == hipSuccess);   // the challenges, before the evaluation
+        }
+    }
     tr.mark("enqueue H2D (+ GPU validation, GPU challenges)");
     if (hasher.t.joinable()) hasher.t.join();
     if (!gpu_sha && !threaded) hash_all();

@@ -317,6 +317,13 @@ struct DeviceCtx {
     hipStream_t copy_stream = nullptr;  // host-to-device staging, overlapped with `stream`
     hipStream_t out_stream = nullptr;   // device-to-host draining of results (OutPipe), created on first use
     hipStream_t aux_stream = nullptr;   // call-time table construction under a long copy (verification), created on first use
+    // Compute-unit partition for the resident verification (round 6, ckzg_api2.hip: verify_blobs_core): the SHA-256
+    // chain is ONE wave per 64 blobs whose speed is its own issue rate -- any wave that shares its SIMD takes issue slots
+    // from it -- so it runs on a stream confined to a quarter of the compute units and the work that runs underneath
+    // it (point validation, call-time table) on streams confined to the rest.  Created on first use; nullptr where the
+    // runtime refuses a masked stream (the call then uses the plain streams).
+    hipStream_t sha_stream = nullptr, side_stream[2] = {nullptr, nullptr};
+    bool cu_partition_tried = false;
     void *h_stage[2] = {nullptr, nullptr};  // pinned host staging buffers (allocated on first use)
     size_t h_stage_bytes = 0;
     void *h_out[2] = {nullptr, nullptr};    // pinned device-to-host staging (cells+proofs / recover pipelines)
@@ -497,7 +504,8 @@ int bucket_msm_wbits(size_t max_job_terms);
 int bucket_msm_enqueue(DeviceCtx *ctx, G1Affine *d_out, const G1Affine *d_pts, const uint32_t *d_scalars, size_t total,
                        const uint32_t *h_job_off, int njobs, int wbits, uint8_t *scratch);
 // z_i = hash_to_bls_field(SHA-256(domain | degree | blob_i | commitment_i)) for n blobs in HBM
-int sha256_challenges_device(DeviceCtx *ctx, Fr *d_z, const uint8_t *d_blobs, const uint8_t *d_commit48, size_t n);
+int sha256_challenges_device(DeviceCtx *ctx, Fr *d_z, const uint8_t *d_blobs, const uint8_t *d_commit48, size_t n,
+                             hipStream_t stream = nullptr);   // stream: ctx->stream if null
 // d_rows[n][160] <- commitment_i | z_i | y_i | proof_i, the per-blob rows of the batch transcript (eip4844.c:597-680);
 // d_pts48: commitments [0, n), proofs [n, 2n), 16-byte aligned.  Enqueue-only, on ctx->stream.
 int batch_transcript_rows_device(DeviceCtx *ctx, uint8_t *d_rows, const uint8_t *d_pts48, const Fr *d_z, const Fr *d_y, size_t n);

@@ -207,6 +207,10 @@ static void destroy_slot(dev::DeviceCtx *ctx) {
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->out_stream) (void)hipStreamDestroy(ctx->out_stream);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+    if (ctx->sha_stream) (void)hipStreamDestroy(ctx->sha_stream);
+    for (auto &st : ctx->side_stream) {
+        if (st) (void)hipStreamDestroy(st);
+    }
     for (auto &h : ctx->h_stage) {
         if (h) (void)hipHostFree(h);
     }

@@ -1045,9 +1045,10 @@ __global__ __launch_bounds__(128) void k_sha256_challenges(Fr *z_out, const uint
     vst_fr(z_out + g_real, from_raw<FrParams>(raw));
 }
 
-int sha256_challenges_device(DeviceCtx *ctx, Fr *d_z, const uint8_t *d_blobs, const uint8_t *d_commit48, size_t n) {
+int sha256_challenges_device(DeviceCtx *ctx, Fr *d_z, const uint8_t *d_blobs, const uint8_t *d_commit48, size_t n,
+                             hipStream_t stream) {
     if (!n) return 0;
-    hipLaunchKernelGGL(k_sha256_challenges, dim3((unsigned)((n + 63) / 64)), dim3(128), 0, ctx->stream, d_z,
+    hipLaunchKernelGGL(k_sha256_challenges, dim3((unsigned)((n + 63) / 64)), dim3(128), 0, stream ? stream : ctx->stream, d_z,
                        d_blobs, d_commit48, n);
     HIP_TRY(hipGetLastError());
     return 0;

@@ -450,3 +450,21 @@ def test_evaluation_kernel_forms_at_their_switch_points(hip, rt, material, n):
     at = (n - 1) * 131072 + 32 * 777
     nb[at:at + 32] = (R - 1).to_bytes(32, "big")
     assert _device(hip, rt, bytes(nb), cc, pp, n) == (0, False)
+
+
+def test_resident_verification_when_an_earlier_batch_sized_the_arena(hip, rt, material):
+    """A slot's arena keeps its size between calls (one and a half times what the call that grew it needed): a batch
+    one and a half times as large as the one before fits the old block only if every buffer of the call is in the
+    request.  Round 6 forgot the transcript rows (160 bytes per blob) of the resident form there: 512 blobs and then 768
+    came back C_KZG_MALLOC (found by tools/ubench/sha_contention_probe.py).  Ratios around 1.5 in both forms, growing
+    and shrinking, with and without the call-time table."""
+    for table in (1, 0):
+        assert hip.lib.ckzg_hip_set_option(b"verify_call_table", table) == 0
+        try:
+            for n in (512, 768, 769, 1152, 1153, 767, 512, 8, 12, 13):
+                bb, cc, pp, _ = _inputs(material, n)
+                assert _device(hip, rt, bb, cc, pp, n) == (0, True), (table, n)
+                if n <= 768:
+                    assert _host(hip, bb, cc, pp, n) == (0, True), (table, n)
+        finally:
+            hip.lib.ckzg_hip_set_option(b"verify_call_table", 1)
