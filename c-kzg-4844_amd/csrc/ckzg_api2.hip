@@ -53,7 +53,7 @@ struct DBuf {
 // MEASURED on first use (44-66 us per blob with the x86 SHA extensions, ~320 us without): a rank of an 8-GPU job in a
 // 16-core container has 2 threads and hashes a 512-blob shard in 11-17 ms on the host, in 4.9 + 1.2 ms on the GPU; one
 // process with 16 threads keeps a 4096-blob batch on the host (11 ms under a 9.8 ms copy, against 16.6 ms).
-static constexpr double GPU_SHA_US = 4900.0;   // k_sha256_challenges at n <= 4096 (profiles/r04_pmc_verify_wide.json: 4.84 ms)
+static constexpr double GPU_SHA_US = 3900.0;   // k_sha256_challenges at n <= 4096 with its SIMDs to itself (profiles/r06_cu_partition_ab.txt; 4.9 ms shared)
 Fr challenge_from_bytes(const uint8_t *blob, const uint8_t *commitment48);   // below
 static double host_sha_us_per_blob() {
     static const double us = []() {
@@ -660,7 +660,9 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     // call goes 7.5 -> 6.3 ms (2048 blobs: 6.7 -> 5.7).  Below ~640 blobs the side work rarely collides (768 blobs: 3 calls of 16 took the extra 1.1 ms) and the
     // masked streams only cost their 0.07 ms.
     static const size_t partition_min = (size_t)dev::ab_knob("CKZG_HIP_CU_PARTITION_MIN", 640);
-    const bool partition = resident && n >= partition_min && g_verify_cu_partition.load(std::memory_order_relaxed) != 0 &&
+    // (host-pointer batches whose challenges are hashed on the GPU -- a rank with few host threads -- partition the same
+    // way: there the validation runs before the copy on the main stream, hash and table build after it)
+    const bool partition = gpu_sha && !small && n >= partition_min && g_verify_cu_partition.load(std::memory_order_relaxed) != 0 &&
                            ensure_cu_partition(ctx);
     StreamDrain drain_sha{partition ? ctx->sha_stream : nullptr}, drain_val{partition ? ctx->side_stream[0] : nullptr};
     if (!small) {
@@ -673,7 +675,7 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
         // (resident inputs: nothing blocks the host, so the validation ladders always run on the second stream,
         // underneath the challenge hashing -- the longest kernel of that form -- and the evaluation)
         hipStream_t vs = (split_validation || resident) ? ctx->copy_stream : ctx->stream;
-        if (partition) vs = ctx->side_stream[0];
+        if (partition && resident) vs = ctx->side_stream[0];
         if (!ctx->stage_ev[0]) OKB(hipEventCreateWithFlags(&ctx->stage_ev[0], hipEventDisableTiming) == hipSuccess);
         if (!ctx->stage_ev[1]) OKB(hipEventCreateWithFlags(&ctx->stage_ev[1], hipEventDisableTiming) == hipSuccess);
         const hipMemcpyKind kind = resident ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
@@ -825,10 +827,16 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     OKB(hipMemsetAsync(d_bad.p, 0, n * 4, ctx->stream) == hipSuccess);
     if (!small && !resident) OKB(hipStreamWaitEvent(ctx->stream, ctx->stage_ev[0], 0) == hipSuccess);  // d_ptb, d_pts, d_st ready
     if (gpu_sha) {
+        if (partition && !resident) {
+            // the blobs and the commitments' bytes reach HBM on the main stream: the hash stream starts behind them
+            if (!ctx->stage_ev[2]) OKB(hipEventCreateWithFlags(&ctx->stage_ev[2], hipEventDisableTiming) == hipSuccess);
+            OKB(hipEventRecord(ctx->stage_ev[2], ctx->stream) == hipSuccess);
+            OKB(hipStreamWaitEvent(ctx->sha_stream, ctx->stage_ev[2], 0) == hipSuccess);
+        }
         RC(dev::sha256_challenges_device(ctx, d_z.p, d_blob_bytes, resident ? reinterpret_cast<const uint8_t *>(d_cb) : d_ptb.p, n,
                                          partition ? ctx->sha_stream : nullptr));
         if (partition) {
-            // (stage_ev[1] is free in this form: only the split validation of small host-pointer batches records it)
+            // (stage_ev[1] is free in these forms: only the split validation of small host-pointer batches records it)
             OKB(hipEventRecord(ctx->stage_ev[1], ctx->sha_stream) == hipSuccess);
             OKB(hipStreamWaitEvent(ctx->stream, ctx->stage_ev[1], 0) == hipSuccess);   // the challenges, before the evaluation
         }

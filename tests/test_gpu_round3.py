@@ -450,6 +450,18 @@ def test_evaluation_kernel_forms_at_their_switch_points(hip, rt, material, n):
     at = (n - 1) * 131072 + 32 * 777
     nb[at:at + 32] = (R - 1).to_bytes(32, "big")
     assert _device(hip, rt, bytes(nb), cc, pp, n) == (0, False)
+    # host pointers with the challenges hashed on the GPU (what a rank with few host threads takes): from 640 blobs the
+    # hash runs on its own compute units as in the resident form, with and without the partition
+    hip.lib.ckzg_hip_set_option(b"gpu_sha_min", 1)
+    try:
+        for part in (1, 0):
+            assert hip.lib.ckzg_hip_set_option(b"verify_cu_partition", part) == 0
+            assert _host(hip, bb, cc, pp, n) == (0, True), part
+            assert _host(hip, bb, cc, bad, n) == (0, False), part
+            assert _device(hip, rt, bb, cc, pp, n) == (0, True), part
+    finally:
+        hip.lib.ckzg_hip_set_option(b"gpu_sha_min", 0)
+        hip.lib.ckzg_hip_set_option(b"verify_cu_partition", 1)
 
 
 def test_resident_verification_when_an_earlier_batch_sized_the_arena(hip, rt, material):
