@@ -83,6 +83,10 @@ extern "C" {
  *                   of the compute units and the point validation / call-time table, which run underneath it, on streams
  *                   confined to the rest (hipExtStreamCreateWithCUMask): 4096 blobs 7.5 -> 6.3 ms.  0: plain streams
  *                   (also what the call uses where the runtime refuses a masked stream).  Takes effect immediately.
+ *                   (HIP offers no flags for a masked stream: unlike the library's other streams these three are not
+ *                   hipStreamNonBlocking, i.e. they order themselves against work the process puts on the legacy NULL
+ *                   stream while such a call runs.  A process that relies on NULL-stream work overlapping a large
+ *                   resident verification sets the option to 0.)
  *   "commit_graph"  1 (default): a lone blob_to_kzg_commitment call submits its copies and kernels as ONE hipGraph (one
  *                   submission instead of six; -20 us).  The graph is built node by node (hipGraphAddMemcpyNode /
  *                   KernelNode), once per stream slot and table set -- no stream capture is involved, so HIP calls
