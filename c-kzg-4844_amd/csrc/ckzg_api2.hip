@@ -8,6 +8,7 @@
 #include <thread>
 
 #include "api_common.hpp"
+#include <optional>
 #include "combiner.hpp"
 
 using namespace ckzg;
@@ -529,6 +530,19 @@ struct OrderedHasher {
 // the compute units for the SHA-256 chain, the rest for what runs underneath it.  The mask bits of a multi-XCD part are
 // dealt round the XCDs, so "the first quarter of the bits" is the same share of every XCD, which is where the workgroups
 // of a launch go as well.  false (and plain streams) where the runtime refuses.
+// Verifications with a GPU hash in flight per device: the partition confines EVERY such call's hash to the same quarter
+// of the compute units, so a second concurrent one would crowd the first where, unpartitioned, it spreads over the
+// chip.  Only a call that finds no other takes the partition.
+static std::atomic<int> g_gpu_hash_calls[64];
+struct GpuHashCall {
+    int dev;
+    bool alone;
+    explicit GpuHashCall(int d) : dev(d >= 0 && d < 64 ? d : 0), alone(g_gpu_hash_calls[dev].fetch_add(1, std::memory_order_acq_rel) == 0) {}
+    ~GpuHashCall() { g_gpu_hash_calls[dev].fetch_sub(1, std::memory_order_acq_rel); }
+    GpuHashCall(const GpuHashCall &) = delete;
+    GpuHashCall &operator=(const GpuHashCall &) = delete;
+};
+
 static bool ensure_cu_partition(dev::DeviceCtx *ctx) {
     if (ctx->cu_partition_tried) return ctx->sha_stream != nullptr;
     ctx->cu_partition_tried = true;
@@ -662,8 +676,10 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     static const size_t partition_min = (size_t)dev::ab_knob("CKZG_HIP_CU_PARTITION_MIN", 640);
     // (host-pointer batches whose challenges are hashed on the GPU -- a rank with few host threads -- partition the same
     // way: there the validation runs before the copy on the main stream, hash and table build after it)
-    const bool partition = gpu_sha && !small && n >= partition_min && g_verify_cu_partition.load(std::memory_order_relaxed) != 0 &&
-                           ensure_cu_partition(ctx);
+    const bool partition_wanted = gpu_sha && !small && n >= partition_min && g_verify_cu_partition.load(std::memory_order_relaxed) != 0;
+    std::optional<GpuHashCall> hash_call;   // (counted only by calls that could partition; lives until the call returns)
+    if (partition_wanted) hash_call.emplace(ctx->device);
+    const bool partition = partition_wanted && hash_call->alone && ensure_cu_partition(ctx);
     StreamDrain drain_sha{partition ? ctx->sha_stream : nullptr}, drain_val{partition ? ctx->side_stream[0] : nullptr};
     if (!small) {
         // commitments [0,n), proofs [n,2n): decompress + subgroup-check on the GPU, on the second stream

@@ -480,3 +480,32 @@ def test_resident_verification_when_an_earlier_batch_sized_the_arena(hip, rt, ma
                     assert _host(hip, bb, cc, pp, n) == (0, True), (table, n)
         finally:
             hip.lib.ckzg_hip_set_option(b"verify_call_table", 1)
+
+
+def test_concurrent_resident_verifications_share_the_partition_rule(hip, rt, material):
+    """Four threads verify resident batches of >= 640 blobs at once: the first to arrive hashes on the partitioned
+    compute units, the others (a GPU hash is already in flight on the device) on the plain streams -- every verdict
+    right, valid and invalid batches mixed (ckzg_api2.hip: GpuHashCall)."""
+    import threading
+    blobs, cm, pr = material
+    n = 700
+    bb, cc, pp, order = _inputs(material, n)
+    bad = pp[:48 * 333] + pr[(order[333] + 1) % 8] + pp[48 * 334:]
+    results = {}
+
+    def worker(k):
+        out = []
+        for rep in range(3):
+            want_bad = (k + rep) % 2 == 1
+            out.append((_device(hip, rt, bb, cc, bad if want_bad else pp, n), want_bad))
+        results[k] = out
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=240)
+    assert all(not t.is_alive() for t in ts)
+    for k in range(4):
+        for (rc, ok), want_bad in results[k]:
+            assert rc == 0 and ok == (not want_bad), (k, rc, ok, want_bad)
