@@ -676,7 +676,10 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     static const size_t partition_min = (size_t)dev::ab_knob("CKZG_HIP_CU_PARTITION_MIN", 640);
     // (host-pointer batches whose challenges are hashed on the GPU -- a rank with few host threads -- partition the same
     // way: there the validation runs before the copy on the main stream, hash and table build after it)
-    const bool partition_wanted = gpu_sha && !small && n >= partition_min && g_verify_cu_partition.load(std::memory_order_relaxed) != 0;
+    // (up to 8192 blobs: 128 hash workgroups of two waves have a SIMD per wave on a quarter of 256 compute units; a
+    // larger batch would crowd the quarter and spreads over the chip instead)
+    const bool partition_wanted = gpu_sha && !small && n >= partition_min && n <= 8192 &&
+                                  g_verify_cu_partition.load(std::memory_order_relaxed) != 0;
     std::optional<GpuHashCall> hash_call;   // (counted only by calls that could partition; lives until the call returns)
     if (partition_wanted) hash_call.emplace(ctx->device);
     const bool partition = partition_wanted && hash_call->alone && ensure_cu_partition(ctx);

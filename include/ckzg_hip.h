@@ -78,7 +78,7 @@ extern "C" {
  *   "verify_call_table"  1 (default): verifications of >= 8 blobs / >= 128 cells build a fixed-base table over the
  *                   points of the call and take their sums from it; 0: ladder sums (also what a call does by itself when
  *                   the device is too full for the table).  Takes effect immediately.
- *   "verify_cu_partition"  1 (default): ckzg_hip_verify_blob_kzg_proof_batch_device on >= 640 blobs runs its SHA-256
+ *   "verify_cu_partition"  1 (default): ckzg_hip_verify_blob_kzg_proof_batch_device on 640 .. 8192 blobs runs its SHA-256
  *                   chain (one wave per 64 blobs, as fast as its SIMD issues for it) on a stream confined to a quarter
  *                   of the compute units and the point validation / call-time table, which run underneath it, on streams
  *                   confined to the rest (hipExtStreamCreateWithCUMask): 4096 blobs 7.5 -> 6.3 ms.  0: plain streams
