@@ -684,6 +684,23 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
     if (partition_wanted) hash_call.emplace(ctx->device);
     const bool partition = partition_wanted && hash_call->alone && ensure_cu_partition(ctx);
     StreamDrain drain_sha{partition ? ctx->sha_stream : nullptr}, drain_val{partition ? ctx->side_stream[0] : nullptr};
+    // The hash of the challenges: the enqueue-only step every GPU-hash form shares.  The resident form runs it HERE --
+    // its inputs are the caller's buffers, nothing precedes it, and every 10 us the longest kernel of the call starts
+    // earlier is 10 us off the call --, the host-pointer form further down, behind its copies.
+    bool hash_enqueued = false;
+    auto enqueue_hash = [&]() -> C_KZG_RET {
+        RC(dev::sha256_challenges_device(ctx, d_z.p, d_blob_bytes, resident ? reinterpret_cast<const uint8_t *>(d_cb) : d_ptb.p, n,
+                                         partition ? ctx->sha_stream : nullptr));
+        if (partition) {
+            // (stage_ev[1] is free in these forms: only the split validation of small host-pointer batches records it)
+            if (!ctx->stage_ev[1]) OKB(hipEventCreateWithFlags(&ctx->stage_ev[1], hipEventDisableTiming) == hipSuccess);
+            OKB(hipEventRecord(ctx->stage_ev[1], ctx->sha_stream) == hipSuccess);
+            OKB(hipStreamWaitEvent(ctx->stream, ctx->stage_ev[1], 0) == hipSuccess);   // the challenges, before the evaluation
+        }
+        hash_enqueued = true;
+        return C_KZG_OK;
+    };
+    if (resident && gpu_sha) RC(enqueue_hash());
     if (!small) {
         // commitments [0,n), proofs [n,2n): decompress + subgroup-check on the GPU, on the second stream
         // so that the ladder kernel runs under the (host-blocking, pageable) copy of the blobs
@@ -852,13 +869,7 @@ C_KZG_RET verify_blobs_core(bool *ok, const Blob *blobs, const Bytes48 *cb, cons
             OKB(hipEventRecord(ctx->stage_ev[2], ctx->stream) == hipSuccess);
             OKB(hipStreamWaitEvent(ctx->sha_stream, ctx->stage_ev[2], 0) == hipSuccess);
         }
-        RC(dev::sha256_challenges_device(ctx, d_z.p, d_blob_bytes, resident ? reinterpret_cast<const uint8_t *>(d_cb) : d_ptb.p, n,
-                                         partition ? ctx->sha_stream : nullptr));
-        if (partition) {
-            // (stage_ev[1] is free in these forms: only the split validation of small host-pointer batches records it)
-            OKB(hipEventRecord(ctx->stage_ev[1], ctx->sha_stream) == hipSuccess);
-            OKB(hipStreamWaitEvent(ctx->stream, ctx->stage_ev[1], 0) == hipSuccess);   // the challenges, before the evaluation
-        }
+        if (!hash_enqueued) RC(enqueue_hash());
     }
     tr.mark("enqueue H2D (+ GPU validation, GPU challenges)");
     if (hasher.t.joinable()) hasher.t.join();
