@@ -638,7 +638,7 @@ def predicted_scaling(value_n1, host_ptr_n1, sec, lib_budget=None, effective_cor
         cores = min(cores, lib_budget)      # what the library itself sizes its pools by (affinity mask)
     if effective_cores:
         cores = min(cores, effective_cores)  # what the host really delivered to the CPU baseline of this run
-    MEMCPY_GBPS_PER_CORE, SHA_US_PER_BLOB_THREAD, COPY_US_PER_BLOB, GPU_SHA_US, EVAL_US, TAIL_US = 8.0, 66.0, 2.4, 4900.0, 1900.0, 2000.0
+    MEMCPY_GBPS_PER_CORE, SHA_US_PER_BLOB_THREAD, COPY_US_PER_BLOB, GPU_SHA_US, EVAL_US, TAIL_US = 8.0, 66.0, 2.4, 3900.0, 600.0, 2000.0   # (round 6: hash on compute units of its own, evaluation from the bytes)
     out = {"host_cpus_visible": visible, "host_cores_assumed": cores,
            "host_cores_source": "min(affinity mask, the library's ckzg_hip_host_thread_budget, parallel speed-up the CPU baseline of this run reached)",
            "model": {"memcpy_GBps_per_core": MEMCPY_GBPS_PER_CORE, "sha256_us_per_blob_per_thread": SHA_US_PER_BLOB_THREAD,
